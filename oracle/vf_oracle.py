@@ -1,0 +1,410 @@
+"""CPU oracle for the VariantFormer hot path  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module; the product path (variantformer_amd/) never does and fails loudly without its
+HIP library.
+
+What it is: a plain-PyTorch (CPU, fp32) functional restatement of the reference's
+algorithm for the hot path, operating directly on a state dict with the
+reference's key names.  Each function cites the reference file:line it follows
+(paths relative to /root/reference).
+
+How it is pinned:
+  * tests/test_oracle_golden.py checks it against tests/golden/*.npz, which were produced
+    by running the reference's own classes (fp32, CPU) via tests/golden/make_golden.py;
+    agreement is to fp32 round-off (<= 2e-5 relative).
+  * The attention arithmetic inside flash_attn.modules.mha.MHA (flash-attn v2.8.3,
+    third-party, CUDA-only, absent from /root/reference and from this image) is restated
+    from its published semantics: softmax(Q K^T / sqrt(dh) - slope_h * |i - j|) V,
+    non-causal, Wqkv rows ordered (three, head, dh), Wkv rows (two, head, dh).
+    The fixtures were generated with the same restatement standing in for flash-attn, so
+    AT THE ATTENTION BOUNDARY PARITY IS UNPINNED by anything runnable offline.
+
+Two arithmetic modes:
+  rounding=None    pure fp32 (what the golden fixtures hold)
+  rounding="bf16"  fp32 residual stream / LayerNorm / softmax / accumulation, with operands
+                   rounded to bf16 exactly where the HIP kernels round them (DESIGN.md
+                   "Rounding points").  This is the checker for the GPU path: kernels and
+                   oracle then differ only by accumulation order and exp/erf ulps.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+
+import torch
+import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------------------
+# small pieces
+# --------------------------------------------------------------------------------------
+def alibi_slopes(n: int) -> list[float]:
+    """seq2gene/modules/layers.py:15-37 (identical to seq2reg/modules.py:13-33 and to
+    flash_attn's own helper)."""
+    def pow2(n):
+        start = 2 ** (-(2 ** -(math.log2(n) - 3)))
+        return [start * start ** i for i in range(n)]
+    if math.log2(n).is_integer():
+        return pow2(n)
+    c = 2 ** math.floor(math.log2(n))
+    return pow2(c) + alibi_slopes(2 * c)[0::2][: n - c]
+
+
+def positional_encoding_1d(d_model: int, length: int) -> torch.Tensor:
+    """seq2reg/model.py:15-37."""
+    pe = torch.zeros(length, d_model)
+    position = torch.arange(0, length).unsqueeze(1)
+    div_term = torch.exp(torch.arange(0, d_model, 2, dtype=torch.float) * -(math.log(10000.0) / d_model))
+    pe[:, 0::2] = torch.sin(position.float() * div_term)
+    pe[:, 1::2] = torch.cos(position.float() * div_term)
+    return pe
+
+
+def precision2dtype(precision_str: str) -> torch.dtype:
+    """utils/functions.py:12-32."""
+    s = precision_str.lower().strip()
+    if "bf16" in s:
+        return torch.bfloat16
+    if "16" in s:
+        return torch.float16
+    if "32" in s:
+        return torch.float32
+    raise ValueError(f"Unknown precision string: {precision_str}")
+
+
+def unpad_input(hidden: torch.Tensor, keep_mask: torch.Tensor):
+    """flash_attn.bert_padding.unpad_input [3p] as used at model_combined_modulator.py:179-181:
+    returns (packed rows, flat indices int64, cu_seqlens int32 [B+1], max_seqlen, seqlens)."""
+    seqlens = keep_mask.sum(dim=-1, dtype=torch.int32)
+    indices = torch.nonzero(keep_mask.flatten(), as_tuple=False).flatten()
+    cu = F.pad(torch.cumsum(seqlens, 0, dtype=torch.int32), (1, 0))
+    flat = hidden.reshape(-1, *hidden.shape[2:])
+    return flat[indices], indices, cu, int(seqlens.max()), seqlens
+
+
+def pad_input(packed: torch.Tensor, indices: torch.Tensor, batch: int, seqlen: int):
+    """flash_attn.bert_padding.pad_input [3p]: scatter rows into zeros [B,S,...]."""
+    out = torch.zeros(batch * seqlen, *packed.shape[1:], dtype=packed.dtype)
+    out[indices] = packed
+    return out.view(batch, seqlen, *packed.shape[1:])
+
+
+class Rounding:
+    """Rounding policy: where the HIP kernels store bf16, the oracle rounds to bf16."""
+
+    def __init__(self, mode: str | None):
+        assert mode in (None, "bf16")
+        self.mode = mode
+
+    def r(self, x: torch.Tensor) -> torch.Tensor:
+        if self.mode is None:
+            return x
+        return x.to(torch.bfloat16).to(torch.float32)
+
+
+def linear(x, w, b, rnd: Rounding):
+    """nn.Linear under the kernel contract: bf16 operands (x already rounded by its
+    producer, w rounded once at load), fp32 accumulate, fp32 bias."""
+    return F.linear(rnd.r(x), rnd.r(w), b)
+
+
+def layer_norm(x, w, b):
+    return F.layer_norm(x, (x.shape[-1],), w, b, 1e-5)
+
+
+def attention(q, k, v, slopes, rnd: Rounding):
+    """Textbook restatement of flash-attn's varlen forward for ONE sequence [3p].
+    q [sq,H,dh], k/v [sk,H,dh] (already rounded to the storage dtype by their producer).
+    scores fp32, ALiBi bias -slope*|i + (sk - sq) - j|, softmax fp32; P is rounded to the
+    operand dtype before PV while the normaliser is summed from the unrounded P."""
+    dh = q.shape[-1]
+    s = torch.einsum("qhd,khd->hqk", q, k) * (1.0 / math.sqrt(dh))
+    if slopes is not None:
+        sq, sk = q.shape[0], k.shape[0]
+        i = torch.arange(sq)[:, None] + (sk - sq)
+        j = torch.arange(sk)[None, :]
+        s = s - slopes.to(s.dtype)[:, None, None] * (i - j).abs().to(s.dtype)[None]
+    m = s.max(dim=-1, keepdim=True).values
+    p = torch.exp(s - m)
+    l = p.sum(dim=-1, keepdim=True)
+    o = torch.einsum("hqk,khd->hqd", rnd.r(p), v) / l
+    return o.permute(1, 0, 2)          # [sq,H,dh]
+
+
+def geglu_ffn(x, sd, pfx, rnd: Rounding):
+    """LN'd input -> Linear(d,2048) -> a * gelu(gate) -> Linear(1024,d)
+    (layers.py:159-162, seq2reg/modules.py:184-187; erf GELU)."""
+    h = linear(x, sd[pfx + "linear_geglu_1.weight"], sd[pfx + "linear_geglu_1.bias"], rnd)
+    a, g = h.chunk(2, dim=-1)
+    h = rnd.r(a * F.gelu(g))
+    return linear(h, sd[pfx + "linear_geglu_2.weight"], sd[pfx + "linear_geglu_2.bias"], rnd)
+
+
+def mha_self(x, sd, pfx, H, cu, slopes, rnd: Rounding):
+    """flash_attn MHA self path [3p] on a packed stream x [tokens, D] with cu_seqlens."""
+    D = x.shape[-1]
+    dh = D // H
+    qkv = rnd.r(linear(x, sd[pfx + "Wqkv.weight"], sd[pfx + "Wqkv.bias"], rnd)).view(-1, 3, H, dh)
+    out = torch.empty(x.shape[0], D)
+    for b in range(len(cu) - 1):
+        a, e = int(cu[b]), int(cu[b + 1])
+        if e > a:
+            out[a:e] = attention(qkv[a:e, 0], qkv[a:e, 1], qkv[a:e, 2], slopes, rnd).reshape(e - a, D)
+    out = rnd.r(out)
+    return linear(out, sd[pfx + "out_proj.weight"], sd[pfx + "out_proj.bias"], rnd)
+
+
+def mha_cross(xq, xkv, sd, pfx, H, cu_q, cu_k, rnd: Rounding):
+    """flash_attn MHA cross path [3p]: Wq on the query stream, Wkv on the context stream;
+    no ALiBi (cross_alibi: false, configs/vf_model.yaml:13)."""
+    D = xq.shape[-1]
+    dh = D // H
+    q = rnd.r(linear(xq, sd[pfx + "Wq.weight"], sd[pfx + "Wq.bias"], rnd)).view(-1, H, dh)
+    kv = rnd.r(linear(xkv, sd[pfx + "Wkv.weight"], sd[pfx + "Wkv.bias"], rnd)).view(-1, 2, H, dh)
+    out = torch.empty(xq.shape[0], D)
+    for b in range(len(cu_q) - 1):
+        a, e = int(cu_q[b]), int(cu_q[b + 1])
+        ka, ke = int(cu_k[b]), int(cu_k[b + 1])
+        if e > a:
+            out[a:e] = attention(q[a:e], kv[ka:ke, 0], kv[ka:ke, 1], None, rnd).reshape(e - a, D)
+    out = rnd.r(out)
+    return linear(out, sd[pfx + "out_proj.weight"], sd[pfx + "out_proj.bias"], rnd)
+
+
+# --------------------------------------------------------------------------------------
+# seq2reg (a-4, a-5)
+# --------------------------------------------------------------------------------------
+@dataclass
+class Seq2RegHP:
+    embedding_dim: int
+    num_heads: int
+    num_layers: int
+    token_length: int
+    positional_encoding: str = "sinusoidal"
+    seq_pool: str = "mean"
+
+    @classmethod
+    def from_hparams(cls, hp: dict):
+        return cls(hp["embedding_dim"], hp["num_heads"], hp["num_layers"], hp["token_length"],
+                   hp.get("positional_encoding", "sinusoidal"), hp.get("seq_pool", "mean"))
+
+
+def seq2reg_layer(x, cu, sd, pfx, hp: Seq2RegHP, slopes, rnd: Rounding):
+    """FlashTransformerLayer.forward (seq2reg/modules.py:149-191) on the packed valid tokens.
+    Pad positions never influence valid ones (attention runs on the unpadded stream, :159-171;
+    everything else is per-token) and are excluded from the pool, so only valid tokens are kept."""
+    h = rnd.r(layer_norm(x, sd[pfx + "norm1.weight"], sd[pfx + "norm1.bias"]))
+    a = mha_self(h, sd, pfx + "MHA.", hp.num_heads, cu, slopes, rnd)
+    x1 = a + x                                                       # :179  x += res_short
+    h = rnd.r(layer_norm(x1, sd[pfx + "norm2.weight"], sd[pfx + "norm2.bias"]))
+    return geglu_ffn(h, sd, pfx, rnd) + x                            # :188  x += res_long (= layer input)
+
+
+def seq2reg_embed(ids, pad_mask, sd, pfx, hp: Seq2RegHP, rnd: Rounding):
+    """Seq2RegPredictor.forward(only_embed=True) (seq2reg/model.py:193-279).
+    ids int64 [b,1,L], pad_mask bool [b,1,L] (True = pad) -> [b,1,d]."""
+    b, ns, L = ids.shape
+    ids = ids.reshape(b * ns, L)
+    pad = pad_mask.reshape(b * ns, L)
+    x = sd[pfx + "token_embedding.weight"][ids]                       # :215
+    if hp.positional_encoding == "sinusoidal":
+        x = x + positional_encoding_1d(hp.embedding_dim, hp.token_length)   # :219-220
+        slopes = None
+    else:
+        slopes = torch.tensor(alibi_slopes(hp.num_heads), dtype=torch.float32)
+    xp, idx, cu, _, lens = unpad_input(x, ~pad)
+    for l in range(hp.num_layers):
+        xp = seq2reg_layer(xp, cu, sd, f"{pfx}transformer_encoder.{l}.", hp, slopes, rnd)
+    d = hp.embedding_dim
+    if hp.seq_pool == "mean":                                         # :263-267
+        out = torch.zeros(b * ns, d)
+        for w in range(b * ns):
+            a, e = int(cu[w]), int(cu[w + 1])
+            out[w] = xp[a:e].sum(dim=0) / float(e - a) if e > a else float("nan")
+    elif hp.seq_pool == "max":                                        # :257-261
+        out = torch.full((b * ns, d), float("-inf"))
+        for w in range(b * ns):
+            a, e = int(cu[w]), int(cu[w + 1])
+            if e > a:
+                out[w] = xp[a:e].max(dim=0).values
+    else:
+        raise NotImplementedError("seq_pool='linear' needs the padded positions; not used by shipped configs")
+    return out.view(b, ns, d)
+
+
+# --------------------------------------------------------------------------------------
+# seq2gene (a-2, a-3, a-6 .. a-13)
+# --------------------------------------------------------------------------------------
+@dataclass
+class Seq2GeneHP:
+    emb_dim: int
+    num_heads: int
+    num_layers: int
+    token_dim: int
+    gene_emb_dim: int
+    num_tissues: int = 63
+    use_alibi: bool = True
+    extras: dict = field(default_factory=dict)
+
+    @classmethod
+    def from_kwargs(cls, kw: dict):
+        assert kw.get("use_context", False) and not kw.get("only_cross_attention", True), \
+            "oracle covers the shipped configuration (configs/vf_model.yaml:12-37)"
+        assert kw.get("gene_pooling") == "multi_registry" and not kw.get("multi_head", True)
+        assert kw.get("use_bigger_head", False) and not kw.get("add_context_to_cres", False)
+        assert not kw.get("use_res", False) and not kw.get("cross_alibi", False)
+        return cls(kw["emb_dim"], kw["num_heads"], kw["num_layers"], kw["token_dim"], kw["gene_emb_dim"],
+                   kw.get("num_tissues", 63), kw.get("use_alibi", True))
+
+
+def modulator_layer(src, ctx, cu_src, cu_ctx, sd, pfx, H, slopes, rnd: Rounding):
+    """ContextFlashAttentionEncoderLayer.forward (seq2gene/modules/layers.py:88-165) on packed
+    streams: LN1 -> self-MHA(ALiBi) -> +src -> LN2 -> cross-MHA(q = x, kv = ctx RAW, no norm)
+    -> +res_short -> LN3 -> GeGLU -> + src (the LAYER INPUT, :99,163)."""
+    h = rnd.r(layer_norm(src, sd[pfx + "norm1.weight"], sd[pfx + "norm1.bias"]))
+    x1 = mha_self(h, sd, pfx + "mixer.MHA.", H, cu_src, slopes, rnd) + src
+    h = rnd.r(layer_norm(x1, sd[pfx + "norm2.weight"], sd[pfx + "norm2.bias"]))
+    x2 = mha_cross(h, ctx, sd, pfx + "crossMHA.MHA.", H, cu_src, cu_ctx, rnd) + x1
+    h = rnd.r(layer_norm(x2, sd[pfx + "norm3.weight"], sd[pfx + "norm3.bias"]))
+    return geglu_ffn(h, sd, pfx, rnd) + src
+
+
+def combined_modulator(cre_x, gene_x, ctx_labels, cu_cre, cu_gene, sd, pfx, hp: Seq2GeneHP, rnd: Rounding,
+                       collect=None):
+    """CombinedModulator.forward (model_combined_modulator.py:137-328) on packed streams.
+    cre_x [sum N, D], gene_x [sum G, D], ctx_labels int64 [sum N]."""
+    slopes = torch.tensor(alibi_slopes(hp.num_heads), dtype=torch.float32) if hp.use_alibi else None
+    ctx = sd[pfx + "second_level_context_embedding.weight"][ctx_labels]          # :166-168
+    cre, gene = cre_x, gene_x
+    gene = modulator_layer(gene, cre, cu_gene, cu_cre, sd, pfx + "gene_layers.0.", hp.num_heads, slopes, rnd)  # :244-250
+    if collect is not None:
+        collect["first_gene_layer_out"] = gene.clone()
+    for i in range(hp.num_layers - 1):                                           # :258-285
+        cre = modulator_layer(cre, ctx, cu_cre, cu_cre, sd, f"{pfx}cre_layers.{i}.", hp.num_heads, slopes, rnd)
+        if collect is not None and i == 0:
+            collect["first_cre_layer_out"] = cre.clone()
+        gene = modulator_layer(gene, cre, cu_gene, cu_cre, sd, f"{pfx}gene_layers.{i + 1}.", hp.num_heads, slopes, rnd)
+    return gene, cre
+
+
+def tissue_head(emb, sd, pfx, rnd: Rounding):
+    """TissueExpressionHeads, shared 'bigger' head (layers.py:1078-1087, :1113-1144):
+    Linear -> LayerNorm -> GELU -> Linear -> GELU -> Linear(D,1) -> Softplus.
+    Kernel contract: first two Linears are bf16-operand GEMMs; the final D->1 dot product and
+    everything elementwise stay fp32."""
+    p = pfx + "tissue_expressions."
+    h = linear(emb, sd[p + "0.weight"], sd[p + "0.bias"], rnd)
+    h = rnd.r(F.gelu(layer_norm(h, sd[p + "1.weight"], sd[p + "1.bias"])))
+    h = F.gelu(linear(h, sd[p + "4.weight"], sd[p + "4.bias"], rnd))
+    h = F.linear(h, sd[p + "6.weight"], sd[p + "6.bias"])
+    return F.softplus(h)
+
+
+def forward(batch: dict, sd: dict, cre_hp: Seq2RegHP, gene_hp: Seq2RegHP, hp: Seq2GeneHP,
+            rounding: str | None = None, share_cre_stream: bool = False, collect: dict | None = None):
+    """Seq2GenePredictorCombinedModulator.forward (model_combined_modulator.py:540-720) for a
+    collate_fn_batching dict.  Returns (pred [sum T,1], emb [sum T,D]).
+
+    share_cre_stream=False follows the reference literally: every gene's CRE stream and gene
+    stream are repeated once per requested tissue (:622-649).  share_cre_stream=True evaluates
+    the tissue-independent CRE stream once per gene -- the exact de-duplication the HIP path
+    uses; tests assert both give the same numbers.
+    """
+    rnd = Rounding(rounding)
+    n_genes = len(batch["cre_sequences"])
+    D = hp.emb_dim
+    # --- seq2reg over CRE windows and gene chunks (transform_with_batching, :722-829).  The
+    # reference chunks by <=1024 windows (:760-785); windows are independent, so chunking does
+    # not change any value.
+    cre_tok = [seq2reg_embed(batch["cre_sequences"][i], batch["cre_attention_masks"][i], sd,
+                             "cre_tokenizer.", cre_hp, rnd)[:, 0, :] for i in range(n_genes)]
+    gene_tok = [seq2reg_embed(batch["gene_embeddings"][i], batch["gene_attention_masks"][i], sd,
+                              "gene_tokenizer.", gene_hp, rnd)[:, 0, :] for i in range(n_genes)]
+    if collect is not None:
+        collect["cre_tok"], collect["gene_tok"] = cre_tok, gene_tok
+    # --- maps (:610-612)
+    if "cre_map.weight" in sd:
+        cre_x = [linear(t, sd["cre_map.weight"], sd["cre_map.bias"], rnd) for t in cre_tok]
+    else:
+        cre_x = cre_tok
+    gene_x = [linear(t, sd["gene_map.weight"], sd["gene_map.bias"], rnd) for t in gene_tok]
+    reg = sd["start_tkn.registry_tokens.weight"]
+
+    embs = []
+    first_gene, first_cre, mod_out = [], [], []
+    for i in range(n_genes):
+        tissues = [int(t) for t in batch["tissue_context"][i]]
+        T, N, C = len(tissues), cre_x[i].shape[0], gene_x[i].shape[0]
+        labels = batch["ref_cre_labels"][i].long()
+        # registry token prepended per tissue (MultiRegistry.forward layers.py:508-521; prepare_input :357-366)
+        g = torch.cat([torch.cat([reg[t][None, :], gene_x[i]], dim=0) for t in tissues], dim=0)   # [T*(C+1), D]
+        cu_g = torch.arange(0, T + 1, dtype=torch.int32) * (C + 1)
+        col = {} if collect is not None else None
+        if share_cre_stream:
+            # one CRE stream; all T tissue copies of the gene stream attend to it
+            out, _ = _modulator_shared(cre_x[i], g, labels, T, C + 1, sd, hp, rnd, col)
+        else:
+            cre_rep = cre_x[i].repeat(T, 1)
+            lab_rep = labels.repeat(T)
+            cu_c = torch.arange(0, T + 1, dtype=torch.int32) * N
+            out, _ = combined_modulator(cre_rep, g, lab_rep, cu_c, cu_g, sd, "combined_modulator.", hp, rnd, col)
+        if collect is not None:
+            first_gene.append(col["first_gene_layer_out"])
+            first_cre.append(col["first_cre_layer_out"])
+            mod_out.append(out.view(T, C + 1, D))
+        embs.append(out.view(T, C + 1, D)[:, 0, :])            # pool_outputs multi_registry (:391-392)
+    if collect is not None:
+        collect["first_gene_layer_out"] = torch.cat(first_gene)
+        collect["first_cre_layer_out"] = torch.cat(first_cre)
+        collect["modulator_gene_out"] = mod_out
+    emb = torch.cat(embs, dim=0)
+    pred = tissue_head(emb, sd, "tissue_heads.", rnd)
+    return pred, emb
+
+
+def _modulator_shared(cre_x, gene_x, labels, T, G, sd, hp: Seq2GeneHP, rnd: Rounding, collect=None):
+    """De-duplicated evaluation of CombinedModulator.forward for ONE gene: the CRE stream
+    (tissue-independent while add_context_to_cres is false, configs/vf_model.yaml:16) runs once;
+    gene-layer cross-attention has no positional bias, so the T*G query rows form one query
+    block against the gene's N keys."""
+    pfx = "combined_modulator."
+    H = hp.num_heads
+    slopes = torch.tensor(alibi_slopes(H), dtype=torch.float32) if hp.use_alibi else None
+    N = cre_x.shape[0]
+    ctx = sd[pfx + "second_level_context_embedding.weight"][labels]
+    cu_c = torch.tensor([0, N], dtype=torch.int32)
+    cu_g = torch.arange(0, T + 1, dtype=torch.int32) * G
+
+    def gene_layer(src, kvsrc, p):
+        h = rnd.r(layer_norm(src, sd[p + "norm1.weight"], sd[p + "norm1.bias"]))
+        x1 = mha_self(h, sd, p + "mixer.MHA.", H, cu_g, slopes, rnd) + src
+        h = rnd.r(layer_norm(x1, sd[p + "norm2.weight"], sd[p + "norm2.bias"]))
+        x2 = mha_cross(h, kvsrc, sd, p + "crossMHA.MHA.", H, torch.tensor([0, T * G], dtype=torch.int32), cu_c, rnd) + x1
+        h = rnd.r(layer_norm(x2, sd[p + "norm3.weight"], sd[p + "norm3.bias"]))
+        return geglu_ffn(h, sd, p, rnd) + src
+
+    cre, gene = cre_x, gene_x
+    gene = gene_layer(gene, cre, pfx + "gene_layers.0.")
+    if collect is not None:
+        collect["first_gene_layer_out"] = gene.clone()
+    for i in range(hp.num_layers - 1):
+        cre = modulator_layer(cre, ctx, cu_c, cu_c, sd, f"{pfx}cre_layers.{i}.", H, slopes, rnd)
+        if collect is not None and i == 0:
+            collect["first_cre_layer_out"] = cre.repeat(T, 1)
+        gene = gene_layer(gene, cre, f"{pfx}gene_layers.{i + 1}.")
+    return gene, cre
+
+
+def predict_step(batch: dict, sd: dict, cre_hp, gene_hp, hp, rounding=None, share_cre_stream=False):
+    """Seq2GenePredictorCombinedModulator.predict_step (model_combined_modulator.py:857-907):
+    per-gene split of the fp32 outputs."""
+    with torch.no_grad():
+        pred, emb = forward(batch, sd, cre_hp, gene_hp, hp, rounding, share_cre_stream)
+    preds, embs, s = [], [], 0
+    for t in batch["tissue_context"]:
+        n = len(t)
+        preds.append(pred[s:s + n].numpy())
+        embs.append(emb[s:s + n].numpy())
+        s += n
+    return {"pred_gene_exp": preds, "embeddings": embs, "batch_idx": 0, "dataloader_idx": None}

@@ -1,0 +1,374 @@
+#!/usr/bin/env python
+"""Generate golden fixtures by running the *reference itself* on CPU in this container.
+
+Runs only where /root/reference exists (the dev container); the fixtures it writes
+(tests/golden/*.npz, *.json) are data: seeded inputs and the reference's outputs.
+The Python reference never travels to the GPU box; these vectors do.
+
+What is real and what is a stand-in:
+  * real reference code executed: seq2reg.model.Seq2RegPredictor,
+    seq2reg.modules.FlashTransformerLayer,
+    seq2gene.model_combined_modulator.{Seq2GenePredictorCombinedModulator,CombinedModulator},
+    seq2gene.modules.layers.{ContextFlashAttentionEncoderLayer,FlashAttLayer,MultiRegistry,
+    TissueExpressionHeads}, utils.seq.BPEEncoder, utils.functions.precision2dtype.
+  * stand-ins written here (third-party packages absent from the image):
+    - lightning.pytorch.LightningModule -> nn.Module + save_hyperparameters()/log()
+    - pybedtools -> empty module
+    - flash_attn.modules.mha.MHA and flash_attn.bert_padding.{pad_input,unpad_input}
+      (flash-attn v2.8.3, README.md:66 of the reference; CUDA only, not installable here):
+      restated below from its published semantics: softmax(QK^T/sqrt(dh) - slope_h*|i-j|)V,
+      non-causal, Wqkv packed "(three h d)", Wkv packed "(two h d)".
+    => at the attention boundary parity is UNPINNED by anything runnable offline.
+
+A fake trainer with precision "bf16-mixed" and no autocast selects the reference's
+cast-free branch (model_combined_modulator.py:741-742), i.e. a clean fp32 run of the
+reference's own orchestration.
+
+Usage:  python tests/golden/make_golden.py      (writes next to this file)
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+
+
+# --------------------------------------------------------------------------------------
+# stand-ins for absent third-party packages
+# --------------------------------------------------------------------------------------
+def _alibi_slopes(n):
+    def pow2(n):
+        start = 2 ** (-(2 ** -(math.log2(n) - 3)))
+        return [start * start**i for i in range(n)]
+    if math.log2(n).is_integer():
+        return pow2(n)
+    c = 2 ** math.floor(math.log2(n))
+    return pow2(c) + _alibi_slopes(2 * c)[0::2][: n - c]
+
+
+class _MHA(nn.Module):
+    """Pure-PyTorch stand-in with flash_attn.modules.mha.MHA's parameter names."""
+
+    def __init__(self, embed_dim, num_heads, dropout=0.0, use_flash_attn=True, use_alibi=False,
+                 cross_attn=False, **kw):
+        super().__init__()
+        self.embed_dim, self.num_heads, self.cross_attn = embed_dim, num_heads, cross_attn
+        self.head_dim = embed_dim // num_heads
+        if cross_attn:
+            self.Wq = nn.Linear(embed_dim, embed_dim)
+            self.Wkv = nn.Linear(embed_dim, 2 * embed_dim)
+        else:
+            self.Wqkv = nn.Linear(embed_dim, 3 * embed_dim)
+        self.out_proj = nn.Linear(embed_dim, embed_dim)
+        self.use_alibi = use_alibi
+        if use_alibi:
+            self.register_buffer("alibi_slopes", torch.tensor(_alibi_slopes(num_heads), dtype=torch.float32),
+                                 persistent=False)
+
+    def _attend(self, q, k, v):
+        # q [sq,H,dh], k,v [sk,H,dh]
+        s = torch.einsum("qhd,khd->hqk", q, k) / math.sqrt(self.head_dim)
+        if self.use_alibi:
+            sq, sk = q.shape[0], k.shape[0]
+            i = torch.arange(sq)[:, None] + (sk - sq)
+            j = torch.arange(sk)[None, :]
+            s = s - self.alibi_slopes.to(s.dtype)[:, None, None] * (i - j).abs().to(s.dtype)[None]
+        p = torch.softmax(s, dim=-1)
+        return torch.einsum("hqk,khd->qhd", p, v)
+
+    def forward(self, x, x_kv=None, cu_seqlens=None, max_seqlen=None, cu_seqlens_k=None, max_seqlen_k=None, **kw):
+        H, dh = self.num_heads, self.head_dim
+        if self.cross_attn:
+            q = self.Wq(x)
+            kv = self.Wkv(x_kv if x_kv is not None else x)
+        else:
+            qkv = self.Wqkv(x)
+        if cu_seqlens is None:
+            # padded [B,S,D], no masking
+            B = x.shape[0]
+            outs = []
+            for b in range(B):
+                if self.cross_attn:
+                    qb = q[b].view(-1, H, dh)
+                    kvb = kv[b].view(-1, 2, H, dh)
+                    outs.append(self._attend(qb, kvb[:, 0], kvb[:, 1]).reshape(-1, H * dh))
+                else:
+                    t = qkv[b].view(-1, 3, H, dh)
+                    outs.append(self._attend(t[:, 0], t[:, 1], t[:, 2]).reshape(-1, H * dh))
+            return self.out_proj(torch.stack(outs))
+        out = torch.empty(x.shape[0], H * dh, dtype=x.dtype)
+        n = cu_seqlens.numel() - 1
+        for b in range(n):
+            a, e = int(cu_seqlens[b]), int(cu_seqlens[b + 1])
+            if self.cross_attn:
+                ka, ke = int(cu_seqlens_k[b]), int(cu_seqlens_k[b + 1])
+                kvb = kv[ka:ke].view(-1, 2, H, dh)
+                out[a:e] = self._attend(q[a:e].view(-1, H, dh), kvb[:, 0], kvb[:, 1]).reshape(-1, H * dh)
+            else:
+                t = qkv[a:e].view(-1, 3, H, dh)
+                out[a:e] = self._attend(t[:, 0], t[:, 1], t[:, 2]).reshape(-1, H * dh)
+        return self.out_proj(out)
+
+
+def _unpad_input(hidden_states, attention_mask, unused_mask=None):
+    seqlens = attention_mask.sum(dim=-1, dtype=torch.int32)
+    indices = torch.nonzero(attention_mask.flatten(), as_tuple=False).flatten()
+    max_len = int(seqlens.max().item())
+    cu = torch.nn.functional.pad(torch.cumsum(seqlens, dim=0, dtype=torch.int32), (1, 0))
+    flat = hidden_states.reshape(-1, *hidden_states.shape[2:])
+    return flat[indices], indices, cu, max_len, seqlens
+
+
+def _pad_input(hidden_states, indices, batch, seqlen):
+    out = torch.zeros(batch * seqlen, *hidden_states.shape[1:], dtype=hidden_states.dtype)
+    out[indices] = hidden_states
+    return out.view(batch, seqlen, *hidden_states.shape[1:])
+
+
+class _LightningModule(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.trainer = None
+
+    def save_hyperparameters(self, *a, ignore=None, **k):
+        import inspect
+        frame = inspect.currentframe().f_back
+        args = inspect.getargvalues(frame)
+        hp = {n: args.locals[n] for n in args.args if n != "self"}
+        if args.keywords:
+            hp.update(args.locals[args.keywords])
+        for n in (ignore or []):
+            hp.pop(n, None)
+        self.hparams = types.SimpleNamespace(**hp)
+
+    def log(self, *a, **k):
+        pass
+
+
+def install_stubs():
+    lightning = types.ModuleType("lightning")
+    pl = types.ModuleType("lightning.pytorch")
+    pl.LightningModule = _LightningModule
+    lightning.pytorch = pl
+    sys.modules["lightning"] = lightning
+    sys.modules["lightning.pytorch"] = pl
+    sys.modules["pybedtools"] = types.ModuleType("pybedtools")
+    fa = types.ModuleType("flash_attn")
+    fam = types.ModuleType("flash_attn.modules")
+    mha = types.ModuleType("flash_attn.modules.mha")
+    mha.MHA = _MHA
+    bp = types.ModuleType("flash_attn.bert_padding")
+    bp.pad_input, bp.unpad_input = _pad_input, _unpad_input
+    fa.modules, fam.mha, fa.bert_padding = fam, mha, bp
+    for n, m in [("flash_attn", fa), ("flash_attn.modules", fam), ("flash_attn.modules.mha", mha),
+                 ("flash_attn.bert_padding", bp)]:
+        sys.modules[n] = m
+    # the reference's top-level packages (utils, datasets, ...) must win over site-packages
+    for n in list(sys.modules):
+        if n == "datasets" or n.startswith("datasets.") or n == "utils" or n.startswith("utils."):
+            del sys.modules[n]
+    sys.path.insert(0, REF)
+
+
+# --------------------------------------------------------------------------------------
+# fixture configs
+# --------------------------------------------------------------------------------------
+# name -> (seq2reg hparams, seq2gene kwargs, batch geometry)
+FIXTURES = {
+    # sinusoidal seq2reg (dh=64), modulator dh=48, ragged N / C / T, padded genes
+    "small_sin": dict(
+        seed=101,
+        seq2reg=dict(vocab_size=500, embedding_dim=128, num_heads=2, num_layers=2, num_tissues=3,
+                     num_classes=2, learning_rate=1e-4, loss_fn=["cross_entropy", "0"], seq_pool="mean",
+                     cre_type="binary", token_length=40, use_context=False,
+                     positional_encoding="sinusoidal", use_flash=True),
+        seq2gene=dict(num_tissues=63, emb_dim=192, gene_emb_dim=128, num_heads=4, num_layers=3,
+                      use_alibi=True, mlp_dout=0.1, use_context=True, token_dim=128,
+                      gene_pooling="multi_registry", multi_head=False, use_bigger_head=True,
+                      only_cross_attention=False, cross_alibi=False, add_context_to_cres=False,
+                      use_res=False, train_gene_tokenizer=True, use_batching=True),
+        n_cres=[5, 9], n_chunks=[3, 4], tissues=[[7, 20, 62], [33]], token_length=40,
+        cre_len_range=(8, 30),
+    ),
+    # ALiBi seq2reg, 3 genes, more tissues, a gene with a single CRE
+    "small_alibi": dict(
+        seed=202,
+        seq2reg=dict(vocab_size=500, embedding_dim=128, num_heads=2, num_layers=2, num_tissues=3,
+                     num_classes=2, learning_rate=1e-4, loss_fn=["cross_entropy", "0"], seq_pool="mean",
+                     cre_type="binary", token_length=32, use_context=False,
+                     positional_encoding="alibi", use_flash=True),
+        seq2gene=dict(num_tissues=63, emb_dim=96, gene_emb_dim=128, num_heads=2, num_layers=2,
+                      use_alibi=True, mlp_dout=0.1, use_context=True, token_dim=128,
+                      gene_pooling="multi_registry", multi_head=False, use_bigger_head=True,
+                      only_cross_attention=False, cross_alibi=False, add_context_to_cres=False,
+                      use_res=False, train_gene_tokenizer=True, use_batching=True),
+        n_cres=[1, 12, 7], n_chunks=[2, 1, 5], tissues=[[10, 11], [7, 8, 9, 59], [62]], token_length=32,
+        cre_len_range=(4, 33),
+    ),
+}
+
+
+def build_reference_model(fx):
+    from seq2reg.model import Seq2RegPredictor
+    from seq2gene.model_combined_modulator import Seq2GenePredictorCombinedModulator
+    from variantformer_amd.utils.synthetic import fill_state_dict
+
+    cre_tok = Seq2RegPredictor(**fx["seq2reg"])
+    gene_tok = Seq2RegPredictor(**fx["seq2reg"])
+    model = Seq2GenePredictorCombinedModulator(cre_tokenizer=cre_tok, gene_tokenizer=gene_tok, **fx["seq2gene"])
+    fill_state_dict(model, fx["seed"])
+    model.eval()
+    model.vep = False
+    model.trainer = types.SimpleNamespace(precision="bf16-mixed")   # cast-free fp32 branch, no autocast
+    return model
+
+
+def run_fixture(name, fx):
+    from variantformer_amd.utils.synthetic import make_batch
+
+    torch.manual_seed(0)
+    torch.set_num_threads(4)
+    model = build_reference_model(fx)
+    batch = make_batch(fx["seed"], fx["n_cres"], fx["n_chunks"], fx["tissues"], fx["token_length"],
+                       cre_len_range=fx["cre_len_range"])
+    captured = {}
+
+    # capture seq2reg embeddings and modulator output through forward hooks (no reference edits)
+    def hook_tok(tag):
+        def _h(mod, inp, out):
+            captured.setdefault(tag, []).append(out.detach().clone())
+        return _h
+    h1 = model.cre_tokenizer.register_forward_hook(hook_tok("cre_tok"))
+    h2 = model.gene_tokenizer.register_forward_hook(hook_tok("gene_tok"))
+    h3 = model.combined_modulator.register_forward_hook(
+        lambda m, i, o: captured.__setitem__("modulator_gene_out", o[0].detach().clone()))
+    layer_out = []
+    hs = [l.register_forward_hook(lambda m, i, o: layer_out.append(o.detach().clone()))
+          for l in list(model.combined_modulator.gene_layers) + list(model.combined_modulator.cre_layers)]
+    with torch.no_grad():
+        out = model.predict_step(batch, 0)
+    for h in [h1, h2, h3] + hs:
+        h.remove()
+
+    arrays = {}
+    for i, (p, e) in enumerate(zip(out["pred_gene_exp"], out["embeddings"])):
+        arrays[f"pred_gene_exp_{i}"] = np.asarray(p, np.float32)
+        arrays[f"embeddings_{i}"] = np.asarray(e, np.float32)
+    for i, t in enumerate(captured["cre_tok"]):
+        arrays[f"cre_tok_{i}"] = t.numpy()
+    for i, t in enumerate(captured["gene_tok"]):
+        arrays[f"gene_tok_{i}"] = t.numpy()
+    arrays["modulator_gene_out"] = captured["modulator_gene_out"].numpy()
+    # order of layer hooks firing: gene0, (cre_i, gene_{i+1})*
+    arrays["first_gene_layer_out"] = layer_out[0].numpy()
+    arrays["first_cre_layer_out"] = layer_out[1].numpy()
+    # state-dict inventory (names + shapes) and a checksum of the generated weights
+    sd = model.state_dict()
+    inv = {k: list(v.shape) for k, v in sd.items()}
+    chk = float(sum(float(v.double().abs().sum()) for v in sd.values() if torch.is_floating_point(v)))
+    meta = dict(name=name, seed=fx["seed"], seq2reg=fx["seq2reg"], seq2gene=fx["seq2gene"],
+                n_cres=fx["n_cres"], n_chunks=fx["n_chunks"], tissues=fx["tissues"],
+                token_length=fx["token_length"], cre_len_range=list(fx["cre_len_range"]),
+                state_dict_shapes=inv, weight_abs_sum=chk,
+                generated_by="tests/golden/make_golden.py against /root/reference (fp32, CPU, stubbed flash_attn)")
+    np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **arrays)
+    with open(os.path.join(HERE, f"{name}.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print(f"[golden] {name}: pred", [a.ravel()[:3] for k, a in arrays.items() if k.startswith("pred")])
+
+
+def bpe_fixture():
+    """Token-id golden vectors from the reference's BPEEncoder (utils/seq.py:8-62)."""
+    from utils.seq import BPEEncoder
+    from variantformer_amd.utils.synthetic import randint
+
+    enc = BPEEncoder()
+    enc.load_vocabulary(os.path.join(REF, "vocabs", "bpe_vocabulary_500.json"))
+    alphabet = "ACGT"
+    het = "RYSWKM"
+    seqs = ["ACGTNNNNACGTRYACGT", "A", "acgtacgtnnacg", "NNNN", "ACGTBDHVACGT", "TTTTTTTTTTTTTTTTTTTT",
+            "GATTACAGATTACAGATTACA", "N", "ANA", "CGCGCGCGCGCGCGCGCGCGCGCGCGCGCGCG"]
+    for k in range(24):
+        n = [17, 64, 150, 251, 350, 450, 1000, 5000][k % 8]
+        r = randint(n, 0, 1000, 777 + k, 1)
+        s = []
+        for v in r:
+            if v < 3:
+                s.append("N")
+            elif v < 8:
+                s.append(het[int(v) % 6])
+            else:
+                s.append(alphabet[int(v) % 4])
+        seqs.append("".join(s))
+    out = []
+    for s in seqs:
+        ids, toks, ids_r, _ = enc.encode([s, "A"])
+        out.append({"seq": s, "ids": [int(i) for i in ids]})
+    # encode_with_position known answers (utils/seq.py:68-174)
+    pos_cases = []
+    for s in seqs[10:20]:
+        for p in (0, len(s) // 3, len(s) - 1):
+            try:
+                r = enc.encode_with_position(s, p)
+                pos_cases.append({"seq_index": seqs.index(s), "position": p,
+                                  "result": json.loads(json.dumps(r, default=lambda o: o if isinstance(o, (int, float, str)) else list(o)))})
+            except Exception as ex:  # record the reference's error behaviour too
+                pos_cases.append({"seq_index": seqs.index(s), "position": p, "error": type(ex).__name__})
+    with open(os.path.join(HERE, "bpe_ids.json"), "w") as f:
+        json.dump({"cases": out, "position_cases": pos_cases,
+                   "generated_by": "reference utils/seq.BPEEncoder + vocabs/bpe_vocabulary_500.json (tokenizers %s)"
+                   % __import__("tokenizers").__version__}, f)
+    print(f"[golden] bpe: {len(out)} strings; known answer:", out[0]["ids"])
+
+
+def misc_fixture():
+    """ALiBi slopes, sinusoidal PE, precision2dtype and pad/unpad conventions from the reference."""
+    from seq2gene.modules.layers import get_alibi_slopes
+    from seq2reg.model import positionalencoding1d
+    from utils.functions import precision2dtype
+
+    arrays = {}
+    for h in (2, 4, 8, 12, 32):
+        arrays[f"alibi_{h}"] = get_alibi_slopes(h).numpy().astype(np.float64)
+    arrays["pe_128_40"] = positionalencoding1d(128, 40).numpy()
+    arrays["pe_512_200"] = positionalencoding1d(512, 200).numpy()
+    np.savez_compressed(os.path.join(HERE, "misc.npz"), **arrays)
+    prec = {}
+    for s in ["bf16-mixed", "16-mixed", "32", "32-true", "bf16", "16", "64"]:
+        try:
+            prec[s] = str(precision2dtype(s))
+        except Exception as ex:
+            prec[s] = "ERR:" + type(ex).__name__
+    with open(os.path.join(HERE, "misc.json"), "w") as f:
+        json.dump({"precision2dtype": prec}, f, indent=1, sort_keys=True)
+    print("[golden] misc:", prec)
+
+
+def main():
+    assert os.path.isdir(REF), "reference checkout not present: fixtures can only be generated in the dev container"
+    sys.path.insert(0, REPO)
+    import variantformer_amd.utils.synthetic  # noqa: F401  (import ours before the reference's `utils`)
+    install_stubs()
+    import seq2reg.model  # noqa: F401  (its import sets torch.set_float32_matmul_precision("medium"), seq2reg/model.py:12)
+    # "medium" lets oneDNN run fp32 matmuls through bf16 on this CPU (observed: 2e-3 error on the
+    # seq2reg embeddings), which would make the fixtures a noisy fp32 reference.  The flag is a
+    # speed/precision knob, not part of the algorithm: restore exact fp32 for the golden run.
+    torch.set_float32_matmul_precision("highest")
+    for name, fx in FIXTURES.items():
+        run_fixture(name, fx)
+    bpe_fixture()
+    misc_fixture()
+
+
+if __name__ == "__main__":
+    main()

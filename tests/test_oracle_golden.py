@@ -1,0 +1,102 @@
+"""Pin the CPU oracle against vectors produced by the reference's own classes
+(tests/golden/make_golden.py; fp32, CPU).  No GPU, no reference checkout needed."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from oracle import vf_oracle as O
+from tests.conftest import GOLDEN
+
+RTOL = 2e-5   # fp32 round-off between two fp32 CPU evaluations of the same graph
+ATOL = 2e-5
+
+
+def _hps(meta):
+    hp = O.Seq2RegHP.from_hparams(meta["seq2reg"])
+    return hp, hp, O.Seq2GeneHP.from_kwargs(meta["seq2gene"])
+
+
+def test_oracle_matches_reference_outputs(golden):
+    meta, arrays, sd, batch = golden
+    cre_hp, gene_hp, hp = _hps(meta)
+    out = O.predict_step(batch, sd, cre_hp, gene_hp, hp)
+    for i in range(len(meta["n_cres"])):
+        np.testing.assert_allclose(out["pred_gene_exp"][i], arrays[f"pred_gene_exp_{i}"], rtol=RTOL, atol=ATOL)
+        np.testing.assert_allclose(out["embeddings"][i], arrays[f"embeddings_{i}"], rtol=RTOL, atol=ATOL)
+        assert out["pred_gene_exp"][i].shape == (len(meta["tissues"][i]), 1)
+        assert out["embeddings"][i].dtype == np.float32
+
+
+def test_oracle_matches_reference_intermediates(golden):
+    meta, arrays, sd, batch = golden
+    cre_hp, gene_hp, hp = _hps(meta)
+    col = {}
+    with torch.no_grad():
+        O.forward(batch, sd, cre_hp, gene_hp, hp, collect=col)
+    for i in range(len(meta["n_cres"])):
+        np.testing.assert_allclose(col["cre_tok"][i].numpy(), arrays[f"cre_tok_{i}"][:, 0], rtol=RTOL, atol=ATOL)
+        np.testing.assert_allclose(col["gene_tok"][i].numpy(), arrays[f"gene_tok_{i}"][:, 0], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(col["first_gene_layer_out"].numpy(), arrays["first_gene_layer_out"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(col["first_cre_layer_out"].numpy(), arrays["first_cre_layer_out"], rtol=RTOL, atol=ATOL)
+    # padded [sum T, maxG, D] modulator output of the reference vs the per-gene packed oracle output
+    ref = arrays["modulator_gene_out"]
+    row = 0
+    for i, t in enumerate(meta["tissues"]):
+        o = col["modulator_gene_out"][i].numpy()
+        G = o.shape[1]
+        np.testing.assert_allclose(o, ref[row:row + len(t), :G], rtol=RTOL, atol=ATOL)
+        assert np.all(ref[row:row + len(t), G:] == 0)     # pad_input zero fill
+        row += len(t)
+
+
+def test_shared_cre_stream_is_exact_dedup(golden):
+    """The CRE stream is tissue-independent: evaluating it once per gene gives the
+    reference's numbers."""
+    meta, arrays, sd, batch = golden
+    cre_hp, gene_hp, hp = _hps(meta)
+    a = O.predict_step(batch, sd, cre_hp, gene_hp, hp, share_cre_stream=True)
+    for i in range(len(meta["n_cres"])):
+        np.testing.assert_allclose(a["pred_gene_exp"][i], arrays[f"pred_gene_exp_{i}"], rtol=RTOL, atol=ATOL)
+        np.testing.assert_allclose(a["embeddings"][i], arrays[f"embeddings_{i}"], rtol=RTOL, atol=ATOL)
+
+
+def test_bf16_rounding_mode_is_close_to_fp32(golden):
+    """The kernel-contract mode (bf16 operands, fp32 everything else) stays within bf16-level
+    distance of the fp32 reference outputs; documents the precision of the shipped arithmetic."""
+    meta, arrays, sd, batch = golden
+    cre_hp, gene_hp, hp = _hps(meta)
+    out = O.predict_step(batch, sd, cre_hp, gene_hp, hp, rounding="bf16", share_cre_stream=True)
+    for i in range(len(meta["n_cres"])):
+        np.testing.assert_allclose(out["pred_gene_exp"][i], arrays[f"pred_gene_exp_{i}"], rtol=3e-2, atol=3e-2)
+
+
+def test_alibi_pe_precision_known_answers():
+    misc = np.load(os.path.join(GOLDEN, "misc.npz"))
+    for h in (2, 4, 8, 12, 32):
+        np.testing.assert_allclose(np.array(O.alibi_slopes(h)), misc[f"alibi_{h}"], rtol=1e-6)
+    # a-priori known answer: H=32 -> 2^(-(k+1)/4)
+    np.testing.assert_allclose(O.alibi_slopes(32), [2 ** (-(k + 1) / 4) for k in range(32)], rtol=1e-12)
+    np.testing.assert_array_equal(O.positional_encoding_1d(128, 40).numpy(), misc["pe_128_40"])
+    np.testing.assert_array_equal(O.positional_encoding_1d(512, 200).numpy(), misc["pe_512_200"])
+    with open(os.path.join(GOLDEN, "misc.json")) as f:
+        prec = json.load(f)["precision2dtype"]
+    for s, want in prec.items():
+        if want.startswith("ERR"):
+            try:
+                O.precision2dtype(s)
+                raise AssertionError("expected ValueError")
+            except ValueError:
+                pass
+        else:
+            assert str(O.precision2dtype(s)) == want
+
+
+def test_pad_unpad_conventions():
+    x = torch.arange(2 * 4 * 3, dtype=torch.float32).view(2, 4, 3)
+    keep = torch.tensor([[1, 1, 0, 0], [1, 1, 1, 0]], dtype=torch.bool)
+    packed, idx, cu, mx, _ = O.unpad_input(x, keep)
+    assert idx.tolist() == [0, 1, 4, 5, 6] and cu.tolist() == [0, 2, 5] and mx == 3 and cu.dtype == torch.int32
+    back = O.pad_input(packed, idx, 2, 4)
+    assert torch.equal(back[keep], x[keep]) and float(back[~keep].abs().sum()) == 0.0
