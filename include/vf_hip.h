@@ -1,0 +1,132 @@
+/* vf_hip.h -- C ABI of libvf_hip.so: hand-written HIP kernels (gfx950 / MI355X) for the
+ * VariantFormer inference hot path.
+ *
+ * The reference (czi-ai/variantformer) has no FFI of its own: its only native code on this
+ * path is the third-party flash-attn wheel plus ATen/cuBLAS behind nn.Linear / nn.LayerNorm.
+ * Each entry point below names the reference call site it replaces (paths relative to the
+ * reference checkout; [3p] = third-party flash-attn 2.8.3 API used at that site).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (incl. outputs and workspace);
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing syncs;
+ *   - bf16 tensors are raw uint16 storage (torch.bfloat16 compatible), row-major;
+ *   - return value 0 = ok, otherwise a VF_ERR_* code; vf_last_error() gives the message for
+ *     the calling thread; no global mutable state besides that message; re-entrant per stream;
+ *   - "ld*" / "*_stride" arguments are row strides in ELEMENTS.
+ */
+#ifndef VF_HIP_H
+#define VF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VF_ABI_VERSION 1
+
+enum vf_status {
+    VF_OK = 0,
+    VF_ERR_INVALID_ARG = 1,   /* shape / alignment / enum not supported */
+    VF_ERR_LAUNCH = 2         /* hipGetLastError() after the launch was not hipSuccess */
+};
+
+enum vf_dtype { VF_F32 = 0, VF_BF16 = 1 };
+
+/* Epilogues of vf_gemm_bf16 (acc = fp32 accumulator of A @ W^T, + bias[n] always) */
+enum vf_epilogue {
+    VF_EPI_BF16 = 0,        /* out bf16 [M,N]                      (Wqkv / Wq / Wkv projections)      */
+    VF_EPI_F32 = 1,         /* out fp32 [M,N]                      (cre_map, gene_map, head layer 0)   */
+    VF_EPI_RES_F32 = 2,     /* out fp32 [M,N] = acc + residual     (out_proj + res, geglu_2 + res)     */
+    VF_EPI_GEGLU_BF16 = 3,  /* out bf16 [M,N/2] = a * gelu(gate); W rows interleaved in blocks of 16:
+                               W'[32b+t] = W[16b+t], W'[32b+16+t] = W[N/2+16b+t], bias likewise
+                               (vf_pack_geglu_rows does the permutation)                               */
+    VF_EPI_GELU_F32 = 4,    /* out fp32 [M,N] = gelu(acc)          (head layer 4)                      */
+    VF_EPI_GELU_BF16 = 5    /* out bf16 [M,N] = gelu(acc)                                              */
+};
+
+int vf_version(void);
+const char* vf_last_error(void);
+
+/* out = epilogue(A[M,K] @ W[N,K]^T + bias[N]).   A, W bf16; bias fp32 (may be NULL = 0).
+ * Replaces every nn.Linear on the path: flash_attn MHA Wqkv/Wq/Wkv/out_proj [3p]
+ * (seq2reg/modules.py:140-142, seq2gene/modules/layers.py:344-351), linear_geglu_1/2
+ * (layers.py:78-80,159-162; seq2reg/modules.py:145-147,184-187), cre_map/gene_map
+ * (seq2gene/model_combined_modulator.py:502-507,610-612), TissueExpressionHeads Linear layers
+ * (layers.py:1078-1087).  Requires K % 8 == 0, N % 8 == 0 (N % 32 == 0 for GEGLU); fast MFMA
+ * path when K % 64 == 0. */
+int vf_gemm_bf16(const void* A, int64_t lda, const void* W, const float* bias,
+                 const float* residual, int64_t ldr, void* out, int64_t ldo,
+                 int M, int N, int K, int epilogue, void* stream);
+
+/* Permute rows of a [2F, K] bf16 weight (and its fp32 bias, may be NULL) into the VF_EPI_GEGLU_BF16
+ * layout (one-time weight repack at checkpoint load). */
+int vf_pack_geglu_rows(const void* W, const float* bias, void* W_out, float* bias_out,
+                       int two_f, int K, void* stream);
+
+/* Variable-length multi-head attention forward, non-causal:
+ *   out[t, h, :] = softmax_j( scale * q[t,h,:].k[j,h,:] - slope[h] * |i + (sk - sq) - j| ) v[j,h,:]
+ * over the keys j of t's sequence; i, j are positions inside the sequence.
+ * Replaces flash_attn_varlen_{qkvpacked,kvpacked}_func inside flash_attn.modules.mha.MHA [3p]
+ * (call sites seq2reg/modules.py:167; seq2gene/modules/layers.py:437-439,465,482).
+ * q/k/v point at the first head of token 0 (so a packed [tokens,3,H,dh] buffer is passed as
+ * q=base, k=base+H*dh, v=base+2*H*dh with row stride 3*H*dh).  bf16 in/out, fp32 softmax and
+ * accumulation.  dh in {32, 48, 64}.  cu_seqlens_*: int32 [n_seq+1] device arrays.
+ * alibi_slopes: fp32 [H] device array or NULL.  Sequences with 0 queries or 0 keys are skipped
+ * (their output rows are left untouched). */
+int vf_attn_varlen_fwd(const void* q, const void* k, const void* v, void* out,
+                       int64_t q_stride, int64_t k_stride, int64_t v_stride, int64_t o_stride,
+                       const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k,
+                       int n_seq, int max_seqlen_q, int max_seqlen_k,
+                       int H, int dh, const float* alibi_slopes, float scale, void* stream);
+
+/* y = LayerNorm(x) * gamma + beta over the last dim (eps inside sqrt, biased variance), optional
+ * exact-erf GELU, output bf16 or fp32.  x fp32 [rows, D], D % 4 == 0, D <= 8192.
+ * Replaces nn.LayerNorm (seq2reg/modules.py:143-144, layers.py:75-77, head layers.py:1080-1081). */
+int vf_layernorm(const float* x, const float* gamma, const float* beta, void* out,
+                 int64_t rows, int D, float eps, int out_dtype, int gelu, void* stream);
+
+/* Token embedding + optional positional table on the PACKED valid tokens of W windows:
+ *   row r = cu[w] + (rank of position p among the valid positions of window w)
+ *   out[r, :] = table[ids[w, p], :] + (pos_table ? pos_table[p, :] : 0)
+ * ids int64 [W, L]; pad u8/bool [W, L] (non-zero = pad, reference convention
+ * datasets/vcfdataset.py:209-213); cu int32 [W+1] = exclusive prefix sum of valid counts.
+ * Replaces nn.Embedding + PE add + unpad_input [3p] (seq2reg/model.py:215-220,
+ * seq2reg/modules.py:159-161). */
+int vf_embed_pack(const int64_t* ids, const uint8_t* pad, const int32_t* cu,
+                  const float* table, const float* pos_table, float* out,
+                  int W, int L, int d, int vocab, void* stream);
+
+/* Per-window valid-token count and exclusive prefix sum: cu[0]=0, cu[w+1]=cu[w]+#valid(w).
+ * Replaces the cu_seqlens half of unpad_input [3p].  Single-block scan; W <= 2^24. */
+int vf_mask_to_cu_seqlens(const uint8_t* pad, int32_t* cu, int W, int L, void* stream);
+
+/* Masked mean over each window's packed tokens: out[w,:] = mean(x[cu[w]:cu[w+1], :]) (NaN if the
+ * window is empty, as the reference's 0/0).  x fp32 [n_tok, d]; out bf16 or fp32 [W, d].
+ * Replaces seq2reg/model.py:263-267. */
+int vf_segment_mean(const float* x, const int32_t* cu, void* out, int W, int d, int out_dtype, void* stream);
+
+/* Row gather from two fp32 sources: out[i,:] = idx[i] >= 0 ? a[idx[i],:] : b[-idx[i]-1,:].
+ * out fp32 or bf16 [n, d].  Replaces MultiRegistry/prepare_input concat (layers.py:508-521,
+ * model_combined_modulator.py:357-366), nn.Embedding lookups (:166-168), pool_outputs row 0
+ * (:391-392) and pad_input/unpad_input row moves [3p]. */
+int vf_gather_rows_f32(const float* a, const float* b, const int64_t* idx, void* out,
+                       int64_t n, int d, int out_dtype, void* stream);
+
+/* bf16 row gather: out[i,:] = src[idx[i],:], ld in elements. */
+int vf_gather_rows_bf16(const void* src, int64_t ld_src, const int64_t* idx, void* out, int64_t ld_out,
+                        int64_t n, int d, void* stream);
+
+/* out[i] = softplus(dot(x[i,:], w) + b), softplus threshold 20 (nn.Softplus defaults), or the plain
+ * affine value when softplus == 0.  x fp32 [n, d].  Replaces the last Linear(D,1) + Softplus of
+ * TissueExpressionHeads (layers.py:1085-1086). */
+int vf_rowdot_softplus(const float* x, const float* w, const float* b, float* out,
+                       int64_t n, int d, int softplus, void* stream);
+
+/* fp32 -> bf16 (round to nearest even), n elements. */
+int vf_cast_f32_bf16(const float* x, void* out, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VF_HIP_H */

@@ -1,0 +1,293 @@
+"""Per-kernel parity on a real MI355X: every C-ABI entry point against the CPU oracle's arithmetic
+(oracle/vf_oracle.py, bf16-operand mode) on seeded inputs.  Tolerances are written next to each check."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import vf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from variantformer_amd import ops as _ops
+    from variantformer_amd import _lib
+    _lib.load()      # must be the in-tree HIP library; raises if missing
+    return _ops
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(shape, generator=g) * 2 - 1) * scale
+
+
+def _bf(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def _rel_err(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+# ---------------------------------------------------------------------------------------------
+# GEMM: all epilogues, MFMA path (K % 64 == 0) and generic path, ragged M / N tails
+# ---------------------------------------------------------------------------------------------
+GEMM_SHAPES = [
+    (1, 128, 64), (7, 8, 64), (128, 128, 128), (300, 192, 192), (257, 576, 192), (1000, 1536, 512),
+    (130, 2048, 128), (64, 96, 96), (33, 288, 96), (513, 4608, 1536), (200, 1536, 1024), (77, 40, 72),
+]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+@pytest.mark.parametrize("epi", ["bf16", "f32", "res", "gelu_f32", "gelu_bf16"])
+def test_gemm_epilogues(ops, M, N, K, epi):
+    a = _bf(_rand((M, K), 1))
+    w = _bf(_rand((N, K), 2, 1.0 / math.sqrt(K)))
+    b = _rand((N,), 3, 0.5)
+    res = _rand((M, N), 4)
+    ref = a @ w.t() + b
+    code = {"bf16": ops.EPI_BF16, "f32": ops.EPI_F32, "res": ops.EPI_RES_F32, "gelu_f32": ops.EPI_GELU_F32,
+            "gelu_bf16": ops.EPI_GELU_BF16}[epi]
+    if epi == "res":
+        ref = ref + res
+    if epi.startswith("gelu"):
+        ref = F.gelu(ref)
+    out = ops.gemm(a.cuda().bfloat16(), w.cuda().bfloat16(), b.cuda(), code,
+                   residual=res.cuda() if epi == "res" else None)
+    torch.cuda.synchronize()
+    got = out.float().cpu()
+    if epi in ("bf16", "gelu_bf16"):
+        # bf16 store: half an ulp of bf16 (2^-9 relative) on top of fp32 accumulation-order noise
+        np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=2 ** -8, atol=2e-3)
+    else:
+        # same bf16 operands, fp32 accumulate: only summation order differs
+        np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=2e-5, atol=2e-5 * math.sqrt(K))
+
+
+@pytest.mark.parametrize("M,F2,K", [(5, 64, 64), (300, 2048, 192), (129, 2048, 512), (64, 64, 96), (1000, 2048, 1536)])
+def test_gemm_geglu(ops, M, F2, K):
+    a = _bf(_rand((M, K), 11))
+    w = _bf(_rand((F2, K), 12, 1.0 / math.sqrt(K)))
+    b = _rand((F2,), 13, 0.5)
+    h = a @ w.t() + b
+    x, gate = h.chunk(2, dim=-1)
+    ref = x * F.gelu(gate)
+    wp, bp = ops.pack_geglu_rows(w.cuda().bfloat16(), b.cuda())
+    out = ops.gemm(a.cuda().bfloat16(), wp, bp, ops.EPI_GEGLU_BF16)
+    torch.cuda.synchronize()
+    assert out.shape == (M, F2 // 2)
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), rtol=2 ** -8, atol=2e-3)
+
+
+def test_gemm_linearity_full_size(ops):
+    """Size-independent property at production shape: A @ W^T is linear in A (bf16-exact inputs)."""
+    M, N, K = 8192, 4608, 1536
+    a1 = torch.randint(-4, 5, (M, K), generator=torch.Generator().manual_seed(5)).float()
+    a2 = torch.randint(-4, 5, (M, K), generator=torch.Generator().manual_seed(6)).float()
+    w = torch.randint(-3, 4, (N, K), generator=torch.Generator().manual_seed(7)).float()
+    wc = w.cuda().bfloat16()
+    o1 = ops.gemm(a1.cuda().bfloat16(), wc, None, ops.EPI_F32)
+    o2 = ops.gemm(a2.cuda().bfloat16(), wc, None, ops.EPI_F32)
+    o12 = ops.gemm((a1 + a2).cuda().bfloat16(), wc, None, ops.EPI_F32)
+    torch.cuda.synchronize()
+    assert torch.equal(o1 + o2, o12)            # small integers: every partial sum is exact in fp32
+    ref_rows = (a1[:64] @ w.t())
+    assert torch.equal(o1[:64].cpu(), ref_rows)
+
+
+def test_gemm_rejects_bad_shapes(ops):
+    from variantformer_amd._lib import VFError
+    a = torch.zeros((4, 20), dtype=torch.bfloat16, device="cuda")
+    w = torch.zeros((8, 20), dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(VFError):
+        ops.gemm(a, w, None, ops.EPI_F32)           # K % 8 != 0
+    with pytest.raises(VFError):
+        ops.gemm(torch.zeros((4, 64), dtype=torch.bfloat16), torch.zeros((8, 64), dtype=torch.bfloat16), None, ops.EPI_F32)  # CPU tensors
+
+
+# ---------------------------------------------------------------------------------------------
+# attention
+# ---------------------------------------------------------------------------------------------
+def _attn_ref(q, k, v, cu_q, cu_k, H, dh, slopes):
+    rnd = O.Rounding("bf16")
+    out = torch.zeros(q.shape[0], H * dh)
+    for b in range(len(cu_q) - 1):
+        a, e = int(cu_q[b]), int(cu_q[b + 1])
+        ka, ke = int(cu_k[b]), int(cu_k[b + 1])
+        if e > a and ke > ka:
+            out[a:e] = O.attention(q[a:e].view(-1, H, dh), k[ka:ke].view(-1, H, dh), v[ka:ke].view(-1, H, dh),
+                                   slopes, rnd).reshape(e - a, H * dh)
+    return out
+
+
+ATTN_CASES = [
+    # (dh, H, q lens, k lens (None = self), alibi)
+    (64, 2, [5, 40, 1, 33], None, False),
+    (64, 8, [200, 70, 125, 64, 65, 128, 129], None, True),
+    (48, 4, [201, 201, 17], None, True),
+    (48, 4, [300, 1], None, True),                       # > 256 -> 2 query groups per wave
+    (48, 32, [603], [1024], False),                      # gene -> CRE cross attention, shared K/V
+    (48, 4, [10, 50, 7], [9, 300, 64], False),
+    (32, 2, [31, 64, 100], None, True),
+    (64, 2, [1000], None, True),
+    (48, 2, [130, 257], [1, 63], False),
+]
+
+
+@pytest.mark.parametrize("dh,H,ql,kl,alibi", ATTN_CASES)
+def test_attention_matches_oracle(ops, dh, H, ql, kl, alibi):
+    self_attn = kl is None
+    kl = ql if self_attn else kl
+    D = H * dh
+    tq, tk = sum(ql), sum(kl)
+    cu_q = torch.tensor([0] + list(np.cumsum(ql)), dtype=torch.int32)
+    cu_k = torch.tensor([0] + list(np.cumsum(kl)), dtype=torch.int32)
+    slopes = torch.tensor(O.alibi_slopes(H), dtype=torch.float32) if alibi else None
+    if self_attn:
+        qkv = _bf(_rand((tq, 3 * D), 21, 2.0))
+        q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+        dev = qkv.cuda().bfloat16()
+        dq, dk, dv = dev[:, :D], dev[:, D:2 * D], dev[:, 2 * D:]
+    else:
+        q = _bf(_rand((tq, D), 22, 2.0))
+        kv = _bf(_rand((tk, 2 * D), 23, 2.0))
+        k, v = kv[:, :D], kv[:, D:]
+        dq = q.cuda().bfloat16()
+        dkv = kv.cuda().bfloat16()
+        dk, dv = dkv[:, :D], dkv[:, D:]
+    ref = _attn_ref(q, k, v, cu_q, cu_k, H, dh, slopes)
+    out = ops.attn_varlen(dq, dk, dv, cu_q.cuda(), cu_k.cuda(), max(ql), max(kl), H, dh,
+                          slopes.cuda() if alibi else None)
+    torch.cuda.synchronize()
+    got = out.float().cpu()
+    # bf16 output (2^-9) + bf16 P rounding at a different running max than the oracle's final max
+    np.testing.assert_allclose(got.numpy(), _bf(ref).numpy(), rtol=2 ** -7, atol=6e-3)
+
+
+def test_attention_online_softmax_rescale_branch(ops):
+    """Force the running max to jump at a late key tile (guide rule 26): one key far larger than the rest."""
+    dh, H, n = 64, 1, 200
+    g = torch.Generator().manual_seed(3)
+    q = _bf(torch.randn(n, dh, generator=g))
+    k = _bf(torch.randn(n, dh, generator=g) * 0.1)
+    v = _bf(torch.randn(n, dh, generator=g))
+    k[150] = q[7] * 4.0                      # spike in the third key tile for query 7 (and large for others)
+    cu = torch.tensor([0, n], dtype=torch.int32)
+    ref = _attn_ref(q, k, v, cu, cu, H, dh, None)
+    out = ops.attn_varlen(q.cuda().bfloat16(), k.cuda().bfloat16(), v.cuda().bfloat16(), cu.cuda(), cu.cuda(), n, n, H, dh)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.float().cpu().numpy(), _bf(ref).numpy(), rtol=2 ** -7, atol=6e-3)
+
+
+def test_attention_uniform_values_property(ops):
+    """Size-independent property at full size: with V constant along keys the output equals that
+    constant row exactly up to bf16 rounding of P (softmax weights sum to one)."""
+    dh, H, nq, nk = 48, 32, 54 * 201, 1024
+    D = H * dh
+    q = _bf(_rand((nq, D), 31, 3.0)).cuda().bfloat16()
+    k = _bf(_rand((nk, D), 32, 3.0)).cuda().bfloat16()
+    row = _bf(_rand((1, D), 33, 2.0))
+    v = row.repeat(nk, 1).cuda().bfloat16()
+    cu_q = torch.tensor([0, nq], dtype=torch.int32).cuda()
+    cu_k = torch.tensor([0, nk], dtype=torch.int32).cuda()
+    out = ops.attn_varlen(q, k, v, cu_q, cu_k, nq, nk, H, dh)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.float().cpu().numpy(), row.repeat(nq, 1).numpy(), rtol=2 ** -6, atol=1e-2)
+    assert torch.isfinite(out.float()).all()
+
+
+# ---------------------------------------------------------------------------------------------
+# streaming kernels
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rows,D", [(1, 96), (7, 128), (1000, 512), (333, 1536), (5, 2048), (3, 4096)])
+@pytest.mark.parametrize("gelu", [False, True])
+def test_layernorm(ops, rows, D, gelu):
+    x = _rand((rows, D), 41, 3.0) + 0.5
+    g, b = 1 + 0.1 * _rand((D,), 42), 0.1 * _rand((D,), 43)
+    ref = F.layer_norm(x, (D,), g, b, 1e-5)
+    if gelu:
+        ref = F.gelu(ref)
+    o32 = ops.layernorm(x.cuda(), g.cuda(), b.cuda(), torch.float32, gelu)
+    o16 = ops.layernorm(x.cuda(), g.cuda(), b.cuda(), torch.bfloat16, gelu)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(o32.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)    # fp32 throughout
+    assert torch.equal(o16.cpu(), o32.cpu().bfloat16())                                  # same value, RNE to bf16
+
+
+def test_embed_pack_and_cu_seqlens_bit_exact(ops):
+    W, L, d, V = 37, 200, 128, 500
+    g = torch.Generator().manual_seed(7)
+    ids = torch.randint(0, V, (W, L), generator=g)
+    pad = torch.rand((W, L), generator=g) < 0.3           # arbitrary (non-suffix) masks, incl. edge windows
+    pad[0] = True
+    pad[0, 5] = False
+    pad[1] = False
+    pad[2] = True                                          # empty window
+    table = _rand((V, d), 8)
+    pos = _rand((L, d), 9)
+    cu = ops.mask_to_cu_seqlens(pad.cuda())
+    lens = (~pad).sum(1)
+    ref_cu = torch.cat([torch.zeros(1, dtype=torch.int64), lens.cumsum(0)]).to(torch.int32)
+    assert torch.equal(cu.cpu(), ref_cu)
+    n = int(ref_cu[-1])
+    out = ops.embed_pack(ids.cuda(), pad.cuda(), cu, table.cuda(), pos.cuda(), n)
+    out_nopos = ops.embed_pack(ids.cuda(), pad.cuda(), cu, table.cuda(), None, n)
+    torch.cuda.synchronize()
+    x = table[ids] + pos[None]
+    keep = ~pad
+    assert torch.equal(out.cpu(), x[keep])                 # one fp32 add: bit exact
+    assert torch.equal(out_nopos.cpu(), table[ids][keep])
+
+
+def test_mask_to_cu_seqlens_many_windows(ops):
+    W, L = 5000, 40
+    pad = torch.rand((W, L), generator=torch.Generator().manual_seed(1)) < 0.5
+    cu = ops.mask_to_cu_seqlens(pad.cuda()).cpu()
+    ref = torch.cat([torch.zeros(1, dtype=torch.int64), (~pad).sum(1).cumsum(0)]).to(torch.int32)
+    assert torch.equal(cu, ref)
+
+
+def test_segment_mean(ops):
+    lens = [3, 1, 200, 0, 77]
+    d = 512
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32)
+    x = _rand((sum(lens), d), 51, 2.0)
+    o32 = ops.segment_mean(x.cuda(), cu.cuda(), torch.float32).cpu()
+    o16 = ops.segment_mean(x.cuda(), cu.cuda(), torch.bfloat16).cpu()
+    for w, n in enumerate(lens):
+        a = int(cu[w])
+        if n == 0:
+            assert torch.isnan(o32[w]).all()               # reference: 0/0 -> NaN (seq2reg/model.py:264-267)
+        else:
+            # sequential fp32 sum in token order, then * (1/n)
+            np.testing.assert_allclose(o32[w].numpy(), x[a:a + n].sum(0).numpy() / n, rtol=1e-5, atol=1e-6)
+    ok = ~torch.isnan(o32)
+    assert torch.equal(o16[ok], o32.bfloat16()[ok])
+
+
+def test_gathers_bit_exact(ops):
+    a, b = _rand((50, 192), 61), _rand((9, 192), 62)
+    idx = torch.tensor([0, 49, -1, -9, 7, 7, -3], dtype=torch.int64)
+    ref = torch.stack([a[i] if i >= 0 else b[-i - 1] for i in idx.tolist()])
+    o = ops.gather_rows_f32(a.cuda(), b.cuda(), idx.cuda()).cpu()
+    ob = ops.gather_rows_f32(a.cuda(), b.cuda(), idx.cuda(), torch.bfloat16).cpu()
+    assert torch.equal(o, ref) and torch.equal(ob, ref.bfloat16())
+    s = _rand((9, 384), 63).bfloat16()
+    i2 = torch.tensor([8, 0, 0, 3, 5], dtype=torch.int64)
+    assert torch.equal(ops.gather_rows_bf16(s.cuda(), i2.cuda()).cpu(), s[i2])
+    assert torch.equal(ops.cast_bf16(a.cuda()).cpu(), a.bfloat16())
+
+
+def test_rowdot_softplus(ops):
+    x = _rand((11, 1536), 71, 2.0)
+    x[3] *= 30                                              # exercises the softplus threshold branch
+    w, b = _rand((1536,), 72, 0.05), torch.tensor([0.3])
+    ref = F.softplus(x @ w[:, None] + b)
+    got = ops.rowdot_softplus(x.cuda(), w.cuda(), b.cuda()).cpu()
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)

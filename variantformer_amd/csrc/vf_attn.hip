@@ -1,0 +1,308 @@
+// vf_attn_varlen_fwd: variable-length multi-head attention forward for gfx950 (flash-style, online
+// softmax, no S x S matrix in memory).  bf16 Q/K/V/O, fp32 scores / softmax / accumulation.
+//
+// Roofline: HBM/L2-bound for the short sequences of this model (seq2reg windows <= 200 tokens, gene
+// stream <= 201: intensity ~ s/2 flop/B), MFMA-bound only for the long shared-K/V cross attention.
+// Algorithmic bytes per (sequence, head) = 2*dh*(2*sq + 2*sk); flops = 4*sq*sk*dh.
+//
+// Work split: block = (sequence, head, q-tile), 256 threads = 4 waves, each wave owns QG groups of
+// 16 queries.  K/V tiles of 64 keys are staged through LDS (two stages, register-prefetched while
+// the previous tile is being consumed -- T14 issue-early / write-late).
+//
+// MFMA formulation (v_mfma_f32_16x16x32_bf16, lane = (r = lane&15, g = lane>>4)):
+//   S^T[key][q]  = K . Q^T   A = K rows (ds_read_b128 from the swizzled K tile), B = Q (registers);
+//                  the accumulator leaves lane (r,g) with keys 16*kt+4g+reg of QUERY r, so the
+//                  softmax row reduction is in-lane plus two cross-lane steps (xor 16, xor 32).
+//   O^T[d][q]   += V^T . P^T A = V^T gathered by ds_read_b64_tr_b16 from the row-major V tile,
+//                  B = P^T straight from the score registers (bf16-packed).  The contraction index
+//                  of one 32-key step is permuted (element j of lane group g <-> key 4g+j for j<4,
+//                  16+4g+(j-4) for j>=4) identically on both operands, so no lane movement is needed.
+// dh = 48 (the modulator's 1536/32) is padded to 64 only along the QK^T contraction (zero chunks in
+// the K tile and zero Q fragments); PV uses exactly dh/16 output tiles.
+#include "vf_common.h"
+
+namespace {
+
+constexpr int BKV = 64;
+constexpr int K_ROW_BYTES = 128;                 // 64 (padded dh) bf16
+constexpr int K_TILE_BYTES = BKV * K_ROW_BYTES;  // 8 KiB
+
+template <int DH>
+struct VLayout {
+    // V row stride in bytes: a multiple of 32 with an odd 32-byte count, so that the 8 rows a
+    // 32-lane half touches in one transposed read fall on 8 distinct 32-byte bank windows.
+    static constexpr int ROW = (((DH * 2) / 32) & 1) ? DH * 2 : DH * 2 + 32;
+    static constexpr int TILE = BKV * ROW;
+};
+
+struct AttnParams {
+    const unsigned short* q;
+    const unsigned short* k;
+    const unsigned short* v;
+    unsigned short* out;
+    int64_t q_stride, k_stride, v_stride, o_stride;
+    const int32_t* cu_q;
+    const int32_t* cu_k;
+    const float* slopes;
+    float scale_log2;   // scale * log2(e)
+    int H;
+};
+
+__device__ __forceinline__ s16x4_t lds_tr_read(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
+}
+
+template <int DH, int QG>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P) {
+    constexpr int CPR = DH / 8;                       // 16-byte chunks per K/V row
+    constexpr int NCHUNK = BKV * CPR;                 // chunks per tile
+    constexpr int NLD = (NCHUNK + 255) / 256;         // chunk loads per thread per operand
+    constexpr int DT = DH / 16;                       // output d-tiles
+    constexpr int VROW = VLayout<DH>::ROW;
+    constexpr int STAGE = K_TILE_BYTES + VLayout<DH>::TILE;
+    constexpr int BQ = 4 * QG * 16;
+
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+    const int seq = blockIdx.x, h = blockIdx.y;
+    const int q_tok0 = P.cu_q[seq], len_q = P.cu_q[seq + 1] - q_tok0;
+    const int k_tok0 = P.cu_k[seq], len_k = P.cu_k[seq + 1] - k_tok0;
+    const int qb0 = blockIdx.z * BQ;
+    if (qb0 >= len_q || len_k <= 0) return;           // block-uniform
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+
+    // ---- zero the K pad chunks (d >= DH) of both stages once; loads never touch them
+    if (CPR < 8) {
+        constexpr int PADC = 8 - CPR;
+        for (int i = tid; i < 2 * BKV * PADC; i += 256) {
+            const int st = i / (BKV * PADC), rem = i % (BKV * PADC);
+            const int row = rem / PADC, c = CPR + rem % PADC;
+            *reinterpret_cast<u32x4_t*>(smem + st * STAGE + row * K_ROW_BYTES + ((c ^ ((row >> 1) & 7)) << 4)) =
+                (u32x4_t){0u, 0u, 0u, 0u};
+        }
+    }
+
+    // ---- Q fragments (B operand): lane (r,g) holds Q[q = r][d = 32ks + 8g .. +7]
+    bf16x8_t qf[QG][2];
+    int q_abs[QG];
+#pragma unroll
+    for (int qg = 0; qg < QG; ++qg) {
+        q_abs[qg] = qb0 + (wave * QG + qg) * 16 + r;
+        const int row = q_abs[qg] < len_q ? q_abs[qg] : len_q - 1;
+        const unsigned short* qp = P.q + (int64_t)(q_tok0 + row) * P.q_stride + h * DH;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int d0 = 32 * ks + 8 * g;
+            u32x4_t raw = (u32x4_t){0u, 0u, 0u, 0u};
+            if (d0 < DH) raw = *reinterpret_cast<const u32x4_t*>(qp + d0);
+            qf[qg][ks] = *reinterpret_cast<bf16x8_t*>(&raw);
+        }
+    }
+
+    const float slope2 = P.slopes ? P.slopes[h] * 1.4426950408889634f : 0.f;
+    const bool use_alibi = P.slopes != nullptr;
+    const int rel0 = len_k - len_q;
+
+    f32x4_t o[QG][DT];
+    float m_run[QG], l_run[QG];
+#pragma unroll
+    for (int qg = 0; qg < QG; ++qg) {
+        m_run[qg] = -INFINITY;
+        l_run[qg] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[qg][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
+
+    // ---- K/V tile staging: global -> registers -> LDS
+    u32x4_t kreg[NLD], vreg[NLD];
+    const unsigned short* kbase = P.k + (int64_t)k_tok0 * P.k_stride + h * DH;
+    const unsigned short* vbase = P.v + (int64_t)k_tok0 * P.v_stride + h * DH;
+    auto load_regs = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int ci = tid + 256 * i;
+            if (ci < NCHUNK) {
+                const int row = ci / CPR, c = ci % CPR;
+                int key = t * BKV + row;
+                key = key < len_k ? key : len_k - 1;                 // finite data for masked keys
+                kreg[i] = *reinterpret_cast<const u32x4_t*>(kbase + (int64_t)key * P.k_stride + c * 8);
+                vreg[i] = *reinterpret_cast<const u32x4_t*>(vbase + (int64_t)key * P.v_stride + c * 8);
+            }
+        }
+    };
+    auto write_lds = [&](int stage) {
+        char* sK = smem + stage * STAGE;
+        char* sV = sK + K_TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int ci = tid + 256 * i;
+            if (ci < NCHUNK) {
+                const int row = ci / CPR, c = ci % CPR;
+                *reinterpret_cast<u32x4_t*>(sK + row * K_ROW_BYTES + ((c ^ ((row >> 1) & 7)) << 4)) = kreg[i];
+                *reinterpret_cast<u32x4_t*>(sV + row * VROW + (c << 4)) = vreg[i];
+            }
+        }
+    };
+
+    const int nkv = (len_k + BKV - 1) / BKV;
+    load_regs(0);
+    write_lds(0);
+    __syncthreads();
+
+    for (int t = 0; t < nkv; ++t) {
+        if (t + 1 < nkv) load_regs(t + 1);
+        const char* sK = smem + (t & 1) * STAGE;
+        const char* sV = sK + K_TILE_BYTES;
+        const int kb0 = t * BKV;
+
+        // ---- S^T = K . Q^T : 4 key tiles x 2 k-steps, K fragments shared by the QG query groups
+        f32x4_t s[QG][4];
+#pragma unroll
+        for (int qg = 0; qg < QG; ++qg)
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) s[qg][kt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(
+                    sK + (16 * kt + r) * K_ROW_BYTES + (((4 * ks + g) ^ (r >> 1)) << 4));
+#pragma unroll
+                for (int qg = 0; qg < QG; ++qg)
+                    s[qg][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qg][ks], s[qg][kt], 0, 0, 0);
+            }
+        }
+
+        // ---- online softmax per query group (lane (r,g): query r, keys 16kt+4g+reg)
+        bf16x8_t pf[QG][2];
+#pragma unroll
+        for (int qg = 0; qg < QG; ++qg) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int kpos = kb0 + 16 * kt + 4 * g + e;
+                    float v = s[qg][kt][e] * P.scale_log2;
+                    if (use_alibi) {
+                        const int rel = q_abs[qg] + rel0 - kpos;
+                        v -= slope2 * (float)(rel < 0 ? -rel : rel);
+                    }
+                    v = kpos < len_k ? v : -INFINITY;
+                    s[qg][kt][e] = v;
+                    mx = fmaxf(mx, v);
+                }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run[qg], mx);          // finite: tile 0 always has a valid key
+            const float alpha = __builtin_amdgcn_exp2f(m_run[qg] - m_new);
+            m_run[qg] = m_new;
+            float psum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float p = __builtin_amdgcn_exp2f(s[qg][kt][e] - m_new);
+                    s[qg][kt][e] = p;
+                    psum += p;
+                }
+            }
+            l_run[qg] = l_run[qg] * alpha + psum;             // lane-partial; reduced over g at the end
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) o[qg][dt] *= alpha;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                u32x4_t pk;
+                pk[0] = pack2bf(s[qg][2 * kb][0], s[qg][2 * kb][1]);
+                pk[1] = pack2bf(s[qg][2 * kb][2], s[qg][2 * kb][3]);
+                pk[2] = pack2bf(s[qg][2 * kb + 1][0], s[qg][2 * kb + 1][1]);
+                pk[3] = pack2bf(s[qg][2 * kb + 1][2], s[qg][2 * kb + 1][3]);
+                pf[qg][kb] = *reinterpret_cast<bf16x8_t*>(&pk);
+            }
+        }
+
+        // ---- O^T += V^T . P^T : V^T fragments by transposed LDS reads, shared by the QG groups
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const char* vp = sV + (32 * kb + 4 * g + (r >> 2)) * VROW + 32 * dt + 8 * (r & 3);
+                const s16x4_t lo = lds_tr_read(vp);
+                const s16x4_t hi = lds_tr_read(vp + 16 * VROW);
+                const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                for (int qg = 0; qg < QG; ++qg)
+                    o[qg][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qg][kb], o[qg][dt], 0, 0, 0);
+            }
+        }
+
+        if (t + 1 < nkv) write_lds((t + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- normalise and store: lane (r,g) holds O[q = r][d = 16dt + 4g .. +3]
+#pragma unroll
+    for (int qg = 0; qg < QG; ++qg) {
+        float l = l_run[qg];
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        const float inv = 1.0f / l;
+        if (q_abs[qg] < len_q) {
+            unsigned short* op = P.out + (int64_t)(q_tok0 + q_abs[qg]) * P.o_stride + h * DH + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                u32x2_t pk;
+                pk[0] = pack2bf(o[qg][dt][0] * inv, o[qg][dt][1] * inv);
+                pk[1] = pack2bf(o[qg][dt][2] * inv, o[qg][dt][3] * inv);
+                *reinterpret_cast<u32x2_t*>(op + 16 * dt) = pk;
+            }
+        }
+    }
+}
+
+template <int DH>
+int launch_attn(const AttnParams& P, int n_seq, int max_q, hipStream_t st) {
+    // long query streams: 2 query groups per wave (halves K/V LDS traffic per MFMA);
+    // short ones (seq2reg windows, gene stream): 64-query blocks to limit tail waste.
+    if (max_q > 256) {
+        dim3 grid(n_seq, P.H, (max_q + 127) / 128);
+        hipLaunchKernelGGL((attn_fwd_kernel<DH, 2>), grid, dim3(256), 0, st, P);
+    } else {
+        dim3 grid(n_seq, P.H, (max_q + 63) / 64);
+        hipLaunchKernelGGL((attn_fwd_kernel<DH, 1>), grid, dim3(256), 0, st, P);
+    }
+    VF_CHECK_LAUNCH("vf_attn_varlen_fwd");
+    return VF_OK;
+}
+
+}  // namespace
+
+extern "C" int vf_attn_varlen_fwd(const void* q, const void* k, const void* v, void* out, int64_t q_stride,
+                                  int64_t k_stride, int64_t v_stride, int64_t o_stride, const int32_t* cu_seqlens_q,
+                                  const int32_t* cu_seqlens_k, int n_seq, int max_seqlen_q, int max_seqlen_k, int H,
+                                  int dh, const float* alibi_slopes, float scale, void* stream) {
+    VF_REQUIRE(q && k && v && out && cu_seqlens_q, "vf_attn_varlen_fwd: null pointer");
+    VF_REQUIRE(dh == 32 || dh == 48 || dh == 64, "vf_attn_varlen_fwd: head_dim %d not supported (32/48/64)", dh);
+    VF_REQUIRE(H > 0 && H <= 65535 && n_seq >= 0, "vf_attn_varlen_fwd: H=%d n_seq=%d out of range", H, n_seq);
+    VF_REQUIRE(max_seqlen_q <= 64 * 65535, "vf_attn_varlen_fwd: max_seqlen_q=%d too large", max_seqlen_q);
+    VF_REQUIRE(q_stride % 8 == 0 && k_stride % 8 == 0 && v_stride % 8 == 0 && o_stride % 4 == 0,
+               "vf_attn_varlen_fwd: row strides must keep 16-byte alignment");
+    VF_REQUIRE(((uintptr_t)q % 16 == 0) && ((uintptr_t)k % 16 == 0) && ((uintptr_t)v % 16 == 0) && ((uintptr_t)out % 8 == 0),
+               "vf_attn_varlen_fwd: pointers must be 16-byte aligned");
+    if (n_seq == 0 || max_seqlen_q <= 0 || max_seqlen_k <= 0) return VF_OK;
+    AttnParams P;
+    P.q = (const unsigned short*)q; P.k = (const unsigned short*)k; P.v = (const unsigned short*)v;
+    P.out = (unsigned short*)out;
+    P.q_stride = q_stride; P.k_stride = k_stride; P.v_stride = v_stride; P.o_stride = o_stride;
+    P.cu_q = cu_seqlens_q; P.cu_k = cu_seqlens_k ? cu_seqlens_k : cu_seqlens_q;
+    P.slopes = alibi_slopes; P.scale_log2 = scale * 1.4426950408889634f; P.H = H;
+    hipStream_t st = (hipStream_t)stream;
+    switch (dh) {
+        case 32: return launch_attn<32>(P, n_seq, max_seqlen_q, st);
+        case 48: return launch_attn<48>(P, n_seq, max_seqlen_q, st);
+        default: return launch_attn<64>(P, n_seq, max_seqlen_q, st);
+    }
+}

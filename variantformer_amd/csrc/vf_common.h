@@ -1,0 +1,55 @@
+// Shared device/host helpers for libvf_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/vf_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+
+#define VF_WAVE 64
+
+void vf_set_error(const char* fmt, ...);
+
+#define VF_REQUIRE(cond, ...)                        \
+    do {                                             \
+        if (!(cond)) {                               \
+            vf_set_error(__VA_ARGS__);               \
+            return VF_ERR_INVALID_ARG;               \
+        }                                            \
+    } while (0)
+
+#define VF_CHECK_LAUNCH(name)                                                          \
+    do {                                                                               \
+        hipError_t e_ = hipGetLastError();                                             \
+        if (e_ != hipSuccess) {                                                        \
+            vf_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));        \
+            return VF_ERR_LAUNCH;                                                      \
+        }                                                                              \
+    } while (0)
+
+// fp32 -> bf16 bits, round to nearest even (plain cast lowers to v_cvt_pk_bf16_f32 on gfx950,
+// NaN stays NaN).
+__device__ __forceinline__ unsigned short f2bf(float x) {
+    __bf16 b = (__bf16)x;
+    return *reinterpret_cast<unsigned short*>(&b);
+}
+__device__ __forceinline__ unsigned int pack2bf(float lo, float hi) {
+    return (unsigned int)f2bf(lo) | ((unsigned int)f2bf(hi) << 16);
+}
+__device__ __forceinline__ float bf2f(unsigned short b) {
+    return __uint_as_float(((unsigned int)b) << 16);
+}
+// exact (erf) GELU, as nn.GELU() / F.gelu default
+__device__ __forceinline__ float gelu_erf(float x) {
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}

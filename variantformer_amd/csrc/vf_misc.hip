@@ -1,0 +1,349 @@
+// HBM-bound helper kernels of libvf_hip: LayerNorm, token embedding + packing, segment mean pooling,
+// row gathers, the expression head's final dot + softplus, casts; plus vf_version / vf_last_error.
+// All are streaming kernels: roofline = HBM, algorithmic bytes = (input + output) bytes of one pass.
+#include <stdarg.h>
+#include "vf_common.h"
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void vf_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" int vf_version(void) { return VF_ABI_VERSION; }
+extern "C" const char* vf_last_error(void) { return g_err; }
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm: one wave per row, row held in registers (two-pass mean / variance like ATen),
+// float4 loads, bf16x4 or float4 stores.
+// ---------------------------------------------------------------------------------------------
+template <int MAXC>   // MAXC float4 chunks per lane: D <= 256*MAXC
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, void* __restrict__ out,
+                                                        int64_t rows, int D, float eps, int out_bf16, int gelu) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int n4 = D >> 2;
+    const f32x4_t* xr = reinterpret_cast<const f32x4_t*>(x + row * D);
+    f32x4_t v[MAXC];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int i = lane + 64 * c;
+        v[c] = i < n4 ? xr[i] : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        s += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int i = lane + 64 * c;
+        if (i < n4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[c][e] - mean;
+                ss += d * d;
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(ss) / (float)D + eps);
+    const f32x4_t* g4 = reinterpret_cast<const f32x4_t*>(gamma);
+    const f32x4_t* b4 = reinterpret_cast<const f32x4_t*>(beta);
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int i = lane + 64 * c;
+        if (i < n4) {
+            const f32x4_t gg = g4[i], bb = b4[i];
+            f32x4_t y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                y[e] = (v[c][e] - mean) * rstd * gg[e] + bb[e];
+                if (gelu) y[e] = gelu_erf(y[e]);
+            }
+            if (out_bf16) {
+                u32x2_t p;
+                p[0] = pack2bf(y[0], y[1]);
+                p[1] = pack2bf(y[2], y[3]);
+                reinterpret_cast<u32x2_t*>(reinterpret_cast<unsigned short*>(out) + row * D)[i] = p;
+            } else {
+                reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(out) + row * D)[i] = y;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// valid-token counts + exclusive scan (single block)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void mask_to_cu_kernel(const uint8_t* __restrict__ pad, int32_t* __restrict__ cu,
+                                                         int W, int L) {
+    __shared__ int part[1024];
+    __shared__ int carry_s;
+    const int tid = threadIdx.x;
+    if (tid == 0) { carry_s = 0; cu[0] = 0; }
+    __syncthreads();
+    for (int base = 0; base < W; base += 1024) {
+        const int w = base + tid;
+        int cnt = 0;
+        if (w < W) {
+            const uint8_t* p = pad + (int64_t)w * L;
+            for (int i = 0; i < L; ++i) cnt += p[i] == 0;
+        }
+        part[tid] = cnt;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {          // Hillis-Steele inclusive scan
+            const int add = tid >= off ? part[tid - off] : 0;
+            __syncthreads();
+            part[tid] += add;
+            __syncthreads();
+        }
+        const int carry = carry_s;
+        if (w < W) cu[w + 1] = carry + part[tid];
+        __syncthreads();
+        if (tid == 1023) carry_s = carry + part[1023];
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// embedding + positional table on packed valid tokens: one block per window
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_pack_kernel(const int64_t* __restrict__ ids, const uint8_t* __restrict__ pad,
+                                                        const int32_t* __restrict__ cu, const float* __restrict__ table,
+                                                        const float* __restrict__ pos_table, float* __restrict__ out,
+                                                        int L, int d, int vocab) {
+    extern __shared__ int sh[];          // [L] position of the k-th valid token, [L] its token id
+    int* vpos = sh;
+    int* vid = sh + L;
+    __shared__ int nvalid_s;
+    const int w = blockIdx.x, tid = threadIdx.x;
+    if (tid < 64) {                      // wave 0 compacts the valid positions in order
+        int base = 0;
+        for (int p0 = 0; p0 < L; p0 += 64) {
+            const int p = p0 + tid;
+            const bool valid = p < L && pad[(int64_t)w * L + p] == 0;
+            const unsigned long long bal = __ballot(valid);
+            if (valid) {
+                const int rank = __popcll(bal & ((1ull << tid) - 1ull));
+                long long id = ids[(int64_t)w * L + p];
+                id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+                vpos[base + rank] = p;
+                vid[base + rank] = (int)id;
+            }
+            base += __popcll(bal);
+        }
+        if (tid == 0) nvalid_s = base;
+    }
+    __syncthreads();
+    const int nvalid = nvalid_s;
+    const int64_t row0 = cu[w];
+    const int n4 = d >> 2;
+    for (int i = tid; i < nvalid * n4; i += 256) {
+        const int k = i / n4, c = i - k * n4;
+        f32x4_t e = reinterpret_cast<const f32x4_t*>(table + (int64_t)vid[k] * d)[c];
+        if (pos_table) e += reinterpret_cast<const f32x4_t*>(pos_table + (int64_t)vpos[k] * d)[c];
+        reinterpret_cast<f32x4_t*>(out + (row0 + k) * d)[c] = e;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// segment mean (masked mean pool): one block per window, threads over float4 columns
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void segment_mean_kernel(const float* __restrict__ x, const int32_t* __restrict__ cu,
+                                                          void* __restrict__ out, int d, int out_bf16) {
+    const int w = blockIdx.x;
+    const int a = cu[w], e = cu[w + 1];
+    const int n4 = d >> 2;
+    const float inv = 1.0f / (float)(e - a);      // e == a -> inf; 0 * inf = NaN like the reference's 0/0
+    for (int c = threadIdx.x; c < n4; c += 256) {
+        f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int t = a; t < e; ++t) acc += reinterpret_cast<const f32x4_t*>(x + (int64_t)t * d)[c];
+        acc *= inv;
+        if (out_bf16) {
+            u32x2_t p;
+            p[0] = pack2bf(acc[0], acc[1]);
+            p[1] = pack2bf(acc[2], acc[3]);
+            reinterpret_cast<u32x2_t*>(reinterpret_cast<unsigned short*>(out) + (int64_t)w * d)[c] = p;
+        } else {
+            reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(out) + (int64_t)w * d)[c] = acc;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// gathers
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_rows_f32_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                             const int64_t* __restrict__ idx, void* __restrict__ out,
+                                                             int64_t n, int d, int out_bf16) {
+    const int n4 = d >> 2;
+    const int64_t total = n * n4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / n4;
+        const int c = (int)(i - row * n4);
+        const int64_t j = idx[row];
+        const float* src = j >= 0 ? a + j * d : b + (-j - 1) * d;
+        const f32x4_t v = reinterpret_cast<const f32x4_t*>(src)[c];
+        if (out_bf16) {
+            u32x2_t p;
+            p[0] = pack2bf(v[0], v[1]);
+            p[1] = pack2bf(v[2], v[3]);
+            reinterpret_cast<u32x2_t*>(reinterpret_cast<unsigned short*>(out) + row * d)[c] = p;
+        } else {
+            reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(out) + row * d)[c] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void gather_rows_bf16_kernel(const unsigned short* __restrict__ src, int64_t ld_src,
+                                                              const int64_t* __restrict__ idx,
+                                                              unsigned short* __restrict__ out, int64_t ld_out,
+                                                              int64_t n, int d) {
+    const int n8 = d >> 3;
+    const int64_t total = n * n8;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / n8;
+        const int c = (int)(i - row * n8);
+        reinterpret_cast<u32x4_t*>(out + row * ld_out)[c] = reinterpret_cast<const u32x4_t*>(src + idx[row] * ld_src)[c];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// head tail: out[i] = softplus(x[i,:] . w + b)   (one wave per row)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rowdot_softplus_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ b, float* __restrict__ out,
+                                                             int64_t n, int d, int softplus) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const int n4 = d >> 2;
+    float s = 0.f;
+    for (int c = lane; c < n4; c += 64) {
+        const f32x4_t xv = reinterpret_cast<const f32x4_t*>(x + row * d)[c];
+        const f32x4_t wv = reinterpret_cast<const f32x4_t*>(w)[c];
+        s += xv[0] * wv[0] + xv[1] * wv[1] + xv[2] * wv[2] + xv[3] * wv[3];
+    }
+    s = wave_sum(s);
+    if (lane == 0) {
+        float y = s + (b ? b[0] : 0.f);
+        if (softplus) y = y > 20.f ? y : log1pf(expf(y));
+        out[row] = y;
+    }
+}
+
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ out,
+                                                           int64_t n) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const f32x4_t v = reinterpret_cast<const f32x4_t*>(x)[i];
+        u32x2_t p;
+        p[0] = pack2bf(v[0], v[1]);
+        p[1] = pack2bf(v[2], v[3]);
+        reinterpret_cast<u32x2_t*>(out)[i] = p;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) out[(n4 << 2) + threadIdx.x] = f2bf(x[(n4 << 2) + threadIdx.x]);
+}
+
+inline int stream_grid(int64_t work_items) {
+    int64_t b = (work_items + 255) / 256;
+    if (b < 1) b = 1;
+    if (b > 2048) b = 2048;             // 256 CUs x 8 blocks, grid-stride beyond
+    return (int)b;
+}
+
+}  // namespace
+
+extern "C" int vf_layernorm(const float* x, const float* gamma, const float* beta, void* out, int64_t rows, int D,
+                            float eps, int out_dtype, int gelu, void* stream) {
+    VF_REQUIRE(x && gamma && beta && out, "vf_layernorm: null pointer");
+    VF_REQUIRE(D > 0 && D % 4 == 0 && D <= 8192, "vf_layernorm: D=%d must be a multiple of 4 and <= 8192", D);
+    VF_REQUIRE(out_dtype == VF_F32 || out_dtype == VF_BF16, "vf_layernorm: bad out_dtype %d", out_dtype);
+    if (rows <= 0) return VF_OK;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)((rows + 3) / 4));
+    const int bf = out_dtype == VF_BF16;
+    if (D <= 512) hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, st, x, gamma, beta, out, rows, D, eps, bf, gelu);
+    else if (D <= 2048) hipLaunchKernelGGL(layernorm_kernel<8>, grid, dim3(256), 0, st, x, gamma, beta, out, rows, D, eps, bf, gelu);
+    else hipLaunchKernelGGL(layernorm_kernel<32>, grid, dim3(256), 0, st, x, gamma, beta, out, rows, D, eps, bf, gelu);
+    VF_CHECK_LAUNCH("vf_layernorm");
+    return VF_OK;
+}
+
+extern "C" int vf_mask_to_cu_seqlens(const uint8_t* pad, int32_t* cu, int W, int L, void* stream) {
+    VF_REQUIRE(pad && cu && W >= 0 && L > 0, "vf_mask_to_cu_seqlens: bad arguments");
+    hipLaunchKernelGGL(mask_to_cu_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, pad, cu, W, L);
+    VF_CHECK_LAUNCH("vf_mask_to_cu_seqlens");
+    return VF_OK;
+}
+
+extern "C" int vf_embed_pack(const int64_t* ids, const uint8_t* pad, const int32_t* cu, const float* table,
+                             const float* pos_table, float* out, int W, int L, int d, int vocab, void* stream) {
+    VF_REQUIRE(ids && pad && cu && table && out, "vf_embed_pack: null pointer");
+    VF_REQUIRE(L > 0 && L <= 4096 && d > 0 && d % 4 == 0 && vocab > 0, "vf_embed_pack: bad shape L=%d d=%d vocab=%d", L, d, vocab);
+    if (W <= 0) return VF_OK;
+    hipLaunchKernelGGL(embed_pack_kernel, dim3(W), dim3(256), 2 * L * sizeof(int), (hipStream_t)stream, ids, pad, cu,
+                       table, pos_table, out, L, d, vocab);
+    VF_CHECK_LAUNCH("vf_embed_pack");
+    return VF_OK;
+}
+
+extern "C" int vf_segment_mean(const float* x, const int32_t* cu, void* out, int W, int d, int out_dtype, void* stream) {
+    VF_REQUIRE(x && cu && out && d > 0 && d % 4 == 0, "vf_segment_mean: bad arguments (d=%d)", d);
+    VF_REQUIRE(out_dtype == VF_F32 || out_dtype == VF_BF16, "vf_segment_mean: bad out_dtype %d", out_dtype);
+    if (W <= 0) return VF_OK;
+    hipLaunchKernelGGL(segment_mean_kernel, dim3(W), dim3(256), 0, (hipStream_t)stream, x, cu, out, d, out_dtype == VF_BF16);
+    VF_CHECK_LAUNCH("vf_segment_mean");
+    return VF_OK;
+}
+
+extern "C" int vf_gather_rows_f32(const float* a, const float* b, const int64_t* idx, void* out, int64_t n, int d,
+                                  int out_dtype, void* stream) {
+    VF_REQUIRE(a && idx && out && d > 0 && d % 4 == 0, "vf_gather_rows_f32: bad arguments (d=%d)", d);
+    VF_REQUIRE(out_dtype == VF_F32 || out_dtype == VF_BF16, "vf_gather_rows_f32: bad out_dtype %d", out_dtype);
+    if (n <= 0) return VF_OK;
+    hipLaunchKernelGGL(gather_rows_f32_kernel, dim3(stream_grid(n * (d / 4))), dim3(256), 0, (hipStream_t)stream, a,
+                       b ? b : a, idx, out, n, d, out_dtype == VF_BF16);
+    VF_CHECK_LAUNCH("vf_gather_rows_f32");
+    return VF_OK;
+}
+
+extern "C" int vf_gather_rows_bf16(const void* src, int64_t ld_src, const int64_t* idx, void* out, int64_t ld_out,
+                                   int64_t n, int d, void* stream) {
+    VF_REQUIRE(src && idx && out && d > 0 && d % 8 == 0 && ld_src % 8 == 0 && ld_out % 8 == 0,
+               "vf_gather_rows_bf16: d and strides must be multiples of 8 (d=%d)", d);
+    if (n <= 0) return VF_OK;
+    hipLaunchKernelGGL(gather_rows_bf16_kernel, dim3(stream_grid(n * (d / 8))), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)src, ld_src, idx, (unsigned short*)out, ld_out, n, d);
+    VF_CHECK_LAUNCH("vf_gather_rows_bf16");
+    return VF_OK;
+}
+
+extern "C" int vf_rowdot_softplus(const float* x, const float* w, const float* b, float* out, int64_t n, int d,
+                                  int softplus, void* stream) {
+    VF_REQUIRE(x && w && out && d > 0 && d % 4 == 0, "vf_rowdot_softplus: bad arguments (d=%d)", d);
+    if (n <= 0) return VF_OK;
+    hipLaunchKernelGGL(rowdot_softplus_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, w, b,
+                       out, n, d, softplus);
+    VF_CHECK_LAUNCH("vf_rowdot_softplus");
+    return VF_OK;
+}
+
+extern "C" int vf_cast_f32_bf16(const float* x, void* out, int64_t n, void* stream) {
+    VF_REQUIRE(x && out && n >= 0, "vf_cast_f32_bf16: bad arguments");
+    VF_REQUIRE(((uintptr_t)x % 16 == 0) && ((uintptr_t)out % 8 == 0), "vf_cast_f32_bf16: misaligned pointer");
+    if (n == 0) return VF_OK;
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(stream_grid(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, x,
+                       (unsigned short*)out, n);
+    VF_CHECK_LAUNCH("vf_cast_f32_bf16");
+    return VF_OK;
+}

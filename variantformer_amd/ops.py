@@ -1,0 +1,179 @@
+"""Tensor-level wrappers over the C ABI of libvf_hip.so.
+
+torch is used only as the owner of device memory and of the HIP stream; every computation is a
+hand-written HIP kernel.  All wrappers require CUDA(ROCm) tensors and raise otherwise.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import _lib
+from ._lib import (EPI_BF16, EPI_F32, EPI_GEGLU_BF16, EPI_GELU_BF16, EPI_GELU_F32, EPI_RES_F32, VF_BF16,  # noqa: F401
+                   VF_F32, check)
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.VFError("variantformer_amd ops need tensors on the GPU (no CPU fallback)")
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _dt(dtype) -> int:
+    if dtype == torch.float32:
+        return VF_F32
+    if dtype == torch.bfloat16:
+        return VF_BF16
+    raise _lib.VFError(f"unsupported dtype {dtype}")
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None, epilogue: int,
+         residual: torch.Tensor | None = None, out: torch.Tensor | None = None) -> torch.Tensor:
+    """out = epilogue(a[M,K] @ w[N,K]^T + bias).  a, w bf16 (a may be a row-strided view)."""
+    _dev(a, w, bias, residual, out)
+    assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and a.dim() == 2 and w.dim() == 2
+    assert a.stride(1) == 1 and w.is_contiguous() and a.shape[1] == w.shape[1]
+    M, K = a.shape
+    N = w.shape[0]
+    n_out = N // 2 if epilogue == EPI_GEGLU_BF16 else N
+    odt = torch.float32 if epilogue in (EPI_F32, EPI_RES_F32, EPI_GELU_F32) else torch.bfloat16
+    if out is None:
+        out = torch.empty((M, n_out), dtype=odt, device=a.device)
+    assert out.dtype == odt and out.shape == (M, n_out) and out.stride(1) == 1
+    ldr = 0
+    if residual is not None:
+        assert residual.dtype == torch.float32 and residual.shape == (M, N) and residual.stride(1) == 1
+        ldr = residual.stride(0)
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous()
+    lib = _lib.load()
+    check(lib.vf_gemm_bf16(a.data_ptr(), a.stride(0) if M > 1 else max(a.stride(0), K), w.data_ptr(), _ptr(bias),
+                           _ptr(residual), ldr, out.data_ptr(), out.stride(0) if M > 1 else max(out.stride(0), n_out),
+                           M, N, K, epilogue, _stream()), "vf_gemm_bf16")
+    return out
+
+
+def pack_geglu_rows(w: torch.Tensor, bias: torch.Tensor | None):
+    """Permute a [2F,K] bf16 weight (+ fp32 bias) into the GEGLU-epilogue row order."""
+    _dev(w, bias)
+    assert w.dtype == torch.bfloat16 and w.is_contiguous()
+    wo = torch.empty_like(w)
+    bo = torch.empty_like(bias) if bias is not None else None
+    check(_lib.load().vf_pack_geglu_rows(w.data_ptr(), _ptr(bias), wo.data_ptr(), _ptr(bo), w.shape[0], w.shape[1],
+                                         _stream()), "vf_pack_geglu_rows")
+    return wo, bo
+
+
+def attn_varlen(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_q: torch.Tensor, cu_k: torch.Tensor | None,
+                max_q: int, max_k: int, n_heads: int, head_dim: int, slopes: torch.Tensor | None = None,
+                scale: float | None = None, out: torch.Tensor | None = None) -> torch.Tensor:
+    """q [tq, >=H*dh] / k, v [tk, >=H*dh] bf16 row-strided views whose first H*dh columns are the heads."""
+    _dev(q, k, v, cu_q, cu_k, slopes, out)
+    for t in (q, k, v):
+        assert t.dtype == torch.bfloat16 and t.dim() == 2 and t.stride(1) == 1
+    assert cu_q.dtype == torch.int32 and (cu_k is None or cu_k.dtype == torch.int32)
+    D = n_heads * head_dim
+    if out is None:
+        out = torch.empty((q.shape[0], D), dtype=torch.bfloat16, device=q.device)
+    if scale is None:
+        scale = 1.0 / math.sqrt(head_dim)
+    if slopes is not None:
+        assert slopes.dtype == torch.float32 and slopes.numel() == n_heads
+    check(_lib.load().vf_attn_varlen_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), q.stride(0),
+                                         k.stride(0), v.stride(0), out.stride(0), cu_q.data_ptr(), _ptr(cu_k),
+                                         cu_q.numel() - 1, int(max_q), int(max_k), n_heads, head_dim, _ptr(slopes),
+                                         float(scale), _stream()), "vf_attn_varlen_fwd")
+    return out
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out_dtype=torch.bfloat16, gelu: bool = False,
+              eps: float = 1e-5, out: torch.Tensor | None = None) -> torch.Tensor:
+    _dev(x, gamma, beta, out)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 2
+    rows, D = x.shape
+    if out is None:
+        out = torch.empty((rows, D), dtype=out_dtype, device=x.device)
+    check(_lib.load().vf_layernorm(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), rows, D, eps,
+                                   _dt(out.dtype), int(gelu), _stream()), "vf_layernorm")
+    return out
+
+
+def mask_to_cu_seqlens(pad: torch.Tensor) -> torch.Tensor:
+    """pad bool/uint8 [W, L] (True = pad) -> int32 [W+1] exclusive prefix sum of valid counts."""
+    _dev(pad)
+    pad = pad.view(torch.uint8) if pad.dtype == torch.bool else pad
+    assert pad.dtype == torch.uint8 and pad.is_contiguous() and pad.dim() == 2
+    W, L = pad.shape
+    cu = torch.empty(W + 1, dtype=torch.int32, device=pad.device)
+    check(_lib.load().vf_mask_to_cu_seqlens(pad.data_ptr(), cu.data_ptr(), W, L, _stream()), "vf_mask_to_cu_seqlens")
+    return cu
+
+
+def embed_pack(ids: torch.Tensor, pad: torch.Tensor, cu: torch.Tensor, table: torch.Tensor,
+               pos_table: torch.Tensor | None, n_tokens: int) -> torch.Tensor:
+    _dev(ids, pad, cu, table, pos_table)
+    pad = pad.view(torch.uint8) if pad.dtype == torch.bool else pad
+    assert ids.dtype == torch.int64 and ids.is_contiguous() and ids.dim() == 2 and pad.shape == ids.shape
+    assert table.dtype == torch.float32 and table.is_contiguous()
+    W, L = ids.shape
+    d = table.shape[1]
+    out = torch.empty((n_tokens, d), dtype=torch.float32, device=ids.device)
+    check(_lib.load().vf_embed_pack(ids.data_ptr(), pad.data_ptr(), cu.data_ptr(), table.data_ptr(), _ptr(pos_table),
+                                    out.data_ptr(), W, L, d, table.shape[0], _stream()), "vf_embed_pack")
+    return out
+
+
+def segment_mean(x: torch.Tensor, cu: torch.Tensor, out_dtype=torch.bfloat16) -> torch.Tensor:
+    _dev(x, cu)
+    assert x.dtype == torch.float32 and x.is_contiguous() and cu.dtype == torch.int32
+    W = cu.numel() - 1
+    out = torch.empty((W, x.shape[1]), dtype=out_dtype, device=x.device)
+    check(_lib.load().vf_segment_mean(x.data_ptr(), cu.data_ptr(), out.data_ptr(), W, x.shape[1], _dt(out_dtype),
+                                      _stream()), "vf_segment_mean")
+    return out
+
+
+def gather_rows_f32(a: torch.Tensor, b: torch.Tensor | None, idx: torch.Tensor, out_dtype=torch.float32) -> torch.Tensor:
+    """out[i] = a[idx[i]] if idx[i] >= 0 else b[-idx[i]-1]."""
+    _dev(a, b, idx)
+    assert a.dtype == torch.float32 and a.is_contiguous() and idx.dtype == torch.int64
+    assert b is None or (b.dtype == torch.float32 and b.is_contiguous() and b.shape[1] == a.shape[1])
+    out = torch.empty((idx.numel(), a.shape[1]), dtype=out_dtype, device=a.device)
+    check(_lib.load().vf_gather_rows_f32(a.data_ptr(), _ptr(b), idx.data_ptr(), out.data_ptr(), idx.numel(), a.shape[1],
+                                         _dt(out_dtype), _stream()), "vf_gather_rows_f32")
+    return out
+
+
+def gather_rows_bf16(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    _dev(src, idx)
+    assert src.dtype == torch.bfloat16 and src.stride(1) == 1 and idx.dtype == torch.int64
+    out = torch.empty((idx.numel(), src.shape[1]), dtype=torch.bfloat16, device=src.device)
+    check(_lib.load().vf_gather_rows_bf16(src.data_ptr(), src.stride(0), idx.data_ptr(), out.data_ptr(), out.stride(0),
+                                          idx.numel(), src.shape[1], _stream()), "vf_gather_rows_bf16")
+    return out
+
+
+def rowdot_softplus(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor | None, softplus: bool = True) -> torch.Tensor:
+    _dev(x, w, b)
+    assert x.dtype == torch.float32 and x.is_contiguous() and w.dtype == torch.float32 and w.numel() == x.shape[1]
+    out = torch.empty((x.shape[0], 1), dtype=torch.float32, device=x.device)
+    check(_lib.load().vf_rowdot_softplus(x.data_ptr(), w.data_ptr(), _ptr(b), out.data_ptr(), x.shape[0], x.shape[1],
+                                         int(softplus), _stream()), "vf_rowdot_softplus")
+    return out
+
+
+def cast_bf16(x: torch.Tensor) -> torch.Tensor:
+    _dev(x)
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    check(_lib.load().vf_cast_f32_bf16(x.data_ptr(), out.data_ptr(), x.numel(), _stream()), "vf_cast_f32_bf16")
+    return out
