@@ -1,0 +1,104 @@
+"""Host-side logic of the drop-in boundary, on CPU: state-dict key parity with the reference, batch
+preparation, config handling, ModelManager error behaviour.  No kernel is launched."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.conftest import GOLDEN, load_fixture
+from tests.helpers import build_model
+
+
+def test_state_dict_keys_and_shapes_match_reference(golden):
+    meta, arrays, sd, batch = golden
+    model = build_model(meta["seq2reg"], meta["seq2gene"])
+    ours = {k: list(v.shape) for k, v in model.state_dict().items()}
+    assert ours == meta["state_dict_shapes"]          # same keys, same shapes as the reference's own modules
+    model.load_state_dict(sd, strict=True)
+
+
+def test_prepare_batch_structure(golden):
+    meta, arrays, sd, batch = golden
+    model = build_model(meta["seq2reg"], meta["seq2gene"])
+    pb = model.prepare_batch(batch)
+    T = [len(t) for t in meta["tissues"]]
+    G = [c + 1 for c in meta["n_chunks"]]
+    assert pb.n_cre == meta["n_cres"] and pb.n_chunk == meta["n_chunks"]
+    assert pb.cu_cre.tolist() == np.concatenate([[0], np.cumsum(meta["n_cres"])]).tolist()
+    assert pb.cu_gene_cross.tolist() == np.concatenate([[0], np.cumsum([t * g for t, g in zip(T, G)])]).tolist()
+    assert pb.cu_gene_self.numel() == sum(T) + 1 and pb.total_tissue_rows == sum(T)
+    idx = pb.gene_stream_idx.tolist()
+    regs = [idx[r] for r in pb.registry_rows.tolist()]
+    assert regs == [-(t + 1) for ts in meta["tissues"] for t in ts]      # registry row = tissue id
+    assert pb.cre_tokens == int(sum((~m).sum() for m in batch["cre_attention_masks"]))
+    assert pb.cre_ids.dtype == torch.int64 and pb.cre_pad.dtype == torch.uint8
+
+
+def test_unsupported_configurations_fail_loudly():
+    meta, *_ = load_fixture("small_sin")
+    kw = dict(meta["seq2gene"])
+    kw["only_cross_attention"] = True
+    with pytest.raises(NotImplementedError):
+        build_model(meta["seq2reg"], kw)
+    hp = dict(meta["seq2reg"])
+    hp["use_context"] = True
+    with pytest.raises(NotImplementedError):
+        build_model(hp, meta["seq2gene"])
+
+
+def test_model_manager_contract(tmp_path):
+    """load_model(): tokenizers from {'hyper_parameters','state_dict'} files, token_dim override, 'Checkpoint
+    not found' ValueError (reference model_manager.py:44-51,77,103-104); without a GPU it refuses to continue."""
+    from variantformer_amd.processors.model_manager import ModelManager
+    from variantformer_amd.utils.config import Config
+    meta, arrays, sd, batch = load_fixture("small_sin")
+    tok_sd = {k[len("cre_tokenizer."):]: v for k, v in sd.items() if k.startswith("cre_tokenizer.")}
+    tok_path = tmp_path / "tok.pth"
+    torch.save({"hyper_parameters": meta["seq2reg"], "state_dict": tok_sd}, tok_path)
+    cfg = Config(dict(meta["seq2gene"], model_class="Seq2GenePredictorCombinedModulator", token_dim=7,
+                      checkpoint_path=str(tmp_path / "missing.pth"), precision="bf16-mixed",
+                      cre_tokenizer={"path": str(tok_path)}, gene_tokenizer={"path": str(tok_path)}))
+    with pytest.raises(ValueError, match="Checkpoint not found"):
+        ModelManager(cfg).load_model()
+    ck = tmp_path / "model.pth"
+    torch.save({"state_dict": sd}, ck)
+    cfg.checkpoint_path = str(ck)
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            ModelManager(cfg).load_model()
+    assert "cre_tokenizer" in cfg          # the caller's config is not mutated (reference copies it, :64)
+
+
+def test_config_loader_matches_reference_contract():
+    from variantformer_amd.utils.config import load_yaml
+    from tests.conftest import REPO
+    c = load_yaml(os.path.join(REPO, "variantformer_amd", "configs", "vf_model.yaml"))
+    for name in ("v4_pcg", "v4_ag"):
+        m = c[name].model
+        assert (m.emb_dim, m.num_heads, m.num_layers, m.gene_emb_dim, m.num_tissues) == (1536, 32, 25, 512, 63)
+        assert m.model_class == "Seq2GenePredictorCombinedModulator" and m.precision == "bf16-mixed"
+        assert m.use_context and not m.only_cross_attention and m.gene_pooling == "multi_registry"
+        assert c[name].dataset.max_length == 200 and c[name].dataset.max_chunks == 200
+    cp = c.v4_pcg.model.copy()
+    delattr(cp, "cre_tokenizer")
+    assert "cre_tokenizer" in c.v4_pcg.model and "cre_tokenizer" not in cp
+
+
+def test_trainer_and_format_output_contract():
+    import pandas as pd
+    from variantformer_amd.processors.trainer import Trainer
+    from variantformer_amd.processors.vcfprocessor import VCFProcessor
+
+    class Fake(torch.nn.Module):
+        def predict_step(self, batch, i):
+            return {"pred_gene_exp": [np.ones((2, 1), np.float32) * i], "embeddings": [np.zeros((2, 4), np.float32)]}
+    tr = Trainer(precision="bf16-mixed")
+    preds = tr.predict(Fake(), [None, None], ckpt_path="ignored")
+    assert tr.precision == "bf16-mixed" and len(preds) == 2
+    vp = VCFProcessor.__new__(VCFProcessor)
+    df = vp.format_output(pd.DataFrame({"gene_id": ["a", "b"]}), preds)
+    assert list(df.columns) == ["gene_id", "predicted_expression", "embeddings"] and df["predicted_expression"][1][0, 0] == 1
+    with pytest.raises(AssertionError):
+        vp.format_output(pd.DataFrame({"gene_id": ["a"]}), preds)

@@ -49,6 +49,10 @@ def load(path: str | None = None):
     if _lib is not None and path is None:
         return _lib
     path = path or LIB_PATH
+    # torch ships its own libamdhip64; import it FIRST so that libvf_hip.so binds to the HIP runtime torch
+    # already loaded.  Loaded the other way round the process ends up with two HIP runtimes and the second
+    # one to initialise reports "no ROCm-capable device".
+    import torch  # noqa: F401
     if not os.path.exists(path):
         raise VFError(
             f"{path} not found: the HIP extension has not been built "

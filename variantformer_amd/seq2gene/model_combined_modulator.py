@@ -1,0 +1,402 @@
+"""Seq2GenePredictorCombinedModulator on the MI355X HIP kernels.
+
+Same constructor keywords, sub-module names / state-dict keys and predict_step contract as the reference
+(seq2gene/model_combined_modulator.py:36-135, 399-538, 857-907) so that
+ModelManager(cfg).load_model() and VCFProcessor drive it unchanged.
+
+What is different by design (all exact re-orderings of the same arithmetic):
+  * The 24-layer CRE stream never sees the tissue id (add_context_to_cres false), so it is evaluated
+    ONCE per gene instead of once per requested tissue (reference repeat: :622-649).
+  * Gene-layer cross attention has no positional bias, so the T tissue copies of a gene form one query
+    block against the gene's single K/V projection of the CRE stream.
+  * CRE-layer cross attention reads K/V = Wkv(Embedding(9)[labels]); Wkv is applied to the 9-row table
+    once per layer and rows are gathered per label.
+  * All windows of all genes of a batch go through seq2reg together (the reference's <=1024-window chunks,
+    :760-785, are independent of each other), and the head is evaluated for all rows in one pass.
+"""
+from __future__ import annotations
+
+import logging
+import types
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..utils.constants import REF_CREs
+from ..utils.functions import precision2dtype
+from .modules.layers import (ContextFlashAttentionEncoderLayer, MultiRegistry, TissueExpressionHeads, packed_linear,
+                             pad_input, unpad_input)
+
+logger = logging.getLogger(__name__)
+MAX_WINDOW_SIZE = 30000000
+MAX_CHUNK_SIZE = 1024
+
+
+@dataclass
+class PreparedBatch:
+    """Device-resident inputs of one batch plus the host-known structure (sizes and index maps).
+    Built by Seq2GenePredictorCombinedModulator.prepare_batch from a collate_fn_batching dict."""
+    n_genes: int
+    tissues: list                      # per gene: list[int]
+    n_cre: list                        # per gene N_i
+    n_chunk: list                      # per gene C_i
+    cre_ids: torch.Tensor              # int64 [sum N, L]
+    cre_pad: torch.Tensor              # uint8 [sum N, L]
+    cre_tokens: int                    # valid tokens over all CRE windows
+    gene_ids: torch.Tensor             # int64 [sum C, L]
+    gene_pad: torch.Tensor
+    gene_tokens: int
+    labels: torch.Tensor               # int64 [sum N]
+    cu_cre: torch.Tensor               # int32 [n_genes+1]           CRE tokens per gene
+    max_cre: int
+    cu_gene_self: torch.Tensor         # int32 [sum T + 1]           one sequence per (gene, tissue), G_i tokens
+    max_gene: int
+    cu_gene_cross: torch.Tensor        # int32 [n_genes+1]           T_i * G_i query rows per gene
+    max_gene_cross: int
+    gene_stream_idx: torch.Tensor      # int64 [sum T_i*G_i]: >=0 row of gene_x, <0 registry row -(t+1)
+    registry_rows: torch.Tensor        # int64 [sum T]: row of each registry token in the gene stream
+    total_tissue_rows: int
+    registry_rows_host: np.ndarray = None
+    cu_cre_host: np.ndarray = None
+
+
+class CombinedModulator(nn.Module):
+    """24 CRE layers + 25 gene layers, interleaved, on packed streams
+    (reference model_combined_modulator.py:36-328)."""
+
+    def __init__(self, emb_dim, num_heads, num_layers, use_alibi, mlp_dout, use_context, num_ref_cres=None,
+                 only_cross_attention=True, use_res=False, cross_alibi=False, flash_attn_3=False):
+        super().__init__()
+        if not use_context or only_cross_attention or use_res or cross_alibi:
+            raise NotImplementedError(
+                "HIP path implements the shipped configuration: use_context=True, only_cross_attention=False, "
+                "use_res=False, cross_alibi=False (configs/vf_model.yaml:13-31)")
+        assert num_ref_cres is not None, "num_ref_cres must be provided when use_context is True"
+        self.emb_dim, self.num_heads, self.num_layers = emb_dim, num_heads, num_layers
+        self.use_context, self.only_cross_attention = use_context, only_cross_attention
+        self.use_res, self.cross_alibi = use_res, cross_alibi
+        self.second_level_context_embedding = nn.Embedding(num_ref_cres, emb_dim)
+        mk = lambda: ContextFlashAttentionEncoderLayer(  # noqa: E731
+            d_model=emb_dim, nhead=num_heads, batch_first=True, use_alibi=use_alibi, mlp_dout=mlp_dout,
+            cross_alibi=cross_alibi, flash_attn_3=flash_attn_3)
+        self.cre_layers = nn.ModuleList([mk() for _ in range(num_layers - 1)])
+        self.gene_layers = nn.ModuleList([mk() for _ in range(num_layers)])
+
+    # ---------------------------------------------------------------------------------------------
+    def _context_kv_table(self, layer) -> torch.Tensor:
+        """bf16 [9, 2D] = Wkv_layer(context embedding table); constant per weights, cached."""
+        tab = self.second_level_context_embedding.weight
+        mha = layer.crossMHA.MHA
+        key = (tab.data_ptr(), tab._version, mha.Wkv.weight.data_ptr(), mha.Wkv.weight._version)
+        c = getattr(layer, "_vf_ctx_kv", None)
+        if c is None or c[0] != key:
+            with torch.no_grad():
+                c = (key, mha.project_kv(ops.cast_bf16(tab.detach().float().contiguous())))
+            layer._vf_ctx_kv = c
+        return c[1]
+
+    def forward_packed(self, cre_x, gene_x, labels, cu_cre, max_cre, cu_gene_self, max_gene, cu_gene_cross=None,
+                       max_gene_cross=None, cu_cre_for_gene=None):
+        """cre_x fp32 [sum N, D] (one CRE stream per K/V group), gene_x fp32 [tokens_g, D], labels int64 [sum N].
+        cu_gene_self: self-attention sequences of the gene stream; cu_gene_cross / cu_cre_for_gene: matching
+        query / key groups for the gene->CRE cross attention (default: same grouping as self-attention)."""
+        cq = cu_gene_self if cu_gene_cross is None else cu_gene_cross
+        mq = max_gene if max_gene_cross is None else max_gene_cross
+        ck = cu_cre if cu_cre_for_gene is None else cu_cre_for_gene
+        cre, gene = cre_x, gene_x
+        gene = self.gene_layers[0].forward_packed(gene, cu_gene_self, max_gene, context=cre, cu_ctx=ck, max_ctx=max_cre,
+                                                  cu_cross_q=cq, max_cross_q=mq)                      # :244-250
+        for i in range(self.num_layers - 1):                                                          # :258-285
+            kv = ops.gather_rows_bf16(self._context_kv_table(self.cre_layers[i]), labels)
+            cre = self.cre_layers[i].forward_packed(cre, cu_cre, max_cre, context_kv=kv, cu_ctx=cu_cre, max_ctx=max_cre)
+            gene = self.gene_layers[i + 1].forward_packed(gene, cu_gene_self, max_gene, context=cre, cu_ctx=ck,
+                                                          max_ctx=max_cre, cu_cross_q=cq, max_cross_q=mq)
+        return gene, cre
+
+    def forward(self, cre_x, gene_x, context=None, cre_padding_mask=None, gene_padding_mask=None,
+                context_padding_mask=None, precision=None, cre_token_position=None, gene_token_position=None):
+        """Reference signature on padded, per-tissue-repeated tensors (:137-328).  No de-duplication is
+        possible at this level (the caller already materialised the copies); same kernels otherwise."""
+        B, Nc = cre_x.shape[:2]
+        G = gene_x.shape[1]
+        dev = cre_x.device
+        if cre_padding_mask is None:
+            cre_padding_mask = torch.zeros((B, Nc), dtype=torch.bool, device=dev)
+        if gene_padding_mask is None:
+            gene_padding_mask = torch.zeros((B, G), dtype=torch.bool, device=dev)
+        cre_p, cre_idx, cu_c, max_c, _ = unpad_input(cre_x, ~cre_padding_mask)
+        gene_p, gene_idx, cu_g, max_g, _ = unpad_input(gene_x, ~gene_padding_mask)
+        labels = context.reshape(-1)[cre_idx].long().contiguous()
+        gene_out, cre_out = self.forward_packed(cre_p, gene_p, labels, cu_c, max_c, cu_g, max_g)
+        gene_current = pad_input(gene_out, gene_idx, B, G)
+        cre_current = pad_input(cre_out, cre_idx, B, Nc)
+        ar = torch.arange(B, device=dev)
+        if gene_token_position is not None:
+            gene_tok = gene_current[ar, gene_token_position.long().reshape(-1), :]
+        else:
+            gene_tok = torch.zeros(B, gene_current.size(2), device=dev)
+        if cre_token_position is not None:
+            cre_tok = cre_current[ar, cre_token_position.long().reshape(-1), :]
+        else:
+            cre_tok = torch.zeros(B, cre_current.size(2), device=dev)
+        return gene_current, gene_tok, cre_tok
+
+    def prepare_input(self, g_exp, gene_pooling, start_tkn=None, tissue_vector=None, padding_mask_gene=None):
+        """Reference :330-368 (multi_registry branch)."""
+        res = g_exp.clone()
+        if gene_pooling == "multi_registry" and start_tkn is not None:
+            g_exp, res = start_tkn(g_exp, tissue_vector)
+            if padding_mask_gene is not None:
+                start = torch.zeros((padding_mask_gene.size(0), 1), dtype=padding_mask_gene.dtype,
+                                    device=padding_mask_gene.device)
+                padding_mask_gene = torch.cat((start, padding_mask_gene), dim=1)
+        return g_exp, res, padding_mask_gene
+
+    def pool_outputs(self, g_exp, gene_pooling, padding_mask_gene=None):
+        """Reference :370-396; only the registry-token pooling of the shipped config."""
+        if gene_pooling in ["start_token", "multi_registry"]:
+            return g_exp[:, 0, :]
+        raise NotImplementedError(f"gene pooling {gene_pooling!r} is not on the shipped path")
+
+
+class Seq2GenePredictorCombinedModulator(nn.Module):
+    def __init__(self, num_tissues: int, emb_dim: int, gene_emb_dim: int, num_heads: int, num_layers: int,
+                 use_alibi: bool = True, mlp_dout: float = 0.1, weight_decay: float = 0.0, learning_rate: float = 1e-4,
+                 lr_scale: float = 1, use_context: bool = False, token_dim: int = 128, cre_tokenizer=None,
+                 gene_tokenizer=None, cre_tokenizer_train_mode="val", cre_tokenizer_val_mode="val",
+                 gene_tokenizer_train_mode="val", gene_tokenizer_val_mode="val", tissues: list = None,
+                 optimizer="adam", gene_pooling="mean", flash_attn_3=False, **kwargs):
+        super().__init__()
+        hp = dict(num_tissues=num_tissues, emb_dim=emb_dim, gene_emb_dim=gene_emb_dim, num_heads=num_heads,
+                  num_layers=num_layers, use_alibi=use_alibi, mlp_dout=mlp_dout, use_context=use_context,
+                  token_dim=token_dim, gene_pooling=gene_pooling, flash_attn_3=flash_attn_3)
+        hp.update(kwargs)
+        self.hparams = types.SimpleNamespace(**hp)
+        self.trainer = None
+        self.vep = False
+        self.precision = None
+        if gene_pooling != "multi_registry":
+            raise NotImplementedError("only gene_pooling='multi_registry' (configs/vf_model.yaml:32) is implemented")
+        self.gene_pooling = gene_pooling
+        self.start_tkn = MultiRegistry(num_tissues, emb_dim)
+        self.train_gene_tokenizer = kwargs.get("train_gene_tokenizer", False)
+        self.cre_tokenizer = cre_tokenizer
+        self.gene_tokenizer = gene_tokenizer
+        self.add_context_to_cres = kwargs.get("add_context_to_cres", False)
+        if self.add_context_to_cres:
+            raise NotImplementedError("add_context_to_cres=True makes the CRE stream tissue-dependent; not shipped")
+        self.add_context = None
+        self.emb_dim = emb_dim
+        self.use_context = use_context
+        self.tissues = tissues
+        self.use_res = kwargs.get("use_res", False)
+        self.loss_fn = kwargs.get("loss_fn", "poisson")
+        self.use_bigger_head = kwargs.get("use_bigger_head", False)
+        self.multi_head = kwargs.get("multi_head", True)
+        self.only_cross_attention = kwargs.get("only_cross_attention", True)
+        self.cross_alibi = kwargs.get("cross_alibi", False) if use_alibi else False
+        self.gene_map = nn.Linear(gene_emb_dim, emb_dim)
+        if token_dim != emb_dim:
+            self.cre_map = nn.Linear(token_dim, emb_dim)
+        self.combined_modulator = CombinedModulator(
+            emb_dim=emb_dim, num_heads=num_heads, num_layers=num_layers, use_alibi=use_alibi, mlp_dout=mlp_dout,
+            use_context=use_context, num_ref_cres=len(REF_CREs) if use_context else None,
+            only_cross_attention=self.only_cross_attention, use_res=self.use_res, cross_alibi=self.cross_alibi,
+            flash_attn_3=flash_attn_3)
+        self.tissue_heads = TissueExpressionHeads(emb_dim, num_tissues, use_bigger_head=self.use_bigger_head,
+                                                  multi_head=self.multi_head, mlp_dout=mlp_dout, loss_fn=self.loss_fn,
+                                                  head_type=kwargs.get("head_type", "mlp"))
+        for p in self.parameters():            # inference-only build
+            p.requires_grad_(False)
+
+    # ---------------------------------------------------------------------------------------------
+    @property
+    def device(self):
+        return self.gene_map.weight.device
+
+    def _precision_branch(self):
+        """Reference :736-744: bf16/fp16-mixed -> None (autocast path), anything else -> fp32 (which the
+        reference then runs through an fp16 flash-attn round trip).  Both branches run the same bf16-operand
+        / fp32-accumulate kernels here; the value is only reported."""
+        try:
+            p = precision2dtype(self.trainer.precision)
+        except Exception:
+            p = torch.float32
+        return None if p in (torch.float16, torch.bfloat16) else torch.float32
+
+    def prepare_batch(self, batch: dict) -> PreparedBatch:
+        """collate_fn_batching dict (datasets/vcfdataset.py:18-63) -> device tensors + structure."""
+        dev = self.device
+        x, m = batch["cre_sequences"], batch["cre_attention_masks"]
+        gx, gm = batch["gene_embeddings"], batch["gene_attention_masks"]
+        n_genes = len(x)
+        tissues = [[int(t) for t in tv] for tv in batch["tissue_context"]]
+        n_cre = [int(v.shape[0]) for v in x]
+        n_chunk = [int(v.shape[0]) for v in gx]
+        for v in list(x) + list(gx):
+            assert v.shape[1] == 1, "one strand per window (strand is picked in the dataloader)"
+        cre_ids = torch.cat([v[:, 0, :] for v in x]).long().contiguous()
+        cre_pad = torch.cat([v[:, 0, :] for v in m]).bool().contiguous()
+        gene_ids = torch.cat([v[:, 0, :] for v in gx]).long().contiguous()
+        gene_pad = torch.cat([v[:, 0, :] for v in gm]).bool().contiguous()
+        labels = torch.cat([v.reshape(-1) for v in batch["ref_cre_labels"]]).long().contiguous()
+        cre_tokens = int((~cre_pad).sum())
+        gene_tokens = int((~gene_pad).sum())
+        # structure
+        cu_cre = np.concatenate([[0], np.cumsum(n_cre)]).astype(np.int32)
+        self_lens, cross_lens, idx, reg_rows = [], [], [], []
+        gx_off, row = 0, 0
+        for i in range(n_genes):
+            G = n_chunk[i] + 1
+            chunk_rows = np.arange(gx_off, gx_off + n_chunk[i], dtype=np.int64)
+            for t in tissues[i]:
+                self_lens.append(G)
+                reg_rows.append(row)
+                idx.append(np.concatenate([[-(t + 1)], chunk_rows]))
+                row += G
+            cross_lens.append(G * len(tissues[i]))
+            gx_off += n_chunk[i]
+        cu_self = np.concatenate([[0], np.cumsum(self_lens)]).astype(np.int32)
+        cu_cross = np.concatenate([[0], np.cumsum(cross_lens)]).astype(np.int32)
+        to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+        return PreparedBatch(
+            n_genes=n_genes, tissues=tissues, n_cre=n_cre, n_chunk=n_chunk,
+            cre_ids=cre_ids.to(dev), cre_pad=cre_pad.to(dev).view(torch.uint8), cre_tokens=cre_tokens,
+            gene_ids=gene_ids.to(dev), gene_pad=gene_pad.to(dev).view(torch.uint8), gene_tokens=gene_tokens,
+            labels=labels.to(dev), cu_cre=to(cu_cre), max_cre=max(n_cre), cu_gene_self=to(cu_self),
+            max_gene=max(self_lens), cu_gene_cross=to(cu_cross), max_gene_cross=max(cross_lens),
+            gene_stream_idx=to(np.concatenate(idx)), registry_rows=to(np.array(reg_rows, dtype=np.int64)),
+            total_tissue_rows=len(reg_rows), registry_rows_host=np.array(reg_rows, dtype=np.int64), cu_cre_host=cu_cre)
+
+    def forward_prepared(self, pb: PreparedBatch, return_cre: bool = False):
+        """The hot path: everything below runs as HIP kernels on the current stream.
+        Returns (pred fp32 [sum T, 1], emb fp32 [sum T, D])."""
+        # seq2reg over every CRE window / gene chunk of the batch (HOT LOOP A)
+        cre_tok = self.cre_tokenizer.embed_packed(pb.cre_ids, pb.cre_pad, pb.cre_tokens)        # bf16 [sum N, d]
+        gene_tokenizer = self.gene_tokenizer if self.gene_tokenizer is not None else self.cre_tokenizer
+        gene_tok = gene_tokenizer.embed_packed(pb.gene_ids, pb.gene_pad, pb.gene_tokens)        # bf16 [sum C, d]
+        # maps (:610-612)
+        if hasattr(self, "cre_map"):
+            w, b = packed_linear(self.cre_map)
+            cre_x = ops.gemm(cre_tok, w, b, ops.EPI_F32)
+        else:
+            cre_x = cre_tok.float()
+        w, b = packed_linear(self.gene_map)
+        gene_x = ops.gemm(gene_tok, w, b, ops.EPI_F32)
+        # registry token per (gene, tissue) + that gene's chunk rows (:357-366, layers.py:508-521)
+        gene_stream = ops.gather_rows_f32(gene_x, self.start_tkn.registry_tokens.weight, pb.gene_stream_idx)
+        gene_out, cre_out = self.combined_modulator.forward_packed(
+            cre_x, gene_stream, pb.labels, pb.cu_cre, pb.max_cre, pb.cu_gene_self, pb.max_gene,
+            cu_gene_cross=pb.cu_gene_cross, max_gene_cross=pb.max_gene_cross)
+        emb = ops.gather_rows_f32(gene_out, None, pb.registry_rows)                             # pool_outputs (:391-392)
+        pred = self.tissue_heads(emb)
+        if return_cre:
+            return pred, emb, gene_out, cre_out
+        return pred, emb
+
+    def forward(self, inp, attention_mask, tissue_vector, cre_context, strand, gene_embedding, gene_att_mask,
+                return_embedding=False, get_all=False, **kwargs):
+        """Reference signature (:540-720).  Token-position outputs (VEP) come from variant_prediction."""
+        batch = {"cre_sequences": inp, "cre_attention_masks": attention_mask, "tissue_context": tissue_vector,
+                 "ref_cre_labels": cre_context, "strand_val": strand, "gene_embeddings": gene_embedding,
+                 "gene_attention_masks": gene_att_mask}
+        pb = self.prepare_batch(batch)
+        donors = list(range(pb.n_genes))
+        cre_pos, gene_pos = kwargs.get("cre_token_position"), kwargs.get("gene_token_position")
+        if kwargs.get("only_embedding", False):
+            return {"embedding": self.forward_prepared(pb)[1], "donors": donors}
+        pred, emb, gene_out, cre_out = self.forward_prepared(pb, return_cre=True)
+        if not return_embedding:
+            return pred, donors
+        gene_tok_emb = torch.zeros(pb.total_tissue_rows, self.emb_dim, device=pred.device)
+        cre_tok_emb = torch.zeros(pb.total_tissue_rows, self.emb_dim, device=pred.device)
+        if gene_pos is not None or cre_pos is not None:
+            g_rows, c_rows, r = [], [], 0
+            for i in range(pb.n_genes):
+                for _ in pb.tissues[i]:
+                    if gene_pos is not None:     # +1: registry token (:665-666)
+                        g_rows.append(int(pb.registry_rows_host[r]) + 1 + int(torch.as_tensor(gene_pos[i]).reshape(-1)[0]))
+                    if cre_pos is not None:
+                        c_rows.append(int(pb.cu_cre_host[i]) + int(torch.as_tensor(cre_pos[i]).reshape(-1)[0]))
+                    r += 1
+            if g_rows:
+                gene_tok_emb = ops.gather_rows_f32(gene_out, None, torch.tensor(g_rows, device=pred.device))
+            if c_rows:
+                cre_tok_emb = ops.gather_rows_f32(cre_out, None, torch.tensor(c_rows, device=pred.device))
+        return pred, donors, emb, gene_tok_emb, cre_tok_emb
+
+    def transform_with_batching(self, x, attention_mask, tissue_context, ref_labels_tensor, strand, embedder,
+                                detach_embedding=True):
+        """Reference :722-829: per-gene seq2reg embeddings stacked and padded to the longest gene.
+        Returns (X [B,maxN,d] fp32, mask [B,maxN] bool True=pad, ref_labels [B,maxN] int64, precision, donors)."""
+        precision = self._precision_branch()
+        dev = self.device
+        n = [int(v.shape[0]) for v in x]
+        ids = torch.cat([v[:, 0, :] for v in x]).long().contiguous().to(dev)
+        pad = torch.cat([v[:, 0, :] for v in attention_mask]).bool().contiguous().to(dev)
+        emb = embedder.embed_packed(ids, pad, int((~pad).sum().item()), torch.float32)
+        maxn = max(n)
+        X = torch.zeros((len(n), maxn, emb.shape[1]), dtype=torch.float32, device=dev)
+        mask = torch.ones((len(n), maxn), dtype=torch.bool, device=dev)
+        labels = torch.zeros((len(n), maxn), dtype=torch.long, device=dev)
+        off = 0
+        for i, ni in enumerate(n):
+            X[i, :ni] = emb[off:off + ni]
+            mask[i, :ni] = False
+            labels[i, :ni] = torch.as_tensor(ref_labels_tensor[i]).to(dev).long()[:ni]
+            off += ni
+        return X, mask, labels, precision, list(range(len(n)))
+
+    def predict_step(self, batch, batch_idx, dataloader_idx=None):
+        """Reference :857-907: dict of per-gene fp32 numpy arrays."""
+        self.eval()
+        if self.vep:
+            return self.variant_prediction(batch)
+        with torch.no_grad():
+            pb = self.prepare_batch(batch)
+            pred, emb = self.forward_prepared(pb)
+        pred = pred.detach().cpu().float().numpy()
+        emb = emb.detach().cpu().float().numpy()
+        preds, embs, s = [], [], 0
+        for t in pb.tissues:
+            preds.append(pred[s:s + len(t)])
+            embs.append(emb[s:s + len(t)])
+            s += len(t)
+        return {"pred_gene_exp": preds, "embeddings": embs, "batch_idx": batch_idx, "dataloader_idx": dataloader_idx}
+
+    def variant_prediction(self, batch):
+        """Reference :909-1004 (VEP: ref / het / hom genotypes, one forward each, plus the embeddings at the
+        variant's CRE index and gene-chunk index)."""
+        x = batch["cre_sequences"]
+        num_batch = len(x)
+        if num_batch == 0:
+            return {"pred_gene_exp": [], "embd": [], "variant_type": batch["variant_type"],
+                    "gene_token_embedding": [], "cre_token_embedding": []}
+        cre_pos, gene_pos = batch["cre_token_position"], batch["gene_token_position"]
+        assert len(cre_pos) == 3, "there should be 3 samples in the batch for ref, het, hom"
+        assert len(gene_pos) == 3, "there should be 3 samples in the batch for ref, het, hom"
+        if torch.isnan(torch.as_tensor(cre_pos, dtype=torch.float32)).any():
+            cre_pos = None
+        if torch.isnan(torch.as_tensor(gene_pos, dtype=torch.float32)).any():
+            gene_pos = None
+        with torch.no_grad():
+            pred, _, embd, gtok, ctok = self(
+                x, batch["cre_attention_masks"], batch["tissue_context"], batch["ref_labels"], batch["strand"],
+                batch["gene_embeddings"], batch["gene_attention_masks"], return_embedding=True,
+                cre_token_position=cre_pos, gene_token_position=gene_pos)
+        pred, embd = pred.cpu().float().numpy(), embd.cpu().float().numpy()
+        gtok, ctok = gtok.cpu().float().numpy(), ctok.cpu().float().numpy()
+        out = {"pred_gene_exp": [], "embd": [], "variant_type": batch["variant_type"],
+               "gene_token_embedding": [], "cre_token_embedding": []}
+        s = 0
+        for i in range(num_batch):
+            n = len(batch["tissue_context"][i])
+            out["pred_gene_exp"].append(pred[s:s + n])
+            out["embd"].append(embd[s:s + n])
+            out["gene_token_embedding"].append(gtok[s:s + n])
+            out["cre_token_embedding"].append(ctok[s:s + n])
+            s += n
+        return out

@@ -1,0 +1,309 @@
+"""seq2gene layers on the MI355X HIP kernels, with the reference's class names, constructor arguments
+and state-dict keys (reference: seq2gene/modules/layers.py; flash_attn.modules.mha.MHA [3p]).
+
+Data layout: every stream is PACKED -- [total_tokens, D] with int32 cu_seqlens -- for the whole stack
+(the reference unpads once and threads cu_seqlens through, model_combined_modulator.py:170-233).
+The residual stream is fp32 in HBM; GEMM / attention operands are bf16 (DESIGN.md "Rounding points").
+Padded [B,S,D] inputs with boolean masks are accepted at the same call sites the reference accepts
+them and are packed on entry.
+
+Nothing here falls back to PyTorch math: each step is a call into libvf_hip.so (variantformer_amd.ops).
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from ... import ops
+
+
+def get_alibi_slopes(n: int) -> torch.Tensor:
+    """ALiBi slopes; same values as the reference helper (layers.py:15-37) and flash-attn's."""
+    def pow2(n):
+        start = 2 ** (-(2 ** -(math.log2(n) - 3)))
+        return [start * start ** i for i in range(n)]
+
+    def slopes(n):
+        if math.log2(n).is_integer():
+            return pow2(n)
+        c = 2 ** math.floor(math.log2(n))
+        return pow2(c) + slopes(2 * c)[0::2][: n - c]
+    return torch.tensor(slopes(n))
+
+
+# ---------------------------------------------------------------------------------------------
+# weight packing (fp32 master parameters -> bf16 kernel operands), cached per parameter version
+# ---------------------------------------------------------------------------------------------
+def packed_linear(lin: nn.Linear, geglu: bool = False):
+    """(bf16 weight [N,K], fp32 bias [N]) for vf_gemm_bf16; `geglu` applies the GEGLU row interleave.
+    Rebuilt whenever the parameter is modified in place (load_state_dict) or moved."""
+    w = lin.weight
+    key = (w.data_ptr(), w._version, str(w.device), geglu,
+           None if lin.bias is None else (lin.bias.data_ptr(), lin.bias._version))
+    cache = getattr(lin, "_vf_packed", None)
+    if cache is not None and cache[0] == key:
+        return cache[1], cache[2]
+    with torch.no_grad():
+        wb = ops.cast_bf16(w.detach().float().contiguous())
+        b = None if lin.bias is None else lin.bias.detach().float().contiguous()
+        if geglu:
+            wb, b = ops.pack_geglu_rows(wb, b)
+    lin._vf_packed = (key, wb, b)
+    return wb, b
+
+
+def _cu_from_padded(batch: int, seqlen: int, device) -> torch.Tensor:
+    return torch.arange(0, batch + 1, dtype=torch.int32, device=device) * seqlen
+
+
+def unpad_input(hidden: torch.Tensor, keep_mask: torch.Tensor):
+    """flash_attn.bert_padding.unpad_input [3p] contract: (packed, indices int64, cu_seqlens int32,
+    max_seqlen int, seqlens).  Index bookkeeping by torch; the row move is vf_gather_rows_f32."""
+    seqlens = keep_mask.sum(dim=-1, dtype=torch.int32)
+    indices = torch.nonzero(keep_mask.flatten(), as_tuple=False).flatten()
+    cu = torch.nn.functional.pad(torch.cumsum(seqlens, 0, dtype=torch.int32), (1, 0))
+    flat = hidden.reshape(-1, hidden.shape[-1]).float().contiguous()
+    packed = ops.gather_rows_f32(flat, None, indices)
+    return packed, indices, cu, int(seqlens.max().item()), seqlens
+
+
+def pad_input(packed: torch.Tensor, indices: torch.Tensor, batch: int, seqlen: int) -> torch.Tensor:
+    """flash_attn.bert_padding.pad_input [3p]: scatter packed rows into a zero [B,S,D] tensor."""
+    inv = torch.full((batch * seqlen,), -1, dtype=torch.int64, device=packed.device)
+    inv[indices] = torch.arange(indices.numel(), device=packed.device)
+    zero = torch.zeros((1, packed.shape[-1]), dtype=torch.float32, device=packed.device)
+    out = ops.gather_rows_f32(packed.float().contiguous(), zero, inv)      # -1 -> row 0 of `zero`
+    return out.view(batch, seqlen, packed.shape[-1])
+
+
+class MHA(nn.Module):
+    """Parameter names and call signature of flash_attn.modules.mha.MHA [3p] as the reference uses it
+    (layers.py:344-351, 437-439, 465, 482-487; seq2reg/modules.py:140-142,167): Wqkv (self) or Wq+Wkv
+    (cross) and out_proj; rows of Wqkv are (three, head, dh), of Wkv (two, head, dh).
+
+    __call__(x[, x_kv], cu_seqlens=, max_seqlen=, cu_seqlens_k=, max_seqlen_k=) on packed [tokens, D]
+    (or padded [B,S,D] with no kwargs) returns out_proj(attention) in x's dtype, like the original.
+    The layers use `fused()` which also folds the residual add into the out_proj epilogue."""
+
+    def __init__(self, embed_dim, num_heads, dropout=0.0, use_flash_attn=True, use_alibi=False, cross_attn=False, **kw):
+        super().__init__()
+        assert embed_dim % num_heads == 0
+        self.embed_dim, self.num_heads, self.cross_attn = embed_dim, num_heads, cross_attn
+        self.head_dim = embed_dim // num_heads
+        self.use_alibi = use_alibi
+        if cross_attn:
+            self.Wq = nn.Linear(embed_dim, embed_dim)
+            self.Wkv = nn.Linear(embed_dim, 2 * embed_dim)
+        else:
+            self.Wqkv = nn.Linear(embed_dim, 3 * embed_dim)
+        self.out_proj = nn.Linear(embed_dim, embed_dim)
+        if use_alibi:
+            self.register_buffer("alibi_slopes", get_alibi_slopes(num_heads).float(), persistent=False)
+        else:
+            self.alibi_slopes = None
+
+    # -- pieces -------------------------------------------------------------------------------
+    def project_kv(self, x_kv_bf16: torch.Tensor) -> torch.Tensor:
+        """bf16 [tokens_k, 2D] = Wkv(x_kv): exposed so that a caller can compute it once and share it."""
+        w, b = packed_linear(self.Wkv)
+        return ops.gemm(x_kv_bf16, w, b, ops.EPI_BF16)
+
+    def attend(self, x_bf16, kv_bf16, cu_q, max_q, cu_k, max_k) -> torch.Tensor:
+        """bf16 attention output [tokens_q, D] (before out_proj)."""
+        D = self.embed_dim
+        if self.cross_attn:
+            w, b = packed_linear(self.Wq)
+            q = ops.gemm(x_bf16, w, b, ops.EPI_BF16)
+            return ops.attn_varlen(q, kv_bf16[:, :D], kv_bf16[:, D:], cu_q, cu_k, max_q, max_k, self.num_heads,
+                                   self.head_dim, self.alibi_slopes)
+        w, b = packed_linear(self.Wqkv)
+        qkv = ops.gemm(x_bf16, w, b, ops.EPI_BF16)
+        return ops.attn_varlen(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], cu_q, None, max_q, max_q,
+                               self.num_heads, self.head_dim, self.alibi_slopes)
+
+    def fused(self, x_bf16, residual_f32, cu_q, max_q, kv_bf16=None, cu_k=None, max_k=None) -> torch.Tensor:
+        """fp32 [tokens, D] = out_proj(attention(x)) + residual (one GEMM epilogue)."""
+        a = self.attend(x_bf16, kv_bf16, cu_q, max_q, cu_k, max_k)
+        w, b = packed_linear(self.out_proj)
+        return ops.gemm(a, w, b, ops.EPI_RES_F32, residual=residual_f32)
+
+    # -- flash_attn-compatible call -------------------------------------------------------------
+    def forward(self, x, x_kv=None, cu_seqlens=None, max_seqlen=None, cu_seqlens_k=None, max_seqlen_k=None, **kw):
+        in_dtype, in_shape = x.dtype, x.shape
+        if cu_seqlens is None:                      # padded [B,S,D], no masking (layers.py:487)
+            B, S = x.shape[:2]
+            cu_seqlens, max_seqlen = _cu_from_padded(B, S, x.device), S
+            x = x.reshape(B * S, -1)
+            if x_kv is not None:
+                Sk = x_kv.shape[1]
+                cu_seqlens_k, max_seqlen_k = _cu_from_padded(B, Sk, x.device), Sk
+                x_kv = x_kv.reshape(B * Sk, -1)
+        xb = x if x.dtype == torch.bfloat16 else ops.cast_bf16(x.float().contiguous())
+        kv = None
+        if self.cross_attn:
+            src = x_kv if x_kv is not None else x
+            kv = self.project_kv(src if src.dtype == torch.bfloat16 else ops.cast_bf16(src.float().contiguous()))
+            if cu_seqlens_k is None:
+                cu_seqlens_k, max_seqlen_k = cu_seqlens, max_seqlen
+        a = self.attend(xb, kv, cu_seqlens, max_seqlen, cu_seqlens_k, max_seqlen_k)
+        w, b = packed_linear(self.out_proj)
+        out = ops.gemm(a, w, b, ops.EPI_F32 if in_dtype == torch.float32 else ops.EPI_BF16)
+        return out.to(in_dtype).view(in_shape)
+
+
+class FlashAttLayer(nn.Module):
+    """Varlen wrapper around MHA, self or cross (reference layers.py:328-488)."""
+
+    def __init__(self, d_model, nhead, hidden_dim=2048, dropout=0.1, use_alibi=False, cross_attn=False,
+                 flash_attn_3=False):
+        super().__init__()
+        self.cross_attn = cross_attn
+        if cross_attn and flash_attn_3:
+            raise NotImplementedError("flash-attention-3 is not supported at this time")
+        self.MHA = MHA(d_model, nhead, dropout=dropout, use_flash_attn=True, use_alibi=use_alibi, cross_attn=cross_attn)
+
+    def forward(self, src, cntx=None, src_key_padding_mask=None, context_key_padding_mask=None,
+                precision=torch.float32, unpad_info=None, context_unpad_info=None):
+        if unpad_info is not None:                                   # already packed (:372-378, :454-467)
+            kw = {"cu_seqlens": unpad_info["cu_seqlens"], "max_seqlen": unpad_info["max_seqlen"]}
+            if self.cross_attn:
+                assert cntx is not None
+                if context_unpad_info is not None:
+                    kw.update(cu_seqlens_k=context_unpad_info["cu_seqlens"], max_seqlen_k=context_unpad_info["max_seqlen"])
+                return self.MHA(src, cntx, **kw)
+            return self.MHA(src, **kw)
+        if src_key_padding_mask is not None:                         # padded + mask: pack, run, pad back
+            batch, seqlen = src.shape[:2]
+            xs, idx, cu, mx, _ = unpad_input(src, ~src_key_padding_mask)
+            kw = {"cu_seqlens": cu, "max_seqlen": mx}
+            if self.cross_attn:
+                assert cntx is not None and context_key_padding_mask is not None, \
+                    "context_key_padding_mask must be provided if src_key_padding_mask is provided"
+                cs, _, cuk, mxk, _ = unpad_input(cntx, ~context_key_padding_mask)
+                out = self.MHA(xs, cs, cu_seqlens_k=cuk, max_seqlen_k=mxk, **kw)
+            else:
+                out = self.MHA(xs, **kw)
+            return pad_input(out, idx, batch, seqlen).to(src.dtype)
+        return self.MHA(src, cntx) if self.cross_attn else self.MHA(src)
+
+
+class ContextFlashAttentionEncoderLayer(nn.Module):
+    """LN -> self-MHA(ALiBi) -> +src -> LN -> cross-MHA(q = x, kv = context, un-normalised) -> +res ->
+    LN -> GeGLU(d -> 2048 -> 1024 -> d) -> + src   (reference layers.py:47-165; note the last residual
+    is the LAYER INPUT, :99,163).  Used for the CRE layers and, with only_cross_attention false, for the
+    gene layers."""
+
+    def __init__(self, d_model, nhead, hidden_dim=2048, dropout=0.1, batch_first=True, use_alibi=False,
+                 make_data_kv=False, mlp_dout=0.0, cross_alibi=False, flash_attn_3=False):
+        super().__init__()
+        self.mixer = FlashAttLayer(d_model, nhead, dropout=dropout, use_alibi=use_alibi, cross_attn=False)
+        self.crossMHA = FlashAttLayer(d_model, nhead, dropout=dropout, use_alibi=cross_alibi, cross_attn=True,
+                                      flash_attn_3=flash_attn_3)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.norm3 = nn.LayerNorm(d_model)
+        self.linear_geglu_1 = nn.Linear(d_model, hidden_dim)
+        self.dropout = nn.Dropout(mlp_dout)
+        self.linear_geglu_2 = nn.Linear(hidden_dim // 2, d_model)
+        self.use_alibi = use_alibi
+        self.num_heads = nhead
+        self.make_data_kv = make_data_kv
+        self.activation = nn.GELU()
+        if use_alibi:
+            self.register_buffer("m", get_alibi_slopes(self.num_heads))
+
+    def forward_packed(self, src, cu_src, max_src, context=None, cu_ctx=None, max_ctx=None, context_kv=None,
+                       cu_cross_q=None, max_cross_q=None):
+        """src fp32 [tokens, D] packed residual stream.  Cross-attention keys/values come either from
+        `context` (fp32 packed stream, projected here) or from a precomputed bf16 `context_kv` [tokens_k, 2D].
+        `cu_cross_q` lets several self-attention sequences share one K/V block (tissue copies of a gene)."""
+        assert not self.make_data_kv
+        h = ops.layernorm(src, self.norm1.weight, self.norm1.bias)
+        x1 = self.mixer.MHA.fused(h, src, cu_src, max_src)
+        h = ops.layernorm(x1, self.norm2.weight, self.norm2.bias)
+        if context_kv is None:
+            context_kv = self.crossMHA.MHA.project_kv(ops.cast_bf16(context))
+        cq = cu_src if cu_cross_q is None else cu_cross_q
+        mq = max_src if max_cross_q is None else max_cross_q
+        x2 = self.crossMHA.MHA.fused(h, x1, cq, mq, context_kv, cu_ctx, max_ctx)
+        h = ops.layernorm(x2, self.norm3.weight, self.norm3.bias)
+        w1, b1 = packed_linear(self.linear_geglu_1, geglu=True)
+        hg = ops.gemm(h, w1, b1, ops.EPI_GEGLU_BF16)
+        w2, b2 = packed_linear(self.linear_geglu_2)
+        return ops.gemm(hg, w2, b2, ops.EPI_RES_F32, residual=src)
+
+    def forward(self, src, context, src_key_padding_mask=None, context_padding_mask=None, precision=torch.float32,
+                unpad_info=None, context_unpad_info=None, gene_unpad_info=None):
+        """Reference signature.  `precision` is accepted and ignored: operands are always bf16 with fp32
+        accumulation (the reference's bf16-mixed path); there is no fp16 round trip."""
+        if context_padding_mask is None and src_key_padding_mask is not None:
+            context_padding_mask = src_key_padding_mask.clone()
+        info = gene_unpad_info if gene_unpad_info is not None else unpad_info
+        if info is not None:
+            cinfo = context_unpad_info if context_unpad_info is not None else info
+            return self.forward_packed(src.float().contiguous(), info["cu_seqlens"], info["max_seqlen"],
+                                       context.float().contiguous(), cinfo["cu_seqlens"], cinfo["max_seqlen"]).to(src.dtype)
+        batch, seqlen = src.shape[:2]
+        if src_key_padding_mask is None:
+            xs, cu, mx, idx = src.reshape(batch * seqlen, -1).float().contiguous(), _cu_from_padded(batch, seqlen, src.device), seqlen, None
+            cs, cuk, mxk = context.reshape(-1, context.shape[-1]).float().contiguous(), _cu_from_padded(batch, context.shape[1], src.device), context.shape[1]
+        else:
+            xs, idx, cu, mx, _ = unpad_input(src, ~src_key_padding_mask)
+            cs, _, cuk, mxk, _ = unpad_input(context, ~context_padding_mask)
+        out = self.forward_packed(xs, cu, mx, cs, cuk, mxk)
+        if idx is None:
+            return out.view(batch, seqlen, -1).to(src.dtype)
+        return pad_input(out, idx, batch, seqlen).to(src.dtype)
+
+
+class MultiRegistry(nn.Module):
+    """One registry token per tissue, prepended to the gene tokens (reference layers.py:502-524)."""
+
+    def __init__(self, num_tissues, emb_dim):
+        super().__init__()
+        self.num_registry_tokens = num_tissues
+        self.registry_tokens = nn.Embedding(num_tissues, emb_dim)
+
+    def forward(self, x, tissue_vector):
+        # vectorised form of the reference's per-row list comprehension (:509-515)
+        reg = self.registry_tokens.weight[tissue_vector[:, 0].long()].unsqueeze(1).to(x.dtype)
+        combined = torch.cat((reg, x), dim=1)
+        return combined, combined.clone()
+
+    def get_registry_tokens(self):
+        return self.registry_tokens.weight
+
+
+class TissueExpressionHeads(nn.Module):
+    """MLP + Softplus expression head (reference layers.py:1012-1144).  The shipped configuration is the
+    shared 'bigger' head (multi_head false, use_bigger_head true, :1078-1087):
+    Linear -> LayerNorm -> GELU -> Dropout -> Linear -> GELU -> Linear(D,1) -> Softplus.
+    All rows are evaluated in one batched pass instead of the reference's per-row loop with .item() syncs."""
+
+    def __init__(self, emb_dim, num_tissues, use_bigger_head=False, multi_head=True, mlp_dout=0.1,
+                 loss_fn="poisson", head_type="mlp"):
+        super().__init__()
+        self.multi_head = multi_head
+        self.softplus = loss_fn == "poisson"
+        if head_type != "mlp" or not use_bigger_head or multi_head:
+            raise NotImplementedError(
+                "only the shipped head (head_type='mlp', use_bigger_head=True, multi_head=False; "
+                "configs/vf_model.yaml:19,35) is implemented on the HIP path")
+        self.tissue_expressions = nn.Sequential(
+            nn.Linear(emb_dim, emb_dim), nn.LayerNorm(emb_dim), nn.GELU(), nn.Dropout(mlp_dout),
+            nn.Linear(emb_dim, emb_dim), nn.GELU(), nn.Linear(emb_dim, 1),
+            nn.Softplus() if self.softplus else nn.Identity())
+
+    def forward(self, g_exp, tissue_vector=None):
+        """g_exp fp32 [rows, D] -> fp32 [rows, 1]."""
+        te = self.tissue_expressions
+        x = ops.cast_bf16(g_exp.float().contiguous())
+        w0, b0 = packed_linear(te[0])
+        h = ops.gemm(x, w0, b0, ops.EPI_F32)
+        h = ops.layernorm(h, te[1].weight, te[1].bias, torch.bfloat16, gelu=True)
+        w4, b4 = packed_linear(te[4])
+        h = ops.gemm(h, w4, b4, ops.EPI_GELU_F32)
+        return ops.rowdot_softplus(h, te[6].weight.reshape(-1).contiguous(), te[6].bias, self.softplus)

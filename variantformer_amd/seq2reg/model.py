@@ -1,0 +1,103 @@
+"""Seq2RegPredictor: the DNA -> regulatory-element encoder ("tokenizer") on the HIP kernels.
+
+Same constructor arguments, hyper-parameter record and state-dict keys as the reference
+(seq2reg/model.py:40-191) so that `Seq2RegPredictor(**chk["hyper_parameters"])` followed by
+`load_state_dict(chk["state_dict"])` works unchanged (processors/model_manager.py:44-51).
+Only the inference path the hot loop uses is implemented: forward(only_embed=True)
+(seq2reg/model.py:193-279).  Training / classification heads are out of scope.
+"""
+from __future__ import annotations
+
+import math
+import types
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .modules import FlashTransformerLayer
+
+
+def positionalencoding1d(d_model: int, length: int) -> torch.Tensor:
+    """Sinusoidal table [length, d_model]; same values as the reference (seq2reg/model.py:15-37)."""
+    if d_model % 2 != 0:
+        raise ValueError("Cannot use sin/cos positional encoding with odd dim (got dim={:d})".format(d_model))
+    pe = torch.zeros(length, d_model)
+    position = torch.arange(0, length).unsqueeze(1)
+    div_term = torch.exp(torch.arange(0, d_model, 2, dtype=torch.float) * -(math.log(10000.0) / d_model))
+    pe[:, 0::2] = torch.sin(position.float() * div_term)
+    pe[:, 1::2] = torch.cos(position.float() * div_term)
+    return pe
+
+
+class Seq2RegPredictor(nn.Module):
+    def __init__(self, vocab_size: int, embedding_dim: int, num_heads: int, num_layers: int, num_tissues: int,
+                 num_classes: int, learning_rate: float = 1e-4, loss_fn=("cross_entropy", "0"), seq_pool: str = "mean",
+                 cre_type: str = "multi", token_length: int = None, use_context: bool = False,
+                 positional_encoding: str = "sinusoidal", use_flash: bool = False, majority_weight: float = None,
+                 weight_decay: float = 0.0, lr_scale: float = 1.0, strand_agg: str = "mean",
+                 expand_context: bool = False, mlp_dout: float = 0.1, tissues: list = None, **kwargs):
+        super().__init__()
+        hp = dict(vocab_size=vocab_size, embedding_dim=embedding_dim, num_heads=num_heads, num_layers=num_layers,
+                  num_tissues=num_tissues, num_classes=num_classes, learning_rate=learning_rate, loss_fn=loss_fn,
+                  seq_pool=seq_pool, cre_type=cre_type, token_length=token_length, use_context=use_context,
+                  positional_encoding=positional_encoding, use_flash=use_flash, majority_weight=majority_weight,
+                  weight_decay=weight_decay, lr_scale=lr_scale, strand_agg=strand_agg, expand_context=expand_context,
+                  mlp_dout=mlp_dout, tissues=tissues)
+        hp.update(kwargs)
+        self.hparams = types.SimpleNamespace(**hp)
+        assert use_flash, "Only Flash is supported"
+        assert positional_encoding in ["sinusoidal", "alibi"], "Position encoding must be either 'sinusoidal' or 'alibi'"
+        assert seq_pool in ["mean", "max", "linear"]
+        if use_context:
+            raise NotImplementedError(
+                "use_context=True tokenizers are not on the shipped path (the gene branch passes a float zero "
+                "tensor as context, model_combined_modulator.py:575-577, which only works with use_context=False)")
+        if seq_pool != "mean":
+            raise NotImplementedError("only seq_pool='mean' is implemented on the HIP path")
+        self.token_embedding = nn.Embedding(vocab_size, embedding_dim)
+        self.pos_encoding_type = positional_encoding
+        self.seq_pool = seq_pool
+        self.use_context = use_context
+        self.strand_agg = strand_agg
+        self.num_classes = num_classes
+        self.tissues = tissues
+        use_alibi = positional_encoding == "alibi"
+        if not use_alibi:
+            # plain attribute like the reference (not in the state dict, :105); a device copy is cached
+            self.position_encoding = positionalencoding1d(embedding_dim, token_length)
+        self._pe_dev = None
+        self.transformer_encoder = nn.ModuleList(
+            [FlashTransformerLayer(d_model=embedding_dim, nhead=num_heads, use_alibi=use_alibi) for _ in range(num_layers)])
+        # kept only so that checkpoints load strictly; unused at inference
+        in_f = embedding_dim * 2 if strand_agg == "concat" else embedding_dim
+        self.tissue_classifiers = nn.ModuleDict({str(t): nn.Linear(in_f, num_classes) for t in range(num_tissues)})
+
+    def _pos_table(self, device):
+        if self.pos_encoding_type != "sinusoidal":
+            return None
+        if self._pe_dev is None or self._pe_dev.device != device:
+            self._pe_dev = self.position_encoding.to(device).contiguous()
+        return self._pe_dev
+
+    def embed_packed(self, ids: torch.Tensor, pad: torch.Tensor, n_tokens: int, out_dtype=torch.bfloat16):
+        """ids int64 [W, L], pad bool/u8 [W, L] (True = pad) on the GPU -> pooled [W, d].
+        n_tokens = number of valid tokens (host-known; sizes the packed buffers)."""
+        W, L = ids.shape
+        cu = ops.mask_to_cu_seqlens(pad)
+        x = ops.embed_pack(ids, pad, cu, self.token_embedding.weight, self._pos_table(ids.device), n_tokens)
+        for layer in self.transformer_encoder:
+            x = layer.forward_packed(x, cu, L)
+        return ops.segment_mean(x, cu, out_dtype)
+
+    def forward(self, x, padding_mask, tissue_vector=None, context=None, only_embed=False, precision=torch.float32):
+        """x int64 [b, strands, L]; padding_mask bool [b, strands, L] (True = pad) -> fp32 [b, strands, d]
+        (reference seq2reg/model.py:193-279 with only_embed=True)."""
+        if not only_embed:
+            raise NotImplementedError("only the embedding path (only_embed=True) is part of the inference hot path")
+        b, ns, L = x.size()
+        dev = self.token_embedding.weight.device
+        ids = x.reshape(b * ns, L).to(dev).long().contiguous()
+        pad = padding_mask.reshape(b * ns, L).to(dev).contiguous()
+        n_tokens = int((~pad.bool()).sum().item())
+        return self.embed_packed(ids, pad, n_tokens, torch.float32).view(b, ns, -1)

@@ -1,0 +1,46 @@
+"""seq2reg transformer layer on the HIP kernels (reference: seq2reg/modules.py:129-191)."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..seq2gene.modules.layers import MHA, get_alibi_slopes, packed_linear  # noqa: F401
+
+
+class FlashTransformerLayer(nn.Module):
+    """LN1 -> self-MHA (ALiBi iff configured) -> +src -> LN2 -> GeGLU(d -> 2048 -> 1024 -> d) -> +src
+    (seq2reg/modules.py:149-191; both residuals add the layer INPUT, :152-153,179,188).
+
+    The reference re-pads after attention and zeroes the padded rows (:171-178); pads never feed a valid
+    token (attention is varlen, the rest is per-token) and are dropped by the pooling mask, so this
+    implementation keeps the stream packed from the embedding to the pool."""
+
+    def __init__(self, d_model, nhead, hidden_dim=2048, dropout=0.1, use_alibi=False, mlp_dout=0.1):
+        super().__init__()
+        self.MHA = MHA(d_model, nhead, dropout=dropout, use_flash_attn=True, use_alibi=use_alibi)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.linear_geglu_1 = nn.Linear(d_model, hidden_dim)
+        self.dropout = nn.Dropout(mlp_dout)
+        self.linear_geglu_2 = nn.Linear(hidden_dim // 2, d_model)
+
+    def forward_packed(self, src: torch.Tensor, cu: torch.Tensor, max_seqlen: int) -> torch.Tensor:
+        h = ops.layernorm(src, self.norm1.weight, self.norm1.bias)
+        x1 = self.MHA.fused(h, src, cu, max_seqlen)
+        h = ops.layernorm(x1, self.norm2.weight, self.norm2.bias)
+        w1, b1 = packed_linear(self.linear_geglu_1, geglu=True)
+        hg = ops.gemm(h, w1, b1, ops.EPI_GEGLU_BF16)
+        w2, b2 = packed_linear(self.linear_geglu_2)
+        return ops.gemm(hg, w2, b2, ops.EPI_RES_F32, residual=src)
+
+    def forward(self, src, src_key_padding_mask=None, precision=torch.float32):
+        """Reference signature on padded [b, L, d] input; padded rows of the result are left as the
+        reference leaves them only where they matter (valid rows); pad rows are returned as zeros."""
+        from ..seq2gene.modules.layers import pad_input, unpad_input, _cu_from_padded
+        b, L = src.shape[:2]
+        if src_key_padding_mask is None:
+            out = self.forward_packed(src.reshape(b * L, -1).float().contiguous(), _cu_from_padded(b, L, src.device), L)
+            return out.view(b, L, -1).to(src.dtype)
+        xs, idx, cu, mx, _ = unpad_input(src, ~src_key_padding_mask)
+        return pad_input(self.forward_packed(xs, cu, mx), idx, b, L).to(src.dtype)

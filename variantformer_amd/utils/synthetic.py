@@ -24,6 +24,7 @@ FIRST_REAL_TOKEN = 4  # ids 0..3 are <pad>,<s>,</s>,<unk>
 TISSUES_54 = [t for t in range(7, 63) if t not in (14, 45)]
 assert len(TISSUES_54) == 54
 
+MATRIX_GAIN = 0.4
 _M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
 
 
@@ -69,9 +70,14 @@ def _name_hash(name: str) -> int:
 def make_tensor(name: str, shape, seed: int, scale: float | None = None) -> np.ndarray:
     """Deterministic float32 tensor for a state-dict entry.
 
-    LayerNorm weights ~ 1 + 0.1 u, biases ~ 0.05 u, embeddings ~ 0.5 u,
-    matrices ~ u * sqrt(3 / fan_in) (unit-variance preserving), unless
-    ``scale`` is given.
+    LayerNorm weights ~ 1 + 0.1 u, biases ~ 0.02 u, embeddings ~ 0.5 u,
+    matrices ~ u * MATRIX_GAIN * sqrt(3 / fan_in), unless ``scale`` is given.
+
+    MATRIX_GAIN = 0.4 gives std 0.4/sqrt(fan_in) (0.010 at 1536, 0.018 at 512: the
+    N(0, 0.02)-style init of SURVEY.md §8d).  Unit gain (1.0) makes every residual branch
+    as large as the stream; such a random network amplifies a single bf16 ulp by ~10x per
+    layer (measured), which no trainable 49-layer model does and which would turn an
+    end-to-end parity test into a test of chaos rather than of the kernels.
     """
     shape = tuple(int(s) for s in shape)
     n = int(np.prod(shape)) if len(shape) else 1
@@ -86,11 +92,11 @@ def make_tensor(name: str, shape, seed: int, scale: float | None = None) -> np.n
     if leaf == "weight" and len(shape) == 1 and is_norm:
         return (np.float32(1.0) + np.float32(0.1) * u).astype(np.float32)
     if leaf == "bias" or len(shape) == 1:
-        return (np.float32(0.05) * u).astype(np.float32)
+        return (np.float32(0.02) * u).astype(np.float32)
     if "embedding" in parent or "registry" in parent or "token_embedding" in name:
         return (np.float32(0.5) * u).astype(np.float32)
     fan_in = shape[-1]
-    return (u * np.float32(np.sqrt(3.0 / fan_in))).astype(np.float32)
+    return (u * np.float32(MATRIX_GAIN * np.sqrt(3.0 / fan_in))).astype(np.float32)
 
 
 def fill_state_dict(module: torch.nn.Module, seed: int) -> None:
