@@ -1,0 +1,238 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the VariantFormer hot path on MI355X (contract: see the task statement).
+
+Metric (BASELINE.json): genes/sec/node, 54-tissue expression at a 1 Mb cis-window, bf16 operands.
+Workload at N=1 = BASELINE.json configs[1] ("Full 1.2 B checkpoint, 1 Mb window, 54 tissues, 1 donor VCF on
+1xMI355X bf16") with SURVEY.md §8d's synthetic geometry: per gene N=1024 cCRE windows (70-125 valid tokens of
+200), C=200 gene chunks of 200 tokens, T=54 tissues; model = full architecture (25 modulator layers, D=1536,
+H=32; seq2reg d=512 / h=8 / 6 layers -- survey default until the tokenizer checkpoint can be read), random-init
+weights (no checkpoint offline).
+
+A step = one pass of the hot path (Seq2GenePredictorCombinedModulator.forward_prepared + D2H of the fp32 outputs)
+over one batch of `--genes-per-step` genes whose token ids / masks are already resident in HBM.
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), genes shard across ranks (weak scaling: every
+rank runs `--genes-per-step` genes per step) and one all-gather reassembles the expression matrix each step.
+
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+MFMA_PEAK_TFLOPS = 2500.0      # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+HBM_PEAK_GBS = 8000.0
+
+SEQ2REG_HP = dict(vocab_size=500, embedding_dim=512, num_heads=8, num_layers=6, num_tissues=1, num_classes=2,
+                  learning_rate=1e-4, loss_fn=["cross_entropy", "0"], seq_pool="mean", cre_type="binary",
+                  token_length=200, use_context=False, positional_encoding="sinusoidal", use_flash=True)
+SEQ2GENE_KW = dict(num_tissues=63, emb_dim=1536, gene_emb_dim=512, num_heads=32, num_layers=25, use_alibi=True,
+                   mlp_dout=0.1, use_context=True, token_dim=512, gene_pooling="multi_registry", multi_head=False,
+                   use_bigger_head=True, only_cross_attention=False, cross_alibi=False, add_context_to_cres=False,
+                   use_res=False, train_gene_tokenizer=True, use_batching=True)
+
+
+def build_model(device, layers=None, seq2reg_layers=None, seed=1234):
+    from variantformer_amd.seq2gene.model_combined_modulator import Seq2GenePredictorCombinedModulator
+    from variantformer_amd.seq2reg.model import Seq2RegPredictor
+    hp = dict(SEQ2REG_HP)
+    kw = dict(SEQ2GENE_KW)
+    if layers:
+        kw["num_layers"] = layers
+    if seq2reg_layers:
+        hp["num_layers"] = seq2reg_layers
+    with torch.device(device):
+        cre_tok, gene_tok = Seq2RegPredictor(**hp), Seq2RegPredictor(**hp)
+        model = Seq2GenePredictorCombinedModulator(cre_tokenizer=cre_tok, gene_tokenizer=gene_tok, **kw)
+    for t in (cre_tok, gene_tok):
+        t.position_encoding = t.position_encoding.cpu()
+    g = torch.Generator(device=device).manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            leaf = name.rsplit(".", 1)[-1]
+            if p.dim() >= 2 and "embedding" not in name and "registry" not in name:
+                p.normal_(0.0, 0.4 / float(np.sqrt(p.shape[-1])), generator=g)     # same scale as utils.synthetic
+            elif p.dim() >= 2:
+                p.normal_(0.0, 0.29, generator=g)
+            elif leaf == "weight":
+                p.fill_(1.0)
+            else:
+                p.normal_(0.0, 0.01, generator=g)
+    model.eval()
+    return model, hp, kw
+
+
+def host_threads() -> int:
+    """Usable host cores: min(affinity, cgroup CPU quota) -- the GPU box shows 256 logical CPUs but a 16-CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(model, hp, kw, executed_full: float, threads: int, budget_s: float = 20.0):
+    """Oracle ("port" of the reference algorithm, fp32, tissue copies repeated as the reference does) timed on the
+    host cores on a bounded sample of the same workload, scaled by executed FLOPs to genes/sec.  The sample is
+    grown until the next size would exceed the time budget."""
+    from oracle import vf_oracle as O
+    from variantformer_amd.utils.flops import batch_flops
+    from variantformer_amd.utils.synthetic import TISSUES_54, make_batch
+    torch.set_num_threads(threads)
+    sd = {k: v.detach().cpu().float() if torch.is_floating_point(v) else v.detach().cpu() for k, v in model.state_dict().items()}
+    shp = O.Seq2RegHP.from_hparams(hp)
+    ghp = O.Seq2GeneHP.from_kwargs(kw)
+    best = None
+    for n_cre, n_chunk, n_t in [(16, 3, 1), (48, 9, 3), (128, 25, 6), (256, 50, 8)]:
+        sample = make_batch(777, [n_cre], [n_chunk], [TISSUES_54[:n_t]], 200)
+        f_sample = batch_flops(sample, hp["embedding_dim"], hp["num_layers"], kw["emb_dim"], kw["num_layers"],
+                               executed_by_reference=True)
+        if best is not None and f_sample / best[1] * best[0] > budget_s:
+            break
+        t0 = time.perf_counter()
+        O.predict_step(sample, sd, shp, shp, ghp, rounding=None, share_cre_stream=False)
+        dt = time.perf_counter() - t0
+        best = (dt, f_sample, n_cre, n_chunk, n_t)
+    dt, f_sample, n_cre, n_chunk, n_t = best
+    genes_per_s = 1.0 / (dt * executed_full / f_sample)
+    return {"value": genes_per_s, "unit": "genes/sec", "cores": threads, "kind": "port",
+            "sample": f"1 gene, N={n_cre} cCREs, C={n_chunk} chunks, T={n_t} tissues, full-depth model, fp32 oracle "
+                      f"with per-tissue repeats as the reference executes them: {dt:.1f} s for {f_sample / 1e12:.3f} TFLOP "
+                      f"({f_sample / dt / 1e12:.2f} TFLOP/s), scaled to the {executed_full / 1e12:.1f} TFLOP the reference "
+                      f"executes per full-size gene"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--genes-per-step", type=int, default=1, help="genes per rank per step (cfg 2 of SURVEY §8d: 1)")
+    ap.add_argument("--n-cre", type=int, default=1024)
+    ap.add_argument("--n-chunks", type=int, default=200)
+    ap.add_argument("--tissues", type=int, default=54)
+    ap.add_argument("--layers", type=int, default=None, help="override modulator depth (debug only; invalidates the number)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or (world == 1 and args.gpus == 1), f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback on the product path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from variantformer_amd import ops
+    from variantformer_amd.dist import all_gather_expression
+    from variantformer_amd.utils.flops import batch_flops
+    from variantformer_amd.utils.synthetic import TISSUES_54, make_batch
+
+    model, hp, kw = build_model(dev, args.layers)
+    G = args.genes_per_step
+    tissues = TISSUES_54[: args.tissues]
+    batch = make_batch(20251205 + rank, [args.n_cre] * G, [args.n_chunks] * G, [tissues] * G, 200)
+    flops_step = batch_flops(batch, hp["embedding_dim"], hp["num_layers"], kw["emb_dim"], kw["num_layers"])
+    executed_step = batch_flops(batch, hp["embedding_dim"], hp["num_layers"], kw["emb_dim"], kw["num_layers"],
+                                executed_by_reference=True)
+    owned = [list(range(r * G, (r + 1) * G)) for r in range(world)]
+
+    with torch.no_grad():
+        pb = model.prepare_batch(batch)                      # inputs resident in HBM before the timed region
+
+        def step():
+            pred, emb = model.forward_prepared(pb)
+            expr = pred.view(G, len(tissues))
+            if world > 1:
+                expr = all_gather_expression(expr, owned, world * G)
+            return expr.cpu(), emb                            # D2H of the expression matrix (sync point of a step)
+
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            expr, _ = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        assert torch.isfinite(expr).all()
+
+        roof = None
+        kernels = {}
+        if rank == 0 and not args.no_kernel_timing:
+            # Per-kernel durations: the same K steps replayed with HIP events bracketing each launch on the launch
+            # stream (kept out of the timed region above so that event overhead does not enter `value`).
+            ops.TIMER = ops.KernelTimer()
+            for _ in range(args.steps):
+                step()
+            summ = ops.TIMER.summary()
+            ops.TIMER = None
+            g = summ["gemm"]
+            tf = g["flops"] / (g["total_ms"] * 1e-3) / 1e12
+            roof = {"kernel": "gemm_mfma_kernel (vf_gemm_bf16, all epilogues)", "bound": "mfma", "achieved": round(tf, 1),
+                    "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": g["launches"] // args.steps,
+                    "avg_launch_us": round(g["total_ms"] * 1e3 / g["launches"], 2),
+                    "flop_per_launch": g["flops"] / g["launches"],
+                    "share_of_step_time": round(g["total_ms"] / args.steps / (dt / args.steps * 1e3), 3)}
+            a = summ.get("attn")
+            if a:
+                kernels["attn_fwd_kernel"] = {"launches_per_step": a["launches"] // args.steps,
+                                              "total_ms_per_step": round(a["total_ms"] / args.steps, 3),
+                                              "algorithmic_GBps": round(a["bytes"] / (a["total_ms"] * 1e-3) / 1e9, 1),
+                                              "share_of_step_time": round(a["total_ms"] / args.steps / (dt / args.steps * 1e3), 3)}
+
+    if rank == 0:
+        value = world * G * args.steps / dt
+        out = {
+            "metric": "genes/sec/node (54-tissue expr) at 1 Mb cis-window", "value": round(value, 4), "unit": "genes/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: full 1.2B-architecture model, 1 Mb window, 54 tissues, 1 donor",
+                       "genes_per_step_per_gpu": G, "n_cre_windows": args.n_cre, "gene_chunks": args.n_chunks,
+                       "tissues": len(tissues), "tokens_per_window": 200, "modulator_layers": kw["num_layers"],
+                       "emb_dim": kw["emb_dim"], "heads": kw["num_heads"], "seq2reg": "d=512,h=8,layers=6 (assumed)",
+                       "weights": "random init (no checkpoint offline)", "parallelism": f"gene-shard x{world}"},
+            "algorithmic_tflop_per_gene": round(flops_step / G / 1e12, 3),
+            "reference_executed_tflop_per_gene": round(executed_step / G / 1e12, 3),
+            "achieved_algorithmic_tflops_whole_step": round(world * flops_step * args.steps / dt / 1e12, 1),
+            "roofline": roof, "other_kernels": kernels,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(model, hp, kw, executed_step / G, host_threads())
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

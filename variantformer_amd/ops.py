@@ -18,6 +18,34 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+class KernelTimer:
+    """Brackets individual kernel launches with HIP events ON THE STREAM THE KERNEL IS LAUNCHED ON (torch's
+    current stream, which is the stream handed to the C ABI).  Used by bench.py for the roofline numbers."""
+
+    def __init__(self):
+        self.records = {}
+
+    def time(self, name: str, flops: float, nbytes: float, launch):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        out = launch()
+        b.record()
+        self.records.setdefault(name, []).append((a, b, flops, nbytes))
+        return out
+
+    def summary(self) -> dict:
+        torch.cuda.synchronize()
+        out = {}
+        for name, recs in self.records.items():
+            ms = sum(a.elapsed_time(b) for a, b, _, _ in recs)
+            out[name] = {"launches": len(recs), "total_ms": ms, "flops": sum(r[2] for r in recs),
+                         "bytes": sum(r[3] for r in recs)}
+        return out
+
+
+TIMER: KernelTimer | None = None
+
+
 def _dev(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:
@@ -56,9 +84,16 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None, epilogue: 
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous()
     lib = _lib.load()
-    check(lib.vf_gemm_bf16(a.data_ptr(), a.stride(0) if M > 1 else max(a.stride(0), K), w.data_ptr(), _ptr(bias),
-                           _ptr(residual), ldr, out.data_ptr(), out.stride(0) if M > 1 else max(out.stride(0), n_out),
-                           M, N, K, epilogue, _stream()), "vf_gemm_bf16")
+
+    def launch():
+        check(lib.vf_gemm_bf16(a.data_ptr(), a.stride(0) if M > 1 else max(a.stride(0), K), w.data_ptr(), _ptr(bias),
+                               _ptr(residual), ldr, out.data_ptr(), out.stride(0) if M > 1 else max(out.stride(0), n_out),
+                               M, N, K, epilogue, _stream()), "vf_gemm_bf16")
+    if TIMER is not None:
+        nbytes = 2.0 * (M * K + N * K) + out.numel() * out.element_size() + (0 if residual is None else 4.0 * M * N)
+        TIMER.time("gemm", 2.0 * M * N * K, nbytes, launch)
+    else:
+        launch()
     return out
 
 
@@ -88,10 +123,16 @@ def attn_varlen(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_q: torch.T
         scale = 1.0 / math.sqrt(head_dim)
     if slopes is not None:
         assert slopes.dtype == torch.float32 and slopes.numel() == n_heads
-    check(_lib.load().vf_attn_varlen_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), q.stride(0),
-                                         k.stride(0), v.stride(0), out.stride(0), cu_q.data_ptr(), _ptr(cu_k),
-                                         cu_q.numel() - 1, int(max_q), int(max_k), n_heads, head_dim, _ptr(slopes),
-                                         float(scale), _stream()), "vf_attn_varlen_fwd")
+    def launch():
+        check(_lib.load().vf_attn_varlen_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), q.stride(0),
+                                             k.stride(0), v.stride(0), out.stride(0), cu_q.data_ptr(), _ptr(cu_k),
+                                             cu_q.numel() - 1, int(max_q), int(max_k), n_heads, head_dim, _ptr(slopes),
+                                             float(scale), _stream()), "vf_attn_varlen_fwd")
+    if TIMER is not None:
+        # flops need the per-sequence lengths; the caller may attach them (attn_work), else a bound from max lengths
+        TIMER.time("attn", 0.0, 2.0 * D * (2 * q.shape[0] + 2 * k.shape[0]), launch)
+    else:
+        launch()
     return out
 
 
