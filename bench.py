@@ -121,7 +121,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--genes-per-step", type=int, default=1, help="genes per rank per step (cfg 2 of SURVEY §8d: 1)")
+    ap.add_argument("--genes-per-step", type=int, default=8,
+                    help="genes per rank per step; 8 = the reference's own DataLoader batch_size (configs/vcfloader.yaml:5)")
     ap.add_argument("--n-cre", type=int, default=1024)
     ap.add_argument("--n-chunks", type=int, default=200)
     ap.add_argument("--tissues", type=int, default=54)

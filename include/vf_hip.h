@@ -59,6 +59,12 @@ int vf_gemm_bf16(const void* A, int64_t lda, const void* W, const float* bias,
                  const float* residual, int64_t ldr, void* out, int64_t ldo,
                  int M, int N, int K, int epilogue, void* stream);
 
+/* Same as vf_gemm_bf16 with an explicit tile configuration (tuning and tests): variant 0 = automatic
+ * choice (what vf_gemm_bf16 does), 1..7 = fixed configurations (see vf_gemm.hip, CfgA..CfgG). */
+int vf_gemm_bf16_ex(const void* A, int64_t lda, const void* W, const float* bias,
+                    const float* residual, int64_t ldr, void* out, int64_t ldo,
+                    int M, int N, int K, int epilogue, int variant, void* stream);
+
 /* Permute rows of a [2F, K] bf16 weight (and its fp32 bias, may be NULL) into the VF_EPI_GEGLU_BF16
  * layout (one-time weight repack at checkpoint load). */
 int vf_pack_geglu_rows(const void* W, const float* bias, void* W_out, float* bias_out,

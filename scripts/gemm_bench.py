@@ -1,0 +1,42 @@
+"""GEMM tile-configuration sweep on the shapes of the headline workload (random data, interleaved rounds)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from variantformer_amd import ops
+
+SHAPES = [  # (name, M, N, K, epilogue)
+    ("gene Wqkv", 10854, 4608, 1536, ops.EPI_BF16), ("gene out_proj", 10854, 1536, 1536, ops.EPI_RES_F32),
+    ("gene geglu1", 10854, 2048, 1536, ops.EPI_GEGLU_BF16), ("gene geglu2", 10854, 1536, 1024, ops.EPI_RES_F32),
+    ("s2r Wqkv", 140000, 1536, 512, ops.EPI_BF16), ("s2r out_proj", 140000, 512, 512, ops.EPI_RES_F32),
+    ("s2r geglu1", 140000, 2048, 512, ops.EPI_GEGLU_BF16), ("s2r geglu2", 140000, 512, 1024, ops.EPI_RES_F32),
+    ("cre Wqkv", 1024, 4608, 1536, ops.EPI_BF16), ("cre out_proj", 1024, 1536, 1536, ops.EPI_RES_F32),
+    ("cre kv", 1024, 3072, 1536, ops.EPI_BF16), ("cre geglu2", 1024, 1536, 1024, ops.EPI_RES_F32),
+    ("cre8 Wqkv", 8192, 4608, 1536, ops.EPI_BF16), ("cre8 out_proj", 8192, 1536, 1536, ops.EPI_RES_F32),
+]
+variants = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else "1,2,3,4,5,6,7".split(","))]
+rounds = 5
+print("%-14s %7s %5s %5s | " % ("shape", "M", "N", "K") + " ".join("v%d TF/s" % v for v in variants))
+for name, M, N, K, epi in SHAPES:
+    a = (torch.rand((M, K), device="cuda") * 2 - 1).bfloat16()
+    w = ((torch.rand((N, K), device="cuda") * 2 - 1) / K ** 0.5).bfloat16()
+    b = torch.rand((N,), device="cuda")
+    res = torch.rand((M, N), device="cuda") if epi == ops.EPI_RES_F32 else None
+    ref = None
+    best = {v: 1e9 for v in variants}
+    for rnd in range(rounds + 1):
+        for v in variants:
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            o = ops.gemm(a, w, b, epi, residual=res, variant=v)
+            e.record()
+            torch.cuda.synchronize()
+            if rnd == 0:
+                if ref is None:
+                    ref = o.float()
+                else:
+                    err = float((o.float() - ref).abs().max() / ref.abs().max())
+                    assert err < 1e-2, (name, v, err)
+            else:
+                best[v] = min(best[v], s.elapsed_time(e))
+    fl = 2.0 * M * N * K
+    print("%-14s %7d %5d %5d | " % (name, M, N, K) + " ".join("%8.0f" % (fl / (best[v] * 1e-3) / 1e12) for v in variants))

@@ -137,6 +137,9 @@ ATTN_CASES = [
     (32, 2, [31, 64, 100], None, True),
     (64, 2, [1000], None, True),
     (48, 2, [130, 257], [1, 63], False),
+    (48, 4, [201, 9, 64, 65], [100, 256, 1, 129], False),    # short-sequence kernel, cross attention, ragged
+    (64, 8, [70, 125, 99, 1, 128], None, False),             # short-sequence kernel, 2 query groups per wave
+    (48, 32, [201] * 6, None, True),                         # gene stream shape
 ]
 
 

@@ -52,7 +52,110 @@ __device__ __forceinline__ s16x4_t lds_tr_read(const char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
 }
 
-template <int DH, int QG>
+// One 64-key tile for QG query groups of a wave: S^T = K.Q^T, online softmax, O^T += V^T.P^T.
+// sK / sV point at the tile's first key row in LDS.  All state is per lane (r = query, g = key sub-block).
+template <int DH, int QG, bool ALIBI>
+__device__ __forceinline__ void attn_tile(const char* sK, const char* sV, int kb0, int len_k, int r, int g, float c,
+                                          float slope2, const bf16x8_t (&qf)[QG][2], const float (&q_pos)[QG],
+                                          f32x4_t (&o)[QG][DH / 16], float (&m_run)[QG], float (&l_run)[QG]) {
+    constexpr int DT = DH / 16;
+    constexpr int VROW = VLayout<DH>::ROW;
+    // ---- S^T = K . Q^T : 4 key tiles x 2 k-steps, K fragments shared by the QG query groups
+    f32x4_t s[QG][4];
+#pragma unroll
+    for (int qg = 0; qg < QG; ++qg)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) s[qg][kt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(
+                sK + (16 * kt + r) * K_ROW_BYTES + (((4 * ks + g) ^ (r >> 1)) << 4));
+#pragma unroll
+            for (int qg = 0; qg < QG; ++qg)
+                s[qg][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qg][ks], s[qg][kt], 0, 0, 0);
+        }
+    }
+
+    // ---- online softmax per query group (lane (r,g): query r, keys kb0 + 16kt + 4g + e)
+    bf16x8_t pf[QG][2];
+    const bool tail = kb0 + BKV > len_k;           // wave-uniform: only the last (ragged) key tile masks keys
+    const int klim = len_k - kb0 - 4 * g;          // key 16kt+e of this lane is valid iff 16kt+e < klim
+    const float k_pos0 = (float)(kb0 + 4 * g);
+#pragma unroll
+    for (int qg = 0; qg < QG; ++qg) {
+        if (ALIBI) {
+            const float dq = q_pos[qg] - k_pos0;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    s[qg][kt][e] = fmaf(s[qg][kt][e], c, -slope2 * fabsf(dq - (float)(16 * kt + e)));
+        }
+        if (tail) {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s[qg][kt][e] = (16 * kt + e) < klim ? s[qg][kt][e] : -INFINITY;
+        }
+        float mx = fmaxf(fmaxf(s[qg][0][0], s[qg][0][1]), fmaxf(s[qg][0][2], s[qg][0][3]));
+#pragma unroll
+        for (int kt = 1; kt < 4; ++kt)
+            mx = fmaxf(fmaxf(fmaxf(mx, s[qg][kt][0]), fmaxf(s[qg][kt][1], s[qg][kt][2])), s[qg][kt][3]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_old = m_run[qg];
+        const float m_new = fmaxf(m_old, mx);        // finite: tile 0 always holds a valid key
+        m_run[qg] = m_new;
+        // p = exp2(c*s - c*m) (no ALiBi: scale folded into one packed FMA) or exp2(s - m) (ALiBi: already scaled)
+        const float mc = ALIBI ? -m_new : -m_new * c;
+        const float cc = ALIBI ? 1.0f : c;
+        float psum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float p = __builtin_amdgcn_exp2f(fmaf(s[qg][kt][e], cc, mc));
+                s[qg][kt][e] = p;
+                psum += p;
+            }
+        if (__any(m_new > m_old)) {                  // wave-uniform: rescale only when some running max moved
+            const float alpha = __builtin_amdgcn_exp2f(ALIBI ? (m_old - m_new) : (m_old - m_new) * c);
+            l_run[qg] *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) o[qg][dt] *= alpha;
+        }
+        l_run[qg] += psum;                           // lane-partial; reduced over g at the end
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            u32x4_t pk;
+            pk[0] = pack2bf(s[qg][2 * kb][0], s[qg][2 * kb][1]);
+            pk[1] = pack2bf(s[qg][2 * kb][2], s[qg][2 * kb][3]);
+            pk[2] = pack2bf(s[qg][2 * kb + 1][0], s[qg][2 * kb + 1][1]);
+            pk[3] = pack2bf(s[qg][2 * kb + 1][2], s[qg][2 * kb + 1][3]);
+            pf[qg][kb] = *reinterpret_cast<bf16x8_t*>(&pk);
+        }
+    }
+
+    // ---- O^T += V^T . P^T : V^T fragments by transposed LDS reads, shared by the QG groups
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const char* vp = sV + (32 * kb + 4 * g + (r >> 2)) * VROW + 32 * dt + 8 * (r & 3);
+            const s16x4_t lo = lds_tr_read(vp);
+            const s16x4_t hi = lds_tr_read(vp + 16 * VROW);
+            const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+            for (int qg = 0; qg < QG; ++qg)
+                o[qg][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qg][kb], o[qg][dt], 0, 0, 0);
+        }
+    }
+
+}
+
+template <int DH, int QG, bool ALIBI>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P) {
     constexpr int CPR = DH / 8;                       // 16-byte chunks per K/V row
     constexpr int NCHUNK = BKV * CPR;                 // chunks per tile
@@ -101,9 +204,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P) {
         }
     }
 
-    const float slope2 = P.slopes ? P.slopes[h] * 1.4426950408889634f : 0.f;
-    const bool use_alibi = P.slopes != nullptr;
-    const int rel0 = len_k - len_q;
+    // scores live in the log2 domain: p = exp2(c*s + bias - m).  Without ALiBi the running max is kept on the RAW
+    // score (c > 0, so the arg-max is the same) and scale and max are folded into one FMA per element.
+    const float c = P.scale_log2;
+    const float slope2 = ALIBI ? P.slopes[h] * 1.4426950408889634f : 0.f;
+    float q_pos[QG];                                   // query position + (sk - sq), as float (exact: < 2^24)
+#pragma unroll
+    for (int qg = 0; qg < QG; ++qg) q_pos[qg] = (float)(q_abs[qg] + (len_k - len_q));
 
     f32x4_t o[QG][DT];
     float m_run[QG], l_run[QG];
@@ -157,87 +264,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P) {
         const char* sV = sK + K_TILE_BYTES;
         const int kb0 = t * BKV;
 
-        // ---- S^T = K . Q^T : 4 key tiles x 2 k-steps, K fragments shared by the QG query groups
-        f32x4_t s[QG][4];
-#pragma unroll
-        for (int qg = 0; qg < QG; ++qg)
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) s[qg][kt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(
-                    sK + (16 * kt + r) * K_ROW_BYTES + (((4 * ks + g) ^ (r >> 1)) << 4));
-#pragma unroll
-                for (int qg = 0; qg < QG; ++qg)
-                    s[qg][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qg][ks], s[qg][kt], 0, 0, 0);
-            }
-        }
-
-        // ---- online softmax per query group (lane (r,g): query r, keys 16kt+4g+reg)
-        bf16x8_t pf[QG][2];
-#pragma unroll
-        for (int qg = 0; qg < QG; ++qg) {
-            float mx = -INFINITY;
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int kpos = kb0 + 16 * kt + 4 * g + e;
-                    float v = s[qg][kt][e] * P.scale_log2;
-                    if (use_alibi) {
-                        const int rel = q_abs[qg] + rel0 - kpos;
-                        v -= slope2 * (float)(rel < 0 ? -rel : rel);
-                    }
-                    v = kpos < len_k ? v : -INFINITY;
-                    s[qg][kt][e] = v;
-                    mx = fmaxf(mx, v);
-                }
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float m_new = fmaxf(m_run[qg], mx);          // finite: tile 0 always has a valid key
-            const float alpha = __builtin_amdgcn_exp2f(m_run[qg] - m_new);
-            m_run[qg] = m_new;
-            float psum = 0.f;
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float p = __builtin_amdgcn_exp2f(s[qg][kt][e] - m_new);
-                    s[qg][kt][e] = p;
-                    psum += p;
-                }
-            }
-            l_run[qg] = l_run[qg] * alpha + psum;             // lane-partial; reduced over g at the end
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) o[qg][dt] *= alpha;
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                u32x4_t pk;
-                pk[0] = pack2bf(s[qg][2 * kb][0], s[qg][2 * kb][1]);
-                pk[1] = pack2bf(s[qg][2 * kb][2], s[qg][2 * kb][3]);
-                pk[2] = pack2bf(s[qg][2 * kb + 1][0], s[qg][2 * kb + 1][1]);
-                pk[3] = pack2bf(s[qg][2 * kb + 1][2], s[qg][2 * kb + 1][3]);
-                pf[qg][kb] = *reinterpret_cast<bf16x8_t*>(&pk);
-            }
-        }
-
-        // ---- O^T += V^T . P^T : V^T fragments by transposed LDS reads, shared by the QG groups
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                const char* vp = sV + (32 * kb + 4 * g + (r >> 2)) * VROW + 32 * dt + 8 * (r & 3);
-                const s16x4_t lo = lds_tr_read(vp);
-                const s16x4_t hi = lds_tr_read(vp + 16 * VROW);
-                const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-#pragma unroll
-                for (int qg = 0; qg < QG; ++qg)
-                    o[qg][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qg][kb], o[qg][dt], 0, 0, 0);
-            }
-        }
+        attn_tile<DH, QG, ALIBI>(sK, sV, kb0, len_k, r, g, c, slope2, qf, q_pos, o, m_run, l_run);
 
         if (t + 1 < nkv) write_lds((t + 1) & 1);
         __syncthreads();
@@ -263,16 +290,150 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P) {
     }
 }
 
-template <int DH>
-int launch_attn(const AttnParams& P, int n_seq, int max_q, hipStream_t st) {
+// Short sequences (<= 256 queries and keys: seq2reg windows, the gene stream): one block per (sequence, head).
+// The whole K/V of the sequence is staged into LDS once (all loads issued before the first store: one load latency,
+// no per-tile barriers) and is fetched once per (sequence, head) instead of once per 64-query block.
+// Wave w owns the query groups w, w+4, ... (16 queries each), QG = ceil(max_seqlen_q / 64) of them, processed
+// together so that every K / V fragment read from LDS feeds QG MFMAs.
+template <int DH, int QG, bool ALIBI>
+__global__ __launch_bounds__(256, (QG >= 2 ? 2 : 4)) void attn_short_kernel(AttnParams P, int k_rows) {
+    constexpr int CPR = DH / 8;
+    constexpr int DT = DH / 16;
+    constexpr int VROW = VLayout<DH>::ROW;
+    constexpr int MAXIT = 8;                                      // 256 rows x 8 chunk slots / 256 threads
+    extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
+    char* const sK0 = smem_dyn;
+    char* const sV0 = smem_dyn + k_rows * K_ROW_BYTES;
+
+    const int seq = blockIdx.x, h = blockIdx.y;
+    const int q_tok0 = P.cu_q[seq], len_q = P.cu_q[seq + 1] - q_tok0;
+    const int k_tok0 = P.cu_k[seq], len_k = P.cu_k[seq + 1] - k_tok0;
+    if (len_q <= 0 || len_k <= 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int nkv = (len_k + BKV - 1) / BKV;
+    const int nchunks = nkv * BKV * 8;
+
+    // ---- stage K (swizzled, zero pad chunks) and V; rows >= len_k replicate the last key (finite, masked later)
+    const unsigned short* kbase = P.k + (int64_t)k_tok0 * P.k_stride + h * DH;
+    const unsigned short* vbase = P.v + (int64_t)k_tok0 * P.v_stride + h * DH;
+    {
+        u32x4_t kbuf[MAXIT], vbuf[MAXIT];
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            const int ci = tid + 256 * it;
+            const int row = ci >> 3, cc = ci & 7;
+            kbuf[it] = (u32x4_t){0u, 0u, 0u, 0u};
+            vbuf[it] = (u32x4_t){0u, 0u, 0u, 0u};
+            if (ci < nchunks && cc < CPR) {
+                const int key = row < len_k ? row : len_k - 1;
+                kbuf[it] = *reinterpret_cast<const u32x4_t*>(kbase + (int64_t)key * P.k_stride + cc * 8);
+                vbuf[it] = *reinterpret_cast<const u32x4_t*>(vbase + (int64_t)key * P.v_stride + cc * 8);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            const int ci = tid + 256 * it;
+            const int row = ci >> 3, cc = ci & 7;
+            if (ci < nchunks) {
+                *reinterpret_cast<u32x4_t*>(sK0 + row * K_ROW_BYTES + ((cc ^ ((row >> 1) & 7)) << 4)) = kbuf[it];
+                if (cc < CPR) *reinterpret_cast<u32x4_t*>(sV0 + row * VROW + (cc << 4)) = vbuf[it];
+            }
+        }
+    }
+
+    // ---- Q fragments of this wave's query groups
+    bf16x8_t qf[QG][2];
+    int q_abs[QG];
+    float q_pos[QG];
+#pragma unroll
+    for (int qg = 0; qg < QG; ++qg) {
+        q_abs[qg] = (wave + 4 * qg) * 16 + r;
+        const int row = q_abs[qg] < len_q ? q_abs[qg] : len_q - 1;
+        const unsigned short* qp = P.q + (int64_t)(q_tok0 + row) * P.q_stride + h * DH;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int d0 = 32 * ks + 8 * g;
+            u32x4_t raw = (u32x4_t){0u, 0u, 0u, 0u};
+            if (d0 < DH) raw = *reinterpret_cast<const u32x4_t*>(qp + d0);
+            qf[qg][ks] = *reinterpret_cast<bf16x8_t*>(&raw);
+        }
+        q_pos[qg] = (float)(q_abs[qg] + (len_k - len_q));
+    }
+    const float c = P.scale_log2;
+    const float slope2 = ALIBI ? P.slopes[h] * 1.4426950408889634f : 0.f;
+    f32x4_t o[QG][DT];
+    float m_run[QG], l_run[QG];
+#pragma unroll
+    for (int qg = 0; qg < QG; ++qg) {
+        m_run[qg] = -INFINITY;
+        l_run[qg] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[qg][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+    if (wave * 16 >= len_q) return;                                // this wave owns no valid query (wave-uniform)
+
+    for (int t = 0; t < nkv; ++t)
+        attn_tile<DH, QG, ALIBI>(sK0 + t * BKV * K_ROW_BYTES, sV0 + t * BKV * VROW, t * BKV, len_k, r, g, c, slope2, qf,
+                                 q_pos, o, m_run, l_run);
+
+#pragma unroll
+    for (int qg = 0; qg < QG; ++qg) {
+        float l = l_run[qg];
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        const float inv = 1.0f / l;
+        if (q_abs[qg] < len_q) {
+            unsigned short* op = P.out + (int64_t)(q_tok0 + q_abs[qg]) * P.o_stride + h * DH + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                u32x2_t pk;
+                pk[0] = pack2bf(o[qg][dt][0] * inv, o[qg][dt][1] * inv);
+                pk[1] = pack2bf(o[qg][dt][2] * inv, o[qg][dt][3] * inv);
+                *reinterpret_cast<u32x2_t*>(op + 16 * dt) = pk;
+            }
+        }
+    }
+}
+
+template <int DH, int QG, bool ALIBI>
+int launch_short(const AttnParams& P, int n_seq, int max_k, hipStream_t st) {
+    const int k_rows = ((max_k + BKV - 1) / BKV) * BKV;
+    const int lds = k_rows * (K_ROW_BYTES + VLayout<DH>::ROW);
+    auto kern = attn_short_kernel<DH, QG, ALIBI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                256 * (K_ROW_BYTES + VLayout<DH>::ROW)) != hipSuccess) {
+            (void)hipGetLastError();
+            vf_set_error("vf_attn_varlen_fwd: cannot reserve LDS");
+            return VF_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(n_seq, P.H), dim3(256), lds, st, P, k_rows);
+    VF_CHECK_LAUNCH("vf_attn_varlen_fwd");
+    return VF_OK;
+}
+
+template <int DH, bool ALIBI>
+int launch_attn(const AttnParams& P, int n_seq, int max_q, int max_k, hipStream_t st) {
+    // Measured on MI355X (scripts/attn_bench.py): the one-block-per-(sequence, head) kernel wins for the gene stream
+    // (201-token sequences, dh 48); for seq2reg windows (dh 64, <= 200 tokens) the tiled kernel with 64-query
+    // blocks is faster (more blocks in flight, fewer registers).
+    if (DH <= 48 && max_q > 128 && max_q <= 256 && max_k <= 256) {
+        if (max_q <= 192) return launch_short<DH, 3, ALIBI>(P, n_seq, max_k, st);
+        return launch_short<DH, 4, ALIBI>(P, n_seq, max_k, st);
+    }
     // long query streams: 2 query groups per wave (halves K/V LDS traffic per MFMA);
     // short ones (seq2reg windows, gene stream): 64-query blocks to limit tail waste.
     if (max_q > 256) {
         dim3 grid(n_seq, P.H, (max_q + 127) / 128);
-        hipLaunchKernelGGL((attn_fwd_kernel<DH, 2>), grid, dim3(256), 0, st, P);
+        hipLaunchKernelGGL((attn_fwd_kernel<DH, 2, ALIBI>), grid, dim3(256), 0, st, P);
     } else {
         dim3 grid(n_seq, P.H, (max_q + 63) / 64);
-        hipLaunchKernelGGL((attn_fwd_kernel<DH, 1>), grid, dim3(256), 0, st, P);
+        hipLaunchKernelGGL((attn_fwd_kernel<DH, 1, ALIBI>), grid, dim3(256), 0, st, P);
     }
     VF_CHECK_LAUNCH("vf_attn_varlen_fwd");
     return VF_OK;
@@ -300,9 +461,10 @@ extern "C" int vf_attn_varlen_fwd(const void* q, const void* k, const void* v, v
     P.cu_q = cu_seqlens_q; P.cu_k = cu_seqlens_k ? cu_seqlens_k : cu_seqlens_q;
     P.slopes = alibi_slopes; P.scale_log2 = scale * 1.4426950408889634f; P.H = H;
     hipStream_t st = (hipStream_t)stream;
+    const bool alibi = alibi_slopes != nullptr;
     switch (dh) {
-        case 32: return launch_attn<32>(P, n_seq, max_seqlen_q, st);
-        case 48: return launch_attn<48>(P, n_seq, max_seqlen_q, st);
-        default: return launch_attn<64>(P, n_seq, max_seqlen_q, st);
+        case 32: return alibi ? launch_attn<32, true>(P, n_seq, max_seqlen_q, max_seqlen_k, st) : launch_attn<32, false>(P, n_seq, max_seqlen_q, max_seqlen_k, st);
+        case 48: return alibi ? launch_attn<48, true>(P, n_seq, max_seqlen_q, max_seqlen_k, st) : launch_attn<48, false>(P, n_seq, max_seqlen_q, max_seqlen_k, st);
+        default: return alibi ? launch_attn<64, true>(P, n_seq, max_seqlen_q, max_seqlen_k, st) : launch_attn<64, false>(P, n_seq, max_seqlen_q, max_seqlen_k, st);
     }
 }

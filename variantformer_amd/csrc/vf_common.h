@@ -38,8 +38,13 @@ __device__ __forceinline__ unsigned short f2bf(float x) {
     __bf16 b = (__bf16)x;
     return *reinterpret_cast<unsigned short*>(&b);
 }
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+// two fp32 -> packed bf16 pair (lo in bits 0..15): one v_cvt_pk_bf16_f32
 __device__ __forceinline__ unsigned int pack2bf(float lo, float hi) {
-    return (unsigned int)f2bf(lo) | ((unsigned int)f2bf(hi) << 16);
+    const f32x2_t v = {lo, hi};
+    const bf16x2_t b = __builtin_convertvector(v, bf16x2_t);
+    return __builtin_bit_cast(unsigned int, b);
 }
 __device__ __forceinline__ float bf2f(unsigned short b) {
     return __uint_as_float(((unsigned int)b) << 16);

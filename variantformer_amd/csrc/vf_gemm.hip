@@ -19,14 +19,26 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int OPERAND_BYTES = BM * BK * 2;        // 16 KiB per operand tile
-constexpr int STAGE_BYTES = 2 * OPERAND_BYTES;    // A + W
-constexpr int LDS_BYTES = 2 * STAGE_BYTES;        // double buffered: 64 KiB
+// Bank-conflict swizzle of a [rows][BK] bf16 tile read with ds_read_b128 by lane (r = row & 15, g):
+// the 16-byte chunk c of row `row` is stored at chunk c ^ swz(row).
+//   BK = 64 (128-B rows, 8 chunks): swz = (row >> 1) & 7
+//   BK = 32 ( 64-B rows, 4 chunks): swz = {0,2,3,1}[(row >> 2) & 3]
+// Both make every 16-lane ds_read_b128 group hit 16 distinct 16-byte bank slots (checked by hand against the
+// lane groups of MI355X_MICROARCH.md §LDS and by SQ_LDS_BANK_CONFLICT = 0).
+template <int BK>
+__device__ __forceinline__ int swz(int row) {
+    if (BK == 64) return (row >> 1) & 7;
+    return (0x78 >> (((row >> 2) & 3) * 2)) & 3;     // 0b01'11'10'00 -> 0,2,3,1
+}
 
 __device__ __forceinline__ void glds16(const void* g, void* lds) {
     __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 // Epilogue for 4 consecutive n (n_base .. n_base+3) of row m.  For GEGLU `v` is the `a` half and
@@ -59,103 +71,183 @@ __device__ __forceinline__ void epilogue_store(f32x4_t v, f32x4_t gate, int64_t 
     }
 }
 
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(const unsigned short* __restrict__ A, int64_t lda,
-                                                          const unsigned short* __restrict__ W,
-                                                          const float* __restrict__ bias,
-                                                          const float* __restrict__ res, int64_t ldr, void* out,
-                                                          int64_t ldo, int M, int N, int K, int tiles_n, int n_blocks) {
-    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+// Tile configuration: BM x BN output tile, WM x WN waves (wave tile BM/WM x BN/WN), STAGES-deep LDS ring
+// (STAGES-1 K-tiles of LDS-DMA kept in flight across raw s_barriers with counted vmcnt).
+template <int BM_, int BN_, int WM_, int WN_, int STAGES_, int BK_ = 64>
+struct Cfg {
+    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, STAGES = STAGES_, BK = BK_;
+    static constexpr int NW = WM * WN, THREADS = NW * 64;
+    static constexpr int TM = BM / WM / 16, TN = BN / WN / 16;       // 16x16 tiles per wave
+    static constexpr int ROW_BYTES = BK * 2, CPR = BK / 8, KS = BK / 32; // chunks per row, MFMA k-steps per tile
+    static constexpr int ROWS_PER_PIECE = 1024 / ROW_BYTES;          // one LDS-DMA wave-instruction = 1 KiB
+    static constexpr int A_BYTES = BM * ROW_BYTES, W_BYTES = BN * ROW_BYTES, STAGE_BYTES = A_BYTES + W_BYTES;
+    static constexpr int LDS_BYTES = STAGES * STAGE_BYTES;
+    static constexpr int PA = A_BYTES / 1024 / NW, PW = W_BYTES / 1024 / NW;   // pieces per wave per tile
+    static constexpr int LPT = PA + PW;                               // loads per tile per wave
+    static_assert(BK == 64 || BK == 32, "BK");
+    static_assert(A_BYTES % (1024 * NW) == 0 && W_BYTES % (1024 * NW) == 0, "pieces must divide over the waves");
+    static_assert(STAGES >= 2 && STAGES <= 5 && (STAGES - 2) * LPT <= 48, "vmcnt range");
+};
+
+template <class C, int EPI>
+__global__ __launch_bounds__(C::THREADS, 2) void gemm_mfma_kernel(const unsigned short* __restrict__ A, int64_t lda,
+                                                              const unsigned short* __restrict__ W,
+                                                              const float* __restrict__ bias,
+                                                              const float* __restrict__ res, int64_t ldr, void* out,
+                                                              int64_t ldo, int M, int N, int K, int tiles_n, int n_blocks) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BM = C::BM, BN = C::BN, TM = C::TM, TN = C::TN, STAGES = C::STAGES, LPT = C::LPT;
+    constexpr int BK = C::BK, ROW_BYTES = C::ROW_BYTES, CPR = C::CPR, RPP = C::ROWS_PER_PIECE;
 
     // XCD-aware bijective remap: blocks b and b+8 share an XCD (round-robin dispatch), so give each
     // XCD a contiguous run of tiles; consecutive tiles walk n first and share the A row panel in L2.
     const int bid = blockIdx.x;
     const int q8 = n_blocks >> 3, r8 = n_blocks & 7, xcd = bid & 7, loc = bid >> 3;
     const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
-    const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
+    // Grouped order inside the run: GROUP_M m-panels x all n, m fastest, so the ~64 blocks resident on an XCD form
+    // a squarish patch (8 A-panels x 8 W-panels) and each staged slice is shared by 8 blocks in that XCD's L2.
+    constexpr int GROUP_M = 8;
+    const int tiles_m = n_blocks / tiles_n;
+    const int per_group = GROUP_M * tiles_n;
+    const int grp = wg / per_group, in_grp = wg - grp * per_group;
+    const int first_m = grp * GROUP_M;
+    const int gsz = (tiles_m - first_m) < GROUP_M ? (tiles_m - first_m) : GROUP_M;
+    const int tm = first_m + in_grp % gsz, tn = in_grp / gsz;
     const int m0 = tm * BM, n0 = tn * BN;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / C::WN, wn = wave % C::WN;
     const int r = lane & 15, g = lane >> 4;
 
-    // ---- LDS-DMA source pointers: this wave stages pieces p = 4*wave .. 4*wave+3 of each operand
-    // (piece = 8 rows x 128 B).  lane -> row 8p + (lane>>3), physical chunk lane&7.
-    const unsigned short* srcA[4];
-    const unsigned short* srcW[4];
+    // ---- LDS-DMA source pointers.  A piece = RPP rows x ROW_BYTES written linearly by one wave-instruction;
+    // lane -> row RPP*p + lane/CPR, physical chunk lane%CPR, logical (source) chunk = physical ^ swz(row).
+    const unsigned short* srcA[C::PA];
+    const unsigned short* srcW[C::PW];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int p = wave * 4 + i;
-        const int row = 8 * p + (lane >> 3);
-        const int c = (lane & 7) ^ ((row >> 1) & 7);
+    for (int i = 0; i < C::PA; ++i) {
+        const int row = RPP * (wave * C::PA + i) + lane / CPR;
+        const int c = (lane % CPR) ^ swz<BK>(row);
         int gm = m0 + row; gm = gm < M ? gm : M - 1;
-        int gn = n0 + row; gn = gn < N ? gn : N - 1;
         srcA[i] = A + (int64_t)gm * lda + c * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < C::PW; ++i) {
+        const int row = RPP * (wave * C::PW + i) + lane / CPR;
+        const int c = (lane % CPR) ^ swz<BK>(row);
+        int gn = n0 + row; gn = gn < N ? gn : N - 1;
         srcW[i] = W + (int64_t)gn * K + c * 8;
     }
-    char* const ldsA_piece = smem + wave * 4 * 1024;                     // + stage*STAGE_BYTES + i*1024
-    char* const ldsW_piece = smem + OPERAND_BYTES + wave * 4 * 1024;
+    char* const ldsA_piece = smem + wave * C::PA * 1024;
+    char* const ldsW_piece = smem + C::A_BYTES + wave * C::PW * 1024;
 
     auto issue = [&](int kt, int stage) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            glds16(srcA[i] + kt * BK, ldsA_piece + stage * STAGE_BYTES + i * 1024);
-            glds16(srcW[i] + kt * BK, ldsW_piece + stage * STAGE_BYTES + i * 1024);
-        }
+        for (int i = 0; i < C::PA; ++i) glds16(srcA[i] + kt * BK, ldsA_piece + stage * C::STAGE_BYTES + i * 1024);
+#pragma unroll
+        for (int i = 0; i < C::PW; ++i) glds16(srcW[i] + kt * BK, ldsW_piece + stage * C::STAGE_BYTES + i * 1024);
     };
 
-    f32x4_t acc[4][4];
+    f32x4_t acc[TN][TM];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TN; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    // fragment read offsets (bytes) inside an operand tile: row*128 + ((4*ks+g) ^ (r>>1))*16
-    const int sw = r >> 1;
-    const int offW = (wn * 64 + r) * 128;
-    const int offA = (wm * 64 + r) * 128;
+    // fragment read offsets (bytes) inside an operand tile: row*ROW_BYTES + ((4*ks+g) ^ swz(r))*16
+    const int sw = swz<BK>(r);
+    const int offW = C::A_BYTES + (wn * (BN / C::WN) + r) * ROW_BYTES;
+    const int offA = (wm * (BM / C::WM) + r) * ROW_BYTES;
 
+    auto read_frags = [&](int stage, int ks, bf16x8_t(&wf)[TN], bf16x8_t(&af)[TM]) {
+        const char* base = smem + stage * C::STAGE_BYTES + (((4 * ks + g) ^ sw) << 4);
+#pragma unroll
+        for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const bf16x8_t*>(base + offW + i * 16 * ROW_BYTES);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(base + offA + i * 16 * ROW_BYTES);
+    };
+    auto mma = [&](const bf16x8_t(&wf)[TN], const bf16x8_t(&af)[TM]) {
+#pragma unroll
+        for (int in = 0; in < TN; ++in)
+#pragma unroll
+            for (int im = 0; im < TM; ++im)
+                acc[in][im] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[in], af[im], acc[in][im], 0, 0, 0);
+    };
+    // wait until at most `ahead` younger K-tiles of this wave's LDS-DMA are still in flight
+    auto wait_tiles = [&](int ahead) {
+        if (STAGES >= 5 && ahead >= 3) wait_vmcnt<3 * LPT>();
+        else if (STAGES >= 4 && ahead == 2) wait_vmcnt<2 * LPT>();
+        else if (STAGES >= 3 && ahead == 1) wait_vmcnt<LPT>();
+        else wait_vmcnt<0>();
+    };
+
+    // Software pipeline.  The K loop is a sequence of sub-steps (one 32-deep MFMA k-step each).  The
+    // fragments of sub-step s+1 are read from LDS into the OTHER register set while the MFMAs of
+    // sub-step s execute.  When s+1 opens a new K-tile t+1 the wave first retires its own LDS reads
+    // (every fragment of tile t is then in registers), waits for its share of tile t+1's LDS-DMA,
+    // passes the barrier (tile t+1 visible, stage of tile t free for all) and immediately refills the
+    // freed stage with tile t+STAGES: STAGES-1 tiles stay in flight across the barrier.
     const int nkt = K / BK;
-    issue(0, 0);
-    for (int kt = 0; kt < nkt; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                       // tile kt landed for every wave; stage (kt+1)&1 is free
-        if (kt + 1 < nkt) issue(kt + 1, (kt + 1) & 1);
-        const char* sA = smem + (kt & 1) * STAGE_BYTES;
-        const char* sW = sA + OPERAND_BYTES;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int chunk = ((4 * ks + g) ^ sw) * 16;
-            bf16x8_t wf[4], af[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8_t*>(sW + offW + i * 16 * 128 + chunk);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(sA + offA + i * 16 * 128 + chunk);
-#pragma unroll
-            for (int in = 0; in < 4; ++in)
-#pragma unroll
-                for (int im = 0; im < 4; ++im)
-                    acc[in][im] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[in], af[im], acc[in][im], 0, 0, 0);
+    for (int p = 0; p < STAGES; ++p)
+        if (p < nkt) issue(p, p);
+    wait_tiles((nkt - 1) < (STAGES - 1) ? (nkt - 1) : (STAGES - 1));
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    bf16x8_t wf0[TN], af0[TM], wf1[TN], af1[TM];
+    read_frags(0, 0, wf0, af0);
+    int stage = 0;
+    // cross from tile t (in `stage`) to tile t+1
+    auto boundary = [&](int t) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        wait_tiles((nkt - 2 - t) < (STAGES - 2) ? (nkt - 2 - t) : (STAGES - 2));
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + STAGES < nkt) issue(t + STAGES, stage);
+        stage = stage + 1 == STAGES ? 0 : stage + 1;
+    };
+    if (C::KS == 2) {
+        for (int kt = 0; kt < nkt; ++kt) {
+            read_frags(stage, 1, wf1, af1);
+            mma(wf0, af0);
+            if (kt + 1 < nkt) {
+                boundary(kt);
+                read_frags(stage, 0, wf0, af0);
+            }
+            mma(wf1, af1);
+        }
+    } else {                                   // BK = 32: one sub-step per tile, nkt is even (K % 64 == 0)
+        for (int kt = 0; kt < nkt; kt += 2) {
+            boundary(kt);
+            read_frags(stage, 0, wf1, af1);
+            mma(wf0, af0);
+            if (kt + 2 < nkt) {
+                boundary(kt + 1);
+                read_frags(stage, 0, wf0, af0);
+            }
+            mma(wf1, af1);
         }
     }
 
-    // ---- epilogue: lane holds out[m = m0+wm*64+im*16+r][n = n0+wn*64+in*16+4g .. +3]
+    // ---- epilogue: lane holds out[m = m0 + wm*(BM/WM) + im*16 + r][n = n0 + wn*(BN/WN) + in*16 + 4g .. +3]
+    const int nw0 = n0 + wn * (BN / C::WN);
 #pragma unroll
-    for (int im = 0; im < 4; ++im) {
-        const int64_t m = m0 + wm * 64 + im * 16 + r;
+    for (int im = 0; im < TM; ++im) {
+        const int64_t m = m0 + wm * (BM / C::WM) + im * 16 + r;
         if (m >= M) continue;
         if (EPI == VF_EPI_GEGLU_BF16) {
 #pragma unroll
-            for (int ip = 0; ip < 2; ++ip) {
-                const int nb = n0 + wn * 64 + ip * 32 + 4 * g;          // bias index of the `a` half
+            for (int ip = 0; ip < TN / 2; ++ip) {
+                const int nb = nw0 + ip * 32 + 4 * g;          // bias index of the `a` half
                 if (nb >= N) continue;
-                const int n_out = (n0 + wn * 64) / 2 + ip * 16 + 4 * g;
+                const int n_out = nw0 / 2 + ip * 16 + 4 * g;
                 epilogue_store<EPI>(acc[2 * ip][im], acc[2 * ip + 1][im], m, nb, nb + 16, n_out, bias, res, ldr, out, ldo);
             }
         } else {
 #pragma unroll
-            for (int in = 0; in < 4; ++in) {
-                const int nb = n0 + wn * 64 + in * 16 + 4 * g;
+            for (int in = 0; in < TN; ++in) {
+                const int nb = nw0 + in * 16 + 4 * g;
                 if (nb >= N) continue;
                 epilogue_store<EPI>(acc[in][im], acc[in][im], m, nb, nb, nb, bias, res, ldr, out, ldo);
             }
@@ -219,21 +311,71 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(const unsigned short*
     }
 }
 
+using CfgA = Cfg<128, 128, 2, 2, 2>;       // 64 KiB, 4 waves, 2 blocks/CU
+using CfgB = Cfg<256, 256, 2, 4, 2>;       // 128 KiB, 8 waves, wave tile 128x64
+using CfgC = Cfg<256, 128, 4, 2, 3>;       // 144 KiB, 8 waves, wave tile 64x64, 2 tiles in flight
+using CfgD = Cfg<256, 256, 2, 4, 4, 32>;   // 128 KiB, 8 waves, BK=32, 3 tiles in flight
+using CfgE = Cfg<64, 64, 2, 2, 4>;         // 64 KiB, small-M shapes, 2 blocks/CU
+using CfgF = Cfg<128, 256, 2, 4, 3>;       // 144 KiB, 8 waves, wave tile 64x64
+using CfgG = Cfg<128, 128, 2, 2, 4, 32>;   // 64 KiB, 4 waves, BK=32, 3 tiles in flight, 2 blocks/CU
+using CfgH = Cfg<256, 128, 2, 2, 3, 32>;   // 72 KiB, 4 waves (wave tile 128x64), BK=32, 2 blocks/CU
+using CfgI = Cfg<128, 256, 2, 2, 3, 32>;   // 72 KiB, 4 waves (wave tile 64x128), BK=32, 2 blocks/CU
+
+template <class C, int EPI>
+int launch_cfg(const void* A, int64_t lda, const void* W, const float* bias, const float* res, int64_t ldr, void* out,
+               int64_t ldo, int M, int N, int K, hipStream_t st) {
+    static bool attr_set = false;                 // per (config, epilogue) instantiation
+    auto kern = gemm_mfma_kernel<C, EPI>;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                C::LDS_BYTES) != hipSuccess) {
+            (void)hipGetLastError();
+            vf_set_error("vf_gemm_bf16: cannot reserve %d bytes of LDS", C::LDS_BYTES);
+            return VF_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
+    const int tiles_m = (M + C::BM - 1) / C::BM, tiles_n = (N + C::BN - 1) / C::BN;
+    const int n_blocks = tiles_m * tiles_n;
+    hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(C::THREADS), C::LDS_BYTES, st, (const unsigned short*)A, lda,
+                       (const unsigned short*)W, bias, res, ldr, out, ldo, M, N, K, tiles_n, n_blocks);
+    VF_CHECK_LAUNCH("vf_gemm_bf16");
+    return VF_OK;
+}
+
+// Tile choice (measured on MI355X, scripts/gemm_bench.py, random data): the grouped 128x128 kernel wins or ties on
+// every large shape of this model (it sits at the LDS-DMA fill ceiling, ~13 TB/s chip-wide); grids with fewer than
+// one 128x128 tile per CU slot use 64x64 tiles so that all 256 CUs get work.  variant 0 = automatic; 1..9 force a
+// configuration (tuning / tests).
+int pick_variant(int M, int N, int K) {
+    (void)K;
+    const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+    return t128 >= 256 ? 1 : 5;
+}
+
 template <int EPI>
 int launch_gemm(const void* A, int64_t lda, const void* W, const float* bias, const float* res, int64_t ldr, void* out,
-                int64_t ldo, int M, int N, int K, hipStream_t st) {
-    if (K % BK == 0) {
-        const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
-        const int n_blocks = tiles_m * tiles_n;
-        hipLaunchKernelGGL(gemm_mfma_kernel<EPI>, dim3(n_blocks), dim3(256), 0, st, (const unsigned short*)A, lda,
-                           (const unsigned short*)W, bias, res, ldr, out, ldo, M, N, K, tiles_n, n_blocks);
-    } else {
+                int64_t ldo, int M, int N, int K, int variant, hipStream_t st) {
+    if (K % 64 != 0) {
         dim3 grid((N + 63) / 64, (M + 63) / 64);
         hipLaunchKernelGGL(gemm_generic_kernel<EPI>, grid, dim3(256), 0, st, (const unsigned short*)A, lda,
                            (const unsigned short*)W, bias, res, ldr, out, ldo, M, N, K);
+        VF_CHECK_LAUNCH("vf_gemm_bf16");
+        return VF_OK;
     }
-    VF_CHECK_LAUNCH("vf_gemm_bf16");
-    return VF_OK;
+    if (variant == 0) variant = pick_variant(M, N, K);
+    switch (variant) {
+        case 1: return launch_cfg<CfgA, EPI>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
+        case 2: return launch_cfg<CfgB, EPI>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
+        case 3: return launch_cfg<CfgC, EPI>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
+        case 4: return launch_cfg<CfgD, EPI>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
+        case 5: return launch_cfg<CfgE, EPI>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
+        case 6: return launch_cfg<CfgF, EPI>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
+        case 7: return launch_cfg<CfgG, EPI>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
+        case 8: return launch_cfg<CfgH, EPI>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
+        case 9: return launch_cfg<CfgI, EPI>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
+        default: vf_set_error("vf_gemm_bf16_ex: unknown variant %d", variant); return VF_ERR_INVALID_ARG;
+    }
 }
 
 __global__ void pack_geglu_rows_kernel(const unsigned short* __restrict__ W, const float* __restrict__ bias,
@@ -248,8 +390,8 @@ __global__ void pack_geglu_rows_kernel(const unsigned short* __restrict__ W, con
 
 }  // namespace
 
-extern "C" int vf_gemm_bf16(const void* A, int64_t lda, const void* W, const float* bias, const float* residual,
-                            int64_t ldr, void* out, int64_t ldo, int M, int N, int K, int epilogue, void* stream) {
+static int gemm_dispatch(const void* A, int64_t lda, const void* W, const float* bias, const float* residual,
+                         int64_t ldr, void* out, int64_t ldo, int M, int N, int K, int epilogue, int variant, void* stream) {
     VF_REQUIRE(A && W && out, "vf_gemm_bf16: null pointer");
     VF_REQUIRE(M >= 0 && N > 0 && K > 0, "vf_gemm_bf16: bad shape M=%d N=%d K=%d", M, N, K);
     VF_REQUIRE(K % 8 == 0 && N % 8 == 0, "vf_gemm_bf16: K and N must be multiples of 8 (K=%d N=%d)", K, N);
@@ -257,22 +399,34 @@ extern "C" int vf_gemm_bf16(const void* A, int64_t lda, const void* W, const flo
     VF_REQUIRE(ldo % 4 == 0, "vf_gemm_bf16: ldo=%lld must be a multiple of 4", (long long)ldo);
     VF_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)W % 16 == 0) && ((uintptr_t)out % 16 == 0),
                "vf_gemm_bf16: pointers must be 16-byte aligned");
+    VF_REQUIRE(variant >= 0 && variant <= 9, "vf_gemm_bf16_ex: variant %d out of range", variant);
     if (M == 0) return VF_OK;
     hipStream_t st = (hipStream_t)stream;
     switch (epilogue) {
-        case VF_EPI_BF16: return launch_gemm<VF_EPI_BF16>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, st);
-        case VF_EPI_F32: return launch_gemm<VF_EPI_F32>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, st);
+        case VF_EPI_BF16: return launch_gemm<VF_EPI_BF16>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, variant, st);
+        case VF_EPI_F32: return launch_gemm<VF_EPI_F32>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, variant, st);
         case VF_EPI_RES_F32:
             VF_REQUIRE(residual && ldr % 4 == 0 && ((uintptr_t)residual % 16 == 0), "vf_gemm_bf16: residual epilogue needs an aligned residual");
-            return launch_gemm<VF_EPI_RES_F32>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, st);
+            return launch_gemm<VF_EPI_RES_F32>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, variant, st);
         case VF_EPI_GEGLU_BF16:
             VF_REQUIRE(N % 32 == 0, "vf_gemm_bf16: GEGLU epilogue needs N %% 32 == 0 (N=%d)", N);
-            return launch_gemm<VF_EPI_GEGLU_BF16>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, st);
-        case VF_EPI_GELU_F32: return launch_gemm<VF_EPI_GELU_F32>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, st);
-        case VF_EPI_GELU_BF16: return launch_gemm<VF_EPI_GELU_BF16>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, st);
+            return launch_gemm<VF_EPI_GEGLU_BF16>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, variant, st);
+        case VF_EPI_GELU_F32: return launch_gemm<VF_EPI_GELU_F32>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, variant, st);
+        case VF_EPI_GELU_BF16: return launch_gemm<VF_EPI_GELU_BF16>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, variant, st);
         default: VF_REQUIRE(false, "vf_gemm_bf16: unknown epilogue %d", epilogue);
     }
     return VF_OK;
+}
+
+extern "C" int vf_gemm_bf16(const void* A, int64_t lda, const void* W, const float* bias, const float* residual,
+                            int64_t ldr, void* out, int64_t ldo, int M, int N, int K, int epilogue, void* stream) {
+    return gemm_dispatch(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, epilogue, 0, stream);
+}
+
+extern "C" int vf_gemm_bf16_ex(const void* A, int64_t lda, const void* W, const float* bias, const float* residual,
+                               int64_t ldr, void* out, int64_t ldo, int M, int N, int K, int epilogue, int variant,
+                               void* stream) {
+    return gemm_dispatch(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, epilogue, variant, stream);
 }
 
 extern "C" int vf_pack_geglu_rows(const void* W, const float* bias, void* W_out, float* bias_out, int two_f, int K,

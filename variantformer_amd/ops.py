@@ -65,8 +65,9 @@ def _dt(dtype) -> int:
 
 
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None, epilogue: int,
-         residual: torch.Tensor | None = None, out: torch.Tensor | None = None) -> torch.Tensor:
-    """out = epilogue(a[M,K] @ w[N,K]^T + bias).  a, w bf16 (a may be a row-strided view)."""
+         residual: torch.Tensor | None = None, out: torch.Tensor | None = None, variant: int = 0) -> torch.Tensor:
+    """out = epilogue(a[M,K] @ w[N,K]^T + bias).  a, w bf16 (a may be a row-strided view).
+    variant != 0 forces a tile configuration (vf_gemm_bf16_ex; tuning / tests only)."""
     _dev(a, w, bias, residual, out)
     assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and a.dim() == 2 and w.dim() == 2
     assert a.stride(1) == 1 and w.is_contiguous() and a.shape[1] == w.shape[1]
@@ -86,9 +87,14 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None, epilogue: 
     lib = _lib.load()
 
     def launch():
-        check(lib.vf_gemm_bf16(a.data_ptr(), a.stride(0) if M > 1 else max(a.stride(0), K), w.data_ptr(), _ptr(bias),
-                               _ptr(residual), ldr, out.data_ptr(), out.stride(0) if M > 1 else max(out.stride(0), n_out),
-                               M, N, K, epilogue, _stream()), "vf_gemm_bf16")
+        lda = a.stride(0) if M > 1 else max(a.stride(0), K)
+        ldo = out.stride(0) if M > 1 else max(out.stride(0), n_out)
+        if variant:
+            check(lib.vf_gemm_bf16_ex(a.data_ptr(), lda, w.data_ptr(), _ptr(bias), _ptr(residual), ldr, out.data_ptr(),
+                                      ldo, M, N, K, epilogue, variant, _stream()), "vf_gemm_bf16_ex")
+        else:
+            check(lib.vf_gemm_bf16(a.data_ptr(), lda, w.data_ptr(), _ptr(bias), _ptr(residual), ldr, out.data_ptr(),
+                                   ldo, M, N, K, epilogue, _stream()), "vf_gemm_bf16")
     if TIMER is not None:
         nbytes = 2.0 * (M * K + N * K) + out.numel() * out.element_size() + (0 if residual is None else 4.0 * M * N)
         TIMER.time("gemm", 2.0 * M * N * K, nbytes, launch)
