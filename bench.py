@@ -199,8 +199,20 @@ def main():
             ops.TIMER = None
             g = summ["gemm"]
             tf = g["flops"] / (g["total_ms"] * 1e-3) / 1e12
+            # HBM traffic per launch comes from separate rocprofv3 --pmc passes of this same command (FETCH_SIZE x2 +
+            # WRITE_SIZE, scripts/pmc_summary.py); bench.py cannot collect PMC counters itself.
+            traffic, traffic_src = None, None
+            try:
+                import glob
+                src = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_hbm_traffic.json")))[-1]
+                with open(src) as f:
+                    traffic = json.load(f)["gemm_mfma_kernel"]["hbm_bytes_per_launch"]
+                traffic_src = os.path.relpath(src, REPO)
+            except Exception:
+                pass
             roof = {"kernel": "gemm_mfma_kernel (vf_gemm_bf16, all epilogues)", "bound": "mfma", "achieved": round(tf, 1),
-                    "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                    "traffic_source": traffic_src, "algorithmic_bytes_per_launch": g["bytes"] / g["launches"],
                     "launches_per_step": g["launches"] // args.steps,
                     "avg_launch_us": round(g["total_ms"] * 1e3 / g["launches"], 2),
                     "flop_per_launch": g["flops"] / g["launches"],

@@ -132,6 +132,18 @@ int vf_rowdot_softplus(const float* x, const float* w, const float* b, float* ou
 /* fp32 -> bf16 (round to nearest even), n elements. */
 int vf_cast_f32_bf16(const float* x, void* out, int64_t n, void* stream);
 
+/* ---- host-side (CPU) byte-pair encoder: SURVEY.md section 8f row 1 ------------------------------------------
+ * Replaces the HuggingFace `tokenizers` BPE model (Rust, third party) as used by utils/seq.py:BPEEncoder.encode
+ * (:52-62) with vocabs/bpe_vocabulary_500.json.  char_ids: int32[256], vocab id of each (upper-cased) byte or -1
+ * for bytes that are not symbols (they split the sequence, e.g. 'N'); merges: int32[n_merges][3] = (left id,
+ * right id, merged id) in rank order.  vf_bpe_encode upper-cases, encodes every maximal run of valid bytes as one
+ * word and concatenates; returns the number of tokens (call with capacity 0 to size the buffers), writes at most
+ * `capacity` ids and the raw-sequence start offset of each token (either output may be NULL); -1 on bad args. */
+void* vf_bpe_create(const int32_t* char_ids, int n_ids, const int32_t* merges, int n_merges);
+void vf_bpe_destroy(void* bpe);
+int64_t vf_bpe_encode(const void* bpe, const char* seq, int64_t len, int32_t* ids_out, int64_t* starts_out,
+                      int64_t capacity);
+
 #ifdef __cplusplus
 }
 #endif

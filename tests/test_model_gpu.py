@@ -151,3 +151,21 @@ def test_variant_prediction_contract():
     model.vep = False
     plain = model.predict_step(batch, 0)
     np.testing.assert_allclose(out["pred_gene_exp"][2], plain["pred_gene_exp"][2], rtol=1e-6)
+
+
+def test_full_depth_production_model_vs_oracle():
+    """The full architecture (25 modulator layers, D=1536/H=32, seq2reg d=512/h=8/6 layers; 1.2 B random-init
+    parameters as in bench.py) on a small gene, HIP vs the same-rounding oracle: error accumulated over all
+    49 + 6 layers stays inside the north-star tolerance."""
+    import bench
+    model, hp, kw = bench.build_model(torch.device("cuda", 0))
+    sd = state_dict_cpu(model)
+    batch = make_batch(4321, [24, 9], [6, 3], [TISSUES_54[:3], [62]], 200)
+    out = model.predict_step(batch, 0)
+    shp = O.Seq2RegHP.from_hparams(hp)
+    torch.set_num_threads(min(16, bench.host_threads()))
+    orc = O.predict_step(batch, sd, shp, shp, O.Seq2GeneHP.from_kwargs(kw), rounding="bf16", share_cre_stream=True)
+    for i in range(2):
+        assert np.isfinite(out["pred_gene_exp"][i]).all()
+        assert _rel(out["pred_gene_exp"][i], orc["pred_gene_exp"][i]) < NORTH_STAR_RTOL
+        assert _rel(out["embeddings"][i], orc["embeddings"][i]) < 5e-3

@@ -35,7 +35,11 @@ SIGNATURES = {
     "vf_gather_rows_bf16": [_p, _l, _p, _p, _l, _l, _i, _p],
     "vf_rowdot_softplus": [_p, _p, _p, _p, _l, _i, _i, _p],
     "vf_cast_f32_bf16": [_p, _p, _l, _p],
+    "vf_bpe_create": [_p, _i, _p, _i],
+    "vf_bpe_destroy": [_p],
+    "vf_bpe_encode": [_p, C.c_char_p, _l, _p, _p, _l],
 }
+_RESTYPES = {"vf_last_error": C.c_char_p, "vf_bpe_create": C.c_void_p, "vf_bpe_destroy": None, "vf_bpe_encode": C.c_int64}
 
 _lib = None
 
@@ -66,7 +70,7 @@ def load(path: str | None = None):
         except AttributeError as e:
             raise VFError(f"libvf_hip.so does not export {name}") from e
         fn.argtypes = argtypes
-        fn.restype = C.c_char_p if name == "vf_last_error" else C.c_int
+        fn.restype = _RESTYPES.get(name, C.c_int)
     v = lib.vf_version()
     if v != ABI_VERSION:
         raise VFError(f"libvf_hip.so ABI version {v} != expected {ABI_VERSION}")

@@ -13,7 +13,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["vf_gemm.hip", "vf_attn.hip", "vf_misc.hip"]
+SOURCES = ["vf_gemm.hip", "vf_attn.hip", "vf_misc.hip", "vf_bpe.cpp"]
 HEADERS = ["vf_common.h", os.path.join("..", "..", "include", "vf_hip.h")]
 LIB = os.path.join(HERE, "libvf_hip.so")
 ARCH = "gfx950"
@@ -38,7 +38,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     objs = []
     procs = []
     for src in SOURCES:
-        obj = os.path.join(HERE, src.replace(".hip", ".o"))
+        obj = os.path.join(HERE, os.path.splitext(src)[0] + ".o")
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result",
                "-mllvm", "-amdgpu-mfma-vgpr-form=1"] + EXTRA_FLAGS.get(src, []) + \
               ["-c", os.path.join(HERE, src), "-o", obj]
