@@ -169,3 +169,24 @@ def test_full_depth_production_model_vs_oracle():
         assert np.isfinite(out["pred_gene_exp"][i]).all()
         assert _rel(out["pred_gene_exp"][i], orc["pred_gene_exp"][i]) < NORTH_STAR_RTOL
         assert _rel(out["embeddings"][i], orc["embeddings"][i]) < 5e-3
+
+
+def test_vep_window_dedupe_is_exact():
+    """ref / het / hom batches share every window but the one carrying the variant: embedding unique windows once
+     must give bit-identical results to embedding all of them."""
+    kw = seq2gene_kw(layers=2)
+    model = build_model(SEQ2REG_512, kw, seed=21).cuda()
+    one = make_batch(77, [9], [4], [[7, 8, 9]], 200)
+    batch = {k: (v * 3 if isinstance(v, list) else v.repeat(3, 1)) for k, v in one.items()}
+    batch["cre_sequences"] = [t.clone() for t in batch["cre_sequences"]]
+    batch["gene_embeddings"] = [t.clone() for t in batch["gene_embeddings"]]
+    batch["cre_sequences"][1][4, 0, 10] = 17          # het: one token changes in CRE window 4
+    batch["cre_sequences"][2][4, 0, 10] = 6           # hom
+    batch["gene_embeddings"][2][1, 0, 3] = 9
+    with torch.no_grad():
+        pa = model.prepare_batch(batch)
+        pd = model.prepare_batch(batch, dedupe_windows=True)
+        assert pd.cre_ids.shape[0] == 9 + 2 and pd.gene_ids.shape[0] == 4 + 1 and pa.cre_ids.shape[0] == 27
+        a = model.forward_prepared(pa)
+        d = model.forward_prepared(pd)
+    assert torch.equal(a[0], d[0]) and torch.equal(a[1], d[1])

@@ -1,0 +1,80 @@
+"""API surface end to end on a GPU (reference call sequence of notebooks/vcf2exp.py:192-198,505-534):
+VCFProcessor(model_class) -> create_data -> load_model (ModelManager, Lightning-style checkpoints) -> predict ->
+DataFrame[gene_id, tissues, tissue_names, predicted_expression, embeddings]."""
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+import yaml
+
+from tests.conftest import load_fixture
+from tests.helpers import build_model
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_artifacts(tmp_path, meta, sd):
+    tok_sd = lambda pfx: {k[len(pfx):]: v for k, v in sd.items() if k.startswith(pfx)}  # noqa: E731
+    torch.save({"hyper_parameters": meta["seq2reg"], "state_dict": tok_sd("cre_tokenizer.")}, tmp_path / "tok.pth")
+    torch.save({"state_dict": sd}, tmp_path / "model.pth")
+    cfg_dir = tmp_path / "configs"
+    cfg_dir.mkdir()
+    model_cfg = dict(meta["seq2gene"], model_class="Seq2GenePredictorCombinedModulator", token_dim=999,
+                     checkpoint_path=str(tmp_path / "model.pth"), precision="bf16-mixed",
+                     cre_tokenizer={"path": str(tmp_path / "tok.pth")}, gene_tokenizer={"path": str(tmp_path / "tok.pth")})
+    pd.DataFrame({"gene_id": ["ENSG_A", "ENSG_B", "ENSG_C"], "gene_name": ["a", "b", "c"]}).to_csv(tmp_path / "genes.csv", index=False)
+    block = {"dataset": {"max_length": meta["token_length"], "max_chunks": 200, "cre_neighbour_hood": 50,
+                         "gencode_v24": str(tmp_path / "genes.csv"), "gene_upstream_neighbour_hood": 1000,
+                         "gene_downstream_neighbour_hood": 300000}, "model": model_cfg}
+    with open(cfg_dir / "vf_model.yaml", "w") as f:
+        yaml.safe_dump({"v4_pcg": block, "v4_ag": block}, f)
+    with open(cfg_dir / "vcfloader.yaml", "w") as f:
+        yaml.safe_dump({"CRE_BED": "x", "fasta_path": "y", "precision": "bf16-mixed",
+                        "dataloader": {"num_workers": 0, "batch_size": 2, "pin_memory": False, "drop_last": False,
+                                       "prefetch_factor": 4}}, f)
+    return cfg_dir
+
+
+@pytest.mark.parametrize("model_class", ["v4_pcg", "v4_ag"])
+def test_vcfprocessor_flow(tmp_path, model_class):
+    from variantformer_amd.datasets.vcfdataset import SyntheticGeneDataset
+    from variantformer_amd.processors.vcfprocessor import VCFProcessor
+    meta, arrays, sd, _ = load_fixture("small_sin")
+    cfg_dir = _write_artifacts(tmp_path, meta, sd)
+    vp = VCFProcessor(model_class=model_class, config_dir=str(cfg_dir))
+    assert "whole blood" in vp.get_tissues() and len(vp.get_tissues()) == 62
+    assert list(vp.get_genes()["gene_id"]) == ["ENSG_A", "ENSG_B", "ENSG_C"]
+    query = pd.DataFrame({"gene_id": ["ENSG_A", "ENSG_B", "ENSG_C"],
+                          "tissues": ["whole blood,thyroid,not a tissue", "liver", "brain - cortex,lung"]})
+    factory = lambda vcf_path, query_df, tissue_vocab, dataset_config: SyntheticGeneDataset(  # noqa: E731
+        query_df, tissue_vocab, n_cre=6, n_chunks=3, token_length=dataset_config.max_length)
+    dataset, loader = vp.create_data(None, query, dataset_factory=factory)
+    model, ckpt, trainer = vp.load_model()
+    assert ckpt.endswith("model.pth") and model.vep is False and trainer.precision == "bf16-mixed"
+    assert next(model.parameters()).is_cuda and model.hparams.token_dim == meta["seq2reg"]["embedding_dim"]   # :77 override
+    out = vp.predict(model, ckpt, trainer, loader, dataset)
+    assert list(out.columns) == ["gene_id", "tissues", "tissue_names", "predicted_expression", "embeddings"]
+    assert out["tissue_names"][0] == ["whole blood", "thyroid"] and out["tissues"][0] == [62, 59]
+    assert out["predicted_expression"][0].shape == (2, 1) and out["embeddings"][2].shape == (2, meta["seq2gene"]["emb_dim"])
+    # same numbers as the directly constructed model on the same samples (batch composition must not matter)
+    direct = build_model(meta["seq2reg"], meta["seq2gene"], sd).cuda()
+    from variantformer_amd.datasets.vcfdataset import collate_fn_batching
+    ref = direct.predict_step(collate_fn_batching([dataset[i] for i in range(3)]), 0)
+    for i in range(3):
+        np.testing.assert_allclose(out["predicted_expression"][i], ref["pred_gene_exp"][i], rtol=1e-5, atol=1e-6)
+
+
+def test_model_manager_rejects_missing_checkpoint_and_bad_class(tmp_path):
+    from variantformer_amd.processors.model_manager import ModelManager
+    from variantformer_amd.utils.config import load_yaml
+    meta, arrays, sd, _ = load_fixture("small_sin")
+    cfg_dir = _write_artifacts(tmp_path, meta, sd)
+    cfg = load_yaml(str(cfg_dir / "vf_model.yaml")).v4_pcg.model
+    os.remove(tmp_path / "model.pth")
+    with pytest.raises(ValueError, match="Checkpoint not found"):
+        ModelManager(cfg).load_model()
+    cfg.model_class = "Seq2GenePredictor"
+    with pytest.raises(NotImplementedError):
+        ModelManager(cfg).load_model()

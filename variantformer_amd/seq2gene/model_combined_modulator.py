@@ -61,6 +61,8 @@ class PreparedBatch:
     total_tissue_rows: int
     registry_rows_host: np.ndarray = None
     cu_cre_host: np.ndarray = None
+    cre_unique_inverse: torch.Tensor = None   # int64 [sum N]: row of each window in the de-duplicated cre_ids
+    gene_unique_inverse: torch.Tensor = None
 
 
 class CombinedModulator(nn.Module):
@@ -227,8 +229,21 @@ class Seq2GenePredictorCombinedModulator(nn.Module):
             p = torch.float32
         return None if p in (torch.float16, torch.bfloat16) else torch.float32
 
-    def prepare_batch(self, batch: dict) -> PreparedBatch:
-        """collate_fn_batching dict (datasets/vcfdataset.py:18-63) -> device tensors + structure."""
+    @staticmethod
+    def _unique_windows(ids: torch.Tensor, pad: torch.Tensor):
+        """Rows of (ids, pad) that are byte-identical are embedded once (seq2reg sees windows independently)."""
+        key = np.concatenate([ids.numpy().astype(np.int16), pad.numpy().astype(np.int16)], axis=1)
+        _, first, inverse = np.unique(key, axis=0, return_index=True, return_inverse=True)
+        order = np.argsort(first)                       # keep first-occurrence order
+        rank = np.empty_like(order)
+        rank[order] = np.arange(len(order))
+        keep = torch.from_numpy(np.sort(first))
+        return ids[keep].contiguous(), pad[keep].contiguous(), torch.from_numpy(rank[inverse.reshape(-1)].astype(np.int64))
+
+    def prepare_batch(self, batch: dict, dedupe_windows: bool = False) -> PreparedBatch:
+        """collate_fn_batching dict (datasets/vcfdataset.py:18-63) -> device tensors + structure.
+        dedupe_windows: embed byte-identical CRE windows / gene chunks once (VEP ref/het/hom batches share all but
+        the few windows that carry the variant, datasets/vepdataset.py:347-477)."""
         dev = self.device
         x, m = batch["cre_sequences"], batch["cre_attention_masks"]
         gx, gm = batch["gene_embeddings"], batch["gene_attention_masks"]
@@ -243,6 +258,10 @@ class Seq2GenePredictorCombinedModulator(nn.Module):
         gene_ids = torch.cat([v[:, 0, :] for v in gx]).long().contiguous()
         gene_pad = torch.cat([v[:, 0, :] for v in gm]).bool().contiguous()
         labels = torch.cat([v.reshape(-1) for v in batch["ref_cre_labels"]]).long().contiguous()
+        cre_inv = gene_inv = None
+        if dedupe_windows:
+            cre_ids, cre_pad, cre_inv = self._unique_windows(cre_ids.cpu(), cre_pad.cpu())
+            gene_ids, gene_pad, gene_inv = self._unique_windows(gene_ids.cpu(), gene_pad.cpu())
         cre_tokens = int((~cre_pad).sum())
         gene_tokens = int((~gene_pad).sum())
         # structure
@@ -269,7 +288,9 @@ class Seq2GenePredictorCombinedModulator(nn.Module):
             labels=labels.to(dev), cu_cre=to(cu_cre), max_cre=max(n_cre), cu_gene_self=to(cu_self),
             max_gene=max(self_lens), cu_gene_cross=to(cu_cross), max_gene_cross=max(cross_lens),
             gene_stream_idx=to(np.concatenate(idx)), registry_rows=to(np.array(reg_rows, dtype=np.int64)),
-            total_tissue_rows=len(reg_rows), registry_rows_host=np.array(reg_rows, dtype=np.int64), cu_cre_host=cu_cre)
+            total_tissue_rows=len(reg_rows), registry_rows_host=np.array(reg_rows, dtype=np.int64), cu_cre_host=cu_cre,
+            cre_unique_inverse=None if cre_inv is None else cre_inv.to(dev),
+            gene_unique_inverse=None if gene_inv is None else gene_inv.to(dev))
 
     def forward_prepared(self, pb: PreparedBatch, return_cre: bool = False):
         """The hot path: everything below runs as HIP kernels on the current stream.
@@ -278,6 +299,9 @@ class Seq2GenePredictorCombinedModulator(nn.Module):
         cre_tok = self.cre_tokenizer.embed_packed(pb.cre_ids, pb.cre_pad, pb.cre_tokens)        # bf16 [sum N, d]
         gene_tokenizer = self.gene_tokenizer if self.gene_tokenizer is not None else self.cre_tokenizer
         gene_tok = gene_tokenizer.embed_packed(pb.gene_ids, pb.gene_pad, pb.gene_tokens)        # bf16 [sum C, d]
+        if pb.cre_unique_inverse is not None:            # de-duplicated windows -> one row per original window
+            cre_tok = ops.gather_rows_bf16(cre_tok, pb.cre_unique_inverse)
+            gene_tok = ops.gather_rows_bf16(gene_tok, pb.gene_unique_inverse)
         # maps (:610-612)
         if hasattr(self, "cre_map"):
             w, b = packed_linear(self.cre_map)
@@ -303,7 +327,7 @@ class Seq2GenePredictorCombinedModulator(nn.Module):
         batch = {"cre_sequences": inp, "cre_attention_masks": attention_mask, "tissue_context": tissue_vector,
                  "ref_cre_labels": cre_context, "strand_val": strand, "gene_embeddings": gene_embedding,
                  "gene_attention_masks": gene_att_mask}
-        pb = self.prepare_batch(batch)
+        pb = self.prepare_batch(batch, dedupe_windows=kwargs.get("dedupe_windows", False))
         donors = list(range(pb.n_genes))
         cre_pos, gene_pos = kwargs.get("cre_token_position"), kwargs.get("gene_token_position")
         if kwargs.get("only_embedding", False):
@@ -386,7 +410,7 @@ class Seq2GenePredictorCombinedModulator(nn.Module):
             pred, _, embd, gtok, ctok = self(
                 x, batch["cre_attention_masks"], batch["tissue_context"], batch["ref_labels"], batch["strand"],
                 batch["gene_embeddings"], batch["gene_attention_masks"], return_embedding=True,
-                cre_token_position=cre_pos, gene_token_position=gene_pos)
+                cre_token_position=cre_pos, gene_token_position=gene_pos, dedupe_windows=True)
         pred, embd = pred.cpu().float().numpy(), embd.cpu().float().numpy()
         gtok, ctok = gtok.cpu().float().numpy(), ctok.cpu().float().numpy()
         out = {"pred_gene_exp": [], "embd": [], "variant_type": batch["variant_type"],

@@ -123,7 +123,8 @@ def make_gene(seed: int, n_cre: int, n_chunks: int, tissues, token_length: int =
     (150-350 bp + 2x50 flank at ~3.6 bp/token), gene chunks full
     except a ragged last one, 9-class CRE labels."""
     L = token_length
-    lens = randint(n_cre, cre_len_range[0], min(cre_len_range[1], L + 1), seed, 1)
+    hi = min(cre_len_range[1], L + 1)
+    lens = randint(n_cre, min(cre_len_range[0], max(1, hi // 2)), hi, seed, 1)
     ids = randint(n_cre * L, FIRST_REAL_TOKEN, VOCAB_SIZE, seed, 2).reshape(n_cre, L)
     pos = np.arange(L)[None, :]
     cre_mask = pos >= lens[:, None]                     # True = pad
