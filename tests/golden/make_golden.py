@@ -221,6 +221,8 @@ FIXTURES = {
 def build_reference_model(fx):
     from seq2reg.model import Seq2RegPredictor
     from seq2gene.model_combined_modulator import Seq2GenePredictorCombinedModulator
+    if fx.get("model_class") == "Seq2GenePredictor":
+        from seq2gene.model import Seq2GenePredictor as Seq2GenePredictorCombinedModulator  # noqa: F811
     from variantformer_amd.utils.synthetic import fill_state_dict
 
     cre_tok = Seq2RegPredictor(**fx["seq2reg"])
@@ -233,6 +235,10 @@ def build_reference_model(fx):
     return model
 
 
+FIXTURES["small_twomod"] = dict(FIXTURES["small_sin"], seed=303, model_class="Seq2GenePredictor",
+                                n_cres=[6, 3], n_chunks=[2, 4], tissues=[[62, 7], [20, 33, 59]])
+
+
 def run_fixture(name, fx):
     from variantformer_amd.utils.synthetic import make_batch
 
@@ -241,6 +247,8 @@ def run_fixture(name, fx):
     model = build_reference_model(fx)
     batch = make_batch(fx["seed"], fx["n_cres"], fx["n_chunks"], fx["tissues"], fx["token_length"],
                        cre_len_range=fx["cre_len_range"])
+    if not hasattr(model, "combined_modulator"):
+        batch["cre_attention_mask"] = batch["cre_attention_masks"]   # key the older class reads (seq2gene/model.py:656)
     captured = {}
 
     # capture seq2reg embeddings and modulator output through forward hooks (no reference edits)
@@ -250,11 +258,16 @@ def run_fixture(name, fx):
         return _h
     h1 = model.cre_tokenizer.register_forward_hook(hook_tok("cre_tok"))
     h2 = model.gene_tokenizer.register_forward_hook(hook_tok("gene_tok"))
-    h3 = model.combined_modulator.register_forward_hook(
-        lambda m, i, o: captured.__setitem__("modulator_gene_out", o[0].detach().clone()))
+    combined = hasattr(model, "combined_modulator")
     layer_out = []
-    hs = [l.register_forward_hook(lambda m, i, o: layer_out.append(o.detach().clone()))
-          for l in list(model.combined_modulator.gene_layers) + list(model.combined_modulator.cre_layers)]
+    if combined:
+        h3 = model.combined_modulator.register_forward_hook(
+            lambda m, i, o: captured.__setitem__("modulator_gene_out", o[0].detach().clone()))
+        hs = [l.register_forward_hook(lambda m, i, o: layer_out.append(o.detach().clone()))
+              for l in list(model.combined_modulator.gene_layers) + list(model.combined_modulator.cre_layers)]
+    else:
+        h3 = model.gene_modulator.register_forward_hook(lambda m, i, o: None)
+        hs = []
     with torch.no_grad():
         out = model.predict_step(batch, 0)
     for h in [h1, h2, h3] + hs:
@@ -268,15 +281,17 @@ def run_fixture(name, fx):
         arrays[f"cre_tok_{i}"] = t.numpy()
     for i, t in enumerate(captured["gene_tok"]):
         arrays[f"gene_tok_{i}"] = t.numpy()
-    arrays["modulator_gene_out"] = captured["modulator_gene_out"].numpy()
-    # order of layer hooks firing: gene0, (cre_i, gene_{i+1})*
-    arrays["first_gene_layer_out"] = layer_out[0].numpy()
-    arrays["first_cre_layer_out"] = layer_out[1].numpy()
+    if combined:
+        arrays["modulator_gene_out"] = captured["modulator_gene_out"].numpy()
+        # order of layer hooks firing: gene0, (cre_i, gene_{i+1})*
+        arrays["first_gene_layer_out"] = layer_out[0].numpy()
+        arrays["first_cre_layer_out"] = layer_out[1].numpy()
     # state-dict inventory (names + shapes) and a checksum of the generated weights
     sd = model.state_dict()
     inv = {k: list(v.shape) for k, v in sd.items()}
     chk = float(sum(float(v.double().abs().sum()) for v in sd.values() if torch.is_floating_point(v)))
     meta = dict(name=name, seed=fx["seed"], seq2reg=fx["seq2reg"], seq2gene=fx["seq2gene"],
+                model_class=fx.get("model_class", "Seq2GenePredictorCombinedModulator"),
                 n_cres=fx["n_cres"], n_chunks=fx["n_chunks"], tissues=fx["tissues"],
                 token_length=fx["token_length"], cre_len_range=list(fx["cre_len_range"]),
                 state_dict_shapes=inv, weight_abs_sum=chk,

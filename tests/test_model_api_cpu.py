@@ -19,6 +19,19 @@ def test_state_dict_keys_and_shapes_match_reference(golden):
     model.load_state_dict(sd, strict=True)
 
 
+def test_two_module_variant_keys_match_reference():
+    """Seq2GenePredictor (epigenetics_modulator + gene_modulator prefixes, reference seq2gene/model.py:147-168)."""
+    from variantformer_amd.seq2gene.model import Seq2GenePredictor
+    from variantformer_amd.seq2reg.model import Seq2RegPredictor
+    meta, arrays, sd, batch = load_fixture("small_twomod")
+    assert meta["model_class"] == "Seq2GenePredictor"
+    m = Seq2GenePredictor(cre_tokenizer=Seq2RegPredictor(**meta["seq2reg"]), gene_tokenizer=Seq2RegPredictor(**meta["seq2reg"]),
+                          **meta["seq2gene"])
+    assert {k: list(v.shape) for k, v in m.state_dict().items()} == meta["state_dict_shapes"]
+    assert any(k.startswith("epigenetics_modulator.epigenetics_modulator.0.") for k in meta["state_dict_shapes"])
+    m.load_state_dict(sd, strict=True)
+
+
 def test_prepare_batch_structure(golden):
     meta, arrays, sd, batch = golden
     model = build_model(meta["seq2reg"], meta["seq2gene"])

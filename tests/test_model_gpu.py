@@ -190,3 +190,21 @@ def test_vep_window_dedupe_is_exact():
         a = model.forward_prepared(pa)
         d = model.forward_prepared(pd)
     assert torch.equal(a[0], d[0]) and torch.equal(a[1], d[1])
+
+
+def test_two_module_variant_vs_reference_golden():
+    """model_class Seq2GenePredictor: same network under the older module layout; outputs vs the reference's own
+    Seq2GenePredictor (fixture small_twomod)."""
+    from variantformer_amd.seq2gene.model import Seq2GenePredictor
+    from variantformer_amd.seq2reg.model import Seq2RegPredictor
+    meta, arrays, sd, batch = load_fixture("small_twomod")
+    m = Seq2GenePredictor(cre_tokenizer=Seq2RegPredictor(**meta["seq2reg"]), gene_tokenizer=Seq2RegPredictor(**meta["seq2reg"]),
+                          **meta["seq2gene"])
+    m.load_state_dict(sd, strict=True)
+    m = m.eval().cuda()
+    b = dict(batch)
+    b["cre_attention_mask"] = b.pop("cre_attention_masks")           # the key this class reads in the reference
+    out = m.predict_step(b, 0)
+    for i in range(len(meta["n_cres"])):
+        assert _rel(out["pred_gene_exp"][i], arrays[f"pred_gene_exp_{i}"]) < NORTH_STAR_RTOL
+        assert _rel(out["embeddings"][i], arrays[f"embeddings_{i}"]) < 5e-3

@@ -75,6 +75,6 @@ def test_model_manager_rejects_missing_checkpoint_and_bad_class(tmp_path):
     os.remove(tmp_path / "model.pth")
     with pytest.raises(ValueError, match="Checkpoint not found"):
         ModelManager(cfg).load_model()
-    cfg.model_class = "Seq2GenePredictor"
+    cfg.model_class = "NoSuchModel"
     with pytest.raises(NotImplementedError):
         ModelManager(cfg).load_model()

@@ -13,6 +13,7 @@ from typing import Tuple
 
 import torch
 
+from ..seq2gene.model import Seq2GenePredictor
 from ..seq2gene.model_combined_modulator import Seq2GenePredictorCombinedModulator
 from ..seq2reg.model import Seq2RegPredictor
 from ..utils.config import Config
@@ -52,12 +53,11 @@ class ModelManager:
         delattr(train_cfg, "cre_tokenizer")
         delattr(train_cfg, "gene_tokenizer")
         train_cfg.token_dim = seq2reg.hparams.embedding_dim                      # :77
-        model_classes = {"Seq2GenePredictorCombinedModulator": Seq2GenePredictorCombinedModulator}
+        model_classes = {"Seq2GenePredictor": Seq2GenePredictor,
+                         "Seq2GenePredictorCombinedModulator": Seq2GenePredictorCombinedModulator}
         name = train_cfg.get("model_class", "Seq2GenePredictor")
         if name not in model_classes:
-            raise NotImplementedError(
-                f"model_class {name!r}: only Seq2GenePredictorCombinedModulator (the class every shipped config "
-                "selects, configs/vf_model.yaml:10,51) has a HIP implementation")
+            raise NotImplementedError(f"model_class {name!r} is not one of {sorted(model_classes)}")
         log.info("Creating Seq2Gene model...")
         gene_model = model_classes[name](cre_tokenizer=seq2reg, gene_tokenizer=seq2reg_gene, **train_cfg)
         for cname, module in gene_model.named_children():

@@ -65,6 +65,41 @@ class PreparedBatch:
     gene_unique_inverse: torch.Tensor = None
 
 
+def _context_kv_table(ctx_embedding: nn.Embedding, layer) -> torch.Tensor:
+    """bf16 [9, 2D] = Wkv_layer(context embedding table); constant per weights, cached on the layer."""
+    tab = ctx_embedding.weight
+    mha = layer.crossMHA.MHA
+    key = (tab.data_ptr(), tab._version, mha.Wkv.weight.data_ptr(), mha.Wkv.weight._version)
+    c = getattr(layer, "_vf_ctx_kv", None)
+    if c is None or c[0] != key:
+        with torch.no_grad():
+            c = (key, mha.project_kv(ops.cast_bf16(tab.detach().float().contiguous())))
+        layer._vf_ctx_kv = c
+    return c[1]
+
+
+def modulator_forward_packed(ctx_embedding, cre_layers, gene_layers, cre_x, gene_x, labels, cu_cre, max_cre,
+                             cu_gene_self, max_gene, cu_gene_cross=None, max_gene_cross=None, cu_cre_for_gene=None):
+    """Interleaved CRE / gene layer stack on packed streams (reference model_combined_modulator.py:244-285; the
+    two-module variant seq2gene/model.py:375-412 + layers.py:620-742,797-921 evaluates the same sequence: gene layer
+    i reads the CRE stream after CRE layer i-1, gene layer 0 the raw CRE embeddings).
+    cre_x fp32 [sum N, D] (one CRE stream per K/V group), gene_x fp32 [tokens_g, D], labels int64 [sum N].
+    cu_gene_self: self-attention sequences of the gene stream; cu_gene_cross / cu_cre_for_gene: matching
+    query / key groups for the gene->CRE cross attention (default: same grouping as self-attention)."""
+    cq = cu_gene_self if cu_gene_cross is None else cu_gene_cross
+    mq = max_gene if max_gene_cross is None else max_gene_cross
+    ck = cu_cre if cu_cre_for_gene is None else cu_cre_for_gene
+    cre, gene = cre_x, gene_x
+    gene = gene_layers[0].forward_packed(gene, cu_gene_self, max_gene, context=cre, cu_ctx=ck, max_ctx=max_cre,
+                                         cu_cross_q=cq, max_cross_q=mq)
+    for i in range(len(gene_layers) - 1):
+        kv = ops.gather_rows_bf16(_context_kv_table(ctx_embedding, cre_layers[i]), labels)
+        cre = cre_layers[i].forward_packed(cre, cu_cre, max_cre, context_kv=kv, cu_ctx=cu_cre, max_ctx=max_cre)
+        gene = gene_layers[i + 1].forward_packed(gene, cu_gene_self, max_gene, context=cre, cu_ctx=ck, max_ctx=max_cre,
+                                                 cu_cross_q=cq, max_cross_q=mq)
+    return gene, cre
+
+
 class CombinedModulator(nn.Module):
     """24 CRE layers + 25 gene layers, interleaved, on packed streams
     (reference model_combined_modulator.py:36-328)."""
@@ -87,36 +122,11 @@ class CombinedModulator(nn.Module):
         self.cre_layers = nn.ModuleList([mk() for _ in range(num_layers - 1)])
         self.gene_layers = nn.ModuleList([mk() for _ in range(num_layers)])
 
-    # ---------------------------------------------------------------------------------------------
-    def _context_kv_table(self, layer) -> torch.Tensor:
-        """bf16 [9, 2D] = Wkv_layer(context embedding table); constant per weights, cached."""
-        tab = self.second_level_context_embedding.weight
-        mha = layer.crossMHA.MHA
-        key = (tab.data_ptr(), tab._version, mha.Wkv.weight.data_ptr(), mha.Wkv.weight._version)
-        c = getattr(layer, "_vf_ctx_kv", None)
-        if c is None or c[0] != key:
-            with torch.no_grad():
-                c = (key, mha.project_kv(ops.cast_bf16(tab.detach().float().contiguous())))
-            layer._vf_ctx_kv = c
-        return c[1]
-
     def forward_packed(self, cre_x, gene_x, labels, cu_cre, max_cre, cu_gene_self, max_gene, cu_gene_cross=None,
                        max_gene_cross=None, cu_cre_for_gene=None):
-        """cre_x fp32 [sum N, D] (one CRE stream per K/V group), gene_x fp32 [tokens_g, D], labels int64 [sum N].
-        cu_gene_self: self-attention sequences of the gene stream; cu_gene_cross / cu_cre_for_gene: matching
-        query / key groups for the gene->CRE cross attention (default: same grouping as self-attention)."""
-        cq = cu_gene_self if cu_gene_cross is None else cu_gene_cross
-        mq = max_gene if max_gene_cross is None else max_gene_cross
-        ck = cu_cre if cu_cre_for_gene is None else cu_cre_for_gene
-        cre, gene = cre_x, gene_x
-        gene = self.gene_layers[0].forward_packed(gene, cu_gene_self, max_gene, context=cre, cu_ctx=ck, max_ctx=max_cre,
-                                                  cu_cross_q=cq, max_cross_q=mq)                      # :244-250
-        for i in range(self.num_layers - 1):                                                          # :258-285
-            kv = ops.gather_rows_bf16(self._context_kv_table(self.cre_layers[i]), labels)
-            cre = self.cre_layers[i].forward_packed(cre, cu_cre, max_cre, context_kv=kv, cu_ctx=cu_cre, max_ctx=max_cre)
-            gene = self.gene_layers[i + 1].forward_packed(gene, cu_gene_self, max_gene, context=cre, cu_ctx=ck,
-                                                          max_ctx=max_cre, cu_cross_q=cq, max_cross_q=mq)
-        return gene, cre
+        return modulator_forward_packed(self.second_level_context_embedding, self.cre_layers, self.gene_layers, cre_x,
+                                        gene_x, labels, cu_cre, max_cre, cu_gene_self, max_gene, cu_gene_cross,
+                                        max_gene_cross, cu_cre_for_gene)
 
     def forward(self, cre_x, gene_x, context=None, cre_padding_mask=None, gene_padding_mask=None,
                 context_padding_mask=None, precision=None, cre_token_position=None, gene_token_position=None):
@@ -203,11 +213,7 @@ class Seq2GenePredictorCombinedModulator(nn.Module):
         self.gene_map = nn.Linear(gene_emb_dim, emb_dim)
         if token_dim != emb_dim:
             self.cre_map = nn.Linear(token_dim, emb_dim)
-        self.combined_modulator = CombinedModulator(
-            emb_dim=emb_dim, num_heads=num_heads, num_layers=num_layers, use_alibi=use_alibi, mlp_dout=mlp_dout,
-            use_context=use_context, num_ref_cres=len(REF_CREs) if use_context else None,
-            only_cross_attention=self.only_cross_attention, use_res=self.use_res, cross_alibi=self.cross_alibi,
-            flash_attn_3=flash_attn_3)
+        self._build_modulator(emb_dim, num_heads, num_layers, use_alibi, mlp_dout, use_context, flash_attn_3)
         self.tissue_heads = TissueExpressionHeads(emb_dim, num_tissues, use_bigger_head=self.use_bigger_head,
                                                   multi_head=self.multi_head, mlp_dout=mlp_dout, loss_fn=self.loss_fn,
                                                   head_type=kwargs.get("head_type", "mlp"))
@@ -215,6 +221,16 @@ class Seq2GenePredictorCombinedModulator(nn.Module):
             p.requires_grad_(False)
 
     # ---------------------------------------------------------------------------------------------
+    def _build_modulator(self, emb_dim, num_heads, num_layers, use_alibi, mlp_dout, use_context, flash_attn_3):
+        self.combined_modulator = CombinedModulator(
+            emb_dim=emb_dim, num_heads=num_heads, num_layers=num_layers, use_alibi=use_alibi, mlp_dout=mlp_dout,
+            use_context=use_context, num_ref_cres=len(REF_CREs) if use_context else None,
+            only_cross_attention=self.only_cross_attention, use_res=self.use_res, cross_alibi=self.cross_alibi,
+            flash_attn_3=flash_attn_3)
+
+    def _modulator_forward_packed(self, *a, **k):
+        return self.combined_modulator.forward_packed(*a, **k)
+
     @property
     def device(self):
         return self.gene_map.weight.device
@@ -312,7 +328,7 @@ class Seq2GenePredictorCombinedModulator(nn.Module):
         gene_x = ops.gemm(gene_tok, w, b, ops.EPI_F32)
         # registry token per (gene, tissue) + that gene's chunk rows (:357-366, layers.py:508-521)
         gene_stream = ops.gather_rows_f32(gene_x, self.start_tkn.registry_tokens.weight, pb.gene_stream_idx)
-        gene_out, cre_out = self.combined_modulator.forward_packed(
+        gene_out, cre_out = self._modulator_forward_packed(
             cre_x, gene_stream, pb.labels, pb.cu_cre, pb.max_cre, pb.cu_gene_self, pb.max_gene,
             cu_gene_cross=pb.cu_gene_cross, max_gene_cross=pb.max_gene_cross)
         emb = ops.gather_rows_f32(gene_out, None, pb.registry_rows)                             # pool_outputs (:391-392)
