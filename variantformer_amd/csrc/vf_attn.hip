@@ -35,6 +35,13 @@ struct VLayout {
     static constexpr int TILE = BKV * ROW;
 };
 
+// For dh < 64 the QK^T contraction is padded to 64, so key masking rides on the MFMA: Q carries 1.0 in pad slot
+// d = dh, K carries 0 (valid key) or -32768 (row past the sequence end) there.  Valid scores get exactly +0.0, masked
+// scores ~ -7e3 after scaling -> exp2 underflows to 0.  dh = 64 has no spare slot and masks on the VALU.
+template <int DH> struct HwMask { static constexpr bool value = DH < 64; };
+__device__ __forceinline__ u32x4_t mask_chunk(bool valid) { return (u32x4_t){valid ? 0u : 0xC700u, 0u, 0u, 0u}; }
+__device__ __forceinline__ u32x4_t q_pad_chunk(int d0, int dh) { return (u32x4_t){d0 == dh ? 0x3F80u : 0u, 0u, 0u, 0u}; }
+
 struct AttnParams {
     const unsigned short* q;
     const unsigned short* k;
@@ -93,7 +100,7 @@ __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, int kb
                 for (int e = 0; e < 4; ++e)
                     s[qg][kt][e] = fmaf(s[qg][kt][e], c, -slope2 * fabsf(dq - (float)(16 * kt + e)));
         }
-        if (tail) {
+        if (tail && !HwMask<DH>::value) {
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
@@ -198,7 +205,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int d0 = 32 * ks + 8 * g;
-            u32x4_t raw = (u32x4_t){0u, 0u, 0u, 0u};
+            u32x4_t raw = q_pad_chunk(d0, DH);
             if (d0 < DH) raw = *reinterpret_cast<const u32x4_t*>(qp + d0);
             qf[qg][ks] = *reinterpret_cast<bf16x8_t*>(&raw);
         }
@@ -239,7 +246,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P) {
             }
         }
     };
-    auto write_lds = [&](int stage) {
+    auto write_lds = [&](int stage, int t) {
         char* sK = smem + stage * STAGE;
         char* sV = sK + K_TILE_BYTES;
 #pragma unroll
@@ -251,11 +258,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P) {
                 *reinterpret_cast<u32x4_t*>(sV + row * VROW + (c << 4)) = vreg[i];
             }
         }
+        if (HwMask<DH>::value && tid < BKV)          // pad slot d = DH of every key row: 0 or the mask value
+            *reinterpret_cast<u32x4_t*>(sK + tid * K_ROW_BYTES + ((CPR ^ ((tid >> 1) & 7)) << 4)) =
+                mask_chunk(t * BKV + tid < len_k);
     };
 
     const int nkv = (len_k + BKV - 1) / BKV;
     load_regs(0);
-    write_lds(0);
+    write_lds(0, 0);
     __syncthreads();
 
     for (int t = 0; t < nkv; ++t) {
@@ -266,7 +276,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P) {
 
         attn_tile<DH, QG, ALIBI>(sK, sV, kb0, len_k, r, g, c, slope2, qf, q_pos, o, m_run, l_run);
 
-        if (t + 1 < nkv) write_lds((t + 1) & 1);
+        if (t + 1 < nkv) write_lds((t + 1) & 1, t + 1);
         __syncthreads();
     }
 
@@ -323,7 +333,7 @@ __global__ __launch_bounds__(256, (QG >= 2 ? 2 : 4)) void attn_short_kernel(Attn
         for (int it = 0; it < MAXIT; ++it) {
             const int ci = tid + 256 * it;
             const int row = ci >> 3, cc = ci & 7;
-            kbuf[it] = (u32x4_t){0u, 0u, 0u, 0u};
+            kbuf[it] = (HwMask<DH>::value && cc == CPR) ? mask_chunk(row < len_k) : (u32x4_t){0u, 0u, 0u, 0u};
             vbuf[it] = (u32x4_t){0u, 0u, 0u, 0u};
             if (ci < nchunks && cc < CPR) {
                 const int key = row < len_k ? row : len_k - 1;
@@ -354,7 +364,7 @@ __global__ __launch_bounds__(256, (QG >= 2 ? 2 : 4)) void attn_short_kernel(Attn
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int d0 = 32 * ks + 8 * g;
-            u32x4_t raw = (u32x4_t){0u, 0u, 0u, 0u};
+            u32x4_t raw = q_pad_chunk(d0, DH);
             if (d0 < DH) raw = *reinterpret_cast<const u32x4_t*>(qp + d0);
             qf[qg][ks] = *reinterpret_cast<bf16x8_t*>(&raw);
         }
