@@ -438,7 +438,9 @@ int launch_attn(const AttnParams& P, int n_seq, int max_q, int max_k, hipStream_
     }
     // long query streams: 2 query groups per wave (halves K/V LDS traffic per MFMA);
     // short ones (seq2reg windows, gene stream): 64-query blocks to limit tail waste.
-    if (max_q > 256) {
+    // 2 query groups per wave only when that still leaves >= 4 blocks per CU (measured: CRE stream, 256 blocks, is
+    // 15% faster with 64-query blocks; the 10^4-query gene->CRE cross attention is 17% faster with 128-query blocks)
+    if (max_q > 256 && (long)n_seq * P.H * ((max_q + 127) / 128) >= 1024) {
         dim3 grid(n_seq, P.H, (max_q + 127) / 128);
         hipLaunchKernelGGL((attn_fwd_kernel<DH, 2, ALIBI>), grid, dim3(256), 0, st, P);
     } else {
