@@ -139,7 +139,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
+    use_dist = "RANK" in os.environ          # launched by torch.distributed.run (also with one rank: exercises RCCL)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
@@ -163,25 +164,25 @@ def main():
         def step():
             pred, emb = model.forward_prepared(pb)
             expr = pred.view(G, len(tissues))
-            if world > 1:
+            if use_dist:
                 expr = all_gather_expression(expr, owned, world * G)
             return expr.cpu(), emb                            # D2H of the expression matrix (sync point of a step)
 
         for _ in range(args.warmup):
             step()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             expr, _ = step()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if use_dist:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
@@ -243,7 +244,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(model, hp, kw, executed_step / G, host_threads())
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

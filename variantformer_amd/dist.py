@@ -40,7 +40,7 @@ def all_gather_expression(local: torch.Tensor, owned: list[list[int]], n_genes: 
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     assert local.shape[0] == len(owned[rank])
-    if world == 1:
+    if not dist.is_initialized():
         out = torch.empty((n_genes,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         out[torch.as_tensor(owned[0], device=local.device, dtype=torch.long)] = local
         return out
