@@ -46,13 +46,14 @@ __device__ __forceinline__ void wait_vmcnt() {
 template <int EPI>
 __device__ __forceinline__ void epilogue_store(f32x4_t v, f32x4_t gate, int64_t m, int n_bias, int n_bias_gate,
                                                int n_out, const float* __restrict__ bias,
-                                               const float* __restrict__ res, int64_t ldr, void* out, int64_t ldo) {
+                                               const float* __restrict__ res, int64_t ldr, void* out, int64_t ldo,
+                                               const f32x4_t* res_pre = nullptr) {
     if (bias) {
         const f32x4_t b = *reinterpret_cast<const f32x4_t*>(bias + n_bias);
         v += b;
         if (EPI == VF_EPI_GEGLU_BF16) gate += *reinterpret_cast<const f32x4_t*>(bias + n_bias_gate);
     }
-    if (EPI == VF_EPI_RES_F32) v += *reinterpret_cast<const f32x4_t*>(res + m * ldr + n_out);
+    if (EPI == VF_EPI_RES_F32) v += res_pre ? *res_pre : *reinterpret_cast<const f32x4_t*>(res + m * ldr + n_out);
     if (EPI == VF_EPI_GEGLU_BF16) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = v[i] * gelu_erf(gate[i]);
@@ -207,9 +208,29 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_mfma_kernel(const unsigned
         if (t + STAGES < nkt) issue(t + STAGES, stage);
         stage = stage + 1 == STAGES ? 0 : stage + 1;
     };
+    // fp32-residual epilogue: fetch this lane's residual values while the last K-tile's MFMAs run (after the last
+    // counted vmcnt wait, so they do not disturb the LDS-DMA accounting); the epilogue then only adds and stores.
+    constexpr bool RES_PRE = (EPI == VF_EPI_RES_F32) && (TN * TM <= 16);
+    f32x4_t resv[RES_PRE ? TN : 1][RES_PRE ? TM : 1];
+    auto prefetch_residual = [&]() {
+        if (RES_PRE) {
+#pragma unroll
+            for (int im = 0; im < TM; ++im) {
+                int64_t m = m0 + wm * (BM / C::WM) + im * 16 + r;
+                m = m < M ? m : M - 1;
+#pragma unroll
+                for (int in = 0; in < TN; ++in) {
+                    int nb = n0 + wn * (BN / C::WN) + in * 16 + 4 * g;
+                    nb = nb < N ? nb : N - 4;
+                    resv[RES_PRE ? in : 0][RES_PRE ? im : 0] = *reinterpret_cast<const f32x4_t*>(res + m * ldr + nb);
+                }
+            }
+        }
+    };
     if (C::KS == 2) {
         for (int kt = 0; kt < nkt; ++kt) {
             read_frags(stage, 1, wf1, af1);
+            if (kt + 1 == nkt) prefetch_residual();
             mma(wf0, af0);
             if (kt + 1 < nkt) {
                 boundary(kt);
@@ -225,6 +246,8 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_mfma_kernel(const unsigned
             if (kt + 2 < nkt) {
                 boundary(kt + 1);
                 read_frags(stage, 0, wf0, af0);
+            } else {
+                prefetch_residual();
             }
             mma(wf1, af1);
         }
@@ -249,7 +272,8 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_mfma_kernel(const unsigned
             for (int in = 0; in < TN; ++in) {
                 const int nb = nw0 + in * 16 + 4 * g;
                 if (nb >= N) continue;
-                epilogue_store<EPI>(acc[in][im], acc[in][im], m, nb, nb, nb, bias, res, ldr, out, ldo);
+                epilogue_store<EPI>(acc[in][im], acc[in][im], m, nb, nb, nb, bias, res, ldr, out, ldo,
+                                    RES_PRE ? &resv[RES_PRE ? in : 0][RES_PRE ? im : 0] : nullptr);
             }
         }
     }
