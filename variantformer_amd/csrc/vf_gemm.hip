@@ -90,7 +90,9 @@ struct Cfg {
     static_assert(STAGES >= 2 && STAGES <= 5 && (STAGES - 2) * LPT <= 48, "vmcnt range");
 };
 
-template <class C, int EPI>
+// DBG (diagnostic builds only, never selected automatically): 1 = no global loads (fragment reads + MFMA ceiling),
+// 2 = no fragment reads / MFMA (LDS-DMA fill ceiling).  Results are meaningless in both.
+template <class C, int EPI, int DBG = 0>
 __global__ __launch_bounds__(C::THREADS, 2) void gemm_mfma_kernel(const unsigned short* __restrict__ A, int64_t lda,
                                                               const unsigned short* __restrict__ W,
                                                               const float* __restrict__ bias,
@@ -143,6 +145,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_mfma_kernel(const unsigned
     char* const ldsW_piece = smem + C::A_BYTES + wave * C::PW * 1024;
 
     auto issue = [&](int kt, int stage) {
+        if (DBG == 1 || DBG == 3) return;
 #pragma unroll
         for (int i = 0; i < C::PA; ++i) glds16(srcA[i] + kt * BK, ldsA_piece + stage * C::STAGE_BYTES + i * 1024);
 #pragma unroll
@@ -161,6 +164,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_mfma_kernel(const unsigned
     const int offA = (wm * (BM / C::WM) + r) * ROW_BYTES;
 
     auto read_frags = [&](int stage, int ks, bf16x8_t(&wf)[TN], bf16x8_t(&af)[TM]) {
+        if (DBG == 2) return;
         const char* base = smem + stage * C::STAGE_BYTES + (((4 * ks + g) ^ sw) << 4);
 #pragma unroll
         for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const bf16x8_t*>(base + offW + i * 16 * ROW_BYTES);
@@ -168,6 +172,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_mfma_kernel(const unsigned
         for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(base + offA + i * 16 * ROW_BYTES);
     };
     auto mma = [&](const bf16x8_t(&wf)[TN], const bf16x8_t(&af)[TM]) {
+        if (DBG == 2) return;
 #pragma unroll
         for (int in = 0; in < TN; ++in)
 #pragma unroll
@@ -201,30 +206,47 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_mfma_kernel(const unsigned
     int stage = 0;
     // cross from tile t (in `stage`) to tile t+1
     auto boundary = [&](int t) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        wait_tiles((nkt - 2 - t) < (STAGES - 2) ? (nkt - 2 - t) : (STAGES - 2));
-        __builtin_amdgcn_s_barrier();
+        if (DBG != 3) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            wait_tiles((nkt - 2 - t) < (STAGES - 2) ? (nkt - 2 - t) : (STAGES - 2));
+            __builtin_amdgcn_s_barrier();
+        }
         asm volatile("" ::: "memory");
         if (t + STAGES < nkt) issue(t + STAGES, stage);
         stage = stage + 1 == STAGES ? 0 : stage + 1;
     };
-    // fp32-residual epilogue: fetch this lane's residual values while the last K-tile's MFMAs run (after the last
-    // counted vmcnt wait, so they do not disturb the LDS-DMA accounting); the epilogue then only adds and stores.
+    // ---- coalesced epilogue geometry.  After the K loop every wave stages its own sub-tile through its own slice
+    // of the (then free) LDS ring and writes it out as whole rows, 16 bytes per lane: lane-strided accumulator stores
+    // touch 32-64-byte row segments and are store-issue bound (measured: the K = 512 projections ran 551 TFLOP/s
+    // with them, 942 without any store).  The fp32 residual is read -- and prefetched under the last K-tile's
+    // MFMAs -- in the same coalesced mapping.
+    constexpr bool OUT_F32 = (EPI == VF_EPI_F32 || EPI == VF_EPI_RES_F32 || EPI == VF_EPI_GELU_F32);
+    constexpr int ES = OUT_F32 ? 4 : 2;
+    constexpr int WT_M = BM / C::WM, WT_N = BN / C::WN;
+    constexpr int WT_NO = (EPI == VF_EPI_GEGLU_BF16) ? WT_N / 2 : WT_N;       // output columns of the wave tile
+    constexpr int PITCH = WT_NO * ES + 16;                                   // +16 B: conflict-free ds_write rows
+    constexpr int REGION = C::LDS_BYTES / C::NW;
+    constexpr int RP = (((REGION / PITCH) < WT_M ? (REGION / PITCH) : WT_M) / 16) * 16;   // rows per pass
+    constexpr int IMP = RP / 16, NPASS = (TM + IMP - 1) / IMP;
+    constexpr int CR = WT_NO * ES / 16, RI = 64 / CR, NI = RP / RI;           // chunks per row, rows / instruction
+    static_assert(RP >= 16 && CR >= 1 && CR <= 64 && 64 % CR == 0, "epilogue geometry");
+    const int n_out_total = (EPI == VF_EPI_GEGLU_BF16) ? N / 2 : N;
+    const int64_t mw0 = m0 + wm * WT_M;
+    const int no0 = (EPI == VF_EPI_GEGLU_BF16) ? (n0 + wn * WT_N) / 2 : (n0 + wn * WT_N);
+    const int ep_row = lane / CR, ep_col = no0 + (lane % CR) * (16 / ES);
     constexpr bool RES_PRE = (EPI == VF_EPI_RES_F32) && (TN * TM <= 16);
-    f32x4_t resv[RES_PRE ? TN : 1][RES_PRE ? TM : 1];
+    f32x4_t resv[RES_PRE ? NPASS : 1][RES_PRE ? NI : 1];
     auto prefetch_residual = [&]() {
         if (RES_PRE) {
 #pragma unroll
-            for (int im = 0; im < TM; ++im) {
-                int64_t m = m0 + wm * (BM / C::WM) + im * 16 + r;
-                m = m < M ? m : M - 1;
+            for (int ps = 0; ps < NPASS; ++ps)
 #pragma unroll
-                for (int in = 0; in < TN; ++in) {
-                    int nb = n0 + wn * (BN / C::WN) + in * 16 + 4 * g;
-                    nb = nb < N ? nb : N - 4;
-                    resv[RES_PRE ? in : 0][RES_PRE ? im : 0] = *reinterpret_cast<const f32x4_t*>(res + m * ldr + nb);
+                for (int k = 0; k < NI; ++k) {
+                    int64_t m = mw0 + ps * RP + k * RI + ep_row;
+                    m = m < M ? m : M - 1;
+                    const int col = ep_col < N ? ep_col : N - 4;
+                    resv[RES_PRE ? ps : 0][RES_PRE ? k : 0] = *reinterpret_cast<const f32x4_t*>(res + m * ldr + col);
                 }
-            }
         }
     };
     if (C::KS == 2) {
@@ -253,27 +275,79 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_mfma_kernel(const unsigned
         }
     }
 
-    // ---- epilogue: lane holds out[m = m0 + wm*(BM/WM) + im*16 + r][n = n0 + wn*(BN/WN) + in*16 + 4g .. +3]
-    const int nw0 = n0 + wn * (BN / C::WN);
+    // ---- epilogue: lane holds acc for out[m = mw0 + im*16 + r][n = nw0 + in*16 + 4g .. +3]
+    if (DBG == 4) {                      // diagnostic: no epilogue stores (keep the accumulators live)
+        f32x4_t t = acc[0][0];
 #pragma unroll
-    for (int im = 0; im < TM; ++im) {
-        const int64_t m = m0 + wm * (BM / C::WM) + im * 16 + r;
-        if (m >= M) continue;
-        if (EPI == VF_EPI_GEGLU_BF16) {
+        for (int i = 0; i < TN; ++i)
 #pragma unroll
-            for (int ip = 0; ip < TN / 2; ++ip) {
-                const int nb = nw0 + ip * 32 + 4 * g;          // bias index of the `a` half
-                if (nb >= N) continue;
-                const int n_out = nw0 / 2 + ip * 16 + 4 * g;
-                epilogue_store<EPI>(acc[2 * ip][im], acc[2 * ip + 1][im], m, nb, nb + 16, n_out, bias, res, ldr, out, ldo);
+            for (int k = 0; k < TM; ++k) t += acc[i][k];
+        if (t[0] == 123.456f) reinterpret_cast<float*>(out)[0] = t[1] + t[2] + t[3];
+        return;
+    }
+    const int nw0 = n0 + wn * WT_N;
+    __syncthreads();                     // every wave's last fragments are in registers: the ring is free
+    char* const region = smem + wave * REGION;
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        // (1) accumulators (+bias, activation) -> this wave's LDS slice, in the output dtype
+#pragma unroll
+        for (int iml = 0; iml < IMP; ++iml) {
+            const int im = ps * IMP + iml;
+            if (im < TM) {
+                char* rowp = region + (iml * 16 + r) * PITCH;
+                if (EPI == VF_EPI_GEGLU_BF16) {
+#pragma unroll
+                    for (int ip = 0; ip < TN / 2; ++ip) {
+                        f32x4_t v = acc[2 * ip][im], gt = acc[2 * ip + 1][im];
+                        int nb = nw0 + ip * 32 + 4 * g;
+                        nb = nb < N ? nb : 0;
+                        if (bias) {
+                            v += *reinterpret_cast<const f32x4_t*>(bias + nb);
+                            gt += *reinterpret_cast<const f32x4_t*>(bias + nb + 16);
+                        }
+                        u32x2_t pk;
+                        pk[0] = pack2bf(v[0] * gelu_erf(gt[0]), v[1] * gelu_erf(gt[1]));
+                        pk[1] = pack2bf(v[2] * gelu_erf(gt[2]), v[3] * gelu_erf(gt[3]));
+                        *reinterpret_cast<u32x2_t*>(rowp + (ip * 16 + 4 * g) * 2) = pk;
+                    }
+                } else {
+#pragma unroll
+                    for (int in = 0; in < TN; ++in) {
+                        f32x4_t v = acc[in][im];
+                        int nb = nw0 + in * 16 + 4 * g;
+                        nb = nb < N ? nb : 0;
+                        if (bias) v += *reinterpret_cast<const f32x4_t*>(bias + nb);
+                        if (EPI == VF_EPI_GELU_F32 || EPI == VF_EPI_GELU_BF16) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                        }
+                        if (OUT_F32) {
+                            *reinterpret_cast<f32x4_t*>(rowp + (in * 16 + 4 * g) * 4) = v;
+                        } else {
+                            u32x2_t pk;
+                            pk[0] = pack2bf(v[0], v[1]);
+                            pk[1] = pack2bf(v[2], v[3]);
+                            *reinterpret_cast<u32x2_t*>(rowp + (in * 16 + 4 * g) * 2) = pk;
+                        }
+                    }
+                }
             }
-        } else {
+        }
+        // (2) read the slice back row-wise (same wave: LDS operations are in order) and store whole rows
 #pragma unroll
-            for (int in = 0; in < TN; ++in) {
-                const int nb = nw0 + in * 16 + 4 * g;
-                if (nb >= N) continue;
-                epilogue_store<EPI>(acc[in][im], acc[in][im], m, nb, nb, nb, bias, res, ldr, out, ldo,
-                                    RES_PRE ? &resv[RES_PRE ? in : 0][RES_PRE ? im : 0] : nullptr);
+        for (int k = 0; k < NI; ++k) {
+            const int row = k * RI + ep_row;
+            const int64_t m = mw0 + ps * RP + row;
+            if (ps * RP + row < WT_M && m < M && ep_col < n_out_total) {
+                u32x4_t d = *reinterpret_cast<const u32x4_t*>(region + row * PITCH + (lane % CR) * 16);
+                if (EPI == VF_EPI_RES_F32) {
+                    f32x4_t f = __builtin_bit_cast(f32x4_t, d);
+                    f += RES_PRE ? resv[RES_PRE ? ps : 0][RES_PRE ? k : 0]
+                                 : *reinterpret_cast<const f32x4_t*>(res + m * ldr + ep_col);
+                    d = __builtin_bit_cast(u32x4_t, f);
+                }
+                *reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(out) + (m * ldo + ep_col) * ES) = d;
             }
         }
     }
@@ -523,11 +597,11 @@ using CfgG = Cfg<128, 128, 2, 2, 4, 32>;   // 64 KiB, 4 waves, BK=32, 3 tiles in
 using CfgH = Cfg<256, 128, 2, 2, 3, 32>;   // 72 KiB, 4 waves (wave tile 128x64), BK=32, 2 blocks/CU
 using CfgI = Cfg<128, 256, 2, 2, 3, 32>;   // 72 KiB, 4 waves (wave tile 64x128), BK=32, 2 blocks/CU
 
-template <class C, int EPI>
+template <class C, int EPI, int DBG = 0>
 int launch_cfg(const void* A, int64_t lda, const void* W, const float* bias, const float* res, int64_t ldr, void* out,
                int64_t ldo, int M, int N, int K, hipStream_t st) {
     static bool attr_set = false;                 // per (config, epilogue) instantiation
-    auto kern = gemm_mfma_kernel<C, EPI>;
+    auto kern = gemm_mfma_kernel<C, EPI, DBG>;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 C::LDS_BYTES) != hipSuccess) {
@@ -605,10 +679,21 @@ int launch_gemm(const void* A, int64_t lda, const void* W, const float* bias, co
         case 7: return launch_cfg<CfgG, EPI>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
         case 8: return launch_cfg<CfgH, EPI>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
         case 9: return launch_cfg<CfgI, EPI>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
+        case 104: if (EPI == VF_EPI_BF16) return launch_cfg<CfgA, VF_EPI_BF16, 4>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st); break;
+        case 103: if (EPI == VF_EPI_BF16) return launch_cfg<CfgA, VF_EPI_BF16, 3>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st); break;
+        case 203: if (EPI == VF_EPI_BF16) return launch_cfg<CfgB, VF_EPI_BF16, 3>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st); break;
+        case 101: if (EPI == VF_EPI_BF16) return launch_cfg<CfgA, VF_EPI_BF16, 1>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st); break;
+        case 102: if (EPI == VF_EPI_BF16) return launch_cfg<CfgA, VF_EPI_BF16, 2>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st); break;
+        case 201: if (EPI == VF_EPI_BF16) return launch_cfg<CfgB, VF_EPI_BF16, 1>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st); break;
+        case 202: if (EPI == VF_EPI_BF16) return launch_cfg<CfgB, VF_EPI_BF16, 2>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st); break;
+        case 401: if (EPI == VF_EPI_BF16) return launch_cfg<CfgD, VF_EPI_BF16, 1>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st); break;
+        case 402: if (EPI == VF_EPI_BF16) return launch_cfg<CfgD, VF_EPI_BF16, 2>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st); break;
         case 10: return launch_persist<CfgA, EPI>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
         case 11: return launch_persist<CfgE, EPI>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
-        default: vf_set_error("vf_gemm_bf16_ex: unknown variant %d", variant); return VF_ERR_INVALID_ARG;
+        default: break;
     }
+    vf_set_error("vf_gemm_bf16_ex: unknown variant %d", variant);
+    return VF_ERR_INVALID_ARG;
 }
 
 __global__ void pack_geglu_rows_kernel(const unsigned short* __restrict__ W, const float* __restrict__ bias,
@@ -629,10 +714,11 @@ static int gemm_dispatch(const void* A, int64_t lda, const void* W, const float*
     VF_REQUIRE(M >= 0 && N > 0 && K > 0, "vf_gemm_bf16: bad shape M=%d N=%d K=%d", M, N, K);
     VF_REQUIRE(K % 8 == 0 && N % 8 == 0, "vf_gemm_bf16: K and N must be multiples of 8 (K=%d N=%d)", K, N);
     VF_REQUIRE(lda % 8 == 0 && lda >= K, "vf_gemm_bf16: lda=%lld must be >= K and a multiple of 8", (long long)lda);
-    VF_REQUIRE(ldo % 4 == 0, "vf_gemm_bf16: ldo=%lld must be a multiple of 4", (long long)ldo);
+    VF_REQUIRE(ldo % 8 == 0 || (ldo % 4 == 0 && (epilogue == VF_EPI_F32 || epilogue == VF_EPI_RES_F32 || epilogue == VF_EPI_GELU_F32)),
+               "vf_gemm_bf16: ldo=%lld must keep rows 16-byte aligned (multiple of 8 for bf16, 4 for fp32 outputs)", (long long)ldo);
     VF_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)W % 16 == 0) && ((uintptr_t)out % 16 == 0),
                "vf_gemm_bf16: pointers must be 16-byte aligned");
-    VF_REQUIRE(variant >= 0 && variant <= 11, "vf_gemm_bf16_ex: variant %d out of range", variant);
+    VF_REQUIRE(variant >= 0 && variant <= 999, "vf_gemm_bf16_ex: variant %d out of range", variant);
     if (M == 0) return VF_OK;
     hipStream_t st = (hipStream_t)stream;
     switch (epilogue) {
