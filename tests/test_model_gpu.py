@@ -208,3 +208,21 @@ def test_two_module_variant_vs_reference_golden():
     for i in range(len(meta["n_cres"])):
         assert _rel(out["pred_gene_exp"][i], arrays[f"pred_gene_exp_{i}"]) < NORTH_STAR_RTOL
         assert _rel(out["embeddings"][i], arrays[f"embeddings_{i}"]) < 5e-3
+
+
+def test_edge_geometries_vs_oracle():
+    """Extremes of SURVEY §8d cfg 3 in one batch: a gene with a single CRE and a single chunk and one tissue, a gene
+    with 2048 CREs (clip) and 20 chunks, a gene with 200 full chunks and 54 tissues; production widths, 2 layers."""
+    kw = seq2gene_kw(layers=2)
+    model = build_model(SEQ2REG_512, kw, seed=99)
+    sd = state_dict_cpu(model)
+    model = model.cuda()
+    batch = make_batch(2025, [1, 2048, 40], [1, 20, 200], [[62], [7, 30], TISSUES_54], 200)
+    out = model.predict_step(batch, 0)
+    hp = O.Seq2RegHP.from_hparams(SEQ2REG_512)
+    torch.set_num_threads(8)
+    orc = O.predict_step(batch, sd, hp, hp, O.Seq2GeneHP.from_kwargs(kw), rounding="bf16", share_cre_stream=True)
+    for i in range(3):
+        assert out["pred_gene_exp"][i].shape == orc["pred_gene_exp"][i].shape
+        assert _rel(out["pred_gene_exp"][i], orc["pred_gene_exp"][i]) < NORTH_STAR_RTOL
+        assert _rel(out["embeddings"][i], orc["embeddings"][i]) < 5e-3
