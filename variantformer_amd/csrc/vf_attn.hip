@@ -19,6 +19,7 @@
 //                  16+4g+(j-4) for j>=4) identically on both operands, so no lane movement is needed.
 // dh = 48 (the modulator's 1536/32) is padded to 64 only along the QK^T contraction (zero chunks in
 // the K tile and zero Q fragments); PV uses exactly dh/16 output tiles.
+#include <stdlib.h>
 #include "vf_common.h"
 
 namespace {
@@ -42,6 +43,26 @@ template <int DH> struct HwMask { static constexpr bool value = DH < 64; };
 __device__ __forceinline__ u32x4_t mask_chunk(bool valid) { return (u32x4_t){valid ? 0u : 0xC700u, 0u, 0u, 0u}; }
 __device__ __forceinline__ u32x4_t q_pad_chunk(int d0, int dh) { return (u32x4_t){d0 == dh ? 0x3F80u : 0u, 0u, 0u, 0u}; }
 
+// max over the lanes {l, l^16, l^32, l^48} (the four key sub-blocks g of one query) without LDS round trips:
+// v_permlane16_swap / v_permlane32_swap exchange 16- / 32-lane rows on the VALU (lane semantics checked by
+// tools/hw_probe.hip), replacing two ds_bpermute on the serial softmax chain.
+__device__ __forceinline__ float max_over_g(float x) {
+    const unsigned u = __float_as_uint(x);
+    auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const float y = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    const unsigned v = __float_as_uint(y);
+    auto b = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float sum_over_g(float x) {
+    const unsigned u = __float_as_uint(x);
+    auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const float y = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const unsigned v = __float_as_uint(y);
+    auto b = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
 struct AttnParams {
     const unsigned short* q;
     const unsigned short* k;
@@ -61,7 +82,9 @@ __device__ __forceinline__ s16x4_t lds_tr_read(const char* p) {
 
 // One 64-key tile for QG query groups of a wave: S^T = K.Q^T, online softmax, O^T += V^T.P^T.
 // sK / sV point at the tile's first key row in LDS.  All state is per lane (r = query, g = key sub-block).
-template <int DH, int QG, bool ALIBI>
+// DBGT (diagnostic builds of the long-stream kernel only): 1 = no softmax VALU work (P = S), 2 = additionally no LDS
+// fragment reads (operands reused), used to locate the binding ceiling; results are meaningless.
+template <int DH, int QG, bool ALIBI, int DBGT = 0>
 __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, int kb0, int len_k, int r, int g, float c,
                                           float slope2, const bf16x8_t (&qf)[QG][2], const float (&q_pos)[QG],
                                           f32x4_t (&o)[QG][DH / 16], float (&m_run)[QG], float (&l_run)[QG]) {
@@ -73,17 +96,35 @@ __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, int kb
     for (int qg = 0; qg < QG; ++qg)
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) s[qg][kt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    // all 8 K fragments of the tile are requested before the first MFMA and the V fragments of the first 32-key
+    // block right after, so LDS latency overlaps the MFMAs and the softmax arithmetic instead of preceding every
+    // MFMA pair (diagnostic builds: just-in-time fragment reads cost ~70 of 150 us on the gene->CRE shape)
+    bf16x8_t kf[4][2];
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
+    for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(
+        for (int ks = 0; ks < 2; ++ks)
+            kf[kt][ks] = DBGT >= 2 ? qf[0][ks] : *reinterpret_cast<const bf16x8_t*>(
                 sK + (16 * kt + r) * K_ROW_BYTES + (((4 * ks + g) ^ (r >> 1)) << 4));
+    auto read_v = [&](int kb, bf16x8_t(&vf)[DT]) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const char* vp = sV + (32 * kb + 4 * g + (r >> 2)) * VROW + 32 * dt + 8 * (r & 3);
+            if (DBGT >= 2) { vf[dt] = qf[0][0]; continue; }
+            const s16x4_t lo = lds_tr_read(vp);
+            const s16x4_t hi = lds_tr_read(vp + 16 * VROW);
+            vf[dt] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+    };
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int qg = 0; qg < QG; ++qg)
-                s[qg][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qg][ks], s[qg][kt], 0, 0, 0);
-        }
-    }
+                s[qg][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt][ks], qf[qg][ks], s[qg][kt], 0, 0, 0);
+    bf16x8_t vf0[DT], vf1[DT];
+    read_v(0, vf0);
 
     // ---- online softmax per query group (lane (r,g): query r, keys kb0 + 16kt + 4g + e)
     bf16x8_t pf[QG][2];
@@ -92,6 +133,19 @@ __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, int kb
     const float k_pos0 = (float)(kb0 + 4 * g);
 #pragma unroll
     for (int qg = 0; qg < QG; ++qg) {
+        if (DBGT >= 1) {                              // diagnostic: P = S, no softmax arithmetic
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                u32x4_t pk;
+                pk[0] = pack2bf(s[qg][2 * kb][0], s[qg][2 * kb][1]);
+                pk[1] = pack2bf(s[qg][2 * kb][2], s[qg][2 * kb][3]);
+                pk[2] = pack2bf(s[qg][2 * kb + 1][0], s[qg][2 * kb + 1][1]);
+                pk[3] = pack2bf(s[qg][2 * kb + 1][2], s[qg][2 * kb + 1][3]);
+                pf[qg][kb] = *reinterpret_cast<bf16x8_t*>(&pk);
+            }
+            l_run[qg] = 1.f;
+            continue;
+        }
         if (ALIBI) {
             const float dq = q_pos[qg] - k_pos0;
 #pragma unroll
@@ -110,8 +164,7 @@ __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, int kb
 #pragma unroll
         for (int kt = 1; kt < 4; ++kt)
             mx = fmaxf(fmaxf(fmaxf(mx, s[qg][kt][0]), fmaxf(s[qg][kt][1], s[qg][kt][2])), s[qg][kt][3]);
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        mx = max_over_g(mx);
         const float m_old = m_run[qg];
         const float m_new = fmaxf(m_old, mx);        // finite: tile 0 always holds a valid key
         m_run[qg] = m_new;
@@ -145,24 +198,22 @@ __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, int kb
         }
     }
 
-    // ---- O^T += V^T . P^T : V^T fragments by transposed LDS reads, shared by the QG groups
+    // ---- O^T += V^T . P^T : V^T fragments (transposed LDS reads) shared by the QG groups; block 1 is fetched
+    // under block 0's MFMAs
+    read_v(1, vf1);
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+    for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            const char* vp = sV + (32 * kb + 4 * g + (r >> 2)) * VROW + 32 * dt + 8 * (r & 3);
-            const s16x4_t lo = lds_tr_read(vp);
-            const s16x4_t hi = lds_tr_read(vp + 16 * VROW);
-            const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        for (int qg = 0; qg < QG; ++qg)
+            o[qg][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf0[dt], pf[qg][0], o[qg][dt], 0, 0, 0);
 #pragma unroll
-            for (int qg = 0; qg < QG; ++qg)
-                o[qg][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qg][kb], o[qg][dt], 0, 0, 0);
-        }
-    }
-
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int qg = 0; qg < QG; ++qg)
+            o[qg][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf1[dt], pf[qg][1], o[qg][dt], 0, 0, 0);
 }
 
-template <int DH, int QG, bool ALIBI>
+template <int DH, int QG, bool ALIBI, int DBG = 0>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P) {
     constexpr int CPR = DH / 8;                       // 16-byte chunks per K/V row
     constexpr int NCHUNK = BKV * CPR;                 // chunks per tile
@@ -229,34 +280,38 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P) {
         for (int dt = 0; dt < DT; ++dt) o[qg][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     }
 
-    // ---- K/V tile staging: global -> registers -> LDS
-    u32x4_t kreg[NLD], vreg[NLD];
+    // ---- K/V tile staging: global -> registers -> LDS.  The tile's K chunks and V chunks form ONE list of 2*NCHUNK
+    // 16-byte items, exactly NLD2 per thread, so the prefetch has no divergent branch (with per-thread `if`s hipcc's
+    // wait insertion drained the prefetch -- s_waitcnt vmcnt(0) -- in front of the first MFMA of every tile).
+    constexpr int NLD2 = 2 * NCHUNK / 256;
+    static_assert(2 * NCHUNK % 256 == 0, "staging items must divide over the threads");
+    u32x4_t kvreg[NLD2];
     const unsigned short* kbase = P.k + (int64_t)k_tok0 * P.k_stride + h * DH;
     const unsigned short* vbase = P.v + (int64_t)k_tok0 * P.v_stride + h * DH;
     auto load_regs = [&](int t) {
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int ci = tid + 256 * i;
-            if (ci < NCHUNK) {
-                const int row = ci / CPR, c = ci % CPR;
-                int key = t * BKV + row;
-                key = key < len_k ? key : len_k - 1;                 // finite data for masked keys
-                kreg[i] = *reinterpret_cast<const u32x4_t*>(kbase + (int64_t)key * P.k_stride + c * 8);
-                vreg[i] = *reinterpret_cast<const u32x4_t*>(vbase + (int64_t)key * P.v_stride + c * 8);
-            }
+        for (int i = 0; i < NLD2; ++i) {
+            const int item = tid + 256 * i;
+            const bool is_v = item >= NCHUNK;
+            const int ci = is_v ? item - NCHUNK : item;
+            const int row = ci / CPR, c = ci % CPR;
+            int key = t * BKV + row;
+            key = key < len_k ? key : len_k - 1;                     // finite data for masked keys
+            const unsigned short* src = is_v ? vbase + (int64_t)key * P.v_stride : kbase + (int64_t)key * P.k_stride;
+            kvreg[i] = *reinterpret_cast<const u32x4_t*>(src + c * 8);
         }
     };
     auto write_lds = [&](int stage, int t) {
         char* sK = smem + stage * STAGE;
-        char* sV = sK + K_TILE_BYTES;
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int ci = tid + 256 * i;
-            if (ci < NCHUNK) {
-                const int row = ci / CPR, c = ci % CPR;
-                *reinterpret_cast<u32x4_t*>(sK + row * K_ROW_BYTES + ((c ^ ((row >> 1) & 7)) << 4)) = kreg[i];
-                *reinterpret_cast<u32x4_t*>(sV + row * VROW + (c << 4)) = vreg[i];
-            }
+        for (int i = 0; i < NLD2; ++i) {
+            const int item = tid + 256 * i;
+            const bool is_v = item >= NCHUNK;
+            const int ci = is_v ? item - NCHUNK : item;
+            const int row = ci / CPR, c = ci % CPR;
+            const int off = is_v ? K_TILE_BYTES + row * VROW + (c << 4)
+                                 : row * K_ROW_BYTES + ((c ^ ((row >> 1) & 7)) << 4);
+            *reinterpret_cast<u32x4_t*>(sK + off) = kvreg[i];
         }
         if (HwMask<DH>::value && tid < BKV)          // pad slot d = DH of every key row: 0 or the mask value
             *reinterpret_cast<u32x4_t*>(sK + tid * K_ROW_BYTES + ((CPR ^ ((tid >> 1) & 7)) << 4)) =
@@ -268,24 +323,28 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P) {
     write_lds(0, 0);
     __syncthreads();
 
-    for (int t = 0; t < nkv; ++t) {
-        if (t + 1 < nkv) load_regs(t + 1);
+    // The last tile is peeled so that the loop body has no conditional loads / stores: with them hipcc's wait
+    // bookkeeping turns conservative and drains the just-issued prefetch (s_waitcnt vmcnt(0)) before the first MFMA
+    // of every tile.
+    for (int t = 0; t + 1 < nkv; ++t) {
+        if (DBG < 3) load_regs(t + 1);
         const char* sK = smem + (t & 1) * STAGE;
-        const char* sV = sK + K_TILE_BYTES;
-        const int kb0 = t * BKV;
-
-        attn_tile<DH, QG, ALIBI>(sK, sV, kb0, len_k, r, g, c, slope2, qf, q_pos, o, m_run, l_run);
-
-        if (t + 1 < nkv) write_lds((t + 1) & 1, t + 1);
-        __syncthreads();
+        attn_tile<DH, QG, ALIBI, (DBG > 2 ? 0 : DBG)>(sK, sK + K_TILE_BYTES, t * BKV, len_k, r, g, c, slope2, qf, q_pos,
+                                                       o, m_run, l_run);
+        if (DBG < 3) write_lds((t + 1) & 1, t + 1);
+        if (DBG < 4) __syncthreads();
+    }
+    {
+        const int t = nkv - 1;
+        const char* sK = smem + (t & 1) * STAGE;
+        attn_tile<DH, QG, ALIBI, (DBG > 2 ? 0 : DBG)>(sK, sK + K_TILE_BYTES, t * BKV, len_k, r, g, c, slope2, qf, q_pos,
+                                                       o, m_run, l_run);
     }
 
     // ---- normalise and store: lane (r,g) holds O[q = r][d = 16dt + 4g .. +3]
 #pragma unroll
     for (int qg = 0; qg < QG; ++qg) {
-        float l = l_run[qg];
-        l += __shfl_xor(l, 16);
-        l += __shfl_xor(l, 32);
+        const float l = sum_over_g(l_run[qg]);
         const float inv = 1.0f / l;
         if (q_abs[qg] < len_q) {
             unsigned short* op = P.out + (int64_t)(q_tok0 + q_abs[qg]) * P.o_stride + h * DH + 4 * g;
@@ -390,9 +449,7 @@ __global__ __launch_bounds__(256, (QG >= 2 ? 2 : 4)) void attn_short_kernel(Attn
 
 #pragma unroll
     for (int qg = 0; qg < QG; ++qg) {
-        float l = l_run[qg];
-        l += __shfl_xor(l, 16);
-        l += __shfl_xor(l, 32);
+        const float l = sum_over_g(l_run[qg]);
         const float inv = 1.0f / l;
         if (q_abs[qg] < len_q) {
             unsigned short* op = P.out + (int64_t)(q_tok0 + q_abs[qg]) * P.o_stride + h * DH + 4 * g;
@@ -442,6 +499,13 @@ int launch_attn(const AttnParams& P, int n_seq, int max_q, int max_k, hipStream_
     // 15% faster with 64-query blocks; the 10^4-query gene->CRE cross attention is 17% faster with 128-query blocks)
     if (max_q > 256 && (long)n_seq * P.H * ((max_q + 127) / 128) >= 1024) {
         dim3 grid(n_seq, P.H, (max_q + 127) / 128);
+        if (DH == 48 && !ALIBI) {                  // diagnostic builds (VF_ATTN_DBG=1..4), never used otherwise
+            static const int dbg = getenv("VF_ATTN_DBG") ? atoi(getenv("VF_ATTN_DBG")) : 0;
+            if (dbg == 1) { hipLaunchKernelGGL((attn_fwd_kernel<48, 2, false, 1>), grid, dim3(256), 0, st, P); return VF_OK; }
+            if (dbg == 2) { hipLaunchKernelGGL((attn_fwd_kernel<48, 2, false, 2>), grid, dim3(256), 0, st, P); return VF_OK; }
+            if (dbg == 3) { hipLaunchKernelGGL((attn_fwd_kernel<48, 2, false, 3>), grid, dim3(256), 0, st, P); return VF_OK; }
+            if (dbg == 4) { hipLaunchKernelGGL((attn_fwd_kernel<48, 2, false, 4>), grid, dim3(256), 0, st, P); return VF_OK; }
+        }
         hipLaunchKernelGGL((attn_fwd_kernel<DH, 2, ALIBI>), grid, dim3(256), 0, st, P);
     } else {
         dim3 grid(n_seq, P.H, (max_q + 63) / 64);

@@ -653,7 +653,10 @@ int launch_persist(const void* A, int64_t lda, const void* W, const float* bias,
 int pick_variant(int M, int N, int K, int epilogue) {
     (void)K;
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+    const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
     if (t128 < 256) return 5;
+    if (K >= 4096 && t256 >= 256) return 2;                               // long K: 256x256 (1411 vs 1155 at 8192^3)
+    if (K <= 512 && N >= 1024 && t256 >= 1024 && epilogue == VF_EPI_BF16) return 2;   // seq2reg Wqkv: 773 vs 684
     (void)epilogue;      // in the full pipeline the persistent form measured slower (33.0 vs 34.0 genes/s): not selected
     return 1;
 }
