@@ -86,6 +86,16 @@ int vf_attn_varlen_fwd(const void* q, const void* k, const void* v, void* out,
                        int n_seq, int max_seqlen_q, int max_seqlen_k,
                        int H, int dh, const float* alibi_slopes, float scale, void* stream);
 
+/* Same kernel with the ALiBi query positions aligned to the START of the key sequence (query i of a sequence sits at
+ * position i, bias -slope*|i - j|) instead of flash-attn's end alignment.  Used for the last gene layer, where only
+ * the registry token (position 0 of each sequence) is still needed as a query (pool_outputs keeps row 0 only,
+ * seq2gene/model_combined_modulator.py:391-392) while every token still serves as key / value. */
+int vf_attn_varlen_fwd_qstart(const void* q, const void* k, const void* v, void* out,
+                              int64_t q_stride, int64_t k_stride, int64_t v_stride, int64_t o_stride,
+                              const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k,
+                              int n_seq, int max_seqlen_q, int max_seqlen_k,
+                              int H, int dh, const float* alibi_slopes, float scale, void* stream);
+
 /* y = LayerNorm(x) * gamma + beta over the last dim (eps inside sqrt, biased variance), optional
  * exact-erf GELU, output bf16 or fp32.  x fp32 [rows, D], D % 4 == 0, D <= 8192.
  * Replaces nn.LayerNorm (seq2reg/modules.py:143-144, layers.py:75-77, head layers.py:1080-1081). */

@@ -226,3 +226,17 @@ def test_edge_geometries_vs_oracle():
         assert out["pred_gene_exp"][i].shape == orc["pred_gene_exp"][i].shape
         assert _rel(out["pred_gene_exp"][i], orc["pred_gene_exp"][i]) < NORTH_STAR_RTOL
         assert _rel(out["embeddings"][i], orc["embeddings"][i]) < 5e-3
+
+
+def test_last_layer_registry_only_path_is_exact():
+    """forward_prepared computes only the registry rows of the last gene layer; the full-layer path (used by VEP)
+    must give the same embeddings / predictions."""
+    kw = seq2gene_kw(layers=3)
+    model = build_model(SEQ2REG_512, kw, seed=5).cuda()
+    batch = make_batch(31, [20, 7], [5, 9], [TISSUES_54[:4], [8, 62]], 200)
+    with torch.no_grad():
+        pb = model.prepare_batch(batch)
+        fast = model.forward_prepared(pb)
+        full = model.forward_prepared(pb, return_cre=True)
+    np.testing.assert_allclose(fast[1].cpu().numpy(), full[1].cpu().numpy(), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(fast[0].cpu().numpy(), full[0].cpu().numpy(), rtol=2e-5, atol=2e-6)

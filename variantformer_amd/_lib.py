@@ -27,6 +27,7 @@ SIGNATURES = {
     "vf_gemm_bf16_ex": [_p, _l, _p, _p, _p, _l, _p, _l, _i, _i, _i, _i, _i, _p],
     "vf_pack_geglu_rows": [_p, _p, _p, _p, _i, _i, _p],
     "vf_attn_varlen_fwd": [_p, _p, _p, _p, _l, _l, _l, _l, _p, _p, _i, _i, _i, _i, _i, _p, _f, _p],
+    "vf_attn_varlen_fwd_qstart": [_p, _p, _p, _p, _l, _l, _l, _l, _p, _p, _i, _i, _i, _i, _i, _p, _f, _p],
     "vf_layernorm": [_p, _p, _p, _p, _l, _i, _f, _i, _i, _p],
     "vf_embed_pack": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "vf_mask_to_cu_seqlens": [_p, _p, _i, _i, _p],

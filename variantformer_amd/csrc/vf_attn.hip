@@ -74,6 +74,8 @@ struct AttnParams {
     const float* slopes;
     float scale_log2;   // scale * log2(e)
     int H;
+    int q_at_start;     // ALiBi query positions: 0 = queries are the LAST len_q positions of the key sequence
+                        // (flash-attn convention), 1 = query i sits at position i
 };
 
 __device__ __forceinline__ s16x4_t lds_tr_read(const char* p) {
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P) {
     const float slope2 = ALIBI ? P.slopes[h] * 1.4426950408889634f : 0.f;
     float q_pos[QG];                                   // query position + (sk - sq), as float (exact: < 2^24)
 #pragma unroll
-    for (int qg = 0; qg < QG; ++qg) q_pos[qg] = (float)(q_abs[qg] + (len_k - len_q));
+    for (int qg = 0; qg < QG; ++qg) q_pos[qg] = (float)(q_abs[qg] + (P.q_at_start ? 0 : len_k - len_q));
 
     f32x4_t o[QG][DT];
     float m_run[QG], l_run[QG];
@@ -427,7 +429,7 @@ __global__ __launch_bounds__(256, (QG >= 2 ? 2 : 4)) void attn_short_kernel(Attn
             if (d0 < DH) raw = *reinterpret_cast<const u32x4_t*>(qp + d0);
             qf[qg][ks] = *reinterpret_cast<bf16x8_t*>(&raw);
         }
-        q_pos[qg] = (float)(q_abs[qg] + (len_k - len_q));
+        q_pos[qg] = (float)(q_abs[qg] + (P.q_at_start ? 0 : len_k - len_q));
     }
     const float c = P.scale_log2;
     const float slope2 = ALIBI ? P.slopes[h] * 1.4426950408889634f : 0.f;
@@ -517,10 +519,10 @@ int launch_attn(const AttnParams& P, int n_seq, int max_q, int max_k, hipStream_
 
 }  // namespace
 
-extern "C" int vf_attn_varlen_fwd(const void* q, const void* k, const void* v, void* out, int64_t q_stride,
-                                  int64_t k_stride, int64_t v_stride, int64_t o_stride, const int32_t* cu_seqlens_q,
-                                  const int32_t* cu_seqlens_k, int n_seq, int max_seqlen_q, int max_seqlen_k, int H,
-                                  int dh, const float* alibi_slopes, float scale, void* stream) {
+static int attn_dispatch(const void* q, const void* k, const void* v, void* out, int64_t q_stride,
+                         int64_t k_stride, int64_t v_stride, int64_t o_stride, const int32_t* cu_seqlens_q,
+                         const int32_t* cu_seqlens_k, int n_seq, int max_seqlen_q, int max_seqlen_k, int H,
+                         int dh, const float* alibi_slopes, float scale, int q_at_start, void* stream) {
     VF_REQUIRE(q && k && v && out && cu_seqlens_q, "vf_attn_varlen_fwd: null pointer");
     VF_REQUIRE(dh == 32 || dh == 48 || dh == 64, "vf_attn_varlen_fwd: head_dim %d not supported (32/48/64)", dh);
     VF_REQUIRE(H > 0 && H <= 65535 && n_seq >= 0, "vf_attn_varlen_fwd: H=%d n_seq=%d out of range", H, n_seq);
@@ -535,7 +537,7 @@ extern "C" int vf_attn_varlen_fwd(const void* q, const void* k, const void* v, v
     P.out = (unsigned short*)out;
     P.q_stride = q_stride; P.k_stride = k_stride; P.v_stride = v_stride; P.o_stride = o_stride;
     P.cu_q = cu_seqlens_q; P.cu_k = cu_seqlens_k ? cu_seqlens_k : cu_seqlens_q;
-    P.slopes = alibi_slopes; P.scale_log2 = scale * 1.4426950408889634f; P.H = H;
+    P.slopes = alibi_slopes; P.scale_log2 = scale * 1.4426950408889634f; P.H = H; P.q_at_start = q_at_start;
     hipStream_t st = (hipStream_t)stream;
     const bool alibi = alibi_slopes != nullptr;
     switch (dh) {
@@ -543,4 +545,21 @@ extern "C" int vf_attn_varlen_fwd(const void* q, const void* k, const void* v, v
         case 48: return alibi ? launch_attn<48, true>(P, n_seq, max_seqlen_q, max_seqlen_k, st) : launch_attn<48, false>(P, n_seq, max_seqlen_q, max_seqlen_k, st);
         default: return alibi ? launch_attn<64, true>(P, n_seq, max_seqlen_q, max_seqlen_k, st) : launch_attn<64, false>(P, n_seq, max_seqlen_q, max_seqlen_k, st);
     }
+}
+
+extern "C" int vf_attn_varlen_fwd(const void* q, const void* k, const void* v, void* out, int64_t q_stride,
+                                  int64_t k_stride, int64_t v_stride, int64_t o_stride, const int32_t* cu_seqlens_q,
+                                  const int32_t* cu_seqlens_k, int n_seq, int max_seqlen_q, int max_seqlen_k, int H,
+                                  int dh, const float* alibi_slopes, float scale, void* stream) {
+    return attn_dispatch(q, k, v, out, q_stride, k_stride, v_stride, o_stride, cu_seqlens_q, cu_seqlens_k, n_seq,
+                         max_seqlen_q, max_seqlen_k, H, dh, alibi_slopes, scale, 0, stream);
+}
+
+extern "C" int vf_attn_varlen_fwd_qstart(const void* q, const void* k, const void* v, void* out, int64_t q_stride,
+                                         int64_t k_stride, int64_t v_stride, int64_t o_stride,
+                                         const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k, int n_seq,
+                                         int max_seqlen_q, int max_seqlen_k, int H, int dh, const float* alibi_slopes,
+                                         float scale, void* stream) {
+    return attn_dispatch(q, k, v, out, q_stride, k_stride, v_stride, o_stride, cu_seqlens_q, cu_seqlens_k, n_seq,
+                         max_seqlen_q, max_seqlen_k, H, dh, alibi_slopes, scale, 1, stream);
 }

@@ -116,8 +116,10 @@ def pack_geglu_rows(w: torch.Tensor, bias: torch.Tensor | None):
 
 def attn_varlen(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_q: torch.Tensor, cu_k: torch.Tensor | None,
                 max_q: int, max_k: int, n_heads: int, head_dim: int, slopes: torch.Tensor | None = None,
-                scale: float | None = None, out: torch.Tensor | None = None) -> torch.Tensor:
-    """q [tq, >=H*dh] / k, v [tk, >=H*dh] bf16 row-strided views whose first H*dh columns are the heads."""
+                scale: float | None = None, out: torch.Tensor | None = None, q_at_start: bool = False) -> torch.Tensor:
+    """q [tq, >=H*dh] / k, v [tk, >=H*dh] bf16 row-strided views whose first H*dh columns are the heads.
+    q_at_start: ALiBi positions of the queries count from the start of the key sequence (default: flash-attn's
+    end alignment)."""
     _dev(q, k, v, cu_q, cu_k, slopes, out)
     for t in (q, k, v):
         assert t.dtype == torch.bfloat16 and t.dim() == 2 and t.stride(1) == 1
@@ -130,7 +132,8 @@ def attn_varlen(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_q: torch.T
     if slopes is not None:
         assert slopes.dtype == torch.float32 and slopes.numel() == n_heads
     def launch():
-        check(_lib.load().vf_attn_varlen_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), q.stride(0),
+        fn = _lib.load().vf_attn_varlen_fwd_qstart if q_at_start else _lib.load().vf_attn_varlen_fwd
+        check(fn(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), q.stride(0),
                                              k.stride(0), v.stride(0), out.stride(0), cu_q.data_ptr(), _ptr(cu_k),
                                              cu_q.numel() - 1, int(max_q), int(max_k), n_heads, head_dim, _ptr(slopes),
                                              float(scale), _stream()), "vf_attn_varlen_fwd")

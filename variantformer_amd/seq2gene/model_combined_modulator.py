@@ -61,6 +61,9 @@ class PreparedBatch:
     total_tissue_rows: int
     registry_rows_host: np.ndarray = None
     cu_cre_host: np.ndarray = None
+    cu_registry: torch.Tensor = None          # int32 [sum T + 1] = arange: one registry query per (gene, tissue)
+    cu_registry_cross: torch.Tensor = None    # int32 [n_genes + 1]: T_i registry rows per gene
+    max_tissues: int = 1
     cre_unique_inverse: torch.Tensor = None   # int64 [sum N]: row of each window in the de-duplicated cre_ids
     gene_unique_inverse: torch.Tensor = None
 
@@ -79,7 +82,8 @@ def _context_kv_table(ctx_embedding: nn.Embedding, layer) -> torch.Tensor:
 
 
 def modulator_forward_packed(ctx_embedding, cre_layers, gene_layers, cre_x, gene_x, labels, cu_cre, max_cre,
-                             cu_gene_self, max_gene, cu_gene_cross=None, max_gene_cross=None, cu_cre_for_gene=None):
+                             cu_gene_self, max_gene, cu_gene_cross=None, max_gene_cross=None, cu_cre_for_gene=None,
+                             final_rows=None):
     """Interleaved CRE / gene layer stack on packed streams (reference model_combined_modulator.py:244-285; the
     two-module variant seq2gene/model.py:375-412 + layers.py:620-742,797-921 evaluates the same sequence: gene layer
     i reads the CRE stream after CRE layer i-1, gene layer 0 the raw CRE embeddings).
@@ -92,11 +96,18 @@ def modulator_forward_packed(ctx_embedding, cre_layers, gene_layers, cre_x, gene
     cre, gene = cre_x, gene_x
     gene = gene_layers[0].forward_packed(gene, cu_gene_self, max_gene, context=cre, cu_ctx=ck, max_ctx=max_cre,
                                          cu_cross_q=cq, max_cross_q=mq)
-    for i in range(len(gene_layers) - 1):
+    n = len(gene_layers)
+    for i in range(n - 1):
         kv = ops.gather_rows_bf16(_context_kv_table(ctx_embedding, cre_layers[i]), labels)
         cre = cre_layers[i].forward_packed(cre, cu_cre, max_cre, context_kv=kv, cu_ctx=cu_cre, max_ctx=max_cre)
-        gene = gene_layers[i + 1].forward_packed(gene, cu_gene_self, max_gene, context=cre, cu_ctx=ck, max_ctx=max_cre,
-                                                 cu_cross_q=cq, max_cross_q=mq)
+        if final_rows is not None and i + 1 == n - 1:
+            # last gene layer: only the registry rows are consumed downstream -> compact [R, D] result
+            rows, cu_rows, cu_cross_rows, max_cross_rows = final_rows
+            gene = gene_layers[i + 1].forward_packed_rows(gene, cu_gene_self, max_gene, rows, cu_rows, cre, ck, max_cre,
+                                                          cu_cross_rows, max_cross_rows)
+        else:
+            gene = gene_layers[i + 1].forward_packed(gene, cu_gene_self, max_gene, context=cre, cu_ctx=ck,
+                                                     max_ctx=max_cre, cu_cross_q=cq, max_cross_q=mq)
     return gene, cre
 
 
@@ -123,10 +134,10 @@ class CombinedModulator(nn.Module):
         self.gene_layers = nn.ModuleList([mk() for _ in range(num_layers)])
 
     def forward_packed(self, cre_x, gene_x, labels, cu_cre, max_cre, cu_gene_self, max_gene, cu_gene_cross=None,
-                       max_gene_cross=None, cu_cre_for_gene=None):
+                       max_gene_cross=None, cu_cre_for_gene=None, final_rows=None):
         return modulator_forward_packed(self.second_level_context_embedding, self.cre_layers, self.gene_layers, cre_x,
                                         gene_x, labels, cu_cre, max_cre, cu_gene_self, max_gene, cu_gene_cross,
-                                        max_gene_cross, cu_cre_for_gene)
+                                        max_gene_cross, cu_cre_for_gene, final_rows)
 
     def forward(self, cre_x, gene_x, context=None, cre_padding_mask=None, gene_padding_mask=None,
                 context_padding_mask=None, precision=None, cre_token_position=None, gene_token_position=None):
@@ -305,6 +316,9 @@ class Seq2GenePredictorCombinedModulator(nn.Module):
             max_gene=max(self_lens), cu_gene_cross=to(cu_cross), max_gene_cross=max(cross_lens),
             gene_stream_idx=to(np.concatenate(idx)), registry_rows=to(np.array(reg_rows, dtype=np.int64)),
             total_tissue_rows=len(reg_rows), registry_rows_host=np.array(reg_rows, dtype=np.int64), cu_cre_host=cu_cre,
+            cu_registry=to(np.arange(len(reg_rows) + 1, dtype=np.int32)),
+            cu_registry_cross=to(np.concatenate([[0], np.cumsum([len(t) for t in tissues])]).astype(np.int32)),
+            max_tissues=max(len(t) for t in tissues),
             cre_unique_inverse=None if cre_inv is None else cre_inv.to(dev),
             gene_unique_inverse=None if gene_inv is None else gene_inv.to(dev))
 
@@ -328,10 +342,17 @@ class Seq2GenePredictorCombinedModulator(nn.Module):
         gene_x = ops.gemm(gene_tok, w, b, ops.EPI_F32)
         # registry token per (gene, tissue) + that gene's chunk rows (:357-366, layers.py:508-521)
         gene_stream = ops.gather_rows_f32(gene_x, self.start_tkn.registry_tokens.weight, pb.gene_stream_idx)
-        gene_out, cre_out = self._modulator_forward_packed(
-            cre_x, gene_stream, pb.labels, pb.cu_cre, pb.max_cre, pb.cu_gene_self, pb.max_gene,
-            cu_gene_cross=pb.cu_gene_cross, max_gene_cross=pb.max_gene_cross)
-        emb = ops.gather_rows_f32(gene_out, None, pb.registry_rows)                             # pool_outputs (:391-392)
+        if return_cre:       # VEP needs every gene token of the last layer (token-position gathers)
+            gene_out, cre_out = self._modulator_forward_packed(
+                cre_x, gene_stream, pb.labels, pb.cu_cre, pb.max_cre, pb.cu_gene_self, pb.max_gene,
+                cu_gene_cross=pb.cu_gene_cross, max_gene_cross=pb.max_gene_cross)
+            emb = ops.gather_rows_f32(gene_out, None, pb.registry_rows)                         # pool_outputs (:391-392)
+        else:                # only row 0 (registry token) of the last gene layer is consumed: compute just those rows
+            emb, cre_out = self._modulator_forward_packed(
+                cre_x, gene_stream, pb.labels, pb.cu_cre, pb.max_cre, pb.cu_gene_self, pb.max_gene,
+                cu_gene_cross=pb.cu_gene_cross, max_gene_cross=pb.max_gene_cross,
+                final_rows=(pb.registry_rows, pb.cu_registry, pb.cu_registry_cross, pb.max_tissues))
+            gene_out = None
         pred = self.tissue_heads(emb)
         if return_cre:
             return pred, emb, gene_out, cre_out

@@ -235,6 +235,36 @@ class ContextFlashAttentionEncoderLayer(nn.Module):
         w2, b2 = packed_linear(self.linear_geglu_2)
         return ops.gemm(hg, w2, b2, ops.EPI_RES_F32, residual=src)
 
+    def forward_packed_rows(self, src, cu_src, max_src, rows, cu_rows, context, cu_ctx, max_ctx, cu_cross_rows,
+                            max_cross_rows):
+        """Same layer, but only the output rows `rows` (int64 indices into src, at most one per self-attention
+        sequence and located at position 0 of its sequence) are produced: fp32 [len(rows), D].
+        Every token still contributes keys / values to the self attention; the query side, both out-projections, the
+        cross attention, LayerNorm 2/3 and the GeGLU FFN run on the selected rows only.  Used for the LAST gene layer,
+        whose output is consumed only through the registry token (pool_outputs row 0,
+        model_combined_modulator.py:391-392): exact, and ~1/25 of the gene-stream work less."""
+        assert not self.make_data_kv
+        D = src.shape[1]
+        mha = self.mixer.MHA
+        h = ops.layernorm(src, self.norm1.weight, self.norm1.bias)                       # all rows (K/V need them)
+        w, b = packed_linear(mha.Wqkv)
+        kv = ops.gemm(h, w[D:], None if b is None else b[D:], ops.EPI_BF16)             # [tokens, 2D]
+        hq = ops.gather_rows_bf16(h, rows)
+        q = ops.gemm(hq, w[:D], None if b is None else b[:D], ops.EPI_BF16)             # [R, D]
+        a = ops.attn_varlen(q, kv[:, :D], kv[:, D:], cu_rows, cu_src, 1, max_src, mha.num_heads, mha.head_dim,
+                            mha.alibi_slopes, q_at_start=True)
+        src_rows = ops.gather_rows_f32(src, None, rows)
+        wo, bo = packed_linear(mha.out_proj)
+        x1 = ops.gemm(a, wo, bo, ops.EPI_RES_F32, residual=src_rows)
+        h = ops.layernorm(x1, self.norm2.weight, self.norm2.bias)
+        ckv = self.crossMHA.MHA.project_kv(ops.cast_bf16(context))
+        x2 = self.crossMHA.MHA.fused(h, x1, cu_cross_rows, max_cross_rows, ckv, cu_ctx, max_ctx)
+        h = ops.layernorm(x2, self.norm3.weight, self.norm3.bias)
+        w1, b1 = packed_linear(self.linear_geglu_1, geglu=True)
+        hg = ops.gemm(h, w1, b1, ops.EPI_GEGLU_BF16)
+        w2, b2 = packed_linear(self.linear_geglu_2)
+        return ops.gemm(hg, w2, b2, ops.EPI_RES_F32, residual=src_rows)
+
     def forward(self, src, context, src_key_padding_mask=None, context_padding_mask=None, precision=torch.float32,
                 unpad_info=None, context_unpad_info=None, gene_unpad_info=None):
         """Reference signature.  `precision` is accepted and ignored: operands are always bf16 with fp32

@@ -19,7 +19,11 @@ def gene_flops(N: int, C: int, T: int, S_c: int, S_g: int, sum_sq_cre: float, su
     cre_stream = Lc * (N * (12 * D * D + 3 * F * D) + 8 * N * N * D)
     cre_stream_ref = Lc * (N * (16 * D * D + 3 * F * D) + 8 * N * N * D)      # reference also projects Wkv per token
     kv_proj = Lg * N * 4 * D * D
-    gene_stream = Lg * (G * (12 * D * D + 3 * F * D) + 4 * G * G * D + 4 * G * N * D)
+    gene_layer = G * (12 * D * D + 3 * F * D) + 4 * G * G * D + 4 * G * N * D
+    # last gene layer: only the registry row is consumed downstream (pool_outputs row 0), so algorithmically it needs
+    # the K/V projection of all G tokens and everything else for ONE row
+    gene_last = G * 4 * D * D + (8 * D * D + 3 * F * D) + 4 * G * D + 4 * N * D
+    gene_stream = (Lg - 1) * gene_layer + (gene_layer if executed_by_reference else gene_last)
     head = 2 * (2 * D * D) + 2 * D
     if executed_by_reference:
         total = seq2reg + maps + T * (cre_stream_ref + kv_proj + gene_stream + head)
