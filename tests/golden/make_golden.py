@@ -369,6 +369,66 @@ def misc_fixture():
     print("[golden] misc:", prec)
 
 
+def vep_fixture():
+    """ref/het/hom batches from the reference's VEPDataset (datasets/vepdataset.py:134-799) on synthetic genome
+    artifacts (tests/vep_artifacts.py).  duckdb (imported by utils/assets.py for the S3 manifests, unused here)
+    is absent from the image and stubbed with an empty module; the manifests are plain path tables."""
+    sys.modules.setdefault("duckdb", types.ModuleType("duckdb"))
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import vep_artifacts as va
+    from datasets.vepdataset import VEPDataset, Variant
+    from utils.seq import BPEEncoder
+    import tempfile
+
+    enc = BPEEncoder()
+    enc.load_vocabulary(os.path.join(REF, "vocabs", "bpe_vocabulary_500.json"))
+    spec = va.make_spec()
+
+    def encode_pair(fwd, rev):
+        f, _, r, _ = enc.encode([fwd, rev])
+        return f, r
+
+    class Table:
+        def __init__(self, t):
+            self.t = t
+
+        def get_file_path(self, *key):
+            return self.t[key[0] if len(key) == 1 else tuple(key)]
+
+    arrays, cases = {}, []
+    with tempfile.TemporaryDirectory() as root:
+        gene_csv, gene_npz, cre_pkl = va.write_artifacts(spec, root, encode_pair)
+        genes = {g["gene_id"]: g for g in spec["genes"]}
+        pairs = [{"variant": Variant(chrom=v["chrom"], pos=v["pos"], ref=v["ref"], alt=v["alt"], tissue=v["tissue"],
+                                     gene_id=[v["gene"]]),
+                  "gene": genes[v["gene"]], "sample_name": v["sample_name"], "population": v["population"],
+                  "vcf_path": None} for v in spec["variants"]]
+        ds = VEPDataset(enc, Table(gene_csv), Table(gene_npz), Table(cre_pkl), gene_variant_pairs=pairs,
+                        **spec["settings"])
+        for i in range(len(ds)):
+            try:
+                batch = ds[i]
+            except Exception as ex:
+                cases.append({"error": type(ex).__name__})
+                continue
+            cases.append({"variant_type": batch["variant_type"]})
+            for k, a in va.flatten_batch(batch).items():
+                arrays[f"case{i}.{k}"] = a
+        # string-level known answers of SequenceProcessor (:37-131)
+        from datasets.vepdataset import SequenceProcessor as SP
+        seqs = ["ACGTNRYSWKMBDHVacgtn-.", "GATTACA", "x?ACGU"]
+        sp = {"reverse_complement": {s: SP.reverse_complement(s) for s in seqs},
+              "iupac": {a + b: SP.get_iupac_code(a, b) for a in "ACGTNa" for b in "ACGTNa"},
+              "apply": [list(SP.apply_variant("ACGTAC,GTACGT", Variant("1", 1, r, a, [0], ["g"]), p))
+                        for r, a, p in (("G", "T", 2), ("A", "A", 0), ("C", "N", 5))]}
+    spec["cases"], spec["sequence_processor"] = cases, sp
+    spec["generated_by"] = "tests/golden/make_golden.py: reference datasets/vepdataset.VEPDataset on tests/vep_artifacts.py files"
+    np.savez_compressed(os.path.join(HERE, "vep.npz"), **arrays)
+    with open(os.path.join(HERE, "vep.json"), "w") as f:
+        json.dump(spec, f, indent=1)
+    print("[golden] vep:", [c.get("variant_type", c.get("error")) for c in cases])
+
+
 def main():
     assert os.path.isdir(REF), "reference checkout not present: fixtures can only be generated in the dev container"
     sys.path.insert(0, REPO)
@@ -383,6 +443,7 @@ def main():
         run_fixture(name, fx)
     bpe_fixture()
     misc_fixture()
+    vep_fixture()
 
 
 if __name__ == "__main__":
