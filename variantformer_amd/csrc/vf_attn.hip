@@ -74,9 +74,29 @@ struct AttnParams {
     const float* slopes;
     float scale_log2;   // scale * log2(e)
     int H;
+    int nqb;            // query blocks per (sequence, head) (tiled kernel)
+    int chunk;          // blocks per XCD = ceil(n_seq * H * nqb / 8)
+    int total;          // n_seq * H * nqb
     int q_at_start;     // ALiBi query positions: 0 = queries are the LAST len_q positions of the key sequence
                         // (flash-attn convention), 1 = query i sits at position i
 };
+
+
+// Block -> (sequence, head, query block).  Workgroups are dealt to the 8 XCDs round-robin by linear id, so XCD x gets
+// the logical range [x * chunk, (x + 1) * chunk): all heads and query blocks of a sequence run on one XCD at about the
+// same time.  Their K/V re-reads and the cache lines that neighbouring heads share then hit that XCD's L2, and the
+// 96/128-byte head slices of one token row reach HBM together instead of one DRAM page activation per slice.
+// Logical order: query block fastest, then head, then sequence.  Returns false for the padding blocks.
+__device__ __forceinline__ bool block_coords(const AttnParams& P, int& seq, int& h, int& qb) {
+    const int id = blockIdx.x;
+    const int L = (id & 7) * P.chunk + (id >> 3);
+    if ((id >> 3) >= P.chunk || L >= P.total) return false;
+    qb = L % P.nqb;
+    const int sh = L / P.nqb;
+    h = sh % P.H;
+    seq = sh / P.H;
+    return true;
+}
 
 __device__ __forceinline__ s16x4_t lds_tr_read(const char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
@@ -227,10 +247,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P) {
 
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
 
-    const int seq = blockIdx.x, h = blockIdx.y;
+    int seq, h, qblk;
+    if (!block_coords(P, seq, h, qblk)) return;
     const int q_tok0 = P.cu_q[seq], len_q = P.cu_q[seq + 1] - q_tok0;
     const int k_tok0 = P.cu_k[seq], len_k = P.cu_k[seq + 1] - k_tok0;
-    const int qb0 = blockIdx.z * BQ;
+    const int qb0 = qblk * BQ;
     if (qb0 >= len_q || len_k <= 0) return;           // block-uniform
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -376,7 +397,8 @@ __global__ __launch_bounds__(256, (QG >= 2 ? 2 : 4)) void attn_short_kernel(Attn
     char* const sK0 = smem_dyn;
     char* const sV0 = smem_dyn + k_rows * K_ROW_BYTES;
 
-    const int seq = blockIdx.x, h = blockIdx.y;
+    int seq, h, qblk;
+    if (!block_coords(P, seq, h, qblk)) return;
     const int q_tok0 = P.cu_q[seq], len_q = P.cu_q[seq + 1] - q_tok0;
     const int k_tok0 = P.cu_k[seq], len_k = P.cu_k[seq + 1] - k_tok0;
     if (len_q <= 0 || len_k <= 0) return;
@@ -385,6 +407,24 @@ __global__ __launch_bounds__(256, (QG >= 2 ? 2 : 4)) void attn_short_kernel(Attn
     const int nkv = (len_k + BKV - 1) / BKV;
     const int nchunks = nkv * BKV * 8;
 
+    // ---- Q fragments of this wave's query groups (issued before the K/V loads so that both are in flight together)
+    bf16x8_t qf[QG][2];
+    int q_abs[QG];
+    float q_pos[QG];
+#pragma unroll
+    for (int qg = 0; qg < QG; ++qg) {
+        q_abs[qg] = (wave + 4 * qg) * 16 + r;
+        const int row = q_abs[qg] < len_q ? q_abs[qg] : len_q - 1;
+        const unsigned short* qp = P.q + (int64_t)(q_tok0 + row) * P.q_stride + h * DH;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int d0 = 32 * ks + 8 * g;
+            u32x4_t raw = q_pad_chunk(d0, DH);
+            if (d0 < DH) raw = *reinterpret_cast<const u32x4_t*>(qp + d0);
+            qf[qg][ks] = *reinterpret_cast<bf16x8_t*>(&raw);
+        }
+        q_pos[qg] = (float)(q_abs[qg] + (P.q_at_start ? 0 : len_k - len_q));
+    }
     // ---- stage K (swizzled, zero pad chunks) and V; rows >= len_k replicate the last key (finite, masked later)
     const unsigned short* kbase = P.k + (int64_t)k_tok0 * P.k_stride + h * DH;
     const unsigned short* vbase = P.v + (int64_t)k_tok0 * P.v_stride + h * DH;
@@ -413,24 +453,6 @@ __global__ __launch_bounds__(256, (QG >= 2 ? 2 : 4)) void attn_short_kernel(Attn
         }
     }
 
-    // ---- Q fragments of this wave's query groups
-    bf16x8_t qf[QG][2];
-    int q_abs[QG];
-    float q_pos[QG];
-#pragma unroll
-    for (int qg = 0; qg < QG; ++qg) {
-        q_abs[qg] = (wave + 4 * qg) * 16 + r;
-        const int row = q_abs[qg] < len_q ? q_abs[qg] : len_q - 1;
-        const unsigned short* qp = P.q + (int64_t)(q_tok0 + row) * P.q_stride + h * DH;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int d0 = 32 * ks + 8 * g;
-            u32x4_t raw = q_pad_chunk(d0, DH);
-            if (d0 < DH) raw = *reinterpret_cast<const u32x4_t*>(qp + d0);
-            qf[qg][ks] = *reinterpret_cast<bf16x8_t*>(&raw);
-        }
-        q_pos[qg] = (float)(q_abs[qg] + (P.q_at_start ? 0 : len_k - len_q));
-    }
     const float c = P.scale_log2;
     const float slope2 = ALIBI ? P.slopes[h] * 1.4426950408889634f : 0.f;
     f32x4_t o[QG][DT];
@@ -466,8 +488,17 @@ __global__ __launch_bounds__(256, (QG >= 2 ? 2 : 4)) void attn_short_kernel(Attn
     }
 }
 
+// fills the grid decomposition of block_coords; returns the (padded) 1-D grid size
+static unsigned set_grid(AttnParams& P, int n_seq, int nqb) {
+    const long total = (long)n_seq * P.H * nqb;
+    P.nqb = nqb;
+    P.total = (int)total;
+    P.chunk = (int)((total + 7) / 8);
+    return 8u * (unsigned)P.chunk;
+}
+
 template <int DH, int QG, bool ALIBI>
-int launch_short(const AttnParams& P, int n_seq, int max_k, hipStream_t st) {
+int launch_short(AttnParams P, int n_seq, int max_k, hipStream_t st) {
     const int k_rows = ((max_k + BKV - 1) / BKV) * BKV;
     const int lds = k_rows * (K_ROW_BYTES + VLayout<DH>::ROW);
     auto kern = attn_short_kernel<DH, QG, ALIBI>;
@@ -481,16 +512,18 @@ int launch_short(const AttnParams& P, int n_seq, int max_k, hipStream_t st) {
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(n_seq, P.H), dim3(256), lds, st, P, k_rows);
+    const unsigned nblk = set_grid(P, n_seq, 1);
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), lds, st, P, k_rows);
     VF_CHECK_LAUNCH("vf_attn_varlen_fwd");
     return VF_OK;
 }
 
 template <int DH, bool ALIBI>
-int launch_attn(const AttnParams& P, int n_seq, int max_q, int max_k, hipStream_t st) {
-    // Measured on MI355X (scripts/attn_bench.py): the one-block-per-(sequence, head) kernel wins for the gene stream
-    // (201-token sequences, dh 48); for seq2reg windows (dh 64, <= 200 tokens) the tiled kernel with 64-query
-    // blocks is faster (more blocks in flight, fewer registers).
+int launch_attn(AttnParams P, int n_seq, int max_q, int max_k, hipStream_t st) {
+    // Measured on MI355X (scripts/attn_bench.py, 8 genes): the one-block-per-(sequence, head) kernel wins for the gene
+    // stream (201-token sequences, dh 48: 396 vs 485 us); for seq2reg windows / chunks (dh 64, <= 200 tokens) the tiled
+    // kernel with 64-query blocks is faster (460 vs 613 us on 200-token chunks: more blocks in flight, fewer registers;
+    // the K/V re-reads of its query blocks hit the XCD's L2 thanks to block_coords).
     if (DH <= 48 && max_q > 128 && max_q <= 256 && max_k <= 256) {
         if (max_q <= 192) return launch_short<DH, 3, ALIBI>(P, n_seq, max_k, st);
         return launch_short<DH, 4, ALIBI>(P, n_seq, max_k, st);
@@ -500,7 +533,7 @@ int launch_attn(const AttnParams& P, int n_seq, int max_q, int max_k, hipStream_
     // 2 query groups per wave only when that still leaves >= 4 blocks per CU (measured: CRE stream, 256 blocks, is
     // 15% faster with 64-query blocks; the 10^4-query gene->CRE cross attention is 17% faster with 128-query blocks)
     if (max_q > 256 && (long)n_seq * P.H * ((max_q + 127) / 128) >= 1024) {
-        dim3 grid(n_seq, P.H, (max_q + 127) / 128);
+        const dim3 grid(set_grid(P, n_seq, (max_q + 127) / 128));
         if (DH == 48 && !ALIBI) {                  // diagnostic builds (VF_ATTN_DBG=1..4), never used otherwise
             static const int dbg = getenv("VF_ATTN_DBG") ? atoi(getenv("VF_ATTN_DBG")) : 0;
             if (dbg == 1) { hipLaunchKernelGGL((attn_fwd_kernel<48, 2, false, 1>), grid, dim3(256), 0, st, P); return VF_OK; }
@@ -510,7 +543,7 @@ int launch_attn(const AttnParams& P, int n_seq, int max_q, int max_k, hipStream_
         }
         hipLaunchKernelGGL((attn_fwd_kernel<DH, 2, ALIBI>), grid, dim3(256), 0, st, P);
     } else {
-        dim3 grid(n_seq, P.H, (max_q + 63) / 64);
+        const dim3 grid(set_grid(P, n_seq, (max_q + 63) / 64));
         hipLaunchKernelGGL((attn_fwd_kernel<DH, 1, ALIBI>), grid, dim3(256), 0, st, P);
     }
     VF_CHECK_LAUNCH("vf_attn_varlen_fwd");
@@ -526,7 +559,8 @@ static int attn_dispatch(const void* q, const void* k, const void* v, void* out,
     VF_REQUIRE(q && k && v && out && cu_seqlens_q, "vf_attn_varlen_fwd: null pointer");
     VF_REQUIRE(dh == 32 || dh == 48 || dh == 64, "vf_attn_varlen_fwd: head_dim %d not supported (32/48/64)", dh);
     VF_REQUIRE(H > 0 && H <= 65535 && n_seq >= 0, "vf_attn_varlen_fwd: H=%d n_seq=%d out of range", H, n_seq);
-    VF_REQUIRE(max_seqlen_q <= 64 * 65535, "vf_attn_varlen_fwd: max_seqlen_q=%d too large", max_seqlen_q);
+    VF_REQUIRE((long)n_seq * H * ((max_seqlen_q + 63) / 64) < (1L << 31) - 8,
+               "vf_attn_varlen_fwd: n_seq * H * ceil(max_seqlen_q / 64) exceeds the grid limit");
     VF_REQUIRE(q_stride % 8 == 0 && k_stride % 8 == 0 && v_stride % 8 == 0 && o_stride % 4 == 0,
                "vf_attn_varlen_fwd: row strides must keep 16-byte alignment");
     VF_REQUIRE(((uintptr_t)q % 16 == 0) && ((uintptr_t)k % 16 == 0) && ((uintptr_t)v % 16 == 0) && ((uintptr_t)out % 8 == 0),

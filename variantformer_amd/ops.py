@@ -22,15 +22,18 @@ class KernelTimer:
     """Brackets individual kernel launches with HIP events ON THE STREAM THE KERNEL IS LAUNCHED ON (torch's
     current stream, which is the stream handed to the C ABI).  Used by bench.py for the roofline numbers."""
 
-    def __init__(self):
+    def __init__(self, detail: bool = False):
         self.records = {}
+        self.detail = detail          # also key records by launch geometry (scripts/shape_breakdown.py)
 
-    def time(self, name: str, flops: float, nbytes: float, launch):
+    def time(self, name: str, flops: float, nbytes: float, launch, geometry: str = ""):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         out = launch()
         b.record()
         self.records.setdefault(name, []).append((a, b, flops, nbytes))
+        if self.detail and geometry:
+            self.records.setdefault(f"{name}[{geometry}]", []).append((a, b, flops, nbytes))
         return out
 
     def summary(self) -> dict:
@@ -97,7 +100,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None, epilogue: 
                                    ldo, M, N, K, epilogue, _stream()), "vf_gemm_bf16")
     if TIMER is not None:
         nbytes = 2.0 * (M * K + N * K) + out.numel() * out.element_size() + (0 if residual is None else 4.0 * M * N)
-        TIMER.time("gemm", 2.0 * M * N * K, nbytes, launch)
+        TIMER.time("gemm", 2.0 * M * N * K, nbytes, launch, f"M={M} N={N} K={K} epi={epilogue}")
     else:
         launch()
     return out

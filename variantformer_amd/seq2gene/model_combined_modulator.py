@@ -66,6 +66,8 @@ class PreparedBatch:
     max_tissues: int = 1
     cre_unique_inverse: torch.Tensor = None   # int64 [sum N]: row of each window in the de-duplicated cre_ids
     gene_unique_inverse: torch.Tensor = None
+    cre_max_len: int = 0                      # longest CRE window / gene chunk in valid tokens (0: padded length);
+    gene_max_len: int = 0                     # sizes the attention grid of seq2reg
 
 
 def _context_kv_table(ctx_embedding: nn.Embedding, layer) -> torch.Tensor:
@@ -291,6 +293,8 @@ class Seq2GenePredictorCombinedModulator(nn.Module):
             gene_ids, gene_pad, gene_inv = self._unique_windows(gene_ids.cpu(), gene_pad.cpu())
         cre_tokens = int((~cre_pad).sum())
         gene_tokens = int((~gene_pad).sum())
+        cre_max_len = int((~cre_pad).sum(1).max()) if cre_pad.numel() else 0
+        gene_max_len = int((~gene_pad).sum(1).max()) if gene_pad.numel() else 0
         # structure
         cu_cre = np.concatenate([[0], np.cumsum(n_cre)]).astype(np.int32)
         self_lens, cross_lens, idx, reg_rows = [], [], [], []
@@ -315,6 +319,7 @@ class Seq2GenePredictorCombinedModulator(nn.Module):
             labels=labels.to(dev), cu_cre=to(cu_cre), max_cre=max(n_cre), cu_gene_self=to(cu_self),
             max_gene=max(self_lens), cu_gene_cross=to(cu_cross), max_gene_cross=max(cross_lens),
             gene_stream_idx=to(np.concatenate(idx)), registry_rows=to(np.array(reg_rows, dtype=np.int64)),
+            cre_max_len=cre_max_len, gene_max_len=gene_max_len,
             total_tissue_rows=len(reg_rows), registry_rows_host=np.array(reg_rows, dtype=np.int64), cu_cre_host=cu_cre,
             cu_registry=to(np.arange(len(reg_rows) + 1, dtype=np.int32)),
             cu_registry_cross=to(np.concatenate([[0], np.cumsum([len(t) for t in tissues])]).astype(np.int32)),
@@ -326,9 +331,9 @@ class Seq2GenePredictorCombinedModulator(nn.Module):
         """The hot path: everything below runs as HIP kernels on the current stream.
         Returns (pred fp32 [sum T, 1], emb fp32 [sum T, D])."""
         # seq2reg over every CRE window / gene chunk of the batch (HOT LOOP A, SURVEY §3.1)
-        cre_tok = self.cre_tokenizer.embed_packed(pb.cre_ids, pb.cre_pad, pb.cre_tokens)        # bf16 [sum N, d]
+        cre_tok = self.cre_tokenizer.embed_packed(pb.cre_ids, pb.cre_pad, pb.cre_tokens, max_len=pb.cre_max_len)        # bf16 [sum N, d]
         gene_tokenizer = self.gene_tokenizer if self.gene_tokenizer is not None else self.cre_tokenizer
-        gene_tok = gene_tokenizer.embed_packed(pb.gene_ids, pb.gene_pad, pb.gene_tokens)        # bf16 [sum C, d]
+        gene_tok = gene_tokenizer.embed_packed(pb.gene_ids, pb.gene_pad, pb.gene_tokens, max_len=pb.gene_max_len)        # bf16 [sum C, d]
         if pb.cre_unique_inverse is not None:            # de-duplicated windows -> one row per original window
             cre_tok = ops.gather_rows_bf16(cre_tok, pb.cre_unique_inverse)
             gene_tok = ops.gather_rows_bf16(gene_tok, pb.gene_unique_inverse)

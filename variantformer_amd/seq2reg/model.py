@@ -80,10 +80,14 @@ class Seq2RegPredictor(nn.Module):
             self._pe_dev = self.position_encoding.to(device).contiguous()
         return self._pe_dev
 
-    def embed_packed(self, ids: torch.Tensor, pad: torch.Tensor, n_tokens: int, out_dtype=torch.bfloat16):
+    def embed_packed(self, ids: torch.Tensor, pad: torch.Tensor, n_tokens: int, out_dtype=torch.bfloat16,
+                     max_len: int = 0):
         """ids int64 [W, L], pad bool/u8 [W, L] (True = pad) on the GPU -> pooled [W, d].
-        n_tokens = number of valid tokens (host-known; sizes the packed buffers)."""
+        n_tokens = number of valid tokens (host-known; sizes the packed buffers); max_len = longest window in valid
+        tokens when the host knows it (sizes the attention grid; 0 -> L, an upper bound)."""
         W, L = ids.shape
+        if 0 < max_len < L:
+            L = max_len
         cu = ops.mask_to_cu_seqlens(pad)
         x = ops.embed_pack(ids, pad, cu, self.token_embedding.weight, self._pos_table(ids.device), n_tokens)
         for layer in self.transformer_encoder:
