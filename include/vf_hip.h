@@ -154,6 +154,24 @@ void vf_bpe_destroy(void* bpe);
 int64_t vf_bpe_encode(const void* bpe, const char* seq, int64_t len, int32_t* ids_out, int64_t* starts_out,
                       int64_t capacity);
 
+/* ---- host-side (CPU) VCF reader + per-region IUPAC consensus: SURVEY.md section 8f row 1 ----------------------
+ * Replaces the `samtools faidx | bcftools consensus -H I -e <filter> sample.vcf.gz` subprocess pair the reference
+ * starts per CRE window and per gene body (utils/data_process.py:17-101 apply_bcftools_consensus, :367-467
+ * apply_bcftools_consensus_to_gene).  PARITY UNPINNED: bcftools is third party, absent from the reference tree and
+ * from this image; semantics are restated in variantformer_amd/csrc/vf_vcf.cpp.
+ * vf_vcf_open reads a plain / gzip / bgzip VCF once (genotypes of `sample`, NULL or "" = first sample column) and
+ * returns a handle (NULL on I/O error or unknown sample).  vf_vcf_consensus writes the consensus of the 0-based
+ * interval [start0, start0 + ref_len) of `chrom`, whose reference bases are `ref`, into `out` and returns its
+ * length, or a negative VF_CONS_* code.  snp_only != 0 is the reference's "SNP" filter (TYPE="snp" records only);
+ * indel_policy 0 refuses regions that hold a non-reference insertion / deletion genotype (VF_CONS_INDEL), 1 applies
+ * the first genotype allele of such records. */
+enum { VF_CONS_BAD_ARG = -1, VF_CONS_REF_MISMATCH = -2, VF_CONS_INDEL = -3, VF_CONS_BAD_GT = -4 };
+void* vf_vcf_open(const char* path, const char* sample);
+void vf_vcf_close(void* vcf);
+int64_t vf_vcf_num_records(const void* vcf, const char* chrom);
+int64_t vf_vcf_consensus(const void* vcf, const char* chrom, int64_t start0, const char* ref, int64_t ref_len,
+                         int snp_only, int indel_policy, char* out, int64_t out_cap, int64_t* n_applied);
+
 #ifdef __cplusplus
 }
 #endif

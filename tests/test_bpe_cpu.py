@@ -34,6 +34,7 @@ def test_ids_bit_exact_vs_reference(enc, gold):
     for case in gold["cases"]:
         ids, toks, _, _ = enc.encode([case["seq"], "A"])
         assert ids == case["ids"], case["seq"][:60]
+        assert enc.encode_forward(case["seq"]).tolist() == case["ids"]          # the sample builders' fast path
         assert enc.decode(ids) == "".join(c for c in case["seq"].upper() if c in "ACGTRYSWKMBDHV")
 
 

@@ -1,0 +1,363 @@
+"""In-process IUPAC consensus (vf_vcf_* behind variantformer_amd.utils.data_process) and the VCFDataset sample builder.
+
+bcftools is not available offline, so these are known-answer tests of the semantics restated in
+variantformer_amd/csrc/vf_vcf.cpp (hand-derived expectations plus an independent pure-Python restatement below) --
+"parity unpinned" against the tool itself."""
+import gzip
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+
+from variantformer_amd.datasets.vcfdataset import VCFDataset, collate_fn_batching
+from variantformer_amd.datasets.vepdataset import LocalManifest
+from variantformer_amd.utils import data_process as dp
+from variantformer_amd.utils.functions import reverse_complement
+from variantformer_amd.utils.seq import BPEEncoder
+from variantformer_amd.utils.synthetic import randint
+
+IUPAC = {frozenset("AC"): "M", frozenset("AG"): "R", frozenset("AT"): "W", frozenset("CG"): "S", frozenset("CT"): "Y",
+         frozenset("GT"): "K"}
+
+
+def make_genome(seed=99, n=8000):
+    r = randint(n, 0, 1000, seed, 0)
+    g = np.array(list("ACGT"))[r % 4]
+    g[r >= 992] = "N"
+    s = "".join(g)
+    return s[:3000] + s[3000:3100].lower() + s[3100:]
+
+
+def write_fasta(path, chroms, width=60, with_fai=True):
+    with open(path, "w") as f:
+        for name, seq in chroms.items():
+            f.write(f">{name} test\n")
+            for i in range(0, len(seq), width):
+                f.write(seq[i:i + width] + "\n")
+    if with_fai:
+        off = 0
+        with open(path + ".fai", "w") as f:
+            for name, seq in chroms.items():
+                off += len(f">{name} test\n")
+                f.write(f"{name}\t{len(seq)}\t{off}\t{width}\t{width + 1}\n")
+                off += len(seq) + -(-len(seq) // width)
+
+
+def other_base(b, k=1):
+    b = b.upper()
+    return "ACGT"[("ACGT".index(b) + k) % 4] if b in "ACGT" else "A"
+
+
+def make_records(genome, seed=7):
+    """(pos1, ref, [alts], gt) sorted; a mix of every genotype form on chr1."""
+    pos = sorted(set(int(p) for p in randint(400, 1, len(genome), seed, 1)))
+    recs = []
+    forms = ["0/1", "1/1", "1|0", "0|0", "./.", "1/2", "1", "0/1", "2/1", "./1", "1/."]
+    for i, p in enumerate(pos):
+        ref = genome[p - 1]
+        if ref.upper() == "N":
+            continue
+        gt = forms[i % len(forms)]
+        alts = [other_base(ref, 1)] + ([other_base(ref, 2)] if "2" in gt else [])
+        recs.append((p, ref.upper(), alts, gt))
+    return recs
+
+
+def write_vcf(path, records_by_chrom, samples=("S1",), extra_lines=()):
+    lines = ["##fileformat=VCFv4.2", '##FORMAT=<ID=GT,Number=1,Type=String,Description="Genotype">',
+             "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(samples)]
+    for chrom, recs in records_by_chrom.items():
+        for p, ref, alts, gt in recs:
+            gts = [gt] + ["0/0"] * (len(samples) - 1)
+            lines.append(f"{chrom}\t{p}\t.\t{ref}\t{','.join(alts) if alts else '.'}\t.\tPASS\t.\tGT:DP\t" +
+                         "\t".join(g + ":9" for g in gts))
+    lines += list(extra_lines)
+    text = "\n".join(lines) + "\n"
+    if path.endswith(".gz"):
+        with gzip.open(path, "wt") as f:
+            f.write(text)
+    else:
+        with open(path, "w") as f:
+            f.write(text)
+
+
+def py_consensus(ref, start0, recs, snp_only=True):
+    """Independent restatement for substitutions: see the rules in vf_vcf.cpp."""
+    out = list(ref)
+    frozen = 0
+    for p, r, alts, gt in recs:
+        off = p - start0 - 1
+        if off < 0 or off >= len(ref):
+            continue
+        if any(a.startswith("<") for a in alts) or not alts:
+            continue
+        if len(r) != 1 or any(len(a) != 1 for a in alts):
+            continue
+        al = gt.replace("|", "/").split("/")
+        if al[0] == ".":
+            continue
+        a0 = int(al[0])
+        a1 = a0 if len(al) == 1 or al[1] == "." else int(al[1])
+        if a0 == 0 and a1 == 0:
+            continue
+        if p <= frozen:
+            continue
+        assert ref[off].upper() == r
+        alleles = [r] + alts
+        c = alleles[a0] if a0 == a1 else IUPAC.get(frozenset((alleles[a0], alleles[a1])), "N")
+        out[off] = c.lower() if ref[off].islower() else c
+        frozen = p
+    return "".join(out)
+
+
+@pytest.fixture(scope="module")
+def world(tmp_path_factory):
+    root = tmp_path_factory.mktemp("consensus")
+    g1, g2 = make_genome(99), make_genome(100, 5000)
+    fasta = str(root / "genome.fa")
+    write_fasta(fasta, {"chr1": g1, "chr2": g2})
+    recs1, recs2 = make_records(g1, 7), make_records(g2, 8)
+    vcf = str(root / "s1.vcf.gz")
+    write_vcf(vcf, {"chr1": recs1, "chr2": recs2}, samples=("S1", "S2"))
+    return dict(root=root, fasta=fasta, vcf=vcf, g1=g1, g2=g2, recs1=recs1, recs2=recs2)
+
+
+def test_fasta_reader_matches_strings(world):
+    for with_fai in (True, False):
+        path = str(world["root"] / f"g_{with_fai}.fa")
+        write_fasta(path, {"chr1": world["g1"], "chr2": world["g2"]}, width=70, with_fai=with_fai)
+        fa = dp.FastaReader(path)
+        assert fa.length("chr1") == len(world["g1"]) and fa.length("chr2") == len(world["g2"])
+        for a, b in [(0, 10), (59, 61), (69, 141), (1234, 4321), (7990, 9000), (0, 8000)]:
+            assert fa.fetch("chr1", a, b) == world["g1"][a:b]
+        assert fa.fetch("chr2", 4990, 99999) == world["g2"][4990:]
+        with pytest.raises(KeyError):
+            fa.fetch("chrX", 0, 10)
+
+
+def test_known_answers(tmp_path):
+    ref = "ACGTACGTacgtNNACGT"          # chr1, positions 1..18
+    fasta = str(tmp_path / "k.fa")
+    write_fasta(fasta, {"chr1": ref})
+    recs = [(1, "A", ["G"], "0/1"),      # het          -> R
+            (2, "C", ["T"], "1/1"),      # hom alt      -> T
+            (3, "G", ["A", "C"], "1/2"), # two alts     -> M (A/C)
+            (4, "T", ["C"], "0/0"),      # hom ref      -> T
+            (5, "A", ["C"], "./."),      # missing      -> A
+            (6, "C", ["G"], "1"),        # haploid alt  -> G
+            (7, "G", ["<DEL>"], "0/1"),  # symbolic     -> G
+            (8, "T", ["A"], "0|1"),      # phased het   -> W
+            (8, "T", ["G"], "1/1"),      # same site again: overlaps the applied record -> skipped
+            (9, "A", ["T"], "0/1"),      # lower-case reference base -> lower-case code w
+            (10, "C", ["N"], "0/1"),     # base outside ACGT -> N (lower-case here)
+            (15, "A", ["AT"], "0/0")]    # hom-ref insertion: not applied in any mode
+    vcf = str(tmp_path / "k.vcf")
+    write_vcf(vcf, {"chr1": recs})
+    h = dp.VCFHandle(vcf)
+    assert h.num_records() == len(recs) and h.num_records("chr1") == len(recs) and h.num_records("chr9") == 0
+    seq, n = h.consensus("chr1", 0, ref, snp_only=True)
+    assert seq == "RTMTAGGWwngtNNACGT"
+    assert n == 7
+    # sub-interval: record coordinates are genome positions
+    seq, n = h.consensus("chr1", 5, ref[5:12], snp_only=True)
+    assert seq == "GGWwngt" and n == 4
+    # all-variants mode gives the same here (the only indel record is hom-ref)
+    assert h.consensus("chr1", 0, ref, snp_only=False)[0] == "RTMTAGGWwngtNNACGT"
+    # chromosome without records / empty interval
+    assert h.consensus("chr7", 0, "ACGT", snp_only=True) == ("ACGT", 0)
+
+
+def test_ref_mismatch_and_indel_policy(tmp_path):
+    ref = "ACGTACGTAC"
+    vcf = str(tmp_path / "m.vcf")
+    write_vcf(vcf, {"chr1": [(2, "G", ["T"], "0/1")]})          # genome has C at position 2
+    with pytest.raises(dp.ConsensusError) as ei:
+        dp.VCFHandle(vcf).consensus("chr1", 0, ref, True)
+    assert ei.value.code == -2
+    vcf2 = str(tmp_path / "i.vcf")
+    write_vcf(vcf2, {"chr1": [(2, "C", ["T"], "0/1"), (4, "T", ["TGG"], "1/1"), (7, "GT", ["G"], "1/0"),
+                              (10, "C", ["CA"], "0/1")]})
+    h = dp.VCFHandle(vcf2)
+    assert h.consensus("chr1", 0, ref, True) == ("AYGTACGTAC", 1)              # SNP mode ignores the indels
+    with pytest.raises(dp.ConsensusError) as ei:
+        h.consensus("chr1", 0, ref, False)                                     # nothing guessed by default
+    assert ei.value.code == -3
+    assert h.consensus("chr1", 0, ref, False, "skip") == ("AYGTACGTAC", 1)
+    # first genotype allele of a non-SNP record: insertion applied, deletion applied (1/0), 0/1 insertion not
+    assert h.consensus("chr1", 0, ref, False, "first_allele") == ("AYGTGGACGAC", 3)
+
+
+def test_sample_selection_and_plain_text(world, tmp_path):
+    vcf = str(tmp_path / "two.vcf")
+    write_vcf(vcf, {"chr1": [(1, world["g1"][0].upper(), [other_base(world["g1"][0])], "1/1")]}, samples=("S1", "S2"))
+    ref = world["g1"][:4]
+    assert dp.VCFHandle(vcf, "S1").consensus("chr1", 0, ref, True)[0][0] == other_base(ref[0])
+    assert dp.VCFHandle(vcf, "S2").consensus("chr1", 0, ref, True)[0] == ref            # S2 is 0/0
+    with pytest.raises(Exception):
+        dp.VCFHandle(vcf, "NOPE")
+    with pytest.raises(Exception):
+        dp.VCFHandle(str(tmp_path / "missing.vcf"))
+
+
+def test_random_regions_against_python_restatement(world):
+    h = dp.open_vcf(world["vcf"])
+    assert h.num_records("chr1") == len(world["recs1"])
+    starts = randint(60, 0, 7800, 5, 2)
+    lens = randint(60, 1, 700, 5, 3)
+    total = 0
+    for s, n in zip(starts, lens):
+        s, e = int(s), min(int(s) + int(n), len(world["g1"]))
+        ref = world["g1"][s:e]
+        got, applied = h.consensus("chr1", s, ref, True)
+        want = py_consensus(ref, s, world["recs1"])
+        assert got == want
+        assert applied == sum(a != b for a, b in zip(got, ref))
+        total += applied
+    assert total > 100
+    whole, _ = h.consensus("chr2", 0, world["g2"], True)
+    assert whole == py_consensus(world["g2"], 0, world["recs2"])
+
+
+def test_extract_seq_from_bed_interface(world):
+    bed = pd.DataFrame({"chrom": ["chr1"] * 3, "start": [2000, 500, 3020], "end": [2100, 640, 3080],
+                        "cCRE": ["PLS", "dELS", "pELS"]})
+    ex = dp.ExtractSeqFromBed(neighbour_hood=25, ref_fasta=world["fasta"])
+    df = ex.process_subject(vcf_file=world["vcf"], bed_regions=bed, variant_type="SNP")
+    assert list(df.columns) == ["chrom", "start_cre", "end_cre", "sequence", "cCRE"]
+    assert list(df["start_cre"]) == [475, 1975, 2995] and list(df["cCRE"]) == ["dELS", "PLS", "pELS"]     # sorted by start
+    for _, r in df.iterrows():
+        assert r["sequence"] == py_consensus(world["g1"][r["start_cre"]:r["end_cre"]], r["start_cre"], world["recs1"])
+    # no VCF -> the reference sequence
+    df0 = ex.process_subject(vcf_file=None, bed_regions=bed)
+    assert df0.iloc[0]["sequence"] == world["g1"][475:665]
+    # gene body windows (reference :396-401): + strand uses the shifted start for the downstream clamp
+    exg = dp.ExtractSeqFromBed(neighbour_hood=1500, ref_fasta=world["fasta"], upstream_neighbour_hood=100)
+    plus = exg.process_gene({"chromosome": "chr1", "start": 1000, "end": 4000, "strand": "+"}, world["vcf"], "SNP")
+    assert plus == py_consensus(world["g1"][900:2400], 900, world["recs1"])
+    minus = exg.process_gene({"chromosome": "chr1", "start": 1000, "end": 4000, "strand": "-"}, None)
+    assert minus == world["g1"][2500:4100]
+
+
+def test_vcfdataset_sample_tuple(world, tmp_path):
+    genes = pd.DataFrame([
+        {"gene_id": "ENSG_P", "gene_name": "P", "chromosome": "chr1", "start": 1000, "end": 4000, "strand": "+"},
+        {"gene_id": "ENSG_M", "gene_name": "M", "chromosome": "chr2", "start": 500, "end": 4000, "strand": "-"},
+        {"gene_id": "ENSG_X", "gene_name": "X", "chromosome": "chrX", "start": 500, "end": 4000, "strand": "+"}])
+    cres = {"ENSG_P": [(1040, 1110, "PLS"), (1490, 1560, "pELS"), (2030, 2080, "dELS")],
+            "ENSG_M": [(300, 390, "CTCF-only,CTCF-bound"), (1300, 1345, "DNase-H3K4me3"), (2100, 2180, "pELS,CTCF-bound"),
+                       (4400, 4460, "PLS")]}
+    paths = {}
+    for g, rows in cres.items():
+        chrom = genes.set_index("gene_id").loc[g, "chromosome"]
+        p = str(tmp_path / f"{g}.csv")
+        pd.DataFrame([{"chromosome": chrom, "start_cre": a, "end_cre": b, "cre_name": n} for a, b, n in rows]).to_csv(p, index=False)
+        paths[g] = p
+    query = pd.DataFrame({"gene_id": ["ENSG_P", "ENSG_M", "ENSG_UNKNOWN", "ENSG_P"],
+                          "tissues": ["whole blood,liver,not-a-tissue", "thyroid", "liver", "not-a-tissue"]})
+    ds = VCFDataset(max_length=24, max_chunks=10, cre_neighbour_hood=15, gencode_v24=genes,
+                    gene_cre_manifest=LocalManifest(paths), gene_upstream_neighbour_hood=100,
+                    gene_downstream_neighbour_hood=2500, query_df=query, fasta_path=world["fasta"],
+                    vcf_path=world["vcf"], indel_policy="error")
+    assert len(ds) == 2 and list(ds.query_df["tissue_names"]) == [["whole blood", "liver"], ["thyroid"]]
+    enc = BPEEncoder()
+    enc.load_vocabulary()
+    for idx, (gid, genome, recs) in enumerate([("ENSG_P", world["g1"], world["recs1"]), ("ENSG_M", world["g2"], world["recs2"])]):
+        X, mask, tissues, labels, ref_labels, strand, chunks, chunk_masks = ds[idx]
+        info = genes.set_index("gene_id").loc[gid]
+        minus = info["strand"] == "-"
+        rows = cres[gid][::-1] if minus else cres[gid]
+        assert X.shape == (len(rows), 1, 24) and mask.shape == X.shape and mask.dtype == torch.bool
+        assert strand.tolist() == [1 if minus else 0] and labels.tolist() == [0] * len(rows)
+        assert tissues.tolist() == ds.query_df.iloc[idx]["tissues"]
+        for k, (a, b, name) in enumerate(rows):
+            s, e = max(0, a - 15), b + 15
+            seq = py_consensus(genome[s:e], s, recs)
+            if minus:
+                seq = reverse_complement(seq)
+            ids, _, _, _ = enc.encode([seq, "A"])
+            want = (ids + [0] * 24)[:24]
+            assert X[k, 0].tolist() == want
+            assert mask[k, 0].tolist() == [False] * min(len(ids), 24) + [True] * (24 - min(len(ids), 24))
+        # gene body: + strand [start-100, min(end, start-100+2500)); - strand [max(start, end-2500), end+100)
+        lo, hi = (max(int(info["start"]), int(info["end"]) - 2500), int(info["end"]) + 100) if minus else \
+                 (int(info["start"]) - 100, min(int(info["end"]), int(info["start"]) - 100 + 2500))
+        body = py_consensus(genome[lo:hi], lo, recs)
+        ids, _, _, _ = enc.encode([reverse_complement(body) if minus else body, "A"])
+        n_chunks = min(10, -(-len(ids) // 24))
+        assert chunks.shape == (n_chunks, 1, 24)
+        flat = (ids + [0] * (24 * n_chunks))[: 24 * n_chunks]
+        assert chunks.view(-1).tolist() == flat
+        assert int((~chunk_masks).sum()) == min(len(ids), 24 * n_chunks)
+    batch = collate_fn_batching([ds[0], ds[1]])
+    assert len(batch["cre_sequences"]) == 2 and batch["strand_val"].shape == (2, 1)
+    # sex chromosomes are refused as in the reference
+    dsx = VCFDataset(24, 10, 15, genes, LocalManifest({"ENSG_X": paths["ENSG_P"]}), 100, 2500,
+                     pd.DataFrame({"gene_id": ["ENSG_X"], "tissues": ["liver"]}), world["fasta"], world["vcf"])
+    with pytest.raises(AssertionError, match="not a valid chromosome"):
+        dsx[0]
+    with pytest.raises(ValueError, match="No genes found"):
+        VCFDataset(24, 10, 15, genes, LocalManifest(paths), 100, 2500,
+                   pd.DataFrame({"gene_id": ["nope"], "tissues": ["liver"]}), world["fasta"], world["vcf"])
+
+
+def _configs(tmp_path, fasta, genes_csv):
+    import yaml
+    cfg_dir = tmp_path / "configs"
+    cfg_dir.mkdir()
+    block = {"dataset": {"max_length": 24, "max_chunks": 10, "cre_neighbour_hood": 15, "gencode_v24": str(genes_csv),
+                         "gene_upstream_neighbour_hood": 100, "gene_downstream_neighbour_hood": 2500},
+             "model": {"model_class": "Seq2GenePredictorCombinedModulator", "checkpoint_path": "x.pth", "precision": "bf16-mixed",
+                       "cre_tokenizer": {"path": "t.pth"}, "gene_tokenizer": {"path": "t.pth"}}}
+    with open(cfg_dir / "vf_model.yaml", "w") as f:
+        yaml.safe_dump({"v4_pcg": block}, f)
+    with open(cfg_dir / "vcfloader.yaml", "w") as f:
+        yaml.safe_dump({"CRE_BED": "x", "fasta_path": fasta, "precision": "bf16-mixed",
+                        "dataloader": {"num_workers": 0, "batch_size": 2, "pin_memory": False, "drop_last": False,
+                                       "prefetch_factor": 4}}, f)
+    return cfg_dir
+
+
+def test_create_vcf_from_variant_and_dataloader(world, tmp_path):
+    from variantformer_amd.processors.vcfprocessor import VCFProcessor
+    genes = pd.DataFrame([{"gene_id": "ENSG_P", "gene_name": "P", "chromosome": "chr1", "start": 1000, "end": 4000, "strand": "+"}])
+    genes.to_csv(tmp_path / "genes.csv", index=False)
+    cre_csv = str(tmp_path / "p.csv")
+    pd.DataFrame([{"chromosome": "chr1", "start_cre": 1040, "end_cre": 1110, "cre_name": "PLS"},
+                  {"chromosome": "chr1", "start_cre": 1490, "end_cre": 1560, "cre_name": "pELS"}]).to_csv(cre_csv, index=False)
+    vp = VCFProcessor(config_dir=str(_configs(tmp_path, world["fasta"], tmp_path / "genes.csv")), require_gpu=False,
+                      gene_cre_manifest=LocalManifest({"ENSG_P": cre_csv}))
+    g = world["g1"]
+    taken = {r[0] for r in world["recs1"]}
+    pos = [p for p in (1050, 1051, 1500, 2222) if p not in taken and g[p - 1].upper() != "N"]
+    var = pd.DataFrame({"chrom": "chr1", "pos": pos, "ref": [g[p - 1].upper() for p in pos],
+                        "alt": [other_base(g[p - 1]) for p in pos], "GT": ["0/1", "1/1", "1|0", "0/1"][: len(pos)]})
+    # new file
+    out = vp.create_vcf_from_variant(var, str(tmp_path / "new"))
+    assert out.endswith("new.vcf.gz")
+    h = dp.VCFHandle(out)
+    assert h.num_records("chr1") == len(pos)
+    seq, n = h.consensus("chr1", 1000, g[1000:2300], True)
+    assert n == len(pos) and sum(a != b for a, b in zip(seq, g[1000:2300])) == len(pos)
+    # merged into the sample's VCF (single-sample copy of the fixture VCF)
+    single = str(tmp_path / "single.vcf.gz")
+    write_vcf(single, {"chr1": world["recs1"]}, samples=("DONOR",))
+    merged = vp.create_vcf_from_variant(pd.concat([var, var.iloc[:1]]), str(tmp_path / "merged.vcf.gz"), vcf_path=single)
+    hm = dp.VCFHandle(merged, "DONOR")
+    assert hm.num_records("chr1") == len(world["recs1"]) + len(pos)           # the duplicated row is kept once
+    want = py_consensus(g, 0, sorted(world["recs1"] + [(int(r.pos), r.ref, [r.alt], r.GT) for r in var.itertuples()]))
+    assert hm.consensus("chr1", 0, g, True)[0] == want
+    # REF check against the genome
+    bad = var.copy()
+    bad.loc[0, "ref"] = other_base(bad.loc[0, "ref"], 2)
+    with pytest.raises(ValueError, match="Reference mismatch"):
+        vp.create_vcf_from_variant(bad, str(tmp_path / "bad"))
+    with pytest.raises(ValueError, match="empty"):
+        vp.create_vcf_from_variant(var.iloc[:0], str(tmp_path / "e"))
+    # dataset + loader through the processor
+    ds, loader = vp.create_data(merged, pd.DataFrame({"gene_id": ["ENSG_P"], "tissues": ["liver,thyroid"]}))
+    batch = next(iter(loader))
+    assert batch["cre_sequences"][0].shape == (2, 1, 24) and batch["tissue_context"][0].tolist() == ds.query_df.iloc[0]["tissues"]
+    with pytest.raises(ValueError, match="gene_cre_manifest"):
+        VCFProcessor(config_dir=str(tmp_path / "configs"), require_gpu=False).create_data(merged, ds.query_df)

@@ -78,3 +78,58 @@ def test_model_manager_rejects_missing_checkpoint_and_bad_class(tmp_path):
     cfg.model_class = "NoSuchModel"
     with pytest.raises(NotImplementedError):
         ModelManager(cfg).load_model()
+
+
+def test_vcf2exp_from_fasta_and_vcf(tmp_path):
+    """The whole vcf2exp flow from genome files: FASTA + VCF + per-gene cCRE CSVs -> in-process IUPAC consensus ->
+    BPE -> HIP model.  A donor VCF must change the prediction relative to the reference genome, and the processor's
+    numbers must equal the directly constructed model on the same samples."""
+    from tests.test_consensus_cpu import make_genome, make_records, write_fasta, write_vcf
+    from variantformer_amd.datasets.vcfdataset import collate_fn_batching
+    from variantformer_amd.datasets.vepdataset import LocalManifest
+    from variantformer_amd.processors.vcfprocessor import VCFProcessor
+    meta, arrays, sd, _ = load_fixture("small_sin")
+    cfg_dir = _write_artifacts(tmp_path, meta, sd)
+    g1, g2 = make_genome(99), make_genome(100, 5000)
+    fasta = str(tmp_path / "genome.fa")
+    write_fasta(fasta, {"chr1": g1, "chr2": g2})
+    vcf = str(tmp_path / "donor.vcf.gz")
+    write_vcf(vcf, {"chr1": make_records(g1, 7), "chr2": make_records(g2, 8)})
+    genes = pd.DataFrame([
+        {"gene_id": "ENSG_A", "gene_name": "a", "chromosome": "chr1", "start": 1000, "end": 6000, "strand": "+"},
+        {"gene_id": "ENSG_B", "gene_name": "b", "chromosome": "chr2", "start": 500, "end": 4000, "strand": "-"}])
+    genes.to_csv(tmp_path / "genes.csv", index=False)
+    cres = {"ENSG_A": [(1040, 1110, "PLS"), (1490, 1560, "pELS"), (2030, 2080, "dELS"), (5000, 5100, "dELS")],
+            "ENSG_B": [(300, 390, "CTCF-only,CTCF-bound"), (1300, 1345, "DNase-H3K4me3"), (4400, 4460, "PLS")]}
+    paths = {}
+    for g, rows in cres.items():
+        chrom = genes.set_index("gene_id").loc[g, "chromosome"]
+        paths[g] = str(tmp_path / f"{g}.csv")
+        pd.DataFrame([{"chromosome": chrom, "start_cre": a, "end_cre": b, "cre_name": n} for a, b, n in rows]).to_csv(paths[g], index=False)
+    with open(cfg_dir / "vcfloader.yaml") as f:
+        loader_cfg = yaml.safe_load(f)
+    loader_cfg["fasta_path"] = fasta
+    with open(cfg_dir / "vcfloader.yaml", "w") as f:
+        yaml.safe_dump(loader_cfg, f)
+    with open(cfg_dir / "vf_model.yaml") as f:
+        model_cfg = yaml.safe_load(f)
+    for blk in model_cfg.values():
+        blk["dataset"].update(max_chunks=8, cre_neighbour_hood=15, gene_upstream_neighbour_hood=100,
+                              gene_downstream_neighbour_hood=3000)
+    with open(cfg_dir / "vf_model.yaml", "w") as f:
+        yaml.safe_dump(model_cfg, f)
+    vp = VCFProcessor(config_dir=str(cfg_dir), gene_cre_manifest=LocalManifest(paths))
+    query = pd.DataFrame({"gene_id": ["ENSG_A", "ENSG_B"], "tissues": ["whole blood,thyroid", "liver"]})
+    model, ckpt, trainer = vp.load_model()
+    outs = {}
+    for name, path in (("donor", vcf), ("reference", None)):
+        dataset, loader = vp.create_data(path, query.copy())
+        outs[name] = vp.predict(model, ckpt, trainer, loader, dataset)
+        if name == "donor":
+            direct = build_model(meta["seq2reg"], meta["seq2gene"], sd).cuda()
+            ref = direct.predict_step(collate_fn_batching([dataset[i] for i in range(2)]), 0)
+            for i in range(2):
+                np.testing.assert_allclose(outs[name]["predicted_expression"][i], ref["pred_gene_exp"][i], rtol=1e-5, atol=1e-6)
+    a, b = outs["donor"]["predicted_expression"], outs["reference"]["predicted_expression"]
+    assert a[0].shape == (2, 1) and a[1].shape == (1, 1)
+    assert all(np.isfinite(x).all() for x in a) and not np.allclose(a[0], b[0])

@@ -39,8 +39,14 @@ SIGNATURES = {
     "vf_bpe_create": [_p, _i, _p, _i],
     "vf_bpe_destroy": [_p],
     "vf_bpe_encode": [_p, C.c_char_p, _l, _p, _p, _l],
+    "vf_vcf_open": [C.c_char_p, C.c_char_p],
+    "vf_vcf_close": [_p],
+    "vf_vcf_num_records": [_p, C.c_char_p],
+    "vf_vcf_consensus": [_p, C.c_char_p, _l, C.c_char_p, _l, _i, _i, _p, _l, _p],
 }
-_RESTYPES = {"vf_last_error": C.c_char_p, "vf_bpe_create": C.c_void_p, "vf_bpe_destroy": None, "vf_bpe_encode": C.c_int64}
+_RESTYPES = {"vf_last_error": C.c_char_p, "vf_bpe_create": C.c_void_p, "vf_bpe_destroy": None, "vf_bpe_encode": C.c_int64,
+             "vf_vcf_open": C.c_void_p, "vf_vcf_close": None, "vf_vcf_num_records": C.c_int64,
+             "vf_vcf_consensus": C.c_int64}
 
 _lib = None
 

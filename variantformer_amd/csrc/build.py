@@ -13,7 +13,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["vf_gemm.hip", "vf_attn.hip", "vf_misc.hip", "vf_bpe.cpp"]
+SOURCES = ["vf_gemm.hip", "vf_attn.hip", "vf_misc.hip", "vf_bpe.cpp", "vf_vcf.cpp"]
 HEADERS = ["vf_common.h", os.path.join("..", "..", "include", "vf_hip.h")]
 LIB = os.path.join(HERE, "libvf_hip.so")
 ARCH = "gfx950"
@@ -52,7 +52,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
             raise RuntimeError(f"hipcc failed on {src}:\n{out}")
         if verbose and out:
             print(out)
-    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB + ".tmp"] + objs
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB + ".tmp"] + objs + ["-lz"]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}")

@@ -1,12 +1,23 @@
-"""Batch format of the hot path (reference datasets/vcfdataset.py:18-63) and a synthetic per-gene dataset
-with the reference's sample tuple, used by tests / bench where the genome artifacts are unavailable."""
+"""Batch format of the hot path (reference datasets/vcfdataset.py:18-63), the per-gene sample builder
+`VCFDataset` (:66-394) on the in-process consensus + C++ BPE, and a synthetic per-gene dataset with the same sample
+tuple for tests / bench where the genome artifacts are unavailable."""
 from __future__ import annotations
 
+import os
+
+import numpy as np
 import pandas as pd
 import torch
+import yaml
 from torch.utils.data import Dataset
 
-from ..utils import synthetic
+from ..utils import constants, synthetic
+from ..utils.constants import MAP_REF_CRE_TO_IDX, SPECIAL_TOKENS
+from ..utils.data_process import ExtractSeqFromBed
+from ..utils.functions import reverse_complement
+from ..utils.seq import BPEEncoder
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def collate_fn_batching(batch):
@@ -54,3 +65,137 @@ class SyntheticGeneDataset(Dataset):
         return (g["cre_sequences"], g["cre_attention_masks"], g["tissue_context"],
                 torch.zeros_like(g["ref_cre_labels"]), g["ref_cre_labels"], g["strand"],
                 g["gene_embeddings"], g["gene_attention_masks"])
+
+
+class VCFDataset(Dataset):
+    """(gene, tissues) queries of one sample's VCF -> the hot path's sample tuple (reference :66-394).
+
+    Per gene: CRE list from the per-gene manifest CSV, IUPAC consensus of every CRE window (+- cre_neighbour_hood)
+    and of the gene body, BPE, pad / truncate each window to max_length, gene body in <= max_chunks chunks.
+    Same constructor arguments as the reference plus `indel_policy` / `sample` for the in-process consensus
+    (utils/data_process.py here); `gene_cre_manifest` is anything with `get_file_path(gene_id)`."""
+
+    def __init__(self, max_length: int, max_chunks: int, cre_neighbour_hood: int, gencode_v24, gene_cre_manifest,
+                 gene_upstream_neighbour_hood: int, gene_downstream_neighbour_hood: int, query_df: pd.DataFrame,
+                 fasta_path: str, vcf_path: str = None, indel_policy: str = "error", sample: str = None):
+        self.bpe = BPEEncoder()
+        self.bpe.load_vocabulary()
+        self.vocab = self.bpe.vocab
+        self.pad_token_id = self.vocab.get(SPECIAL_TOKENS["pad_token"])
+        self.max_chunks, self.max_length = max_chunks, max_length
+        self.cre_neighbour_hood = cre_neighbour_hood
+        self.gene_upstream_neighbour_hood = gene_upstream_neighbour_hood
+        self.gene_downstream_neighbour_hood = gene_downstream_neighbour_hood
+        self.query_df = query_df
+        self.gene_cre_manifest = gene_cre_manifest
+        self.fasta_path = fasta_path
+        self.ref_cre_to_idx = MAP_REF_CRE_TO_IDX
+        self.cre_to_idx = constants.MAP_CRE_TO_IDX
+        self.gencode_v24 = gencode_v24 if isinstance(gencode_v24, pd.DataFrame) else pd.read_csv(gencode_v24)
+        with open(os.path.join(_PKG, "vocabs", "tissue_vocab.yaml")) as f:
+            self.tissue_vocab = yaml.safe_load(f)
+        self.vcf_path = vcf_path
+        self.indel_policy, self.sample = indel_policy, sample
+        self._check_filter_query_df()
+
+    def _check_filter_query_df(self):
+        """Keep genes known to gencode with >= 1 known tissue; tissue names -> ids (reference :123-169)."""
+        assert self.query_df is not None, "Query dataframe is not provided"
+        assert "gene_id" in self.query_df.columns, "Query dataframe must contain gene_id column"
+        assert "tissues" in self.query_df.columns, "Query dataframe must contain tissues column"
+        before = len(self.query_df)
+        known_genes = set(self.gencode_v24["gene_id"].values)
+        rows = []
+        for _, row in self.query_df.iterrows():
+            if row["gene_id"] not in known_genes:
+                print(f"Gene {row['gene_id']} not found in the training set so skipping it")
+                continue
+            names = []
+            for t in row["tissues"].split(","):
+                if t in self.tissue_vocab:
+                    names.append(t)
+                else:
+                    print(f"Tissue {t} not found in the tissue vocab so skipping it")
+            if not names:
+                print(f"No tissues found for gene {row['gene_id']}")
+                continue
+            keep = {"gene_id": row["gene_id"], "tissues": [self.tissue_vocab[t] for t in names], "tissue_names": names}
+            if "vcf_path" in self.query_df.columns:
+                keep["vcf_path"] = row["vcf_path"]
+            rows.append(keep)
+        if not rows:
+            raise ValueError("No genes found in the query df that are present in the gencode v24 and have at least "
+                             "one tissue in the training set of VariantFormer")
+        self.query_df = pd.DataFrame(rows)
+        print(f"Filtered query df to {len(self.query_df)} genes reducing from {before}")
+        return True
+
+    def __len__(self):
+        return len(self.query_df)
+
+    def __getitem__(self, idx):
+        return self._load_file(idx)
+
+    def _get_gene_info(self, gene_id: str) -> dict:
+        return self.gencode_v24[self.gencode_v24["gene_id"] == gene_id].iloc[0].to_dict()
+
+    def _adjust_length(self, token_ids):
+        n = len(token_ids)
+        if n < self.max_length:
+            return token_ids + [self.pad_token_id] * (self.max_length - n), [0] * n + [1] * (self.max_length - n)
+        return token_ids[: self.max_length], [0] * self.max_length
+
+    def _extractor(self, neighbour_hood, upstream=None):
+        return ExtractSeqFromBed(neighbour_hood=neighbour_hood, ref_fasta=self.fasta_path,
+                                 upstream_neighbour_hood=upstream, indel_policy=self.indel_policy, sample=self.sample)
+
+    def _get_cres(self, gene_id: str, gene_info: dict, vcf_path: str):
+        """[N,1,L] ids, [N,1,L] pad mask, ref-cCRE class ids, cCRE labels (all "Low-DNase") -- reference :219-283."""
+        table = pd.read_csv(self.gene_cre_manifest.get_file_path(gene_id))
+        bed = table[["chromosome", "start_cre", "end_cre", "cre_name"]].rename(
+            columns={"chromosome": "chrom", "start_cre": "start", "end_cre": "end", "cre_name": "cCRE"})
+        cres = self._extractor(self.cre_neighbour_hood).process_subject(vcf_file=vcf_path, bed_regions=bed)
+        minus = gene_info["strand"] != "+"
+        if gene_info["strand"] == "-":
+            cres = cres.iloc[::-1]
+        n, L = len(cres), self.max_length
+        X = np.full((n, 1, L), self.pad_token_id, dtype=np.int64)
+        masks = np.ones((n, 1, L), dtype=bool)
+        ref_labels = np.empty(n, dtype=np.int64)
+        for k, (seq, name) in enumerate(zip(cres["sequence"], cres["cCRE"])):
+            ids = self.bpe.encode_forward(reverse_complement(seq) if minus else seq)[:L]
+            X[k, 0, : len(ids)] = ids
+            masks[k, 0, : len(ids)] = False
+            ref_labels[k] = self.ref_cre_to_idx[name]
+        labels = np.full(n, self.cre_to_idx["Low-DNase"], dtype=np.int64)
+        return torch.from_numpy(X), torch.from_numpy(masks), torch.from_numpy(ref_labels), torch.from_numpy(labels)
+
+    def _get_gene(self, gene_id: str, gene_info: dict, vcf_path: str):
+        seq = self._extractor(self.gene_downstream_neighbour_hood, self.gene_upstream_neighbour_hood).process_gene(
+            gene_info, vcf_path)
+        assert len(seq) > 1000, f"Mutated sequence is less than 1000bp for gene {gene_id}"
+        ids = self.bpe.encode_forward(seq if gene_info["strand"] == "+" else reverse_complement(seq))
+        return self.chunkify_data(torch.from_numpy(ids.astype(np.int64)).unsqueeze(0))
+
+    def _load_file(self, idx: int):
+        row = self.query_df.iloc[idx]
+        vcf_path = row["vcf_path"] if "vcf_path" in self.query_df.columns else self.vcf_path
+        gene_info = self._get_gene_info(row["gene_id"])
+        assert gene_info["chromosome"] in ["chr" + str(i) for i in range(1, 23)], \
+            f"Chromosome {gene_info['chromosome']} is not a valid chromosome. Sex chromosomes are not supported"
+        X, mask, ref_labels, labels = self._get_cres(row["gene_id"], gene_info, vcf_path)
+        chunks, chunk_masks = self._get_gene(row["gene_id"], gene_info, vcf_path)
+        return (X, mask, torch.tensor(row["tissues"], dtype=torch.long), labels, ref_labels,
+                torch.tensor([0] if gene_info["strand"] == "+" else [1], dtype=torch.long), chunks, chunk_masks)
+
+    def chunkify_data(self, x):
+        """[1, n_tokens] -> ([n_chunks, 1, max_length] ids, pad mask); at most max_chunks chunks (reference :338-394)."""
+        n = x.size(1)
+        n_chunks = min(self.max_chunks, -(-n // self.max_length))
+        flat = x[0, : n_chunks * self.max_length].long().numpy()
+        ids = np.full(n_chunks * self.max_length, self.pad_token_id, dtype=np.int64)
+        mask = np.ones(n_chunks * self.max_length, dtype=bool)
+        ids[: flat.size] = flat
+        mask[: flat.size] = False
+        shape = (n_chunks, 1, self.max_length)
+        return torch.from_numpy(ids).view(shape), torch.from_numpy(mask).view(shape)

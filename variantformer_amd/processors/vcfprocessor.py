@@ -1,12 +1,14 @@
 """VCFProcessor: the vcf2exp API surface (reference processors/vcfprocessor.py:23-277) over the HIP model.
 
-Kept: constructor(model_class), get_tissues, get_genes, create_data, load_model, predict, format_output with
-the same return types.  The genome-side inputs (FASTA, VCF, per-gene cCRE manifests from S3, samtools /
-bcftools) are outside the hot path (SURVEY.md §2 "next"); `create_data` therefore takes a dataset factory:
-anything that yields the reference's per-gene sample tuple works, e.g. datasets.SyntheticGeneDataset here or
-the reference's own VCFDataset when its artifacts are available."""
+Kept: constructor(model_class), create_vcf_from_variant, get_tissues, get_genes, create_data, load_model, predict,
+format_output with the same return types.  `create_data` builds the in-tree `VCFDataset` (FASTA + VCF + per-gene
+cCRE manifest -> IUPAC consensus -> BPE, all in process: no samtools / bcftools subprocesses); the per-gene cCRE
+manifest lookup (S3 + duckdb in the reference, utils/assets.py:307-368) is duck-typed: pass anything with
+`get_file_path(gene_id)` as `gene_cre_manifest`.  A `dataset_factory` may replace the dataset (e.g.
+datasets.SyntheticGeneDataset where no genome is available)."""
 from __future__ import annotations
 
+import gzip
 import os
 from pathlib import Path
 
@@ -15,14 +17,15 @@ import torch
 import yaml
 from torch.utils.data import DataLoader
 
-from ..datasets.vcfdataset import collate_fn_batching
+from ..datasets.vcfdataset import VCFDataset, collate_fn_batching
 from ..utils.config import Config, load_yaml
 from .model_manager import ModelManager
 from .trainer import Trainer
 
 
 class VCFProcessor:
-    def __init__(self, model_class: str = "v4_pcg", config_dir: str | None = None, require_gpu: bool = True):
+    def __init__(self, model_class: str = "v4_pcg", config_dir: str | None = None, require_gpu: bool = True,
+                 gene_cre_manifest=None, indel_policy: str = "error"):
         base_dir = Path(__file__).parent.parent.resolve()
         self.config_location = Path(config_dir) if config_dir else base_dir / "configs"
         self.model_config = load_yaml(str(self.config_location / "vf_model.yaml"))[model_class]
@@ -34,9 +37,67 @@ class VCFProcessor:
                           (self.model_config.model.cre_tokenizer, "path"), (self.model_config.model.gene_tokenizer, "path")):
             if not os.path.isabs(node[key]):
                 node[key] = str(root / node[key])
+        if not os.path.isabs(self.vcf_loader_config.fasta_path):
+            self.vcf_loader_config.fasta_path = str(root / self.vcf_loader_config.fasta_path)
+        self.gene_cre_manifest = gene_cre_manifest
+        self.indel_policy = indel_policy        # insertions / deletions in the consensus: see utils/data_process.py
         if require_gpu:
             assert torch.cuda.is_available(), "GPU is not available"          # reference :60
         self.accelerator = "gpu"
+
+    def create_vcf_from_variant(self, variant_df: pd.DataFrame, output_path: str, vcf_path: str = None):
+        """Write (or merge into a copy of `vcf_path`) a single-sample VCF from rows chrom, pos, ref, alt, GT after
+        checking every REF against the genome (reference :62-219, which shells out to samtools / bgzip / tabix /
+        bcftools sort + concat -a -D).  Output is gzip text sorted by contig order of first appearance and position;
+        a record already present (same chrom, pos, ref, alt) is kept once, the existing file's line first.  No
+        tabix index is written: the in-process reader does not need one."""
+        from ..utils.data_process import open_fasta
+        for col in ("chrom", "pos", "ref", "alt", "GT"):
+            assert col in variant_df.columns, f"{col} column is required"
+        if len(variant_df) == 0:
+            raise ValueError("variant_df is empty")
+        fasta = open_fasta(self.vcf_loader_config.fasta_path)
+        for _, row in variant_df.iterrows():
+            pos, ref = int(row["pos"]), row["ref"]
+            try:
+                found = fasta.fetch(row["chrom"], pos - 1, pos - 1 + len(ref)).upper()
+            except KeyError as e:
+                raise ValueError(f"Failed to extract reference at {row['chrom']}:{pos}-{pos + len(ref) - 1}: {e}")
+            if found != ref.upper():
+                raise ValueError(f"Reference mismatch at {row['chrom']}:{pos}: expected '{ref}' but found '{found}' "
+                                 f"in reference genome")
+        sample, header, body = "SAMPLE", None, []
+        if vcf_path is not None:
+            opener = gzip.open if open(vcf_path, "rb").read(2) == b"\x1f\x8b" else open
+            with opener(vcf_path, "rt") as f:
+                lines = f.read().splitlines()
+            header = [ln for ln in lines if ln.startswith("#")]
+            body = [ln for ln in lines if ln and not ln.startswith("#")]
+            names = header[-1].split("\t")[9:]
+            assert len(names) == 1, "merging needs a single-sample VCF"
+            sample = names[0]
+        if header is None:
+            header = ["##fileformat=VCFv4.2", f"##reference={self.vcf_loader_config.fasta_path}"]
+            header += [f"##contig=<ID={c}>" for c in sorted(variant_df["chrom"].unique())]
+            header += ['##FORMAT=<ID=GT,Number=1,Type=String,Description="Genotype">',
+                       f"#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t{sample}"]
+        new = [f"{r['chrom']}\t{int(r['pos'])}\t.\t{r['ref']}\t{r['alt']}\t.\tPASS\t.\tGT\t{r['GT']}"
+               for _, r in variant_df.sort_values(by=["chrom", "pos"]).iterrows()]
+        order, seen, records = {}, set(), []
+        for ln in body + new:
+            f = ln.split("\t", 5)
+            key = (f[0], int(f[1]), f[3], f[4])
+            if key in seen:
+                continue
+            seen.add(key)
+            order.setdefault(f[0], len(order))
+            records.append((order[f[0]], int(f[1]), len(records), ln))
+        records.sort()
+        final_path = output_path if output_path.endswith(".vcf.gz") else f"{output_path}.vcf.gz"
+        Path(final_path).parent.mkdir(parents=True, exist_ok=True)
+        with gzip.open(final_path, "wt") as f:
+            f.write("\n".join(header + [r[3] for r in records]) + "\n")
+        return final_path
 
     def get_tissues(self):
         return self.tissue_vocab.keys()
@@ -48,11 +109,19 @@ class VCFProcessor:
         cfg = Config(dict(self.vcf_loader_config.dataloader))
         cfg.update(kwargs)
         if dataset_factory is None:
-            raise NotImplementedError(
-                "building samples from FASTA/VCF needs the reference's genome artifacts and samtools/bcftools "
-                "(out of the hot path); pass dataset_factory=... returning a dataset with .query_df")
-        dataset = dataset_factory(vcf_path=vcf_path, query_df=query_df, tissue_vocab=self.tissue_vocab,
-                                  dataset_config=self.model_config.dataset)
+            if self.gene_cre_manifest is None:
+                raise ValueError("VCFProcessor needs gene_cre_manifest (get_file_path(gene_id) -> per-gene cCRE CSV) to "
+                                 "build samples from a VCF; the reference resolves it from S3 (utils/assets.py:307-368)")
+            d = self.model_config.dataset
+            dataset = VCFDataset(max_length=d.max_length, max_chunks=d.max_chunks, cre_neighbour_hood=d.cre_neighbour_hood,
+                                 gencode_v24=d.gencode_v24, gene_cre_manifest=self.gene_cre_manifest,
+                                 gene_upstream_neighbour_hood=d.gene_upstream_neighbour_hood,
+                                 gene_downstream_neighbour_hood=d.gene_downstream_neighbour_hood, query_df=query_df,
+                                 fasta_path=self.vcf_loader_config.fasta_path, vcf_path=vcf_path,
+                                 indel_policy=self.indel_policy)
+        else:
+            dataset = dataset_factory(vcf_path=vcf_path, query_df=query_df, tissue_vocab=self.tissue_vocab,
+                                      dataset_config=self.model_config.dataset)
         if cfg.get("num_workers", 0) == 0:
             cfg.pop("prefetch_factor", None)
         return dataset, DataLoader(dataset, collate_fn=collate_fn_batching, **cfg)

@@ -22,5 +22,10 @@ REF_CREs = [
 ]
 MAP_REF_CRE_TO_IDX = {cre: idx for idx, cre in enumerate(REF_CREs)}
 
+# multi-class cCRE labels of the training data; inference feeds "Low-DNase" everywhere (reference utils/constants.py:75-89)
+CREs = ["Low-DNase", "DNase-only", "CTCF-only,CTCF-bound", "DNase-H3K4me3", "DNase-H3K4me3,CTCF-bound", "PLS",
+        "PLS,CTCF-bound", "dELS", "dELS,CTCF-bound", "pELS", "pELS,CTCF-bound"]
+MAP_CRE_TO_IDX = {cre: idx for idx, cre in enumerate(CREs)}
+
 SPECIAL_TOKENS = {"pad_token": "<pad>", "bos_token": "<s>", "eos_token": "</s>", "unk_token": "<unk>"}
 PAD_TOKEN_ID = 0

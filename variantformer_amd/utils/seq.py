@@ -67,6 +67,12 @@ class BPEEncoder:
             raise _lib.VFError("vf_bpe_encode failed")
         return ids[:n].copy(), starts[:n].copy()
 
+    def encode_forward(self, seq: str) -> np.ndarray:
+        """Token ids of one strand, int32.  Same ids as encode([seq, "A"])[0]: the C++ encoder upper-cases and
+        splits at invalid characters itself, so the Python-side normalize() pass and the token strings are skipped
+        (the sample builders need neither)."""
+        return self.encode_ids(seq)[0]
+
     # -- reference interface ------------------------------------------------------------------------
     def normalize(self, sequences):
         out = []
