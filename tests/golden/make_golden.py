@@ -429,6 +429,41 @@ def vep_fixture():
     print("[golden] vep:", [c.get("variant_type", c.get("error")) for c in cases])
 
 
+def variantprocessor_fixture():
+    """Output stage of the reference's VariantProcessor (processors/variantprocessor.py:303-497) and its log2fc scores
+    (utils/functions.py:184-301) on seeded predictions.  omegaconf (absent) is only used by __init__, which is not
+    run: the three methods are called unbound on a plain namespace carrying the attributes they read."""
+    import tempfile
+    sys.modules.setdefault("duckdb", types.ModuleType("duckdb"))
+    oc = types.ModuleType("omegaconf")
+    oc.OmegaConf = type("OmegaConf", (), {})
+    sys.modules.setdefault("omegaconf", oc)
+    sys.modules["lightning.pytorch"].Trainer = object
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import vep_artifacts as va
+    from datasets.vepdataset import Variant
+    from processors.variantprocessor import VariantProcessor as RefVP
+    from utils.functions import generate_log2fc_score
+    import yaml
+    with open(os.path.join(REF, "vocabs", "tissue_vocab.yaml")) as f:
+        tissue_vocab = yaml.safe_load(f)
+    arrays = {}
+    with tempfile.TemporaryDirectory() as root:
+        for tag, with_sample in (("pop", False), ("sample", True)):
+            pairs, preds, af = va.make_vp_case(Variant, with_sample=with_sample)
+            af_dir = va.write_af_tables(af, os.path.join(root, "af"))
+            me = types.SimpleNamespace(gene_variant_pairs=pairs, config=types.SimpleNamespace(emb_dim=6, af_path=af_dir),
+                                       tissue_idx_to_name={v: k for k, v in tissue_vocab.items()},
+                                       _get_variant_output_path=lambda: os.path.join(root, f"{tag}_VF.parquet"))
+            long_df = RefVP.compile_predictions(me, preds, vcf_path="x.vcf.gz" if with_sample else None)
+            wide_df = RefVP.format_scores(me, long_df.copy())
+            score_df = generate_log2fc_score(wide_df.copy(), af_dir)
+            for name, df in (("long", long_df), ("wide", wide_df), ("score", score_df)):
+                arrays.update(va.frame_to_arrays(df, f"{tag}.{name}"))
+            print(f"[golden] variantprocessor {tag}: long {long_df.shape} wide {wide_df.shape} score {score_df.shape}")
+    np.savez_compressed(os.path.join(HERE, "variantprocessor.npz"), **arrays)
+
+
 def main():
     assert os.path.isdir(REF), "reference checkout not present: fixtures can only be generated in the dev container"
     sys.path.insert(0, REPO)
@@ -444,6 +479,7 @@ def main():
     bpe_fixture()
     misc_fixture()
     vep_fixture()
+    variantprocessor_fixture()
 
 
 if __name__ == "__main__":

@@ -137,3 +137,58 @@ def flatten_batch(batch):
             for j, t in enumerate(v):
                 out[f"{k}.{j}"] = t.numpy()
     return out
+
+
+# ---- VariantProcessor output stage (compile_predictions / format_scores / log2fc scores) ----------------------------
+def make_vp_case(variant_cls, seed=77, emb_dim=6, with_sample=False):
+    """Seeded (gene_variant_pairs, predictions, allele-frequency tables) for the output stage of the VEP flow."""
+    rng = np.random.default_rng(seed)
+    variants = [variant_cls(chrom="1", pos=1075, ref="A", alt="G", tissue=[7, 20], gene_id=["ENSG_PLUS"]),
+                variant_cls(chrom="chr2", pos=3350, ref="C", alt="T", tissue=[3], gene_id=[]),
+                variant_cls(chrom="1", pos=99, ref="G", alt="C", tissue=[5, 6, 9], gene_id=[])]
+    genes = [{"gene_id": "ENSG_PLUS"}, {"gene_id": "ENSG_MINUS"}]
+    pops = [("SAMPLE", "donor1"), ("REF_HG38", "hg38")] if with_sample else \
+        [("REF_HG38", "hg38"), ("EAS", "HG00404"), ("EUR", "HG00096"), ("AFR", "HG01879"), ("SAS", "HG01589"), ("AMR", "HG00551")]
+    pairs, preds = [], []
+    for vi, v in enumerate(variants):
+        for gi, g in enumerate(genes[: 2 if vi == 0 else 1]):
+            for pop, sample in pops:
+                pairs.append({"variant": v, "gene": g, "population": pop, "sample_name": sample,
+                              "vcf_path": "x.vcf.gz" if pop == "SAMPLE" else None})
+                n_t = len(v.tissue)
+                if vi == 2 and pop in ("EAS", "SAMPLE"):          # a pair without overlap: empty prediction
+                    preds.append({"pred_gene_exp": [], "embd": [], "variant_type": "No overlap",
+                                  "gene_token_embedding": [], "cre_token_embedding": []})
+                    continue
+                p = {"variant_type": ["CRE overlap only", "Gene overlap only", "Gene and CRE overlap"][(vi + gi) % 3]}
+                p["pred_gene_exp"] = [rng.random((n_t, 1), dtype=np.float32) * 5 for _ in range(3)]
+                for k in ("embd", "gene_token_embedding", "cre_token_embedding"):
+                    p[k] = [rng.standard_normal((n_t, emb_dim)).astype(np.float32) for _ in range(3)]
+                preds.append(p)
+    af = {"chr1": pd.DataFrame({"chr": ["chr1", "chr1"], "pos": [1075, 99], "ref": ["A", "G"], "alt": ["G", "C"],
+                                "AF_EUR": ["0.10", "."], "AF_AFR": ["0.30", "0.0"], "AF_EAS": ["0.05", "0.0"],
+                                "AF_SAS": [".", "0.0"], "AF_AMR": ["0.20", "0.0"]}),
+          "chr2": pd.DataFrame({"chr": ["chr2"], "pos": [3350], "ref": ["C"], "alt": ["T"], "AF_EUR": ["0.5"],
+                                "AF_AFR": ["0.25"], "AF_EAS": ["0.125"], "AF_SAS": ["0.0625"], "AF_AMR": ["0.0625"]})}
+    return pairs, preds, af
+
+
+def write_af_tables(af, root):
+    os.makedirs(root, exist_ok=True)
+    for chrom, df in af.items():
+        df.to_csv(os.path.join(root, f"1KG_hg38_af_{chrom}.tsv"), sep="\t", index=False)
+    return root
+
+
+def frame_to_arrays(df, prefix):
+    """DataFrame -> {prefix.col: ndarray} (object columns of arrays are stacked; strings kept as str arrays)."""
+    out = {f"{prefix}.__columns__": np.array([str(c) for c in df.columns])}
+    for c in df.columns:
+        col = df[c]
+        if len(col) and isinstance(col.iloc[0], np.ndarray):
+            out[f"{prefix}.{c}"] = np.stack(list(col))
+        elif col.dtype == object:
+            out[f"{prefix}.{c}"] = np.array([str(v) for v in col])
+        else:
+            out[f"{prefix}.{c}"] = col.to_numpy()
+    return out
