@@ -240,3 +240,31 @@ def test_last_layer_registry_only_path_is_exact():
         full = model.forward_prepared(pb, return_cre=True)
     np.testing.assert_allclose(fast[1].cpu().numpy(), full[1].cpu().numpy(), rtol=2e-5, atol=2e-5)
     np.testing.assert_allclose(fast[0].cpu().numpy(), full[0].cpu().numpy(), rtol=2e-5, atol=2e-6)
+
+
+def test_headline_size_gene_vs_oracle_and_properties():
+    """BASELINE configs[1] geometry at full size (N=1024 cCRE windows, C=200 gene chunks, T=54 tissues, 25 modulator
+    layers, seq2reg 6 layers): the HIP path against the same-rounding CPU oracle on one whole gene, plus the
+    size-independent properties at that size -- a gene's result must not depend on the genes sharing its batch, and a
+    tissue's result must not depend on the other tissues requested."""
+    import bench
+    model, hp, kw = bench.build_model(torch.device("cuda", 0))
+    sd = state_dict_cpu(model)
+    batch = make_batch(20251205, [1024, 700], [200, 150], [TISSUES_54, TISSUES_54[:20]], 200)
+    both = model.predict_step(batch, 0)
+    assert both["pred_gene_exp"][0].shape == (54, 1) and both["pred_gene_exp"][1].shape == (20, 1)
+    assert all(np.isfinite(p).all() and (p >= 0).all() for p in both["pred_gene_exp"])      # Softplus output
+    first = {k: v[:1] for k, v in batch.items()}
+    alone = model.predict_step(first, 0)
+    np.testing.assert_allclose(alone["pred_gene_exp"][0], both["pred_gene_exp"][0], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(alone["embeddings"][0], both["embeddings"][0], rtol=1e-5, atol=1e-6)
+    few = dict(first)
+    few["tissue_context"] = [first["tissue_context"][0][[3, 30, 53]]]
+    sub = model.predict_step(few, 0)
+    np.testing.assert_allclose(sub["pred_gene_exp"][0], alone["pred_gene_exp"][0][[3, 30, 53]], rtol=1e-5, atol=1e-6)
+    # whole-gene parity against the oracle (executes the de-duplicated ~18 TFLOP on the host: tens of seconds)
+    shp = O.Seq2RegHP.from_hparams(hp)
+    torch.set_num_threads(min(16, bench.host_threads()))
+    orc = O.predict_step(first, sd, shp, shp, O.Seq2GeneHP.from_kwargs(kw), rounding="bf16", share_cre_stream=True)
+    assert _rel(alone["pred_gene_exp"][0], orc["pred_gene_exp"][0]) < NORTH_STAR_RTOL
+    assert _rel(alone["embeddings"][0], orc["embeddings"][0]) < 5e-3
