@@ -10,6 +10,9 @@ SHAPES = [  # (name, M, N, K, epilogue)
     ("s2r Wqkv", 140000, 1536, 512, ops.EPI_BF16), ("s2r out_proj", 140000, 512, 512, ops.EPI_RES_F32),
     ("s2r geglu1", 140000, 2048, 512, ops.EPI_GEGLU_BF16), ("s2r geglu2", 140000, 512, 1024, ops.EPI_RES_F32),
     ("square 8k", 8192, 8192, 8192, ops.EPI_BF16),
+    ("s2r8 Wqkv", 769460, 1536, 512, ops.EPI_BF16), ("s2r8 geglu", 769460, 2048, 512, ops.EPI_GEGLU_BF16),
+    ("gene8 Wqkv", 86832, 4608, 1536, ops.EPI_BF16), ("gene8 out_proj", 86832, 1536, 1536, ops.EPI_RES_F32),
+    ("gene8 geglu", 86832, 2048, 1536, ops.EPI_GEGLU_BF16), ("gene8 ff", 86832, 1536, 1024, ops.EPI_RES_F32),
     ("cre Wqkv", 1024, 4608, 1536, ops.EPI_BF16), ("cre out_proj", 1024, 1536, 1536, ops.EPI_RES_F32),
     ("cre kv", 1024, 3072, 1536, ops.EPI_BF16), ("cre geglu2", 1024, 1536, 1024, ops.EPI_RES_F32),
     ("cre8 Wqkv", 8192, 4608, 1536, ops.EPI_BF16), ("cre8 out_proj", 8192, 1536, 1536, ops.EPI_RES_F32),

@@ -596,6 +596,7 @@ using CfgF = Cfg<128, 256, 2, 4, 3>;       // 144 KiB, 8 waves, wave tile 64x64
 using CfgG = Cfg<128, 128, 2, 2, 4, 32>;   // 64 KiB, 4 waves, BK=32, 3 tiles in flight, 2 blocks/CU
 using CfgH = Cfg<256, 128, 2, 2, 3, 32>;   // 72 KiB, 4 waves (wave tile 128x64), BK=32, 2 blocks/CU
 using CfgI = Cfg<128, 256, 2, 2, 3, 32>;   // 72 KiB, 4 waves (wave tile 64x128), BK=32, 2 blocks/CU
+using CfgJ = Cfg<128, 128, 2, 2, 3, 32>;   // 48 KiB, 4 waves, BK=32, 2 tiles in flight, 3 blocks/CU
 
 template <class C, int EPI, int DBG = 0>
 int launch_cfg(const void* A, int64_t lda, const void* W, const float* bias, const float* res, int64_t ldr, void* out,
@@ -656,7 +657,9 @@ int pick_variant(int M, int N, int K, int epilogue) {
     const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
     if (t128 < 256) return 5;
     if (K >= 4096 && t256 >= 256) return 2;                               // long K: 256x256 (1411 vs 1155 at 8192^3)
-    if (K <= 512 && N >= 1024 && t256 >= 1024 && epilogue == VF_EPI_BF16) return 2;   // seq2reg Wqkv: 773 vs 684
+    if (K <= 512 && N >= 1024 && t256 >= 1024 && epilogue == VF_EPI_BF16) return 2;   // seq2reg Wqkv: 814 vs 692
+    // seq2reg GeGLU (K = 512): BK = 32 ring, 48 KiB -> 3 blocks per CU hide the short main loop's fill (790 vs 639 / 717)
+    if (K <= 512 && N >= 1024 && t128 >= 4096 && epilogue == VF_EPI_GEGLU_BF16) return 12;
     (void)epilogue;      // in the full pipeline the persistent form measured slower (33.0 vs 34.0 genes/s): not selected
     return 1;
 }
@@ -682,6 +685,7 @@ int launch_gemm(const void* A, int64_t lda, const void* W, const float* bias, co
         case 7: return launch_cfg<CfgG, EPI>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
         case 8: return launch_cfg<CfgH, EPI>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
         case 9: return launch_cfg<CfgI, EPI>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
+        case 12: return launch_cfg<CfgJ, EPI>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
         case 104: if (EPI == VF_EPI_BF16) return launch_cfg<CfgA, VF_EPI_BF16, 4>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st); break;
         case 103: if (EPI == VF_EPI_BF16) return launch_cfg<CfgA, VF_EPI_BF16, 3>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st); break;
         case 203: if (EPI == VF_EPI_BF16) return launch_cfg<CfgB, VF_EPI_BF16, 3>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st); break;

@@ -16,6 +16,8 @@ What is different by design (all exact re-orderings of the same arithmetic, SURV
 """
 from __future__ import annotations
 
+import os
+
 import logging
 import types
 from dataclasses import dataclass
@@ -83,6 +85,17 @@ def _context_kv_table(ctx_embedding: nn.Embedding, layer) -> torch.Tensor:
     return c[1]
 
 
+_SIDE_STREAM_OVERLAP = os.environ.get("VF_SIDE_STREAM", "1") != "0"
+_SIDE_STREAMS: dict = {}
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
+
 def modulator_forward_packed(ctx_embedding, cre_layers, gene_layers, cre_x, gene_x, labels, cu_cre, max_cre,
                              cu_gene_self, max_gene, cu_gene_cross=None, max_gene_cross=None, cu_cre_for_gene=None,
                              final_rows=None):
@@ -96,12 +109,29 @@ def modulator_forward_packed(ctx_embedding, cre_layers, gene_layers, cre_x, gene
     mq = max_gene if max_gene_cross is None else max_gene_cross
     ck = cu_cre if cu_cre_for_gene is None else cu_cre_for_gene
     cre, gene = cre_x, gene_x
+    n = len(gene_layers)
+    # The CRE stream never reads the gene stream, so its (small, tail-heavy) launches go to a second HIP stream and
+    # fill the CUs the big gene-stream launches leave idle; gene layer i+1 waits for the event after CRE layer i.
+    # Per-kernel timing (ops.TIMER) runs everything on one stream so that durations are measured in isolation.
+    overlap = _SIDE_STREAM_OVERLAP and ops.TIMER is None and cre_x.is_cuda and n > 1
+    main = torch.cuda.current_stream() if overlap else None
+    side = _side_stream(cre_x.device) if overlap else None
+    if overlap:
+        side.wait_stream(main)                      # inputs (cre_x, labels, cu arrays) were produced on `main`
     gene = gene_layers[0].forward_packed(gene, cu_gene_self, max_gene, context=cre, cu_ctx=ck, max_ctx=max_cre,
                                          cu_cross_q=cq, max_cross_q=mq)
-    n = len(gene_layers)
     for i in range(n - 1):
-        kv = ops.gather_rows_bf16(_context_kv_table(ctx_embedding, cre_layers[i]), labels)
-        cre = cre_layers[i].forward_packed(cre, cu_cre, max_cre, context_kv=kv, cu_ctx=cu_cre, max_ctx=max_cre)
+        if overlap:
+            with torch.cuda.stream(side):
+                kv = ops.gather_rows_bf16(_context_kv_table(ctx_embedding, cre_layers[i]), labels)
+                cre = cre_layers[i].forward_packed(cre, cu_cre, max_cre, context_kv=kv, cu_ctx=cu_cre, max_ctx=max_cre)
+                done = torch.cuda.Event()
+                done.record(side)
+            cre.record_stream(main)                 # allocated on `side`, read by the gene layer on `main`
+            main.wait_event(done)
+        else:
+            kv = ops.gather_rows_bf16(_context_kv_table(ctx_embedding, cre_layers[i]), labels)
+            cre = cre_layers[i].forward_packed(cre, cu_cre, max_cre, context_kv=kv, cu_ctx=cu_cre, max_ctx=max_cre)
         if final_rows is not None and i + 1 == n - 1:
             # last gene layer: only the registry rows are consumed downstream -> compact [R, D] result
             rows, cu_rows, cu_cross_rows, max_cross_rows = final_rows
