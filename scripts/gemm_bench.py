@@ -13,6 +13,10 @@ SHAPES = [  # (name, M, N, K, epilogue)
     ("s2r8 Wqkv", 769460, 1536, 512, ops.EPI_BF16), ("s2r8 geglu", 769460, 2048, 512, ops.EPI_GEGLU_BF16),
     ("gene8 Wqkv", 86832, 4608, 1536, ops.EPI_BF16), ("gene8 out_proj", 86832, 1536, 1536, ops.EPI_RES_F32),
     ("gene8 geglu", 86832, 2048, 1536, ops.EPI_GEGLU_BF16), ("gene8 ff", 86832, 1536, 1024, ops.EPI_RES_F32),
+    ("gene8 Wq ", 86832, 1536, 1536, ops.EPI_BF16),
+    ("s2r8 out_proj", 769460, 512, 512, ops.EPI_RES_F32), ("s2r8 ff", 769460, 512, 1024, ops.EPI_RES_F32),
+    ("cre8 kv", 8192, 3072, 1536, ops.EPI_BF16), ("cre8 Wq", 8192, 1536, 1536, ops.EPI_BF16),
+    ("cre8 geglu", 8192, 2048, 1536, ops.EPI_GEGLU_BF16), ("cre8 ff", 8192, 1536, 1024, ops.EPI_RES_F32),
     ("cre Wqkv", 1024, 4608, 1536, ops.EPI_BF16), ("cre out_proj", 1024, 1536, 1536, ops.EPI_RES_F32),
     ("cre kv", 1024, 3072, 1536, ops.EPI_BF16), ("cre geglu2", 1024, 1536, 1024, ops.EPI_RES_F32),
     ("cre8 Wqkv", 8192, 4608, 1536, ops.EPI_BF16), ("cre8 out_proj", 8192, 1536, 1536, ops.EPI_RES_F32),

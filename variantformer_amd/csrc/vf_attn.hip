@@ -54,14 +54,6 @@ __device__ __forceinline__ float max_over_g(float x) {
     auto b = __builtin_amdgcn_permlane32_swap(v, v, false, false);
     return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
-__device__ __forceinline__ float sum_over_g(float x) {
-    const unsigned u = __float_as_uint(x);
-    auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-    const float y = __uint_as_float(a[0]) + __uint_as_float(a[1]);
-    const unsigned v = __float_as_uint(y);
-    auto b = __builtin_amdgcn_permlane32_swap(v, v, false, false);
-    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
-}
 
 struct AttnParams {
     const unsigned short* q;
@@ -109,7 +101,7 @@ __device__ __forceinline__ s16x4_t lds_tr_read(const char* p) {
 template <int DH, int QG, bool ALIBI, int DBGT = 0>
 __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, int kb0, int len_k, int r, int g, float c,
                                           float slope2, const bf16x8_t (&qf)[QG][2], const float (&q_pos)[QG],
-                                          f32x4_t (&o)[QG][DH / 16], float (&m_run)[QG], float (&l_run)[QG]) {
+                                          f32x4_t (&o)[QG][DH / 16], float (&m_run)[QG], f32x4_t (&l_acc)[QG]) {
     constexpr int DT = DH / 16;
     constexpr int VROW = VLayout<DH>::ROW;
     // ---- S^T = K . Q^T : 4 key tiles x 2 k-steps, K fragments shared by the QG query groups
@@ -165,7 +157,7 @@ __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, int kb
                 pk[3] = pack2bf(s[qg][2 * kb + 1][2], s[qg][2 * kb + 1][3]);
                 pf[qg][kb] = *reinterpret_cast<bf16x8_t*>(&pk);
             }
-            l_run[qg] = 1.f;
+            l_acc[qg] = (f32x4_t){1.f, 1.f, 1.f, 1.f};
             continue;
         }
         if (ALIBI) {
@@ -193,22 +185,16 @@ __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, int kb
         // p = exp2(c*s - c*m) (no ALiBi: scale folded into one packed FMA) or exp2(s - m) (ALiBi: already scaled)
         const float mc = ALIBI ? -m_new : -m_new * c;
         const float cc = ALIBI ? 1.0f : c;
-        float psum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float p = __builtin_amdgcn_exp2f(fmaf(s[qg][kt][e], cc, mc));
-                s[qg][kt][e] = p;
-                psum += p;
-            }
+            for (int e = 0; e < 4; ++e) s[qg][kt][e] = __builtin_amdgcn_exp2f(fmaf(s[qg][kt][e], cc, mc));
         if (__any(m_new > m_old)) {                  // wave-uniform: rescale only when some running max moved
             const float alpha = __builtin_amdgcn_exp2f(ALIBI ? (m_old - m_new) : (m_old - m_new) * c);
-            l_run[qg] *= alpha;
+            l_acc[qg] *= alpha;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) o[qg][dt] *= alpha;
         }
-        l_run[qg] += psum;                           // lane-partial; reduced over g at the end
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             u32x4_t pk;
@@ -233,6 +219,19 @@ __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, int kb
 #pragma unroll
         for (int qg = 0; qg < QG; ++qg)
             o[qg][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf1[dt], pf[qg][1], o[qg][dt], 0, 0, 0);
+    // ---- softmax denominators on the matrix pipe: a V^T fragment of ones gives l[q] += sum_k P[q][k] in every
+    // accumulator row, i.e. each lane ends up with the complete row sum of its query (no per-element v_add_f32 --
+    // the softmax is VALU-issue bound -- and no cross-lane reduction at the end).  The sum runs over the bf16 P the
+    // PV product uses, so O / l is an exact convex combination of the V rows.
+    if (DBGT == 0) {
+        const u32x4_t ones_bits = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+        const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_bits);
+#pragma unroll
+        for (int qg = 0; qg < QG; ++qg) {
+            l_acc[qg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[qg][0], l_acc[qg], 0, 0, 0);
+            l_acc[qg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[qg][1], l_acc[qg], 0, 0, 0);
+        }
+    }
 }
 
 template <int DH, int QG, bool ALIBI, int DBG = 0>
@@ -294,11 +293,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P) {
     for (int qg = 0; qg < QG; ++qg) q_pos[qg] = (float)(q_abs[qg] + (P.q_at_start ? 0 : len_k - len_q));
 
     f32x4_t o[QG][DT];
-    float m_run[QG], l_run[QG];
+    float m_run[QG];
+    f32x4_t l_acc[QG];
 #pragma unroll
     for (int qg = 0; qg < QG; ++qg) {
         m_run[qg] = -INFINITY;
-        l_run[qg] = 0.f;
+        l_acc[qg] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) o[qg][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     }
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P) {
         if (DBG < 3) load_regs(t + 1);
         const char* sK = smem + (t & 1) * STAGE;
         attn_tile<DH, QG, ALIBI, (DBG > 2 ? 0 : DBG)>(sK, sK + K_TILE_BYTES, t * BKV, len_k, r, g, c, slope2, qf, q_pos,
-                                                       o, m_run, l_run);
+                                                       o, m_run, l_acc);
         if (DBG < 3) write_lds((t + 1) & 1, t + 1);
         if (DBG < 4) __syncthreads();
     }
@@ -361,13 +361,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P) {
         const int t = nkv - 1;
         const char* sK = smem + (t & 1) * STAGE;
         attn_tile<DH, QG, ALIBI, (DBG > 2 ? 0 : DBG)>(sK, sK + K_TILE_BYTES, t * BKV, len_k, r, g, c, slope2, qf, q_pos,
-                                                       o, m_run, l_run);
+                                                       o, m_run, l_acc);
     }
 
     // ---- normalise and store: lane (r,g) holds O[q = r][d = 16dt + 4g .. +3]
 #pragma unroll
     for (int qg = 0; qg < QG; ++qg) {
-        const float l = sum_over_g(l_run[qg]);
+        const float l = l_acc[qg][0];
         const float inv = 1.0f / l;
         if (q_abs[qg] < len_q) {
             unsigned short* op = P.out + (int64_t)(q_tok0 + q_abs[qg]) * P.o_stride + h * DH + 4 * g;
@@ -456,11 +456,12 @@ __global__ __launch_bounds__(256, (QG >= 2 ? 2 : 4)) void attn_short_kernel(Attn
     const float c = P.scale_log2;
     const float slope2 = ALIBI ? P.slopes[h] * 1.4426950408889634f : 0.f;
     f32x4_t o[QG][DT];
-    float m_run[QG], l_run[QG];
+    float m_run[QG];
+    f32x4_t l_acc[QG];
 #pragma unroll
     for (int qg = 0; qg < QG; ++qg) {
         m_run[qg] = -INFINITY;
-        l_run[qg] = 0.f;
+        l_acc[qg] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) o[qg][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     }
@@ -469,11 +470,11 @@ __global__ __launch_bounds__(256, (QG >= 2 ? 2 : 4)) void attn_short_kernel(Attn
 
     for (int t = 0; t < nkv; ++t)
         attn_tile<DH, QG, ALIBI>(sK0 + t * BKV * K_ROW_BYTES, sV0 + t * BKV * VROW, t * BKV, len_k, r, g, c, slope2, qf,
-                                 q_pos, o, m_run, l_run);
+                                 q_pos, o, m_run, l_acc);
 
 #pragma unroll
     for (int qg = 0; qg < QG; ++qg) {
-        const float l = sum_over_g(l_run[qg]);
+        const float l = l_acc[qg][0];
         const float inv = 1.0f / l;
         if (q_abs[qg] < len_q) {
             unsigned short* op = P.out + (int64_t)(q_tok0 + q_abs[qg]) * P.o_stride + h * DH + 4 * g;

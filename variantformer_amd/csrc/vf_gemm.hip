@@ -656,10 +656,15 @@ int pick_variant(int M, int N, int K, int epilogue) {
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
     if (t128 < 256) return 5;
-    if (K >= 4096 && t256 >= 256) return 2;                               // long K: 256x256 (1411 vs 1155 at 8192^3)
-    if (K <= 512 && N >= 1024 && t256 >= 1024 && epilogue == VF_EPI_BF16) return 2;   // seq2reg Wqkv: 814 vs 692
-    // seq2reg GeGLU (K = 512): BK = 32 ring, 48 KiB -> 3 blocks per CU hide the short main loop's fill (790 vs 639 / 717)
-    if (K <= 512 && N >= 1024 && t128 >= 4096 && epilogue == VF_EPI_GEGLU_BF16) return 12;
+    if (K >= 4096 && t256 >= 256) return 2;                               // long K: 256x256 (1380 vs 1170 at 8192^3)
+    // Measured at the 8-gene batch sizes of bench.py (scripts/gemm_bench.py, profiles/r01_g_gemm_sweep_b8.log):
+    if (t256 >= 1024 && (epilogue == VF_EPI_BF16 || epilogue == VF_EPI_GEGLU_BF16)) {
+        // seq2reg GeGLU (K = 512): BK = 32 ring, 48 KiB -> 3 blocks per CU hide the short main loop's fill (772 vs 641 / 699)
+        if (K <= 512 && epilogue == VF_EPI_GEGLU_BF16) return 12;
+        // >= 4 tiles of 256x256 per CU: half the L2 -> LDS traffic per flop (gene Wqkv 1098 vs 975, Wq 1117 vs 970,
+        // GeGLU 1027 vs 942, seq2reg Wqkv 824 vs 684).  The fp32-residual epilogues stay on 128x128 (792 vs 725).
+        return 2;
+    }
     (void)epilogue;      // in the full pipeline the persistent form measured slower (33.0 vs 34.0 genes/s): not selected
     return 1;
 }
