@@ -140,6 +140,8 @@ ATTN_CASES = [
     (48, 4, [201, 9, 64, 65], [100, 256, 1, 129], False),    # short-sequence kernel, cross attention, ragged
     (64, 8, [70, 125, 99, 1, 128], None, False),             # short-sequence kernel, 2 query groups per wave
     (48, 32, [201] * 6, None, True),                         # gene stream shape
+    # >= 2048 blocks of 256 queries -> 4 query groups per wave (batched gene -> CRE cross attention), ragged
+    (48, 32, [1300, 257, 600, 1024, 999, 256, 255, 1, 770, 512, 1100, 300], [300, 64, 100, 1, 129, 200, 65, 77, 256, 31, 128, 90], False),
 ]
 
 

@@ -542,6 +542,13 @@ int launch_attn(AttnParams P, int n_seq, int max_q, int max_k, hipStream_t st) {
             if (dbg == 3) { hipLaunchKernelGGL((attn_fwd_kernel<48, 2, false, 3>), grid, dim3(256), 0, st, P); return VF_OK; }
             if (dbg == 4) { hipLaunchKernelGGL((attn_fwd_kernel<48, 2, false, 4>), grid, dim3(256), 0, st, P); return VF_OK; }
         }
+        // 4 query groups per wave (256-query blocks) once that still leaves >= 8 blocks per CU: every K/V fragment read
+        // feeds 4 MFMAs (gene->CRE cross attention at 8 genes: 948 vs 993 us; no gain at one gene, 1376 blocks)
+        if (DH == 48 && !ALIBI && (long)n_seq * P.H * ((max_q + 255) / 256) >= 2048) {
+            const dim3 grid4(set_grid(P, n_seq, (max_q + 255) / 256));
+            hipLaunchKernelGGL((attn_fwd_kernel<48, 4, false>), grid4, dim3(256), 0, st, P);
+            return VF_OK;
+        }
         hipLaunchKernelGGL((attn_fwd_kernel<DH, 2, ALIBI>), grid, dim3(256), 0, st, P);
     } else {
         const dim3 grid(set_grid(P, n_seq, (max_q + 63) / 64));
