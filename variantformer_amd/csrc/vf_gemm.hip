@@ -249,6 +249,21 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_mfma_kernel(const unsigned
                 }
         }
     };
+    // Wave tiles too large to hold their whole residual in registers (256x256 tiles): the residual rows of epilogue
+    // pass ps+1 are requested while pass ps goes through LDS, so only the first pass pays a load latency.
+    constexpr bool RES_PIPE = (EPI == VF_EPI_RES_F32) && !RES_PRE;
+    f32x4_t rbuf[2][RES_PIPE ? NI : 1];
+    auto load_res_pass = [&](int ps, f32x4_t (&dst)[RES_PIPE ? NI : 1]) {
+        if (RES_PIPE) {
+#pragma unroll
+            for (int k = 0; k < NI; ++k) {
+                int64_t m = mw0 + ps * RP + k * RI + ep_row;
+                m = m < M ? m : M - 1;
+                const int col = ep_col < N ? ep_col : N - 4;
+                dst[RES_PIPE ? k : 0] = *reinterpret_cast<const f32x4_t*>(res + m * ldr + col);
+            }
+        }
+    };
     if (C::KS == 2) {
         for (int kt = 0; kt < nkt; ++kt) {
             read_frags(stage, 1, wf1, af1);
@@ -286,10 +301,12 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_mfma_kernel(const unsigned
         return;
     }
     const int nw0 = n0 + wn * WT_N;
+    load_res_pass(0, rbuf[0]);
     __syncthreads();                     // every wave's last fragments are in registers: the ring is free
     char* const region = smem + wave * REGION;
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
+        if (ps + 1 < NPASS) load_res_pass(ps + 1, rbuf[(ps + 1) & 1]);
         // (1) accumulators (+bias, activation) -> this wave's LDS slice, in the output dtype
 #pragma unroll
         for (int iml = 0; iml < IMP; ++iml) {
@@ -343,8 +360,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_mfma_kernel(const unsigned
                 u32x4_t d = *reinterpret_cast<const u32x4_t*>(region + row * PITCH + (lane % CR) * 16);
                 if (EPI == VF_EPI_RES_F32) {
                     f32x4_t f = __builtin_bit_cast(f32x4_t, d);
-                    f += RES_PRE ? resv[RES_PRE ? ps : 0][RES_PRE ? k : 0]
-                                 : *reinterpret_cast<const f32x4_t*>(res + m * ldr + ep_col);
+                    f += RES_PRE ? resv[RES_PRE ? ps : 0][RES_PRE ? k : 0] : rbuf[ps & 1][RES_PIPE ? k : 0];
                     d = __builtin_bit_cast(u32x4_t, f);
                 }
                 *reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(out) + (m * ldo + ep_col) * ES) = d;
@@ -658,11 +674,13 @@ int pick_variant(int M, int N, int K, int epilogue) {
     if (t128 < 256) return 5;
     if (K >= 4096 && t256 >= 256) return 2;                               // long K: 256x256 (1380 vs 1170 at 8192^3)
     // Measured at the 8-gene batch sizes of bench.py (scripts/gemm_bench.py, profiles/r01_g_gemm_sweep_b8.log):
-    if (t256 >= 1024 && (epilogue == VF_EPI_BF16 || epilogue == VF_EPI_GEGLU_BF16)) {
+    if (t256 >= 1024 && (epilogue == VF_EPI_BF16 || epilogue == VF_EPI_GEGLU_BF16 || epilogue == VF_EPI_RES_F32)) {
         // seq2reg GeGLU (K = 512): BK = 32 ring, 48 KiB -> 3 blocks per CU hide the short main loop's fill (772 vs 641 / 699)
         if (K <= 512 && epilogue == VF_EPI_GEGLU_BF16) return 12;
         // >= 4 tiles of 256x256 per CU: half the L2 -> LDS traffic per flop (gene Wqkv 1098 vs 975, Wq 1117 vs 970,
-        // GeGLU 1027 vs 942, seq2reg Wqkv 824 vs 684).  The fp32-residual epilogues stay on 128x128 (792 vs 725).
+        // GeGLU 1027 vs 942, seq2reg Wqkv 824 vs 684).  The fp32-residual epilogues lost on 256x256 (725 vs 792) until
+        // the residual rows of the next epilogue pass were prefetched under the current one (RES_PIPE): now 783 vs 719
+        // (out_proj), 678 vs 616 (K = 1024), 706 vs 632 (seq2reg K = 1024) on the same box.
         return 2;
     }
     (void)epilogue;      // in the full pipeline the persistent form measured slower (33.0 vs 34.0 genes/s): not selected
