@@ -97,7 +97,8 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_mfma_kernel(const unsigned
                                                               const unsigned short* __restrict__ W,
                                                               const float* __restrict__ bias,
                                                               const float* __restrict__ res, int64_t ldr, void* out,
-                                                              int64_t ldo, int M, int N, int K, int tiles_n, int n_blocks) {
+                                                              int64_t ldo, int M, int N, int K, int tiles_n, int n_blocks,
+                                                              int GROUP_M) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BM = C::BM, BN = C::BN, TM = C::TM, TN = C::TN, STAGES = C::STAGES, LPT = C::LPT;
     constexpr int BK = C::BK, ROW_BYTES = C::ROW_BYTES, CPR = C::CPR, RPP = C::ROWS_PER_PIECE;
@@ -109,7 +110,6 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_mfma_kernel(const unsigned
     const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
     // Grouped order inside the run: GROUP_M m-panels x all n, m fastest, so the ~64 blocks resident on an XCD form
     // a squarish patch (8 A-panels x 8 W-panels) and each staged slice is shared by 8 blocks in that XCD's L2.
-    constexpr int GROUP_M = 8;
     const int tiles_m = n_blocks / tiles_n;
     const int per_group = GROUP_M * tiles_n;
     const int grp = wg / per_group, in_grp = wg - grp * per_group;
@@ -630,8 +630,9 @@ int launch_cfg(const void* A, int64_t lda, const void* W, const float* bias, con
     }
     const int tiles_m = (M + C::BM - 1) / C::BM, tiles_n = (N + C::BN - 1) / C::BN;
     const int n_blocks = tiles_m * tiles_n;
+    const int group_m = 8;      // m-panels per L2 group; 2 / 4 / 16 measured equal or slower for both tile sizes
     hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(C::THREADS), C::LDS_BYTES, st, (const unsigned short*)A, lda,
-                       (const unsigned short*)W, bias, res, ldr, out, ldo, M, N, K, tiles_n, n_blocks);
+                       (const unsigned short*)W, bias, res, ldr, out, ldo, M, N, K, tiles_n, n_blocks, group_m);
     VF_CHECK_LAUNCH("vf_gemm_bf16");
     return VF_OK;
 }
