@@ -139,6 +139,13 @@ int vf_gather_rows_bf16(const void* src, int64_t ld_src, const int64_t* idx, voi
 int vf_rowdot_softplus(const float* x, const float* w, const float* b, float* out,
                        int64_t n, int d, int softplus, void* stream);
 
+/* Max pool over the rows [cu[w], cu[w+1]) of x: out fp32 [W, d] (pool_outputs "max", model_combined_modulator.py:380-389).
+ * Row sum with optional row indirection: out[i] = a[idx_a ? idx_a[i] : i] + b[idx_b ? idx_b[i] : i], fp32 [n, d]
+ * (gene-stream residual `use_res`, model_combined_modulator.py:253-254,284-285; AddContext, layers.py:558-573). */
+int vf_segment_max(const float* x, const int32_t* cu_seqlens, float* out, int W, int d, void* stream);
+int vf_add_rows_f32(const float* a, const int64_t* idx_a, const float* b, const int64_t* idx_b, float* out, int64_t n,
+                    int d, void* stream);
+
 /* fp32 -> bf16 (round to nearest even), n elements. */
 int vf_cast_f32_bf16(const float* x, void* out, int64_t n, void* stream);
 

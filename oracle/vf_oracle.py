@@ -155,9 +155,9 @@ def mha_self(x, sd, pfx, H, cu, slopes, rnd: Rounding):
     return linear(out, sd[pfx + "out_proj.weight"], sd[pfx + "out_proj.bias"], rnd)
 
 
-def mha_cross(xq, xkv, sd, pfx, H, cu_q, cu_k, rnd: Rounding):
+def mha_cross(xq, xkv, sd, pfx, H, cu_q, cu_k, rnd: Rounding, slopes=None):
     """flash_attn MHA cross path [3p]: Wq on the query stream, Wkv on the context stream;
-    no ALiBi (cross_alibi: false, configs/vf_model.yaml:13)."""
+    no ALiBi in the shipped configuration (cross_alibi: false, configs/vf_model.yaml:13)."""
     D = xq.shape[-1]
     dh = D // H
     q = rnd.r(linear(xq, sd[pfx + "Wq.weight"], sd[pfx + "Wq.bias"], rnd)).view(-1, H, dh)
@@ -167,7 +167,7 @@ def mha_cross(xq, xkv, sd, pfx, H, cu_q, cu_k, rnd: Rounding):
         a, e = int(cu_q[b]), int(cu_q[b + 1])
         ka, ke = int(cu_k[b]), int(cu_k[b + 1])
         if e > a:
-            out[a:e] = attention(q[a:e], kv[ka:ke, 0], kv[ka:ke, 1], None, rnd).reshape(e - a, D)
+            out[a:e] = attention(q[a:e], kv[ka:ke, 0], kv[ka:ke, 1], slopes, rnd).reshape(e - a, D)
     out = rnd.r(out)
     return linear(out, sd[pfx + "out_proj.weight"], sd[pfx + "out_proj.bias"], rnd)
 
@@ -246,27 +246,49 @@ class Seq2GeneHP:
     num_tissues: int = 63
     use_alibi: bool = True
     extras: dict = field(default_factory=dict)
+    # options the shipped configuration leaves at these values (configs/vf_model.yaml:12-37)
+    only_cross_attention: bool = False      # gene layers without self attention (layers.py:231-325)
+    use_res: bool = False                   # gene-stream input added back after every gene layer (:236,253,284)
+    cross_alibi: bool = False               # ALiBi on the cross attentions too (layers.py:60-71)
+    add_context_to_cres: bool = False       # tissue embedding added to the CRE tokens (:669-670, layers.py:558-573)
+    gene_pooling: str = "multi_registry"    # or "start_token" / "max" (:330-396; "mean" does not reduce in the reference)
+
+    @property
+    def shipped(self) -> bool:
+        return not (self.only_cross_attention or self.use_res or self.cross_alibi or self.add_context_to_cres) \
+            and self.gene_pooling == "multi_registry"
 
     @classmethod
     def from_kwargs(cls, kw: dict):
-        assert kw.get("use_context", False) and not kw.get("only_cross_attention", True), \
-            "oracle covers the shipped configuration (configs/vf_model.yaml:12-37)"
-        assert kw.get("gene_pooling") == "multi_registry" and not kw.get("multi_head", True)
-        assert kw.get("use_bigger_head", False) and not kw.get("add_context_to_cres", False)
-        assert not kw.get("use_res", False) and not kw.get("cross_alibi", False)
+        assert kw.get("use_context", False), "oracle covers use_context=True (configs/vf_model.yaml:12-37)"
+        assert not kw.get("multi_head", True) and kw.get("use_bigger_head", False), "shared 'bigger' head only"
+        pooling = kw.get("gene_pooling")
+        assert pooling in ("multi_registry", "start_token", "max"), pooling
         return cls(kw["emb_dim"], kw["num_heads"], kw["num_layers"], kw["token_dim"], kw["gene_emb_dim"],
-                   kw.get("num_tissues", 63), kw.get("use_alibi", True))
+                   kw.get("num_tissues", 63), kw.get("use_alibi", True),
+                   only_cross_attention=kw.get("only_cross_attention", True), use_res=kw.get("use_res", False),
+                   cross_alibi=kw.get("cross_alibi", False) and kw.get("use_alibi", True),
+                   add_context_to_cres=kw.get("add_context_to_cres", False), gene_pooling=pooling)
 
 
-def modulator_layer(src, ctx, cu_src, cu_ctx, sd, pfx, H, slopes, rnd: Rounding):
+def modulator_layer(src, ctx, cu_src, cu_ctx, sd, pfx, H, slopes, rnd: Rounding, cross_slopes=None):
     """ContextFlashAttentionEncoderLayer.forward (seq2gene/modules/layers.py:88-165) on packed
     streams: LN1 -> self-MHA(ALiBi) -> +src -> LN2 -> cross-MHA(q = x, kv = ctx RAW, no norm)
     -> +res_short -> LN3 -> GeGLU -> + src (the LAYER INPUT, :99,163)."""
     h = rnd.r(layer_norm(src, sd[pfx + "norm1.weight"], sd[pfx + "norm1.bias"]))
     x1 = mha_self(h, sd, pfx + "mixer.MHA.", H, cu_src, slopes, rnd) + src
     h = rnd.r(layer_norm(x1, sd[pfx + "norm2.weight"], sd[pfx + "norm2.bias"]))
-    x2 = mha_cross(h, ctx, sd, pfx + "crossMHA.MHA.", H, cu_src, cu_ctx, rnd) + x1
+    x2 = mha_cross(h, ctx, sd, pfx + "crossMHA.MHA.", H, cu_src, cu_ctx, rnd, cross_slopes) + x1
     h = rnd.r(layer_norm(x2, sd[pfx + "norm3.weight"], sd[pfx + "norm3.bias"]))
+    return geglu_ffn(h, sd, pfx, rnd) + src
+
+
+def cross_only_layer(src, ctx, cu_src, cu_ctx, sd, pfx, H, rnd: Rounding, cross_slopes=None):
+    """ContextFlashCrossAttentionEncoderLayer.forward (layers.py:231-325): LN1 -> cross-MHA(q = x, kv = ctx raw)
+    -> +src -> LN2 -> GeGLU -> + src (the layer input)."""
+    h = rnd.r(layer_norm(src, sd[pfx + "norm1.weight"], sd[pfx + "norm1.bias"]))
+    x1 = mha_cross(h, ctx, sd, pfx + "crossMHA.MHA.", H, cu_src, cu_ctx, rnd, cross_slopes) + src
+    h = rnd.r(layer_norm(x1, sd[pfx + "norm2.weight"], sd[pfx + "norm2.bias"]))
     return geglu_ffn(h, sd, pfx, rnd) + src
 
 
@@ -275,16 +297,29 @@ def combined_modulator(cre_x, gene_x, ctx_labels, cu_cre, cu_gene, sd, pfx, hp: 
     """CombinedModulator.forward (model_combined_modulator.py:137-328) on packed streams.
     cre_x [sum N, D], gene_x [sum G, D], ctx_labels int64 [sum N]."""
     slopes = torch.tensor(alibi_slopes(hp.num_heads), dtype=torch.float32) if hp.use_alibi else None
+    xs = slopes if hp.cross_alibi else None
     ctx = sd[pfx + "second_level_context_embedding.weight"][ctx_labels]          # :166-168
+
+    def gene_layer(g, c, p):
+        if hp.only_cross_attention:                                               # :106-119
+            return cross_only_layer(g, c, cu_gene, cu_cre, sd, p, hp.num_heads, rnd, xs)
+        return modulator_layer(g, c, cu_gene, cu_cre, sd, p, hp.num_heads, slopes, rnd, xs)
+
     cre, gene = cre_x, gene_x
-    gene = modulator_layer(gene, cre, cu_gene, cu_cre, sd, pfx + "gene_layers.0.", hp.num_heads, slopes, rnd)  # :244-250
+    gene_res = gene_x if hp.use_res else None                                    # :236
+    gene = gene_layer(gene, cre, pfx + "gene_layers.0.")                         # :244-250
     if collect is not None:
-        collect["first_gene_layer_out"] = gene.clone()
+        collect["first_gene_layer_out"] = gene.clone()                          # the layer's own output
+    if gene_res is not None:
+        gene = gene + gene_res                                                   # :253-254
     for i in range(hp.num_layers - 1):                                           # :258-285
+        # the CRE layers are built without cross_alibi (:78-88): their context cross attention never has a bias
         cre = modulator_layer(cre, ctx, cu_cre, cu_cre, sd, f"{pfx}cre_layers.{i}.", hp.num_heads, slopes, rnd)
         if collect is not None and i == 0:
             collect["first_cre_layer_out"] = cre.clone()
-        gene = modulator_layer(gene, cre, cu_gene, cu_cre, sd, f"{pfx}gene_layers.{i + 1}.", hp.num_heads, slopes, rnd)
+        gene = gene_layer(gene, cre, f"{pfx}gene_layers.{i + 1}.")
+        if gene_res is not None:
+            gene = gene + gene_res
     return gene, cre
 
 
@@ -329,7 +364,7 @@ def forward(batch: dict, sd: dict, cre_hp: Seq2RegHP, gene_hp: Seq2RegHP, hp: Se
     else:
         cre_x = cre_tok
     gene_x = [linear(t, sd["gene_map.weight"], sd["gene_map.bias"], rnd) for t in gene_tok]
-    reg = sd["start_tkn.registry_tokens.weight"]
+    assert hp.shipped or not share_cre_stream, "the de-duplicated evaluation exists for the shipped configuration only"
 
     embs = []
     first_gene, first_cre, mod_out = [], [], []
@@ -337,23 +372,39 @@ def forward(batch: dict, sd: dict, cre_hp: Seq2RegHP, gene_hp: Seq2RegHP, hp: Se
         tissues = [int(t) for t in batch["tissue_context"][i]]
         T, N, C = len(tissues), cre_x[i].shape[0], gene_x[i].shape[0]
         labels = batch["ref_cre_labels"][i].long()
-        # registry token prepended per tissue (MultiRegistry.forward layers.py:508-521; prepare_input :357-366)
-        g = torch.cat([torch.cat([reg[t][None, :], gene_x[i]], dim=0) for t in tissues], dim=0)   # [T*(C+1), D]
-        cu_g = torch.arange(0, T + 1, dtype=torch.int32) * (C + 1)
+        # prepare_input (:330-368): registry token per tissue (MultiRegistry.forward layers.py:508-521), one shared
+        # start token (StartToken, layers.py:491-499), or nothing in front of the gene tokens (max pooling)
+        if hp.gene_pooling == "multi_registry":
+            reg = sd["start_tkn.registry_tokens.weight"]
+            g = torch.cat([torch.cat([reg[t][None, :], gene_x[i]], dim=0) for t in tissues], dim=0)   # [T*(C+1), D]
+            G = C + 1
+        elif hp.gene_pooling == "start_token":
+            g = torch.cat([torch.cat([sd["start_tkn.start_token"].reshape(1, D), gene_x[i]], dim=0) for _ in tissues], dim=0)
+            G = C + 1
+        else:
+            g = gene_x[i].repeat(T, 1)
+            G = C
+        cu_g = torch.arange(0, T + 1, dtype=torch.int32) * G
         col = {} if collect is not None else None
         if share_cre_stream:
             # one CRE stream; all T tissue copies of the gene stream attend to it
             out, _ = _modulator_shared(cre_x[i], g, labels, T, C + 1, sd, hp, rnd, col)
         else:
             cre_rep = cre_x[i].repeat(T, 1)
+            if hp.add_context_to_cres:                       # AddContext (layers.py:558-573): + tissue embedding
+                add = sd["add_context.registry_tokens.weight"]
+                cre_rep = cre_rep + torch.cat([add[t][None, :].expand(N, D) for t in tissues], dim=0)
             lab_rep = labels.repeat(T)
             cu_c = torch.arange(0, T + 1, dtype=torch.int32) * N
             out, _ = combined_modulator(cre_rep, g, lab_rep, cu_c, cu_g, sd, "combined_modulator.", hp, rnd, col)
         if collect is not None:
             first_gene.append(col["first_gene_layer_out"])
             first_cre.append(col["first_cre_layer_out"])
-            mod_out.append(out.view(T, C + 1, D))
-        embs.append(out.view(T, C + 1, D)[:, 0, :])            # pool_outputs multi_registry (:391-392)
+            mod_out.append(out.view(T, G, D))
+        if hp.gene_pooling == "max":
+            embs.append(out.view(T, G, D).max(dim=1).values)   # pool_outputs max (:380-389); every chunk is valid here
+        else:
+            embs.append(out.view(T, G, D)[:, 0, :])            # start / registry token (:391-392)
     if collect is not None:
         collect["first_gene_layer_out"] = torch.cat(first_gene)
         collect["first_cre_layer_out"] = torch.cat(first_cre)

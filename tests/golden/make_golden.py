@@ -235,6 +235,17 @@ def build_reference_model(fx):
     return model
 
 
+def _with(base, **opts):
+    fx = dict(FIXTURES[base])
+    fx["seq2gene"] = dict(fx["seq2gene"], **opts)
+    return fx
+
+
+# options the shipped configuration leaves off: cross-attention-only gene layers, gene
+# residual, ALiBi on the cross attentions, one shared start token / tissue embedding added to the CRE tokens, max pooling
+FIXTURES["small_opts_a"] = dict(_with("small_sin", only_cross_attention=True, use_res=True, cross_alibi=True,
+                                      gene_pooling="start_token"), seed=404)
+FIXTURES["small_opts_b"] = dict(_with("small_alibi", add_context_to_cres=True, gene_pooling="max"), seed=505)
 FIXTURES["small_twomod"] = dict(FIXTURES["small_sin"], seed=303, model_class="Seq2GenePredictor",
                                 n_cres=[6, 3], n_chunks=[2, 4], tissues=[[62, 7], [20, 33, 59]])
 

@@ -52,13 +52,35 @@ def test_prepare_batch_structure(golden):
 def test_unsupported_configurations_fail_loudly():
     meta, *_ = load_fixture("small_sin")
     kw = dict(meta["seq2gene"])
-    kw["only_cross_attention"] = True
+    kw["gene_pooling"] = "mean"               # does not reduce over tokens in the reference either
+    with pytest.raises(NotImplementedError):
+        build_model(meta["seq2reg"], kw)
+    kw["gene_pooling"] = "median"
+    with pytest.raises(AssertionError, match="gene_pooling must be one of"):
+        build_model(meta["seq2reg"], kw)
+    kw = dict(meta["seq2gene"], use_context=False)
     with pytest.raises(NotImplementedError):
         build_model(meta["seq2reg"], kw)
     hp = dict(meta["seq2reg"])
     hp["use_context"] = True
     with pytest.raises(NotImplementedError):
         build_model(hp, meta["seq2gene"])
+
+
+def test_non_shipped_options_build_with_reference_state_dict_names():
+    """only_cross_attention / use_res / cross_alibi / start_token and add_context_to_cres / max pooling: module tree
+    and parameter names as in the reference (fixtures' state-dict inventories come from the reference's classes)."""
+    for name in ("small_opts_a", "small_opts_b"):
+        meta, arrays, sd, batch = load_fixture(name)
+        model = build_model(meta["seq2reg"], meta["seq2gene"])
+        assert model._general
+        ours = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+        want = {k: tuple(v) for k, v in meta["state_dict_shapes"].items()}
+        missing = [k for k in want if k not in ours and not k.endswith(".m")]
+        extra = [k for k in ours if k not in want]
+        assert not missing and not extra, (missing[:5], extra[:5])
+        assert all(ours[k] == want[k] for k in ours)
+        model.load_state_dict({k: v for k, v in sd.items() if k in ours}, strict=True)
 
 
 def test_model_manager_contract(tmp_path):

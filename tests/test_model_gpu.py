@@ -268,3 +268,28 @@ def test_headline_size_gene_vs_oracle_and_properties():
     orc = O.predict_step(first, sd, shp, shp, O.Seq2GeneHP.from_kwargs(kw), rounding="bf16", share_cre_stream=True)
     assert _rel(alone["pred_gene_exp"][0], orc["pred_gene_exp"][0]) < NORTH_STAR_RTOL
     assert _rel(alone["embeddings"][0], orc["embeddings"][0]) < 5e-3
+
+
+@pytest.mark.parametrize("name", ["small_opts_a", "small_opts_b"])
+def test_non_shipped_options_vs_reference_golden(name):
+    """Layer options the shipped configuration leaves off, pinned to fixtures produced by the
+    reference's own classes: (a) cross-attention-only gene layers + gene residual + ALiBi on the gene->CRE cross
+    attention + start-token pooling, (b) tissue embedding added to the CRE tokens + max pooling."""
+    meta, arrays, sd, batch = load_fixture(name)
+    model = build_model(meta["seq2reg"], meta["seq2gene"], sd).cuda()
+    assert model._general
+    out = model.predict_step(batch, 0)
+    cre_hp, gene_hp, hp = _hps(meta)
+    orc = O.predict_step(batch, sd, cre_hp, gene_hp, hp, rounding="bf16")
+    for i in range(len(meta["n_cres"])):
+        p, e = out["pred_gene_exp"][i], out["embeddings"][i]
+        assert p.shape == (len(meta["tissues"][i]), 1) and e.shape == (len(meta["tissues"][i]), meta["seq2gene"]["emb_dim"])
+        emb_tol = 1e-2 if meta["seq2gene"]["gene_pooling"] == "max" else 5e-3   # max pooling keeps per-column extremes
+        assert _rel(p, arrays[f"pred_gene_exp_{i}"]) < NORTH_STAR_RTOL                # of bf16-noisy rows
+        assert _rel(e, arrays[f"embeddings_{i}"]) < emb_tol
+        assert _rel(p, orc["pred_gene_exp"][i]) < NORTH_STAR_RTOL
+        assert _rel(e, orc["embeddings"][i]) < emb_tol
+    model.vep = True
+    with pytest.raises(NotImplementedError, match="shipped configuration"):
+        model.forward(batch["cre_sequences"], batch["cre_attention_masks"], batch["tissue_context"], batch["ref_cre_labels"],
+                      batch["strand_val"], batch["gene_embeddings"], batch["gene_attention_masks"], return_embedding=True)

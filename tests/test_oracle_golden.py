@@ -100,3 +100,27 @@ def test_pad_unpad_conventions():
     assert idx.tolist() == [0, 1, 4, 5, 6] and cu.tolist() == [0, 2, 5] and mx == 3 and cu.dtype == torch.int32
     back = O.pad_input(packed, idx, 2, 4)
     assert torch.equal(back[keep], x[keep]) and float(back[~keep].abs().sum()) == 0.0
+
+
+import pytest
+from tests.conftest import load_fixture
+
+
+@pytest.mark.parametrize("name", ["small_opts_a", "small_opts_b"])
+def test_oracle_matches_reference_with_non_shipped_options(name):
+    """only_cross_attention + use_res + cross_alibi + start_token pooling (a); add_context_to_cres + max pooling (b):
+    outputs and intermediates of the reference's own classes with these options switched on."""
+    meta, arrays, sd, batch = load_fixture(name)
+    cre_hp, gene_hp, hp = _hps(meta)
+    assert not hp.shipped
+    col = {}
+    with torch.no_grad():
+        pred, emb = O.forward(batch, sd, cre_hp, gene_hp, hp, collect=col)
+    out = O.predict_step(batch, sd, cre_hp, gene_hp, hp)
+    for i in range(len(meta["n_cres"])):
+        np.testing.assert_allclose(out["pred_gene_exp"][i], arrays[f"pred_gene_exp_{i}"], rtol=RTOL, atol=ATOL)
+        np.testing.assert_allclose(out["embeddings"][i], arrays[f"embeddings_{i}"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(col["first_gene_layer_out"].numpy(), arrays["first_gene_layer_out"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(col["first_cre_layer_out"].numpy(), arrays["first_cre_layer_out"], rtol=RTOL, atol=ATOL)
+    with pytest.raises(AssertionError, match="de-duplicated"):
+        O.predict_step(batch, sd, cre_hp, gene_hp, hp, share_cre_stream=True)

@@ -36,6 +36,8 @@ SIGNATURES = {
     "vf_gather_rows_bf16": [_p, _l, _p, _p, _l, _l, _i, _p],
     "vf_rowdot_softplus": [_p, _p, _p, _p, _l, _i, _i, _p],
     "vf_cast_f32_bf16": [_p, _p, _l, _p],
+    "vf_segment_max": [_p, _p, _p, _i, _i, _p],
+    "vf_add_rows_f32": [_p, _p, _p, _p, _p, _l, _i, _p],
     "vf_bpe_create": [_p, _i, _p, _i],
     "vf_bpe_destroy": [_p],
     "vf_bpe_encode": [_p, C.c_char_p, _l, _p, _p, _l],

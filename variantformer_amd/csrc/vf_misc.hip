@@ -179,6 +179,38 @@ __global__ __launch_bounds__(256) void segment_mean_kernel(const float* __restri
     }
 }
 
+// segment max (max pool over the tokens of a sequence): one block per window, threads over float4 columns
+__global__ __launch_bounds__(256) void segment_max_kernel(const float* __restrict__ x, const int32_t* __restrict__ cu,
+                                                         float* __restrict__ out, int d) {
+    const int w = blockIdx.x;
+    const int a = cu[w], e = cu[w + 1];
+    const int n4 = d >> 2;
+    for (int c = threadIdx.x; c < n4; c += 256) {
+        f32x4_t acc = (f32x4_t){-INFINITY, -INFINITY, -INFINITY, -INFINITY};     // empty window -> -inf, as torch.max
+        for (int t = a; t < e; ++t) {
+            const f32x4_t v = reinterpret_cast<const f32x4_t*>(x + (int64_t)t * d)[c];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] = fmaxf(acc[k], v[k]);
+        }
+        reinterpret_cast<f32x4_t*>(out + (int64_t)w * d)[c] = acc;
+    }
+}
+
+// out[i] = a[ia ? ia[i] : i] + b[ib ? ib[i] : i]   (fp32 rows; gene residual, tissue embedding onto CRE tokens)
+__global__ __launch_bounds__(256) void add_rows_kernel(const float* __restrict__ a, const int64_t* __restrict__ ia,
+                                                      const float* __restrict__ b, const int64_t* __restrict__ ib,
+                                                      float* __restrict__ out, int64_t n, int d) {
+    const int n4 = d >> 2;
+    const int64_t total = n * n4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / n4;
+        const int c = (int)(i - row * n4);
+        const int64_t ra = ia ? ia[row] : row, rb = ib ? ib[row] : row;
+        reinterpret_cast<f32x4_t*>(out + row * d)[c] =
+            reinterpret_cast<const f32x4_t*>(a + ra * d)[c] + reinterpret_cast<const f32x4_t*>(b + rb * d)[c];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // gathers
 // ---------------------------------------------------------------------------------------------
@@ -303,6 +335,24 @@ extern "C" int vf_segment_mean(const float* x, const int32_t* cu, void* out, int
     if (W <= 0) return VF_OK;
     hipLaunchKernelGGL(segment_mean_kernel, dim3(W), dim3(256), 0, (hipStream_t)stream, x, cu, out, d, out_dtype == VF_BF16);
     VF_CHECK_LAUNCH("vf_segment_mean");
+    return VF_OK;
+}
+
+extern "C" int vf_segment_max(const float* x, const int32_t* cu, float* out, int W, int d, void* stream) {
+    VF_REQUIRE(x && cu && out && d > 0 && d % 4 == 0, "vf_segment_max: bad arguments (d=%d)", d);
+    if (W <= 0) return VF_OK;
+    hipLaunchKernelGGL(segment_max_kernel, dim3(W), dim3(256), 0, (hipStream_t)stream, x, cu, out, d);
+    VF_CHECK_LAUNCH("vf_segment_max");
+    return VF_OK;
+}
+
+extern "C" int vf_add_rows_f32(const float* a, const int64_t* idx_a, const float* b, const int64_t* idx_b, float* out,
+                               int64_t n, int d, void* stream) {
+    VF_REQUIRE(a && b && out && d > 0 && d % 4 == 0, "vf_add_rows_f32: bad arguments (d=%d)", d);
+    if (n <= 0) return VF_OK;
+    hipLaunchKernelGGL(add_rows_kernel, dim3(stream_grid(n * (d / 4))), dim3(256), 0, (hipStream_t)stream, a, idx_a, b,
+                       idx_b, out, n, d);
+    VF_CHECK_LAUNCH("vf_add_rows_f32");
     return VF_OK;
 }
 

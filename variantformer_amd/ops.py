@@ -195,6 +195,31 @@ def segment_mean(x: torch.Tensor, cu: torch.Tensor, out_dtype=torch.bfloat16) ->
     return out
 
 
+def segment_max(x: torch.Tensor, cu: torch.Tensor) -> torch.Tensor:
+    _dev(x, cu)
+    assert x.dtype == torch.float32 and x.is_contiguous() and cu.dtype == torch.int32
+    W = cu.numel() - 1
+    out = torch.empty((W, x.shape[1]), dtype=torch.float32, device=x.device)
+    check(_lib.load().vf_segment_max(x.data_ptr(), cu.data_ptr(), out.data_ptr(), W, x.shape[1], _stream()),
+          "vf_segment_max")
+    return out
+
+
+def add_rows(a: torch.Tensor, b: torch.Tensor, idx_a: torch.Tensor | None = None, idx_b: torch.Tensor | None = None) -> torch.Tensor:
+    """out[i] = a[idx_a[i]] + b[idx_b[i]] (identity where an index is None), fp32 rows."""
+    _dev(a, b, idx_a, idx_b)
+    for t in (a, b):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.dim() == 2
+    for t in (idx_a, idx_b):
+        assert t is None or (t.dtype == torch.int64 and t.is_contiguous())
+    n = idx_a.numel() if idx_a is not None else (idx_b.numel() if idx_b is not None else a.shape[0])
+    assert a.shape[1] == b.shape[1] and (idx_a is not None or a.shape[0] == n) and (idx_b is not None or b.shape[0] == n)
+    out = torch.empty((n, a.shape[1]), dtype=torch.float32, device=a.device)
+    check(_lib.load().vf_add_rows_f32(a.data_ptr(), _ptr(idx_a), b.data_ptr(), _ptr(idx_b), out.data_ptr(), n, a.shape[1],
+                                      _stream()), "vf_add_rows_f32")
+    return out
+
+
 def gather_rows_f32(a: torch.Tensor, b: torch.Tensor | None, idx: torch.Tensor, out_dtype=torch.float32) -> torch.Tensor:
     """out[i] = a[idx[i]] if idx[i] >= 0 else b[-idx[i]-1]."""
     _dev(a, b, idx)

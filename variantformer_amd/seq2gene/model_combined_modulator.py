@@ -29,8 +29,8 @@ import torch.nn as nn
 from .. import ops
 from ..utils.constants import REF_CREs
 from ..utils.functions import precision2dtype
-from .modules.layers import (ContextFlashAttentionEncoderLayer, MultiRegistry, TissueExpressionHeads, packed_linear,
-                             pad_input, unpad_input)
+from .modules.layers import (AddContext, ContextFlashAttentionEncoderLayer, ContextFlashCrossAttentionEncoderLayer,
+                             MultiRegistry, StartToken, TissueExpressionHeads, packed_linear, pad_input, unpad_input)
 
 logger = logging.getLogger(__name__)
 MAX_WINDOW_SIZE = 30000000
@@ -98,7 +98,7 @@ def _side_stream(device):
 
 def modulator_forward_packed(ctx_embedding, cre_layers, gene_layers, cre_x, gene_x, labels, cu_cre, max_cre,
                              cu_gene_self, max_gene, cu_gene_cross=None, max_gene_cross=None, cu_cre_for_gene=None,
-                             final_rows=None):
+                             final_rows=None, use_res=False):
     """Interleaved CRE / gene layer stack on packed streams (reference model_combined_modulator.py:244-285; the
     two-module variant seq2gene/model.py:375-412 + layers.py:620-742,797-921 evaluates the same sequence: gene layer
     i reads the CRE stream after CRE layer i-1, gene layer 0 the raw CRE embeddings).
@@ -121,6 +121,8 @@ def modulator_forward_packed(ctx_embedding, cre_layers, gene_layers, cre_x, gene
         side.wait_stream(main)                      # inputs (cre_x, labels, cu arrays) were produced on `main`
     gene = gene_layers[0].forward_packed(gene, cu_gene_self, max_gene, context=cre, cu_ctx=ck, max_ctx=max_cre,
                                          cu_cross_q=cq, max_cross_q=mq)
+    if use_res:                                     # gene-stream input added back after every gene layer (:253-254)
+        gene = ops.add_rows(gene, gene_x)
     for i in range(n - 1):
         if overlap:
             with torch.cuda.stream(side):
@@ -141,6 +143,8 @@ def modulator_forward_packed(ctx_embedding, cre_layers, gene_layers, cre_x, gene
         else:
             gene = gene_layers[i + 1].forward_packed(gene, cu_gene_self, max_gene, context=cre, cu_ctx=ck,
                                                      max_ctx=max_cre, cu_cross_q=cq, max_cross_q=mq)
+            if use_res:                             # :284-285
+                gene = ops.add_rows(gene, gene_x)
     return gene, cre
 
 
@@ -151,26 +155,29 @@ class CombinedModulator(nn.Module):
     def __init__(self, emb_dim, num_heads, num_layers, use_alibi, mlp_dout, use_context, num_ref_cres=None,
                  only_cross_attention=True, use_res=False, cross_alibi=False, flash_attn_3=False):
         super().__init__()
-        if not use_context or only_cross_attention or use_res or cross_alibi:
-            raise NotImplementedError(
-                "HIP path implements the shipped configuration: use_context=True, only_cross_attention=False, "
-                "use_res=False, cross_alibi=False (configs/vf_model.yaml:13-31)")
+        if not use_context:
+            raise NotImplementedError("HIP path implements use_context=True (configs/vf_model.yaml:30)")
         assert num_ref_cres is not None, "num_ref_cres must be provided when use_context is True"
         self.emb_dim, self.num_heads, self.num_layers = emb_dim, num_heads, num_layers
         self.use_context, self.only_cross_attention = use_context, only_cross_attention
         self.use_res, self.cross_alibi = use_res, cross_alibi
         self.second_level_context_embedding = nn.Embedding(num_ref_cres, emb_dim)
-        mk = lambda: ContextFlashAttentionEncoderLayer(  # noqa: E731
+        # the CRE layers are built WITHOUT cross_alibi in the reference (:78-88); only the gene layers receive it
+        mk_cre = lambda: ContextFlashAttentionEncoderLayer(  # noqa: E731
+            d_model=emb_dim, nhead=num_heads, batch_first=True, use_alibi=use_alibi, mlp_dout=mlp_dout,
+            flash_attn_3=flash_attn_3)
+        gene_cls = ContextFlashCrossAttentionEncoderLayer if only_cross_attention else ContextFlashAttentionEncoderLayer
+        mk = lambda: gene_cls(  # noqa: E731
             d_model=emb_dim, nhead=num_heads, batch_first=True, use_alibi=use_alibi, mlp_dout=mlp_dout,
             cross_alibi=cross_alibi, flash_attn_3=flash_attn_3)
-        self.cre_layers = nn.ModuleList([mk() for _ in range(num_layers - 1)])
+        self.cre_layers = nn.ModuleList([mk_cre() for _ in range(num_layers - 1)])
         self.gene_layers = nn.ModuleList([mk() for _ in range(num_layers)])
 
     def forward_packed(self, cre_x, gene_x, labels, cu_cre, max_cre, cu_gene_self, max_gene, cu_gene_cross=None,
                        max_gene_cross=None, cu_cre_for_gene=None, final_rows=None):
         return modulator_forward_packed(self.second_level_context_embedding, self.cre_layers, self.gene_layers, cre_x,
                                         gene_x, labels, cu_cre, max_cre, cu_gene_self, max_gene, cu_gene_cross,
-                                        max_gene_cross, cu_cre_for_gene, final_rows)
+                                        max_gene_cross, cu_cre_for_gene, final_rows, use_res=self.use_res)
 
     def forward(self, cre_x, gene_x, context=None, cre_padding_mask=None, gene_padding_mask=None,
                 context_padding_mask=None, precision=None, cre_token_position=None, gene_token_position=None):
@@ -234,17 +241,19 @@ class Seq2GenePredictorCombinedModulator(nn.Module):
         self.trainer = None
         self.vep = False
         self.precision = None
-        if gene_pooling != "multi_registry":
-            raise NotImplementedError("only gene_pooling='multi_registry' (configs/vf_model.yaml:32) is implemented")
+        assert gene_pooling in ["mean", "max", "start_token", "multi_registry"], \
+            "gene_pooling must be one of mean, max, start_token, or multi_registry"
+        if gene_pooling == "mean":
+            raise NotImplementedError("gene_pooling='mean' does not reduce over tokens in the reference "
+                                      "(model_combined_modulator.py:375-378) and cannot feed the heads")
         self.gene_pooling = gene_pooling
-        self.start_tkn = MultiRegistry(num_tissues, emb_dim)
+        self.start_tkn = (MultiRegistry(num_tissues, emb_dim) if gene_pooling == "multi_registry" else
+                          StartToken(emb_dim) if gene_pooling == "start_token" else None)
         self.train_gene_tokenizer = kwargs.get("train_gene_tokenizer", False)
         self.cre_tokenizer = cre_tokenizer
         self.gene_tokenizer = gene_tokenizer
         self.add_context_to_cres = kwargs.get("add_context_to_cres", False)
-        if self.add_context_to_cres:
-            raise NotImplementedError("add_context_to_cres=True makes the CRE stream tissue-dependent; not shipped")
-        self.add_context = None
+        self.add_context = AddContext(num_tissues, emb_dim) if self.add_context_to_cres else None
         self.emb_dim = emb_dim
         self.use_context = use_context
         self.tissues = tissues
@@ -257,6 +266,10 @@ class Seq2GenePredictorCombinedModulator(nn.Module):
         self.gene_map = nn.Linear(gene_emb_dim, emb_dim)
         if token_dim != emb_dim:
             self.cre_map = nn.Linear(token_dim, emb_dim)
+        # Any option the shipped configuration leaves off takes the literal evaluation order of the reference (one CRE
+        # stream and one gene stream per (gene, tissue), no sharing); same kernels, `_forward_general`.
+        self._general = (self.only_cross_attention or self.use_res or self.cross_alibi or self.add_context_to_cres
+                         or gene_pooling != "multi_registry")
         self._build_modulator(emb_dim, num_heads, num_layers, use_alibi, mlp_dout, use_context, flash_attn_3)
         self.tissue_heads = TissueExpressionHeads(emb_dim, num_tissues, use_bigger_head=self.use_bigger_head,
                                                   multi_head=self.multi_head, mlp_dout=mlp_dout, loss_fn=self.loss_fn,
@@ -376,6 +389,10 @@ class Seq2GenePredictorCombinedModulator(nn.Module):
             cre_x = cre_tok.float()
         w, b = packed_linear(self.gene_map)
         gene_x = ops.gemm(gene_tok, w, b, ops.EPI_F32)
+        if self._general:
+            if return_cre:
+                raise NotImplementedError("token-position outputs (VEP) are implemented for the shipped configuration")
+            return self._forward_general(pb, cre_x, gene_x)
         # registry token per (gene, tissue) + that gene's chunk rows (:357-366, layers.py:508-521)
         gene_stream = ops.gather_rows_f32(gene_x, self.start_tkn.registry_tokens.weight, pb.gene_stream_idx)
         if return_cre:       # VEP needs every gene token of the last layer (token-position gathers)
@@ -393,6 +410,52 @@ class Seq2GenePredictorCombinedModulator(nn.Module):
         if return_cre:
             return pred, emb, gene_out, cre_out
         return pred, emb
+
+    def _forward_general(self, pb: PreparedBatch, cre_x: torch.Tensor, gene_x: torch.Tensor):
+        """Literal evaluation order of the reference for the options the shipped configuration leaves off
+        (reference :614-700): every (gene, tissue) pair owns a copy of the gene's CRE stream (plus the tissue embedding
+        when add_context_to_cres) and a gene sequence (start / registry token in front, or none for max pooling); cross
+        attention pairs sequence b of the gene stream with sequence b of the CRE stream (ALiBi when cross_alibi)."""
+        dev = cre_x.device
+        prefix = 0 if self.gene_pooling == "max" else 1
+        cre_idx, cre_tissue, gene_idx, cre_lens, gene_lens = [], [], [], [], []
+        c_off = 0
+        for i in range(pb.n_genes):
+            n, c = pb.n_cre[i], pb.n_chunk[i]
+            n_off = int(pb.cu_cre_host[i])
+            for t in pb.tissues[i]:
+                cre_idx.append(np.arange(n_off, n_off + n, dtype=np.int64))
+                cre_tissue.append(np.full(n, t, dtype=np.int64))
+                head = [-(t + 1)] if self.gene_pooling == "multi_registry" else [-1] if prefix else []
+                gene_idx.append(np.concatenate([np.asarray(head, dtype=np.int64), np.arange(c_off, c_off + c, dtype=np.int64)]))
+                cre_lens.append(n)
+                gene_lens.append(c + prefix)
+            c_off += c
+        to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+        cre_idx = to(np.concatenate(cre_idx))
+        cu_cre = to(np.concatenate([[0], np.cumsum(cre_lens)]).astype(np.int32))
+        cu_gene = to(np.concatenate([[0], np.cumsum(gene_lens)]).astype(np.int32))
+        if self.add_context is not None:                  # AddContext (layers.py:558-573)
+            cre_rep = ops.add_rows(cre_x, self.add_context.registry_tokens.weight.float().contiguous(), cre_idx,
+                                   to(np.concatenate(cre_tissue)))
+        else:
+            cre_rep = ops.gather_rows_f32(cre_x, None, cre_idx)
+        labels_rep = pb.labels[cre_idx].contiguous()
+        if self.gene_pooling == "multi_registry":
+            table = self.start_tkn.registry_tokens.weight
+        elif self.gene_pooling == "start_token":
+            table = self.start_tkn.start_token.reshape(1, -1)
+        else:
+            table = None
+        gene_stream = ops.gather_rows_f32(gene_x, None if table is None else table.float().contiguous(),
+                                          to(np.concatenate(gene_idx)))
+        gene_out, _ = self._modulator_forward_packed(cre_rep, gene_stream, labels_rep, cu_cre, max(cre_lens), cu_gene,
+                                                     max(gene_lens))
+        if self.gene_pooling == "max":                    # pool_outputs (:380-389)
+            emb = ops.segment_max(gene_out, cu_gene)
+        else:                                             # start / registry token (:391-392)
+            emb = ops.gather_rows_f32(gene_out, None, cu_gene[:-1].long().contiguous())
+        return self.tissue_heads(emb), emb
 
     def forward(self, inp, attention_mask, tissue_vector, cre_context, strand, gene_embedding, gene_att_mask,
                 return_embedding=False, get_all=False, **kwargs):

@@ -289,6 +289,64 @@ class ContextFlashAttentionEncoderLayer(nn.Module):
         return pad_input(out, idx, batch, seqlen).to(src.dtype)
 
 
+class ContextFlashCrossAttentionEncoderLayer(nn.Module):
+    """Gene layer without self attention (`only_cross_attention: true`): LN -> cross-MHA(q = x, kv = context,
+    un-normalised) -> +src -> LN -> GeGLU -> + src   (reference layers.py:231-325)."""
+
+    def __init__(self, d_model, nhead, hidden_dim=2048, dropout=0.1, batch_first=True, use_alibi=False,
+                 make_data_kv=False, mlp_dout=0.0, cross_alibi=False, flash_attn_3=False):
+        super().__init__()
+        self.crossMHA = FlashAttLayer(d_model, nhead, dropout=dropout, use_alibi=cross_alibi, cross_attn=True,
+                                      flash_attn_3=flash_attn_3)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.linear_geglu_1 = nn.Linear(d_model, hidden_dim)
+        self.dropout = nn.Dropout(mlp_dout)
+        self.linear_geglu_2 = nn.Linear(hidden_dim // 2, d_model)
+        self.use_alibi, self.num_heads, self.make_data_kv = use_alibi, nhead, make_data_kv
+        self.activation = nn.GELU()
+        if use_alibi:
+            self.register_buffer("m", get_alibi_slopes(self.num_heads))
+
+    def forward_packed(self, src, cu_src, max_src, context=None, cu_ctx=None, max_ctx=None, context_kv=None,
+                       cu_cross_q=None, max_cross_q=None):
+        assert not self.make_data_kv
+        h = ops.layernorm(src, self.norm1.weight, self.norm1.bias)
+        if context_kv is None:
+            context_kv = self.crossMHA.MHA.project_kv(ops.cast_bf16(context))
+        cq = cu_src if cu_cross_q is None else cu_cross_q
+        mq = max_src if max_cross_q is None else max_cross_q
+        x1 = self.crossMHA.MHA.fused(h, src, cq, mq, context_kv, cu_ctx, max_ctx)
+        h = ops.layernorm(x1, self.norm2.weight, self.norm2.bias)
+        w1, b1 = packed_linear(self.linear_geglu_1, geglu=True)
+        hg = ops.gemm(h, w1, b1, ops.EPI_GEGLU_BF16)
+        w2, b2 = packed_linear(self.linear_geglu_2)
+        return ops.gemm(hg, w2, b2, ops.EPI_RES_F32, residual=src)
+
+
+class StartToken(nn.Module):
+    """One learned token in front of every gene sequence (gene_pooling="start_token", reference layers.py:491-499)."""
+
+    def __init__(self, emb_dim):
+        super().__init__()
+        self.start_token = nn.Parameter(torch.randn(1, 1, emb_dim))
+
+    def forward(self, x):
+        return torch.ones(x.size(0), 1, x.size(2), device=x.device) * self.start_token
+
+
+class AddContext(nn.Module):
+    """Tissue embedding added to every CRE token (add_context_to_cres, reference layers.py:558-573)."""
+
+    def __init__(self, num_tissues, emb_dim):
+        super().__init__()
+        self.num_registry_tokens = num_tissues
+        self.registry_tokens = nn.Embedding(num_tissues, emb_dim)
+
+    def get_registry_tokens(self):
+        return self.registry_tokens.weight
+
+
 class MultiRegistry(nn.Module):
     """One registry token per tissue, prepended to the gene tokens (reference layers.py:502-524)."""
 
