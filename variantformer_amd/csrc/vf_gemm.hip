@@ -171,6 +171,26 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_mfma_kernel(const unsigned
 #pragma unroll
         for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(base + offA + i * 16 * ROW_BYTES);
     };
+    auto issue_piece = [&](int kt, int stage, int i) {       // i in [0, LPT): one LDS-DMA wave-instruction
+        if (i < C::PA) glds16(srcA[i] + kt * BK, ldsA_piece + stage * C::STAGE_BYTES + i * 1024);
+        else glds16(srcW[i - C::PA] + kt * BK, ldsW_piece + stage * C::STAGE_BYTES + (i - C::PA) * 1024);
+    };
+    // MFMAs of one sub-step with the LDS-DMA pieces of K-tile `kt_issue` spread between them (one piece every
+    // TN*TM/LPT MFMAs) instead of a burst right after the barrier
+    auto mma_spread = [&](const bf16x8_t(&wf)[TN], const bf16x8_t(&af)[TM], int kt_issue, int stage_issue, bool do_issue) {
+        constexpr int EVERY = 3;       // measured on 256x256: every 3 MFMAs 1203, every 4 1194, every 2 1195, burst 1161 (1133 before)
+#pragma unroll
+        for (int in = 0; in < TN; ++in)
+#pragma unroll
+            for (int im = 0; im < TM; ++im) {
+                acc[in][im] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[in], af[im], acc[in][im], 0, 0, 0);
+                const int idx = in * TM + im;
+                if (idx % EVERY == EVERY - 1 && idx / EVERY < LPT) {
+                    if (do_issue) issue_piece(kt_issue, stage_issue, idx / EVERY);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+    };
     auto mma = [&](const bf16x8_t(&wf)[TN], const bf16x8_t(&af)[TM]) {
         if (DBG == 2) return;
 #pragma unroll
@@ -264,7 +284,29 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_mfma_kernel(const unsigned
             }
         }
     };
-    if (C::KS == 2) {
+    // 8-wave tiles (256x256): the LDS-DMA pieces of the next K-tile are spread over the MFMA stream of the second
+    // sub-step instead of being issued as a burst behind the barrier, where they queue in front of the fragment
+    // reads (+3...6 % on the K = 1536 shapes).  Neutral to slightly negative on the 4-wave 128x128 tile, which keeps
+    // the burst.
+    constexpr bool SPREAD = C::KS == 2 && C::NW == 8 && STAGES == 2 && (TN * TM) >= 3 * LPT && DBG == 0;
+    if (SPREAD) {
+        for (int kt = 0; kt < nkt; ++kt) {
+            read_frags(stage, 1, wf1, af1);
+            if (kt + 1 == nkt) prefetch_residual();
+            mma(wf0, af0);
+            int freed = stage;
+            const bool more = kt + 1 < nkt;
+            if (more) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                wait_tiles((nkt - 2 - kt) < (STAGES - 2) ? (nkt - 2 - kt) : (STAGES - 2));
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                stage = stage + 1 == STAGES ? 0 : stage + 1;
+                read_frags(stage, 0, wf0, af0);
+            }
+            mma_spread(wf1, af1, kt + STAGES, freed, more && kt + STAGES < nkt);
+        }
+    } else if (C::KS == 2) {
         for (int kt = 0; kt < nkt; ++kt) {
             read_frags(stage, 1, wf1, af1);
             if (kt + 1 == nkt) prefetch_residual();
@@ -712,6 +754,7 @@ int launch_gemm(const void* A, int64_t lda, const void* W, const float* bias, co
         case 12: return launch_cfg<CfgJ, EPI>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
         case 104: if (EPI == VF_EPI_BF16) return launch_cfg<CfgA, VF_EPI_BF16, 4>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st); break;
         case 103: if (EPI == VF_EPI_BF16) return launch_cfg<CfgA, VF_EPI_BF16, 3>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st); break;
+        case 204: if (EPI == VF_EPI_BF16) return launch_cfg<CfgB, VF_EPI_BF16, 4>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st); break;
         case 203: if (EPI == VF_EPI_BF16) return launch_cfg<CfgB, VF_EPI_BF16, 3>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st); break;
         case 101: if (EPI == VF_EPI_BF16) return launch_cfg<CfgA, VF_EPI_BF16, 1>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st); break;
         case 102: if (EPI == VF_EPI_BF16) return launch_cfg<CfgA, VF_EPI_BF16, 2>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st); break;
