@@ -296,3 +296,65 @@ def test_rowdot_softplus(ops):
     ref = F.softplus(x @ w[:, None] + b)
     got = ops.rowdot_softplus(x.cuda(), w.cuda(), b.cuda()).cpu()
     np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------
+# GEMM tile configurations at ragged edges (the automatic choice depends on the grid size, so every configuration the
+# pipeline can select is also forced here on shapes whose M / N are not multiples of any tile)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("variant", [1, 2, 5, 12])
+@pytest.mark.parametrize("epi", ["bf16", "res", "f32"])
+def test_gemm_forced_tile_configs_ragged(ops, variant, epi):
+    M, N, K = 515, 776, 192
+    a = _bf(_rand((M, K), 31))
+    w = _bf(_rand((N, K), 32, 1.0 / math.sqrt(K)))
+    b = _rand((N,), 33, 0.5)
+    res = _rand((M, N), 34)
+    ref = a @ w.t() + b + (res if epi == "res" else 0)
+    code = {"bf16": ops.EPI_BF16, "f32": ops.EPI_F32, "res": ops.EPI_RES_F32}[epi]
+    out = ops.gemm(a.cuda().bfloat16(), w.cuda().bfloat16(), b.cuda(), code, residual=res.cuda() if epi == "res" else None,
+                   variant=variant)
+    torch.cuda.synchronize()
+    tol = dict(rtol=2 ** -8, atol=2e-3) if epi == "bf16" else dict(rtol=2e-5, atol=2e-5 * math.sqrt(K))
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), **tol)
+
+
+@pytest.mark.parametrize("variant", [1, 2, 12])
+def test_gemm_geglu_forced_tile_configs_ragged(ops, variant):
+    M, F2, K = 515, 1056, 192
+    a = _bf(_rand((M, K), 41))
+    w = _bf(_rand((F2, K), 42, 1.0 / math.sqrt(K)))
+    b = _rand((F2,), 43, 0.5)
+    x, gate = (a @ w.t() + b).chunk(2, dim=-1)
+    wp, bp = ops.pack_geglu_rows(w.cuda().bfloat16(), b.cuda())
+    out = ops.gemm(a.cuda().bfloat16(), wp, bp, ops.EPI_GEGLU_BF16, variant=variant)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.float().cpu().numpy(), (x * F.gelu(gate)).numpy(), rtol=2 ** -8, atol=2e-3)
+
+
+@pytest.mark.parametrize("epi", ["bf16", "res", "geglu"])
+def test_gemm_auto_selection_at_batch_size(ops, epi):
+    """Grid large enough for the batch-size rules of pick_variant (256x256 tiles; BK = 32 ring for the K = 512 GeGLU),
+    ragged in M and N; checked on a row sample against fp32 matmul of the same bf16 operands."""
+    M, N, K = 140003, (1056 if epi == "geglu" else 776), 512
+    g = torch.Generator().manual_seed(77)
+    a = _bf(torch.rand((M, K), generator=g) * 2 - 1)
+    w = _bf((torch.rand((N, K), generator=g) * 2 - 1) / math.sqrt(K))
+    b = torch.rand((N,), generator=g)
+    rows = torch.cat([torch.arange(0, 300), torch.arange(70000, 70300), torch.arange(M - 300, M)])
+    h = a[rows] @ w.t() + b
+    if epi == "geglu":
+        wp, bp = ops.pack_geglu_rows(w.cuda().bfloat16(), b.cuda())
+        out = ops.gemm(a.cuda().bfloat16(), wp, bp, ops.EPI_GEGLU_BF16)
+        x, gate = h.chunk(2, dim=-1)
+        ref = x * F.gelu(gate)
+    elif epi == "res":
+        res = torch.rand((M, N), generator=g)
+        out = ops.gemm(a.cuda().bfloat16(), w.cuda().bfloat16(), b.cuda(), ops.EPI_RES_F32, residual=res.cuda())
+        ref = h + res[rows]
+    else:
+        out = ops.gemm(a.cuda().bfloat16(), w.cuda().bfloat16(), b.cuda(), ops.EPI_BF16)
+        ref = h
+    torch.cuda.synchronize()
+    tol = dict(rtol=2e-5, atol=2e-5 * math.sqrt(K)) if epi == "res" else dict(rtol=2 ** -8, atol=2e-3)
+    np.testing.assert_allclose(out[rows.cuda()].float().cpu().numpy(), ref.numpy(), **tol)
