@@ -6,7 +6,9 @@ from variantformer_amd import ops
 SH = [("gene Wqkv", 10854, 4608, 1536), ("gene out_proj", 10854, 1536, 1536), ("gene geglu1", 10854, 2048, 1536),
       ("gene geglu2", 10854, 1536, 1024), ("s2r Wqkv", 140000, 1536, 512), ("s2r out_proj", 140000, 512, 512),
       ("s2r geglu1", 140000, 2048, 512), ("s2r geglu2", 140000, 512, 1024), ("cre8 Wqkv", 8192, 4608, 1536),
-      ("square 8k", 8192, 8192, 8192), ("square 4k", 4096, 4096, 4096)]
+      ("square 8k", 8192, 8192, 8192), ("square 4k", 4096, 4096, 4096),
+      ("gene8 Wqkv", 86832, 4608, 1536), ("gene8 Wq", 86832, 1536, 1536), ("gene8 geglu1", 86832, 2048, 1536),
+      ("s2r8 Wqkv", 769460, 1536, 512), ("s2r8 geglu1", 769460, 2048, 512)]
 def t(fn, n=10):
     for _ in range(3): fn()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
