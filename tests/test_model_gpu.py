@@ -293,3 +293,21 @@ def test_non_shipped_options_vs_reference_golden(name):
     with pytest.raises(NotImplementedError, match="shipped configuration"):
         model.forward(batch["cre_sequences"], batch["cre_attention_masks"], batch["tissue_context"], batch["ref_cre_labels"],
                       batch["strand_val"], batch["gene_embeddings"], batch["gene_attention_masks"], return_embedding=True)
+
+
+def test_run_to_run_determinism_and_sequence_permutation():
+    """No atomics and no data-dependent scheduling on the path: the same batch gives bit-identical results twice, and
+    permuting the genes of a batch permutes the results (every kernel treats sequences independently)."""
+    kw = seq2gene_kw(layers=3)
+    model = build_model(SEQ2REG_512, kw, seed=21).cuda()
+    batch = make_batch(31, [40, 7, 19], [5, 2, 9], [TISSUES_54[:4], [9], [33, 62]], 200)
+    a = model.predict_step(batch, 0)
+    b = model.predict_step(batch, 0)
+    for i in range(3):
+        assert np.array_equal(a["pred_gene_exp"][i], b["pred_gene_exp"][i])
+        assert np.array_equal(a["embeddings"][i], b["embeddings"][i])
+    perm = [2, 0, 1]
+    pb = {k: ([v[j] for j in perm] if isinstance(v, list) else v[perm]) for k, v in batch.items()}
+    c = model.predict_step(pb, 0)
+    for new, old in enumerate(perm):
+        np.testing.assert_allclose(c["pred_gene_exp"][new], a["pred_gene_exp"][old], rtol=1e-5, atol=1e-6)
