@@ -82,10 +82,21 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
-// valid-token counts + exclusive scan (single block)
+// valid-token counts (one wave per window, coalesced byte reads) + exclusive scan of the counts (single block)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void mask_to_cu_kernel(const uint8_t* __restrict__ pad, int32_t* __restrict__ cu,
-                                                         int W, int L) {
+__global__ __launch_bounds__(256) void mask_count_kernel(const uint8_t* __restrict__ pad, int32_t* __restrict__ cu,
+                                                        int W, int L) {
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (w >= W) return;
+    const uint8_t* p = pad + (int64_t)w * L;
+    int cnt = 0;
+    for (int i = lane; i < L; i += 64) cnt += p[i] == 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if (lane == 0) cu[w + 1] = cnt;                          // raw count; mask_scan_kernel turns it into the prefix sum
+}
+
+__global__ __launch_bounds__(1024) void mask_scan_kernel(int32_t* __restrict__ cu, int W) {
     __shared__ int part[1024];
     __shared__ int carry_s;
     const int tid = threadIdx.x;
@@ -93,12 +104,7 @@ __global__ __launch_bounds__(1024) void mask_to_cu_kernel(const uint8_t* __restr
     __syncthreads();
     for (int base = 0; base < W; base += 1024) {
         const int w = base + tid;
-        int cnt = 0;
-        if (w < W) {
-            const uint8_t* p = pad + (int64_t)w * L;
-            for (int i = 0; i < L; ++i) cnt += p[i] == 0;
-        }
-        part[tid] = cnt;
+        part[tid] = w < W ? cu[w + 1] : 0;
         __syncthreads();
         for (int off = 1; off < 1024; off <<= 1) {          // Hillis-Steele inclusive scan
             const int add = tid >= off ? part[tid - off] : 0;
@@ -313,7 +319,8 @@ extern "C" int vf_layernorm(const float* x, const float* gamma, const float* bet
 
 extern "C" int vf_mask_to_cu_seqlens(const uint8_t* pad, int32_t* cu, int W, int L, void* stream) {
     VF_REQUIRE(pad && cu && W >= 0 && L > 0, "vf_mask_to_cu_seqlens: bad arguments");
-    hipLaunchKernelGGL(mask_to_cu_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, pad, cu, W, L);
+    if (W > 0) hipLaunchKernelGGL(mask_count_kernel, dim3((W + 3) / 4), dim3(256), 0, (hipStream_t)stream, pad, cu, W, L);
+    hipLaunchKernelGGL(mask_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, cu, W);
     VF_CHECK_LAUNCH("vf_mask_to_cu_seqlens");
     return VF_OK;
 }
