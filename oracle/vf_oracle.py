@@ -252,6 +252,10 @@ class Seq2GeneHP:
     cross_alibi: bool = False               # ALiBi on the cross attentions too (layers.py:60-71)
     add_context_to_cres: bool = False       # tissue embedding added to the CRE tokens (:669-670, layers.py:558-573)
     gene_pooling: str = "multi_registry"    # or "start_token" / "max" (:330-396; "mean" does not reduce in the reference)
+    use_context: bool = True                # False: context-free CRE layers (FlashAttentionEncoderLayer, layers.py:168-228)
+    multi_head: bool = False                # one expression head per tissue (layers.py:1042-1050,1060-1076,1090-1102)
+    use_bigger_head: bool = True
+    head_type: str = "mlp"                  # or "linear" (layers.py:1040-1055)
 
     @property
     def shipped(self) -> bool:
@@ -260,15 +264,15 @@ class Seq2GeneHP:
 
     @classmethod
     def from_kwargs(cls, kw: dict):
-        assert kw.get("use_context", False), "oracle covers use_context=True (configs/vf_model.yaml:12-37)"
-        assert not kw.get("multi_head", True) and kw.get("use_bigger_head", False), "shared 'bigger' head only"
         pooling = kw.get("gene_pooling")
         assert pooling in ("multi_registry", "start_token", "max"), pooling
         return cls(kw["emb_dim"], kw["num_heads"], kw["num_layers"], kw["token_dim"], kw["gene_emb_dim"],
                    kw.get("num_tissues", 63), kw.get("use_alibi", True),
                    only_cross_attention=kw.get("only_cross_attention", True), use_res=kw.get("use_res", False),
                    cross_alibi=kw.get("cross_alibi", False) and kw.get("use_alibi", True),
-                   add_context_to_cres=kw.get("add_context_to_cres", False), gene_pooling=pooling)
+                   add_context_to_cres=kw.get("add_context_to_cres", False), gene_pooling=pooling,
+                   use_context=kw.get("use_context", False), multi_head=kw.get("multi_head", True),
+                   use_bigger_head=kw.get("use_bigger_head", False), head_type=kw.get("head_type", "mlp"))
 
 
 def modulator_layer(src, ctx, cu_src, cu_ctx, sd, pfx, H, slopes, rnd: Rounding, cross_slopes=None):
@@ -281,6 +285,22 @@ def modulator_layer(src, ctx, cu_src, cu_ctx, sd, pfx, H, slopes, rnd: Rounding,
     x2 = mha_cross(h, ctx, sd, pfx + "crossMHA.MHA.", H, cu_src, cu_ctx, rnd, cross_slopes) + x1
     h = rnd.r(layer_norm(x2, sd[pfx + "norm3.weight"], sd[pfx + "norm3.bias"]))
     return geglu_ffn(h, sd, pfx, rnd) + src
+
+
+def self_only_layer(src, cu_src, sd, pfx, H, slopes, rnd: Rounding):
+    """FlashAttentionEncoderLayer.forward (layers.py:168-228): LN1 -> self-MHA(ALiBi) -> +src -> LN2 -> GeGLU -> + src
+    (norm3 is constructed but never applied)."""
+    h = rnd.r(layer_norm(src, sd[pfx + "norm1.weight"], sd[pfx + "norm1.bias"]))
+    x1 = mha_self(h, sd, pfx + "mixer.MHA.", H, cu_src, slopes, rnd) + src
+    h = rnd.r(layer_norm(x1, sd[pfx + "norm2.weight"], sd[pfx + "norm2.bias"]))
+    return geglu_ffn(h, sd, pfx, rnd) + src
+
+
+def cre_layer(cre, ctx, cu_cre, sd, pfx, hp, slopes, rnd: Rounding):
+    """One CRE layer: with the second-level context (:262-270) or context-free (:271-274).  Never cross_alibi (:78-88)."""
+    if hp.use_context:
+        return modulator_layer(cre, ctx, cu_cre, cu_cre, sd, pfx, hp.num_heads, slopes, rnd)
+    return self_only_layer(cre, cu_cre, sd, pfx, hp.num_heads, slopes, rnd)
 
 
 def cross_only_layer(src, ctx, cu_src, cu_ctx, sd, pfx, H, rnd: Rounding, cross_slopes=None):
@@ -298,7 +318,7 @@ def combined_modulator(cre_x, gene_x, ctx_labels, cu_cre, cu_gene, sd, pfx, hp: 
     cre_x [sum N, D], gene_x [sum G, D], ctx_labels int64 [sum N]."""
     slopes = torch.tensor(alibi_slopes(hp.num_heads), dtype=torch.float32) if hp.use_alibi else None
     xs = slopes if hp.cross_alibi else None
-    ctx = sd[pfx + "second_level_context_embedding.weight"][ctx_labels]          # :166-168
+    ctx = sd[pfx + "second_level_context_embedding.weight"][ctx_labels] if hp.use_context else None   # :166-168
 
     def gene_layer(g, c, p):
         if hp.only_cross_attention:                                               # :106-119
@@ -314,7 +334,7 @@ def combined_modulator(cre_x, gene_x, ctx_labels, cu_cre, cu_gene, sd, pfx, hp: 
         gene = gene + gene_res                                                   # :253-254
     for i in range(hp.num_layers - 1):                                           # :258-285
         # the CRE layers are built without cross_alibi (:78-88): their context cross attention never has a bias
-        cre = modulator_layer(cre, ctx, cu_cre, cu_cre, sd, f"{pfx}cre_layers.{i}.", hp.num_heads, slopes, rnd)
+        cre = cre_layer(cre, ctx, cu_cre, sd, f"{pfx}cre_layers.{i}.", hp, slopes, rnd)
         if collect is not None and i == 0:
             collect["first_cre_layer_out"] = cre.clone()
         gene = gene_layer(gene, cre, f"{pfx}gene_layers.{i + 1}.")
@@ -323,17 +343,32 @@ def combined_modulator(cre_x, gene_x, ctx_labels, cu_cre, cu_gene, sd, pfx, hp: 
     return gene, cre
 
 
-def tissue_head(emb, sd, pfx, rnd: Rounding):
-    """TissueExpressionHeads, shared 'bigger' head (layers.py:1078-1087, :1113-1144):
-    Linear -> LayerNorm -> GELU -> Linear -> GELU -> Linear(D,1) -> Softplus.
-    Kernel contract: first two Linears are bf16-operand GEMMs; the final D->1 dot product and
-    everything elementwise stay fp32."""
-    p = pfx + "tissue_expressions."
-    h = linear(emb, sd[p + "0.weight"], sd[p + "0.bias"], rnd)
+def _one_head(emb, sd, p, hp, rnd: Rounding):
+    """One expression head (layers.py:1040-1110).  Kernel contract: the D x D Linears are bf16-operand GEMMs; the final
+    D -> 1 dot product and everything elementwise stay fp32."""
+    if hp.head_type == "linear":                                             # Linear(D,1) -> Softplus
+        return F.softplus(F.linear(emb, sd[p + "0.weight"], sd[p + "0.bias"]))
+    if not hp.use_bigger_head:                                               # Linear -> GELU -> Linear(D,1) -> Softplus
+        h = F.gelu(linear(emb, sd[p + "0.weight"], sd[p + "0.bias"], rnd))
+        return F.softplus(F.linear(h, sd[p + "2.weight"], sd[p + "2.bias"]))
+    h = linear(emb, sd[p + "0.weight"], sd[p + "0.bias"], rnd)              # the shipped 'bigger' head (:1078-1087)
     h = rnd.r(F.gelu(layer_norm(h, sd[p + "1.weight"], sd[p + "1.bias"])))
     h = F.gelu(linear(h, sd[p + "4.weight"], sd[p + "4.bias"], rnd))
     h = F.linear(h, sd[p + "6.weight"], sd[p + "6.bias"])
     return F.softplus(h)
+
+
+def tissue_head(emb, sd, pfx, rnd: Rounding, hp=None, tissues=None):
+    """TissueExpressionHeads.forward (layers.py:1113-1144): the shared head, or with multi_head the head of each row's
+    tissue (ModuleDict keyed by the tissue id)."""
+    hp = hp if hp is not None else Seq2GeneHP(0, 0, 0, 0, 0)
+    p = pfx + "tissue_expressions."
+    if not hp.multi_head:
+        return _one_head(emb, sd, p, hp, rnd)
+    out = torch.empty(emb.shape[0], 1)
+    for r, t in enumerate(tissues):
+        out[r] = _one_head(emb[r:r + 1], sd, f"{p}{int(t)}.", hp, rnd)[0]
+    return out
 
 
 def forward(batch: dict, sd: dict, cre_hp: Seq2RegHP, gene_hp: Seq2RegHP, hp: Seq2GeneHP,
@@ -410,7 +445,8 @@ def forward(batch: dict, sd: dict, cre_hp: Seq2RegHP, gene_hp: Seq2RegHP, hp: Se
         collect["first_cre_layer_out"] = torch.cat(first_cre)
         collect["modulator_gene_out"] = mod_out
     emb = torch.cat(embs, dim=0)
-    pred = tissue_head(emb, sd, "tissue_heads.", rnd)
+    all_tissues = [int(t) for i in range(n_genes) for t in batch["tissue_context"][i]]
+    pred = tissue_head(emb, sd, "tissue_heads.", rnd, hp, all_tissues)
     return pred, emb
 
 
@@ -423,7 +459,7 @@ def _modulator_shared(cre_x, gene_x, labels, T, G, sd, hp: Seq2GeneHP, rnd: Roun
     H = hp.num_heads
     slopes = torch.tensor(alibi_slopes(H), dtype=torch.float32) if hp.use_alibi else None
     N = cre_x.shape[0]
-    ctx = sd[pfx + "second_level_context_embedding.weight"][labels]
+    ctx = sd[pfx + "second_level_context_embedding.weight"][labels] if hp.use_context else None
     cu_c = torch.tensor([0, N], dtype=torch.int32)
     cu_g = torch.arange(0, T + 1, dtype=torch.int32) * G
 
@@ -440,7 +476,7 @@ def _modulator_shared(cre_x, gene_x, labels, T, G, sd, hp: Seq2GeneHP, rnd: Roun
     if collect is not None:
         collect["first_gene_layer_out"] = gene.clone()
     for i in range(hp.num_layers - 1):
-        cre = modulator_layer(cre, ctx, cu_c, cu_c, sd, f"{pfx}cre_layers.{i}.", H, slopes, rnd)
+        cre = cre_layer(cre, ctx, cu_c, sd, f"{pfx}cre_layers.{i}.", hp, slopes, rnd)
         if collect is not None and i == 0:
             collect["first_cre_layer_out"] = cre.repeat(T, 1)
         gene = gene_layer(gene, cre, f"{pfx}gene_layers.{i + 1}.")

@@ -246,6 +246,9 @@ def _with(base, **opts):
 FIXTURES["small_opts_a"] = dict(_with("small_sin", only_cross_attention=True, use_res=True, cross_alibi=True,
                                       gene_pooling="start_token"), seed=404)
 FIXTURES["small_opts_b"] = dict(_with("small_alibi", add_context_to_cres=True, gene_pooling="max"), seed=505)
+# per-tissue small MLP heads; context-free CRE layers with one shared linear head
+FIXTURES["small_opts_c"] = dict(_with("small_sin", multi_head=True, use_bigger_head=False), seed=606)
+FIXTURES["small_opts_d"] = dict(_with("small_alibi", use_context=False, head_type="linear", use_bigger_head=False), seed=707)
 FIXTURES["small_twomod"] = dict(FIXTURES["small_sin"], seed=303, model_class="Seq2GenePredictor",
                                 n_cres=[6, 3], n_chunks=[2, 4], tissues=[[62, 7], [20, 33, 59]])
 

@@ -58,8 +58,8 @@ def test_unsupported_configurations_fail_loudly():
     kw["gene_pooling"] = "median"
     with pytest.raises(AssertionError, match="gene_pooling must be one of"):
         build_model(meta["seq2reg"], kw)
-    kw = dict(meta["seq2gene"], use_context=False)
-    with pytest.raises(NotImplementedError):
+    kw = dict(meta["seq2gene"], head_type="conv")
+    with pytest.raises(ValueError, match="Invalid head type"):
         build_model(meta["seq2reg"], kw)
     hp = dict(meta["seq2reg"])
     hp["use_context"] = True
@@ -70,10 +70,10 @@ def test_unsupported_configurations_fail_loudly():
 def test_non_shipped_options_build_with_reference_state_dict_names():
     """only_cross_attention / use_res / cross_alibi / start_token and add_context_to_cres / max pooling: module tree
     and parameter names as in the reference (fixtures' state-dict inventories come from the reference's classes)."""
-    for name in ("small_opts_a", "small_opts_b"):
+    for name in ("small_opts_a", "small_opts_b", "small_opts_c", "small_opts_d"):
         meta, arrays, sd, batch = load_fixture(name)
         model = build_model(meta["seq2reg"], meta["seq2gene"])
-        assert model._general
+        assert model._general == (name in ("small_opts_a", "small_opts_b"))
         ours = {k: tuple(v.shape) for k, v in model.state_dict().items()}
         want = {k: tuple(v) for k, v in meta["state_dict_shapes"].items()}
         missing = [k for k in want if k not in ours and not k.endswith(".m")]

@@ -270,17 +270,19 @@ def test_headline_size_gene_vs_oracle_and_properties():
     assert _rel(alone["embeddings"][0], orc["embeddings"][0]) < 5e-3
 
 
-@pytest.mark.parametrize("name", ["small_opts_a", "small_opts_b"])
+@pytest.mark.parametrize("name", ["small_opts_a", "small_opts_b", "small_opts_c", "small_opts_d"])
 def test_non_shipped_options_vs_reference_golden(name):
     """Layer options the shipped configuration leaves off, pinned to fixtures produced by the
     reference's own classes: (a) cross-attention-only gene layers + gene residual + ALiBi on the gene->CRE cross
-    attention + start-token pooling, (b) tissue embedding added to the CRE tokens + max pooling."""
+    attention + start-token pooling, (b) tissue embedding added to the CRE tokens + max pooling, (c) one small MLP head
+    per tissue, (d) context-free CRE layers + a shared linear head."""
     meta, arrays, sd, batch = load_fixture(name)
     model = build_model(meta["seq2reg"], meta["seq2gene"], sd).cuda()
-    assert model._general
+    general = name in ("small_opts_a", "small_opts_b")
+    assert model._general == general
     out = model.predict_step(batch, 0)
     cre_hp, gene_hp, hp = _hps(meta)
-    orc = O.predict_step(batch, sd, cre_hp, gene_hp, hp, rounding="bf16")
+    orc = O.predict_step(batch, sd, cre_hp, gene_hp, hp, rounding="bf16", share_cre_stream=not general)
     for i in range(len(meta["n_cres"])):
         p, e = out["pred_gene_exp"][i], out["embeddings"][i]
         assert p.shape == (len(meta["tissues"][i]), 1) and e.shape == (len(meta["tissues"][i]), meta["seq2gene"]["emb_dim"])
@@ -289,6 +291,8 @@ def test_non_shipped_options_vs_reference_golden(name):
         assert _rel(e, arrays[f"embeddings_{i}"]) < emb_tol
         assert _rel(p, orc["pred_gene_exp"][i]) < NORTH_STAR_RTOL
         assert _rel(e, orc["embeddings"][i]) < emb_tol
+    if not general:
+        return
     model.vep = True
     with pytest.raises(NotImplementedError, match="shipped configuration"):
         model.forward(batch["cre_sequences"], batch["cre_attention_masks"], batch["tissue_context"], batch["ref_cre_labels"],

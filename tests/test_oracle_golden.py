@@ -106,12 +106,22 @@ import pytest
 from tests.conftest import load_fixture
 
 
-@pytest.mark.parametrize("name", ["small_opts_a", "small_opts_b"])
+@pytest.mark.parametrize("name", ["small_opts_a", "small_opts_b", "small_opts_c", "small_opts_d"])
 def test_oracle_matches_reference_with_non_shipped_options(name):
-    """only_cross_attention + use_res + cross_alibi + start_token pooling (a); add_context_to_cres + max pooling (b):
-    outputs and intermediates of the reference's own classes with these options switched on."""
+    """only_cross_attention + use_res + cross_alibi + start_token pooling (a); add_context_to_cres + max pooling (b);
+    per-tissue small MLP heads (c); context-free CRE layers + shared linear head (d): outputs and intermediates of the
+    reference's own classes with these options switched on."""
     meta, arrays, sd, batch = load_fixture(name)
     cre_hp, gene_hp, hp = _hps(meta)
+    if name in ("small_opts_c", "small_opts_d"):      # these keep the tissue-independent CRE stream: dedup stays exact
+        out = O.predict_step(batch, sd, cre_hp, gene_hp, hp, share_cre_stream=True)
+        for i in range(len(meta["n_cres"])):
+            np.testing.assert_allclose(out["pred_gene_exp"][i], arrays[f"pred_gene_exp_{i}"], rtol=RTOL, atol=ATOL)
+            np.testing.assert_allclose(out["embeddings"][i], arrays[f"embeddings_{i}"], rtol=RTOL, atol=ATOL)
+        out = O.predict_step(batch, sd, cre_hp, gene_hp, hp)
+        for i in range(len(meta["n_cres"])):
+            np.testing.assert_allclose(out["pred_gene_exp"][i], arrays[f"pred_gene_exp_{i}"], rtol=RTOL, atol=ATOL)
+        return
     assert not hp.shipped
     col = {}
     with torch.no_grad():

@@ -30,7 +30,7 @@ from .. import ops
 from ..utils.constants import REF_CREs
 from ..utils.functions import precision2dtype
 from .modules.layers import (AddContext, ContextFlashAttentionEncoderLayer, ContextFlashCrossAttentionEncoderLayer,
-                             MultiRegistry, StartToken, TissueExpressionHeads, packed_linear, pad_input, unpad_input)
+                             FlashAttentionEncoderLayer, MultiRegistry, StartToken, TissueExpressionHeads, packed_linear, pad_input, unpad_input)
 
 logger = logging.getLogger(__name__)
 MAX_WINDOW_SIZE = 30000000
@@ -126,14 +126,14 @@ def modulator_forward_packed(ctx_embedding, cre_layers, gene_layers, cre_x, gene
     for i in range(n - 1):
         if overlap:
             with torch.cuda.stream(side):
-                kv = ops.gather_rows_bf16(_context_kv_table(ctx_embedding, cre_layers[i]), labels)
+                kv = None if ctx_embedding is None else ops.gather_rows_bf16(_context_kv_table(ctx_embedding, cre_layers[i]), labels)
                 cre = cre_layers[i].forward_packed(cre, cu_cre, max_cre, context_kv=kv, cu_ctx=cu_cre, max_ctx=max_cre)
                 done = torch.cuda.Event()
                 done.record(side)
             cre.record_stream(main)                 # allocated on `side`, read by the gene layer on `main`
             main.wait_event(done)
         else:
-            kv = ops.gather_rows_bf16(_context_kv_table(ctx_embedding, cre_layers[i]), labels)
+            kv = None if ctx_embedding is None else ops.gather_rows_bf16(_context_kv_table(ctx_embedding, cre_layers[i]), labels)
             cre = cre_layers[i].forward_packed(cre, cu_cre, max_cre, context_kv=kv, cu_ctx=cu_cre, max_ctx=max_cre)
         if final_rows is not None and i + 1 == n - 1:
             # last gene layer: only the registry rows are consumed downstream -> compact [R, D] result
@@ -155,17 +155,20 @@ class CombinedModulator(nn.Module):
     def __init__(self, emb_dim, num_heads, num_layers, use_alibi, mlp_dout, use_context, num_ref_cres=None,
                  only_cross_attention=True, use_res=False, cross_alibi=False, flash_attn_3=False):
         super().__init__()
-        if not use_context:
-            raise NotImplementedError("HIP path implements use_context=True (configs/vf_model.yaml:30)")
-        assert num_ref_cres is not None, "num_ref_cres must be provided when use_context is True"
         self.emb_dim, self.num_heads, self.num_layers = emb_dim, num_heads, num_layers
         self.use_context, self.only_cross_attention = use_context, only_cross_attention
         self.use_res, self.cross_alibi = use_res, cross_alibi
-        self.second_level_context_embedding = nn.Embedding(num_ref_cres, emb_dim)
-        # the CRE layers are built WITHOUT cross_alibi in the reference (:78-88); only the gene layers receive it
-        mk_cre = lambda: ContextFlashAttentionEncoderLayer(  # noqa: E731
-            d_model=emb_dim, nhead=num_heads, batch_first=True, use_alibi=use_alibi, mlp_dout=mlp_dout,
-            flash_attn_3=flash_attn_3)
+        if use_context:
+            assert num_ref_cres is not None, "num_ref_cres must be provided when use_context is True"
+            self.second_level_context_embedding = nn.Embedding(num_ref_cres, emb_dim)
+            # the CRE layers are built WITHOUT cross_alibi in the reference (:78-88); only the gene layers receive it
+            mk_cre = lambda: ContextFlashAttentionEncoderLayer(  # noqa: E731
+                d_model=emb_dim, nhead=num_heads, batch_first=True, use_alibi=use_alibi, mlp_dout=mlp_dout,
+                flash_attn_3=flash_attn_3)
+        else:                                   # context-free CRE layers (:89-103)
+            self.second_level_context_embedding = None
+            mk_cre = lambda: FlashAttentionEncoderLayer(  # noqa: E731
+                d_model=emb_dim, nhead=num_heads, batch_first=True, use_alibi=use_alibi, mlp_dout=mlp_dout)
         gene_cls = ContextFlashCrossAttentionEncoderLayer if only_cross_attention else ContextFlashAttentionEncoderLayer
         mk = lambda: gene_cls(  # noqa: E731
             d_model=emb_dim, nhead=num_heads, batch_first=True, use_alibi=use_alibi, mlp_dout=mlp_dout,
@@ -192,7 +195,7 @@ class CombinedModulator(nn.Module):
             gene_padding_mask = torch.zeros((B, G), dtype=torch.bool, device=dev)
         cre_p, cre_idx, cu_c, max_c, _ = unpad_input(cre_x, ~cre_padding_mask)
         gene_p, gene_idx, cu_g, max_g, _ = unpad_input(gene_x, ~gene_padding_mask)
-        labels = context.reshape(-1)[cre_idx].long().contiguous()
+        labels = context.reshape(-1)[cre_idx].long().contiguous() if (self.use_context and context is not None) else None
         gene_out, cre_out = self.forward_packed(cre_p, gene_p, labels, cu_c, max_c, cu_g, max_g)
         gene_current = pad_input(gene_out, gene_idx, B, G)
         cre_current = pad_input(cre_out, cre_idx, B, Nc)
@@ -406,7 +409,7 @@ class Seq2GenePredictorCombinedModulator(nn.Module):
                 cu_gene_cross=pb.cu_gene_cross, max_gene_cross=pb.max_gene_cross,
                 final_rows=(pb.registry_rows, pb.cu_registry, pb.cu_registry_cross, pb.max_tissues))
             gene_out = None
-        pred = self.tissue_heads(emb)
+        pred = self.tissue_heads(emb, [t for ts in pb.tissues for t in ts])
         if return_cre:
             return pred, emb, gene_out, cre_out
         return pred, emb
@@ -455,7 +458,7 @@ class Seq2GenePredictorCombinedModulator(nn.Module):
             emb = ops.segment_max(gene_out, cu_gene)
         else:                                             # start / registry token (:391-392)
             emb = ops.gather_rows_f32(gene_out, None, cu_gene[:-1].long().contiguous())
-        return self.tissue_heads(emb), emb
+        return self.tissue_heads(emb, [t for ts in pb.tissues for t in ts]), emb
 
     def forward(self, inp, attention_mask, tissue_vector, cre_context, strand, gene_embedding, gene_att_mask,
                 return_embedding=False, get_all=False, **kwargs):

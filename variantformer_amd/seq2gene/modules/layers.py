@@ -289,6 +289,35 @@ class ContextFlashAttentionEncoderLayer(nn.Module):
         return pad_input(out, idx, batch, seqlen).to(src.dtype)
 
 
+class FlashAttentionEncoderLayer(nn.Module):
+    """CRE layer without a context stream (`use_context: false`): LN -> self-MHA(ALiBi) -> +src -> LN -> GeGLU -> + src
+    (reference layers.py:168-228; `norm3` exists there but is never applied, and is kept for the state dict)."""
+
+    def __init__(self, d_model, nhead, hidden_dim=2048, dropout=0.1, batch_first=True, use_alibi=False,
+                 make_data_kv=False, mlp_dout=0.0):
+        super().__init__()
+        self.mixer = FlashAttLayer(d_model, nhead, dropout=dropout, use_alibi=use_alibi, cross_attn=False)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.norm3 = nn.LayerNorm(d_model)
+        self.linear_geglu_1 = nn.Linear(d_model, hidden_dim)
+        self.dropout = nn.Dropout(mlp_dout)
+        self.linear_geglu_2 = nn.Linear(hidden_dim // 2, d_model)
+        self.use_alibi, self.num_heads, self.make_data_kv = use_alibi, nhead, make_data_kv
+        self.activation = nn.GELU()
+        if use_alibi:
+            self.register_buffer("m", get_alibi_slopes(self.num_heads))
+
+    def forward_packed(self, src, cu_src, max_src, **_):
+        h = ops.layernorm(src, self.norm1.weight, self.norm1.bias)
+        x1 = self.mixer.MHA.fused(h, src, cu_src, max_src)
+        h = ops.layernorm(x1, self.norm2.weight, self.norm2.bias)
+        w1, b1 = packed_linear(self.linear_geglu_1, geglu=True)
+        hg = ops.gemm(h, w1, b1, ops.EPI_GEGLU_BF16)
+        w2, b2 = packed_linear(self.linear_geglu_2)
+        return ops.gemm(hg, w2, b2, ops.EPI_RES_F32, residual=src)
+
+
 class ContextFlashCrossAttentionEncoderLayer(nn.Module):
     """Gene layer without self attention (`only_cross_attention: true`): LN -> cross-MHA(q = x, kv = context,
     un-normalised) -> +src -> LN -> GeGLU -> + src   (reference layers.py:231-325)."""
@@ -366,32 +395,64 @@ class MultiRegistry(nn.Module):
 
 
 class TissueExpressionHeads(nn.Module):
-    """MLP + Softplus expression head (reference layers.py:1012-1144).  The shipped configuration is the
-    shared 'bigger' head (multi_head false, use_bigger_head true, :1078-1087):
+    """Expression heads (reference layers.py:1012-1144), same module tree / state-dict keys for every combination of
+    head_type ("mlp" | "linear"), use_bigger_head and multi_head (one head per tissue in a ModuleDict keyed by the
+    tissue id, or one shared head).  The shipped configuration is the shared 'bigger' MLP (:1078-1087):
     Linear -> LayerNorm -> GELU -> Dropout -> Linear -> GELU -> Linear(D,1) -> Softplus.
-    All rows are evaluated in one batched pass instead of the reference's per-row loop with .item() syncs."""
+    Rows are evaluated in batched passes (all rows for a shared head, the rows of one tissue per launch for
+    multi_head) instead of the reference's per-row loop with .item() syncs (:1127-1142)."""
 
     def __init__(self, emb_dim, num_tissues, use_bigger_head=False, multi_head=True, mlp_dout=0.1,
                  loss_fn="poisson", head_type="mlp"):
         super().__init__()
         self.multi_head = multi_head
         self.softplus = loss_fn == "poisson"
-        if head_type != "mlp" or not use_bigger_head or multi_head:
-            raise NotImplementedError(
-                "only the shipped head (head_type='mlp', use_bigger_head=True, multi_head=False; "
-                "configs/vf_model.yaml:19,35) is implemented on the HIP path")
-        self.tissue_expressions = nn.Sequential(
-            nn.Linear(emb_dim, emb_dim), nn.LayerNorm(emb_dim), nn.GELU(), nn.Dropout(mlp_dout),
-            nn.Linear(emb_dim, emb_dim), nn.GELU(), nn.Linear(emb_dim, 1),
-            nn.Softplus() if self.softplus else nn.Identity())
+        out_act = lambda: nn.Softplus() if self.softplus else nn.Identity()  # noqa: E731
+        if head_type == "linear":
+            make = lambda: nn.Sequential(nn.Linear(emb_dim, 1), out_act())  # noqa: E731
+            self.kind = "linear"
+        elif head_type == "mlp":
+            if use_bigger_head:
+                make = lambda: nn.Sequential(  # noqa: E731
+                    nn.Linear(emb_dim, emb_dim), nn.LayerNorm(emb_dim), nn.GELU(), nn.Dropout(mlp_dout),
+                    nn.Linear(emb_dim, emb_dim), nn.GELU(), nn.Linear(emb_dim, 1), out_act())
+                self.kind = "mlp_big"
+            else:
+                make = lambda: nn.Sequential(nn.Linear(emb_dim, emb_dim), nn.GELU(), nn.Linear(emb_dim, 1), out_act())  # noqa: E731
+                self.kind = "mlp_small"
+        else:
+            raise ValueError(f"Invalid head type: {head_type}")
+        if multi_head:
+            self.tissue_expressions = nn.ModuleDict({str(t): make() for t in range(num_tissues)})
+        else:
+            self.tissue_expressions = make()
 
-    def forward(self, g_exp, tissue_vector=None):
-        """g_exp fp32 [rows, D] -> fp32 [rows, 1]."""
-        te = self.tissue_expressions
-        x = ops.cast_bf16(g_exp.float().contiguous())
+    def _apply_head(self, te, g_exp):
+        """One head on fp32 rows [n, D] -> fp32 [n, 1]."""
+        if self.kind == "linear":
+            return ops.rowdot_softplus(g_exp, te[0].weight.reshape(-1).contiguous(), te[0].bias, self.softplus)
+        x = ops.cast_bf16(g_exp)
+        if self.kind == "mlp_small":
+            w0, b0 = packed_linear(te[0])
+            h = ops.gemm(x, w0, b0, ops.EPI_GELU_F32)
+            return ops.rowdot_softplus(h, te[2].weight.reshape(-1).contiguous(), te[2].bias, self.softplus)
         w0, b0 = packed_linear(te[0])
         h = ops.gemm(x, w0, b0, ops.EPI_F32)
         h = ops.layernorm(h, te[1].weight, te[1].bias, torch.bfloat16, gelu=True)
         w4, b4 = packed_linear(te[4])
         h = ops.gemm(h, w4, b4, ops.EPI_GELU_F32)
         return ops.rowdot_softplus(h, te[6].weight.reshape(-1).contiguous(), te[6].bias, self.softplus)
+
+    def forward(self, g_exp, tissue_vector=None):
+        """g_exp fp32 [rows, D] -> fp32 [rows, 1].  tissue_vector: tissue id of every row (needed for multi_head only;
+        a tensor [rows] / [rows, 1] or a flat list)."""
+        g_exp = g_exp.float().contiguous()
+        if not self.multi_head:
+            return self._apply_head(self.tissue_expressions, g_exp)
+        assert tissue_vector is not None, "multi_head needs the tissue id of every row"
+        ids = torch.as_tensor(tissue_vector).reshape(g_exp.shape[0], -1)[:, 0].cpu().tolist()
+        out = torch.empty((g_exp.shape[0], 1), dtype=torch.float32, device=g_exp.device)
+        for t in sorted(set(ids)):
+            rows = torch.tensor([r for r, v in enumerate(ids) if v == t], dtype=torch.int64, device=g_exp.device)
+            out[rows] = self._apply_head(self.tissue_expressions[str(int(t))], ops.gather_rows_f32(g_exp, None, rows))
+        return out
