@@ -711,23 +711,23 @@ int launch_persist(const void* A, int64_t lda, const void* W, const float* bias,
 // more than two waves of tiles and slower for the fp32-residual epilogue (its prefetched residual loads and stores
 // share the vmcnt queue with the next tile's LDS-DMA).
 int pick_variant(int M, int N, int K, int epilogue) {
-    (void)K;
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
     if (t128 < 256) return 5;
-    if (K >= 4096 && t256 >= 256) return 2;                               // long K: 256x256 (1380 vs 1170 at 8192^3)
-    // Measured at the 8-gene batch sizes of bench.py (scripts/gemm_bench.py, profiles/r01_g_gemm_sweep_b8.log):
-    if (t256 >= 1024 && (epilogue == VF_EPI_BF16 || epilogue == VF_EPI_GEGLU_BF16 || epilogue == VF_EPI_RES_F32)) {
-        // seq2reg GeGLU (K = 512): BK = 32 ring, 48 KiB -> 3 blocks per CU hide the short main loop's fill (772 vs 641 / 699)
-        if (K <= 512 && epilogue == VF_EPI_GEGLU_BF16) return 12;
-        // >= 4 tiles of 256x256 per CU: half the L2 -> LDS traffic per flop (gene Wqkv 1098 vs 975, Wq 1117 vs 970,
-        // GeGLU 1027 vs 942, seq2reg Wqkv 824 vs 684).  The fp32-residual epilogues lost on 256x256 (725 vs 792) until
-        // the residual rows of the next epilogue pass were prefetched under the current one (RES_PIPE): now 783 vs 719
-        // (out_proj), 678 vs 616 (K = 1024), 706 vs 632 (seq2reg K = 1024) on the same box.
-        return 2;
-    }
-    (void)epilogue;      // in the full pipeline the persistent form measured slower (33.0 vs 34.0 genes/s): not selected
-    return 1;
+    const bool big_ok = epilogue == VF_EPI_BF16 || epilogue == VF_EPI_GEGLU_BF16 || epilogue == VF_EPI_RES_F32;
+    if (!big_ok) return (K >= 4096 && t256 >= 256) ? 2 : 1;
+    // seq2reg GeGLU (K = 512): BK = 32 ring, 48 KiB -> 3 blocks per CU hide the short main loop's fill (772 vs 641 / 699)
+    if (K <= 512 && epilogue == VF_EPI_GEGLU_BF16 && t128 >= 4096) return 12;
+    // 128x128 (2 blocks per CU, 512 slots) vs 256x256 (1 block per CU, 256 slots, 4x the work per tile): whole waves
+    // of tiles are what a launch pays for, so compare ceil(tiles / slots) x work per wave, with the measured per-flop
+    // advantage of the big tile (half the L2 -> LDS bytes per flop): 1.13x for the bf16 / GeGLU epilogues (gene Wqkv
+    // 1098 vs 975, Wq 1117 vs 970, GeGLU 1027 vs 942 TFLOP/s), 1.06x for the fp32-residual epilogue (783 vs 719 with the
+    // pipelined residual prefetch), more at long K (1380 vs 1170 at 8192^3).  Reproduces every measured ordering of
+    // profiles/r01_g_gemm_sweep_b8.log and of the one-gene shapes (e.g. M = 10854, N = 1536: 258 big tiles = 2 waves
+    // for 1.01 waves of work -> 128x128 wins, 664 vs 468; M = 8192, N = 2048: exactly one wave -> 256x256, 884 vs 781).
+    const long waves_small = (t128 + 511) / 512, waves_big = (t256 + 255) / 256;
+    const double gain = K >= 4096 ? 1.18 : (epilogue == VF_EPI_RES_F32 ? 1.06 : 1.13);
+    return (double)waves_big * 2.0 / gain < (double)waves_small ? 2 : 1;
 }
 
 template <int EPI>
