@@ -231,11 +231,12 @@ def main():
             "metric": "genes/sec/node (54-tissue expr) at 1 Mb cis-window", "value": round(value, 4), "unit": "genes/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: full 1.2B-architecture model, 1 Mb window, 54 tissues, 1 donor",
+            "config": {"workload": ("BASELINE configs[1]: full 1.2B-architecture network (%d modulator layers, width %d, %d "
+                                    "heads; seq2reg width 512, 8 heads, 6 layers, assumed), random-init weights, 1 Mb "
+                                    "cis-window, %d tissues, 1 donor" % (kw["num_layers"], kw["emb_dim"], kw["num_heads"],
+                                                                         len(tissues))),
                        "genes_per_step_per_gpu": G, "n_cre_windows": args.n_cre, "gene_chunks": args.n_chunks,
-                       "tissues": len(tissues), "tokens_per_window": 200, "modulator_layers": kw["num_layers"],
-                       "emb_dim": kw["emb_dim"], "heads": kw["num_heads"], "seq2reg": "d=512,h=8,layers=6 (assumed)",
-                       "weights": "random init (no checkpoint offline)", "parallelism": f"gene-shard x{world}"},
+                       "tissues": len(tissues), "tokens_per_window": 200, "parallelism": f"gene-shard x{world}"},
             "algorithmic_tflop_per_gene": round(flops_step / G / 1e12, 3),
             "reference_executed_tflop_per_gene": round(executed_step / G / 1e12, 3),
             "achieved_algorithmic_tflops_whole_step": round(world * flops_step * args.steps / dt / 1e12, 1),
