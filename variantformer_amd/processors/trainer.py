@@ -17,7 +17,23 @@ class Trainer:
         model.trainer = self
         model.eval()
         out = []
+        pipelined = (not getattr(model, "vep", False)) and hasattr(model, "predict_launch")
         with torch.no_grad():
-            for i, batch in enumerate(dataloaders):
-                out.append(model.predict_step(batch, i))
+            if not pipelined:
+                for i, batch in enumerate(dataloaders):
+                    out.append(model.predict_step(batch, i))
+                return out
+            # Software pipeline over batches: the forward of batch i is enqueued (no host wait), then batch i+1 is
+            # fetched from the loader and prepared on the host (concatenation, structure arrays, H2D) while the GPU
+            # works, and only then are batch i's results copied back.  Same results, same order as predict_step.
+            it = iter(dataloaders)
+            batch = next(it, None)
+            pb = model.prepare_batch(batch) if batch is not None else None
+            i = 0
+            while pb is not None:
+                handle = model.predict_launch(pb)
+                batch = next(it, None)
+                pb = model.prepare_batch(batch) if batch is not None else None
+                out.append(model.predict_finish(handle, i))
+                i += 1
         return out

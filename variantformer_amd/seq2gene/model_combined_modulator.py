@@ -519,12 +519,23 @@ class Seq2GenePredictorCombinedModulator(nn.Module):
         if self.vep:
             return self.variant_prediction(batch)
         with torch.no_grad():
-            pb = self.prepare_batch(batch)
+            return self.predict_finish(self.predict_launch(self.prepare_batch(batch)), batch_idx, dataloader_idx)
+
+    def predict_launch(self, pb: PreparedBatch):
+        """Enqueue the forward of a prepared batch; returns without waiting for the GPU (the kernels run on the
+        current stream).  `predict_finish` turns the handle into predict_step's dict.  Splitting the step lets a driver
+        build the next batch on the host while this one computes (processors/trainer.py)."""
+        with torch.no_grad():
             pred, emb = self.forward_prepared(pb)
-        pred = pred.detach().cpu().float().numpy()
+        return pb.tissues, pred, emb
+
+    @staticmethod
+    def predict_finish(handle, batch_idx, dataloader_idx=None):
+        tissues, pred, emb = handle
+        pred = pred.detach().cpu().float().numpy()          # D2H: the sync point of the step
         emb = emb.detach().cpu().float().numpy()
         preds, embs, s = [], [], 0
-        for t in pb.tissues:
+        for t in tissues:
             preds.append(pred[s:s + len(t)])
             embs.append(emb[s:s + len(t)])
             s += len(t)
