@@ -137,3 +137,44 @@ def test_trainer_and_format_output_contract():
     assert list(df.columns) == ["gene_id", "predicted_expression", "embeddings"] and df["predicted_expression"][1][0, 0] == 1
     with pytest.raises(AssertionError):
         vp.format_output(pd.DataFrame({"gene_id": ["a"]}), preds)
+
+
+def test_trainer_pipelines_host_preparation_with_the_forward():
+    """Trainer.predict enqueues the forward of batch i, prepares batch i+1, then collects batch i: same results and
+    order as predict_step; VEP models (one fused step per batch) keep the plain loop."""
+    from variantformer_amd.processors.trainer import Trainer
+
+    class Fake:
+        vep = False
+
+        def __init__(self):
+            self.log = []
+
+        def eval(self):
+            return self
+
+        def prepare_batch(self, b):
+            self.log.append(("prepare", b))
+            return b * 10
+
+        def predict_launch(self, pb):
+            self.log.append(("launch", pb))
+            return pb + 1
+
+        def predict_finish(self, handle, i, dataloader_idx=None):
+            self.log.append(("finish", handle, i))
+            return {"value": handle, "batch_idx": i}
+
+        def predict_step(self, b, i):
+            self.log.append(("step", b, i))
+            return {"value": b, "batch_idx": i}
+
+    m = Fake()
+    out = Trainer().predict(m, [1, 2, 3])
+    assert [o["value"] for o in out] == [11, 21, 31] and [o["batch_idx"] for o in out] == [0, 1, 2]
+    assert m.log == [("prepare", 1), ("launch", 10), ("prepare", 2), ("finish", 11, 0), ("launch", 20), ("prepare", 3),
+                     ("finish", 21, 1), ("launch", 30), ("finish", 31, 2)]
+    assert Trainer().predict(Fake(), []) == []
+    v = Fake()
+    v.vep = True
+    assert [o["value"] for o in Trainer().predict(v, [4, 5])] == [4, 5] and v.log == [("step", 4, 0), ("step", 5, 1)]
