@@ -85,6 +85,36 @@ def host_threads() -> int:
     return max(1, n)
 
 
+def source_sha() -> str:
+    """Hash of the kernel sources the loaded library was built from (ties a PMC profile to a build)."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(REPO, "variantformer_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            with open(os.path.join(csrc, f), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(kernel: str):
+    """HBM bytes per launch of `kernel` from the rocprofv3 --pmc passes of THIS command on THIS build
+    (scripts/run_profile_set.sh writes profiles/r*_pmc_hbm_traffic.json with the source hash of the build it profiled;
+    FETCH_SIZE x2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes).  bench.py cannot collect PMC counters itself, so a
+    profile of another build is NOT used: traffic is null then."""
+    import glob
+    sha = source_sha()
+    for src in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_hbm_traffic.json")), reverse=True):
+        try:
+            with open(src) as f:
+                d = json.load(f)
+            if d.get("_source_sha") == sha and kernel in d:
+                return d[kernel]["hbm_bytes_per_launch"], os.path.relpath(src, REPO)
+        except Exception:
+            continue
+    return None, None
+
+
 def cpu_baseline(model, hp, kw, executed_full: float, threads: int, budget_s: float = 20.0):
     """Oracle ("port" of the reference algorithm, fp32, tissue copies repeated as the reference does) timed on the
     host cores on a bounded sample of the same workload, scaled by executed FLOPs to genes/sec.  The sample is
@@ -200,30 +230,35 @@ def main():
             ops.TIMER = None
             g = summ["gemm"]
             tf = g["flops"] / (g["total_ms"] * 1e-3) / 1e12
-            # HBM traffic per launch comes from separate rocprofv3 --pmc passes of this same command (FETCH_SIZE x2 +
-            # WRITE_SIZE, scripts/pmc_summary.py); bench.py cannot collect PMC counters itself.
-            traffic, traffic_src = None, None
-            try:
-                import glob
-                src = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_hbm_traffic.json")))[-1]
-                with open(src) as f:
-                    traffic = json.load(f)["gemm_mfma_kernel"]["hbm_bytes_per_launch"]
-                traffic_src = os.path.relpath(src, REPO)
-            except Exception:
-                pass
+            step_ms = dt / args.steps * 1e3
+            traffic, traffic_src = pmc_traffic("gemm_mfma_kernel")
             roof = {"kernel": "gemm_mfma_kernel (vf_gemm_bf16, all epilogues)", "bound": "mfma", "achieved": round(tf, 1),
                     "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                     "traffic_source": traffic_src, "algorithmic_bytes_per_launch": g["bytes"] / g["launches"],
                     "launches_per_step": g["launches"] // args.steps,
                     "avg_launch_us": round(g["total_ms"] * 1e3 / g["launches"], 2),
                     "flop_per_launch": g["flops"] / g["launches"],
-                    "share_of_step_time": round(g["total_ms"] / args.steps / (dt / args.steps * 1e3), 3)}
-            a = summ.get("attn")
-            if a:
-                kernels["attn_fwd_kernel"] = {"launches_per_step": a["launches"] // args.steps,
-                                              "total_ms_per_step": round(a["total_ms"] / args.steps, 3),
-                                              "algorithmic_GBps": round(a["bytes"] / (a["total_ms"] * 1e-3) / 1e9, 1),
-                                              "share_of_step_time": round(a["total_ms"] / args.steps / (dt / args.steps * 1e3), 3)}
+                    "share_of_step_time": round(g["total_ms"] / args.steps / step_ms, 3)}
+            # Per kernel family (KernelTimer families: the module that launched the kernel).  Every family is priced
+            # against ITS roofline = min(dense MFMA peak, arithmetic intensity x HBM peak), SURVEY 8d.
+            for key, r in sorted(summ.items()):
+                if ":" not in key:
+                    continue
+                kind, fam = key.split(":", 1)
+                sec = r["total_ms"] * 1e-3
+                ent = {"launches_per_step": r["launches"] // args.steps, "ms_per_step": round(r["total_ms"] / args.steps, 3),
+                       "share_of_step_time": round(r["total_ms"] / args.steps / step_ms, 4),
+                       "algorithmic_GBps": round(r["bytes"] / sec / 1e9, 1)}
+                if r["flops"] > 0:
+                    inten = r["flops"] / r["bytes"]
+                    ceil_tf = min(MFMA_PEAK_TFLOPS, inten * HBM_PEAK_GBS / 1e3)
+                    ach = r["flops"] / sec / 1e12
+                    ent.update({"achieved_TFLOPs": round(ach, 1), "intensity_flop_per_byte": round(inten, 1),
+                                "bound": "mfma" if ceil_tf >= MFMA_PEAK_TFLOPS else "hbm", "roofline_TFLOPs": round(ceil_tf, 1),
+                                "frac_of_roofline": round(ach / ceil_tf, 4), "frac_of_mfma_peak": round(ach / MFMA_PEAK_TFLOPS, 4)})
+                else:
+                    ent.update({"bound": "hbm", "frac_of_roofline": round(r["bytes"] / sec / 1e9 / HBM_PEAK_GBS, 4)})
+                kernels[f"{kind}/{fam}"] = ent
 
     if rank == 0:
         value = world * G * args.steps / dt
@@ -240,7 +275,7 @@ def main():
             "algorithmic_tflop_per_gene": round(flops_step / G / 1e12, 3),
             "reference_executed_tflop_per_gene": round(executed_step / G / 1e12, 3),
             "achieved_algorithmic_tflops_whole_step": round(world * flops_step * args.steps / dt / 1e12, 1),
-            "roofline": roof, "other_kernels": kernels,
+            "roofline": roof, "kernel_families": kernels, "source_sha": source_sha(),
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(model, hp, kw, executed_step / G, host_threads())

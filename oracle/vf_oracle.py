@@ -402,7 +402,7 @@ def forward(batch: dict, sd: dict, cre_hp: Seq2RegHP, gene_hp: Seq2RegHP, hp: Se
     assert hp.shipped or not share_cre_stream, "the de-duplicated evaluation exists for the shipped configuration only"
 
     embs = []
-    first_gene, first_cre, mod_out = [], [], []
+    first_gene, first_cre, mod_out, mod_cre_out = [], [], [], []
     for i in range(n_genes):
         tissues = [int(t) for t in batch["tissue_context"][i]]
         T, N, C = len(tissues), cre_x[i].shape[0], gene_x[i].shape[0]
@@ -423,7 +423,8 @@ def forward(batch: dict, sd: dict, cre_hp: Seq2RegHP, gene_hp: Seq2RegHP, hp: Se
         col = {} if collect is not None else None
         if share_cre_stream:
             # one CRE stream; all T tissue copies of the gene stream attend to it
-            out, _ = _modulator_shared(cre_x[i], g, labels, T, C + 1, sd, hp, rnd, col)
+            out, cre_out = _modulator_shared(cre_x[i], g, labels, T, C + 1, sd, hp, rnd, col)
+            cre_out = cre_out[None].expand(T, N, D)
         else:
             cre_rep = cre_x[i].repeat(T, 1)
             if hp.add_context_to_cres:                       # AddContext (layers.py:558-573): + tissue embedding
@@ -431,11 +432,13 @@ def forward(batch: dict, sd: dict, cre_hp: Seq2RegHP, gene_hp: Seq2RegHP, hp: Se
                 cre_rep = cre_rep + torch.cat([add[t][None, :].expand(N, D) for t in tissues], dim=0)
             lab_rep = labels.repeat(T)
             cu_c = torch.arange(0, T + 1, dtype=torch.int32) * N
-            out, _ = combined_modulator(cre_rep, g, lab_rep, cu_c, cu_g, sd, "combined_modulator.", hp, rnd, col)
+            out, cre_out = combined_modulator(cre_rep, g, lab_rep, cu_c, cu_g, sd, "combined_modulator.", hp, rnd, col)
+            cre_out = cre_out.view(T, N, D)
         if collect is not None:
             first_gene.append(col["first_gene_layer_out"])
             first_cre.append(col["first_cre_layer_out"])
             mod_out.append(out.view(T, G, D))
+            mod_cre_out.append(cre_out)
         if hp.gene_pooling == "max":
             embs.append(out.view(T, G, D).max(dim=1).values)   # pool_outputs max (:380-389); every chunk is valid here
         else:
@@ -443,7 +446,8 @@ def forward(batch: dict, sd: dict, cre_hp: Seq2RegHP, gene_hp: Seq2RegHP, hp: Se
     if collect is not None:
         collect["first_gene_layer_out"] = torch.cat(first_gene)
         collect["first_cre_layer_out"] = torch.cat(first_cre)
-        collect["modulator_gene_out"] = mod_out
+        collect["modulator_gene_out"] = mod_out          # per gene [T, G, D] (G includes the start / registry token)
+        collect["modulator_cre_out"] = mod_cre_out        # per gene [T, N, D]: the CRE stream after the last CRE layer
     emb = torch.cat(embs, dim=0)
     all_tissues = [int(t) for i in range(n_genes) for t in batch["tissue_context"][i]]
     pred = tissue_head(emb, sd, "tissue_heads.", rnd, hp, all_tissues)
@@ -495,3 +499,38 @@ def predict_step(batch: dict, sd: dict, cre_hp, gene_hp, hp, rounding=None, shar
         embs.append(emb[s:s + n].numpy())
         s += n
     return {"pred_gene_exp": preds, "embeddings": embs, "batch_idx": 0, "dataloader_idx": None}
+
+
+def variant_prediction(batch: dict, sd: dict, cre_hp, gene_hp, hp, rounding=None, share_cre_stream=False):
+    """Seq2GenePredictorCombinedModulator.variant_prediction (model_combined_modulator.py:909-1004): the ref / het / hom
+    samples go through forward one at a time (:944-962) with their token positions; the modulator returns the final
+    gene-stream row at gene_token_position (+1 when a start / registry token is prepended, :665-666) and the row of the
+    CRE stream after its last layer at cre_token_position, repeated for every requested tissue (:296-326, :631-639).
+    NaN positions (variant outside every CRE / chunk) switch the gather off: zeros (:936-939, :303-306, :322-325)."""
+    n = len(batch["cre_sequences"])
+    cre_pos, gene_pos = batch["cre_token_position"], batch["gene_token_position"]
+    assert len(cre_pos) == 3 and len(gene_pos) == 3
+    if torch.isnan(torch.as_tensor(cre_pos, dtype=torch.float32)).any():
+        cre_pos = None
+    if torch.isnan(torch.as_tensor(gene_pos, dtype=torch.float32)).any():
+        gene_pos = None
+    prefix = 0 if hp.gene_pooling == "max" else 1
+    out = {"pred_gene_exp": [], "embd": [], "variant_type": batch["variant_type"], "gene_token_embedding": [],
+           "cre_token_embedding": []}
+    for i in range(n):
+        one = {"cre_sequences": batch["cre_sequences"][i:i + 1], "cre_attention_masks": batch["cre_attention_masks"][i:i + 1],
+               "tissue_context": batch["tissue_context"][i:i + 1], "ref_cre_labels": batch["ref_labels"][i:i + 1],
+               "gene_embeddings": batch["gene_embeddings"][i:i + 1], "gene_attention_masks": batch["gene_attention_masks"][i:i + 1]}
+        col = {}
+        with torch.no_grad():
+            pred, emb = forward(one, sd, cre_hp, gene_hp, hp, rounding, share_cre_stream, collect=col)
+        T = pred.shape[0]
+        g_out, c_out = col["modulator_gene_out"][0], col["modulator_cre_out"][0]
+        gt = torch.zeros(T, hp.emb_dim) if gene_pos is None else \
+            g_out[:, int(torch.as_tensor(gene_pos[i]).reshape(-1)[0]) + prefix, :]
+        ct = torch.zeros(T, hp.emb_dim) if cre_pos is None else c_out[:, int(torch.as_tensor(cre_pos[i]).reshape(-1)[0]), :]
+        out["pred_gene_exp"].append(pred.numpy())
+        out["embd"].append(emb.numpy())
+        out["gene_token_embedding"].append(gt.numpy().copy())
+        out["cre_token_embedding"].append(ct.numpy().copy())
+    return out

@@ -26,6 +26,10 @@ for k, v in acc.items():
     res[k] = {"launches": lf, "hbm_read_bytes_per_launch": 2.0 * v["fetch_kib"] * 1024 / lf,
               "hbm_write_bytes_per_launch": v["write_kib"] * 1024 / lw}
     res[k]["hbm_bytes_per_launch"] = res[k]["hbm_read_bytes_per_launch"] + res[k]["hbm_write_bytes_per_launch"]
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+res["_source_sha"] = bench.source_sha()
 res["_method"] = "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `bench.py --steps 2 --warmup 1`; FETCH_SIZE x2 (gfx950), KiB -> bytes"
 json.dump(res, open(out_path, "w"), indent=1)
 print(json.dumps(res, indent=1))

@@ -1,16 +1,23 @@
-set -x
-mkdir -p gpurun_out/i
-python -m pytest tests -m gpu -x -q > gpurun_out/i/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/i/pytest_gpu.log
-python bench.py > gpurun_out/i/bench.json 2> gpurun_out/i/bench.err
+# usage (on the GPU box, from the repo root): bash scripts/run_profile_set.sh <tag> [--skip-tests]
+# Writes gpurun_out/<tag>/: pytest log, bench line, rocprofv3 kernel stats, HBM-traffic PMC passes, SQ PMC pass.
+# Every rocprofv3 line has the program itself after `--` (no env / bash -c hop) and never mixes --pmc with trace domains
+# other than --kernel-trace.
+TAG=${1:-x}
+O=gpurun_out/$TAG
+mkdir -p $O
+if [ "$2" != "--skip-tests" ]; then
+  python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
+  tail -3 $O/pytest_gpu.log
+fi
+python bench.py > $O/bench.json 2> $O/bench.err; cat $O/bench.json
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/i/prof -- python3 bench.py --no-cpu-baseline > gpurun_out/i/bench_prof.json 2> gpurun_out/i/prof.err
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/i/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > gpurun_out/i/pmc_fetch.json 2> gpurun_out/i/pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/i/pmc_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > gpurun_out/i/pmc_write.json 2> gpurun_out/i/pmc_write.err
-ls -la gpurun_out/i/prof/*/ | head; du -sh gpurun_out/i
-find gpurun_out/i -name '*kernel_trace.csv' -size +20M -delete
-find gpurun_out/i/pmc_fetch gpurun_out/i/pmc_write -name '*counter_collection.csv' | head
-tail -3 gpurun_out/i/pytest_gpu.log; cat gpurun_out/i/bench.json
-python scripts/pmc_summary.py gpurun_out/i/pmc_hbm_traffic.json i/pmc > /dev/null
-find gpurun_out/i -name '*counter_collection.csv' -delete
-find gpurun_out/i -name '*kernel_trace.csv' -delete
-du -sh gpurun_out/i
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench.py --no-cpu-baseline > $O/bench_prof.json 2> $O/prof.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/${TAG}_pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > $O/pmc_fetch.json 2> $O/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/${TAG}_pmc_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > $O/pmc_write.json 2> $O/pmc_write.err
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d gpurun_out/${TAG}_pmc_sq -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing > $O/pmc_sq.json 2> $O/pmc_sq.err
+python scripts/pmc_summary.py $O/pmc_hbm_traffic.json ${TAG}_pmc > /dev/null
+python scripts/pmc_sq_summary.py gpurun_out/${TAG}_pmc_sq $O/pmc_sq.json > $O/pmc_sq_summary.txt; tail -60 $O/pmc_sq_summary.txt
+cp $(find $O/prof -name '*kernel_stats.csv' | head -1) $O/kernel_stats.csv 2>/dev/null
+rm -rf gpurun_out/${TAG}_pmc_fetch gpurun_out/${TAG}_pmc_write gpurun_out/${TAG}_pmc_sq
+find $O -name '*kernel_trace.csv' -delete; find $O -name '*.db' -delete
+du -sh $O

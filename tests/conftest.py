@@ -38,6 +38,25 @@ def load_fixture(name):
     return meta, arrays, sd, batch
 
 
+def load_vep_model_fixture():
+    """(meta, arrays, state_dict, vep_batch) of tests/golden/vep_model.*: outputs of the reference's own
+    variant_prediction on a seeded ref / het / hom batch."""
+    from variantformer_amd.utils.synthetic import make_tensor, make_vep_batch
+    from oracle.vf_oracle import alibi_slopes
+
+    with open(os.path.join(GOLDEN, "vep_model.json")) as f:
+        meta = json.load(f)
+    arrays = dict(np.load(os.path.join(GOLDEN, "vep_model.npz")))
+    sd = {k: (torch.tensor(alibi_slopes(shape[0]), dtype=torch.float32) if k.endswith(".m")
+              else torch.from_numpy(make_tensor(k, shape, meta["seed"]))) for k, shape in meta["state_dict_shapes"].items()}
+    chk = float(sum(float(v.double().abs().sum()) for v in sd.values()))
+    assert abs(chk - meta["weight_abs_sum"]) <= 1e-6 * meta["weight_abs_sum"], "weight regeneration drifted"
+    vb = make_vep_batch(meta["seed"], meta["n_cre"], meta["n_chunks"], meta["tissues"], meta["token_length"],
+                        cre_index=meta["cre_index"], gene_index=tuple(meta["gene_index"]),
+                        cre_len_range=tuple(meta["cre_len_range"]))
+    return meta, arrays, sd, vb
+
+
 @pytest.fixture(params=["small_sin", "small_alibi"])
 def golden(request):
     return load_fixture(request.param)

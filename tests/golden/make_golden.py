@@ -316,6 +316,45 @@ def run_fixture(name, fx):
     print(f"[golden] {name}: pred", [a.ravel()[:3] for k, a in arrays.items() if k.startswith("pred")])
 
 
+VEP_MODEL = dict(base="small_sin", seed=808, n_cre=7, n_chunks=5, tissues=[7, 20, 62], cre_index=2, gene_index=[1, 1, 3])
+
+
+def vep_model_fixture():
+    """The reference's own variant_prediction (seq2gene/model_combined_modulator.py:909-1004) on a ref / het / hom
+    batch with token positions: pred_gene_exp, embd and the token-position gathers (:296-326, +1 for the registry
+    token :665-666).  Also one run with NaN positions (the reference then returns zero token embeddings, :936-939)."""
+    from variantformer_amd.utils.synthetic import make_vep_batch
+    v = VEP_MODEL
+    fx = dict(FIXTURES[v["base"]], seed=v["seed"])
+    torch.manual_seed(0)
+    model = build_reference_model(fx)
+    model.vep = True
+    vb = make_vep_batch(v["seed"], v["n_cre"], v["n_chunks"], v["tissues"], fx["token_length"], cre_index=v["cre_index"],
+                        gene_index=tuple(v["gene_index"]), cre_len_range=fx["cre_len_range"])
+    arrays = {}
+    with torch.no_grad():
+        out = model.predict_step(vb, 0)
+        nan_b = dict(vb, cre_token_position=torch.full((3, 1), float("nan")), gene_token_position=torch.full((3, 1), float("nan")))
+        out_nan = model.predict_step(nan_b, 0)
+    assert set(out) == {"pred_gene_exp", "embd", "variant_type", "gene_token_embedding", "cre_token_embedding"}
+    for tag, o in (("pos", out), ("nan", out_nan)):
+        for k in ("pred_gene_exp", "embd", "gene_token_embedding", "cre_token_embedding"):
+            for i, a in enumerate(o[k]):
+                arrays[f"{tag}.{k}_{i}"] = np.asarray(a, np.float32)
+    sd = model.state_dict()
+    meta = dict(VEP_MODEL, seq2reg=fx["seq2reg"], seq2gene=fx["seq2gene"], token_length=fx["token_length"],
+                cre_len_range=list(fx["cre_len_range"]), state_dict_shapes={k: list(t.shape) for k, t in sd.items()},
+                weight_abs_sum=float(sum(float(t.double().abs().sum()) for t in sd.values() if torch.is_floating_point(t))),
+                variant_type=out["variant_type"],
+                generated_by="tests/golden/make_golden.py: reference Seq2GenePredictorCombinedModulator.variant_prediction "
+                             "(fp32, CPU, stubbed flash_attn) on variantformer_amd.utils.synthetic.make_vep_batch")
+    np.savez_compressed(os.path.join(HERE, "vep_model.npz"), **arrays)
+    with open(os.path.join(HERE, "vep_model.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print("[golden] vep_model: gene_tok", arrays["pos.gene_token_embedding_1"][0, :3], "cre_tok", arrays["pos.cre_token_embedding_2"][0, :3],
+          "nan ->", float(np.abs(arrays["nan.gene_token_embedding_0"]).max()))
+
+
 def bpe_fixture():
     """Token-id golden vectors from the reference's BPEEncoder (utils/seq.py:8-62)."""
     from utils.seq import BPEEncoder
@@ -488,8 +527,17 @@ def main():
     # seq2reg embeddings), which would make the fixtures a noisy fp32 reference.  The flag is a
     # speed/precision knob, not part of the algorithm: restore exact fp32 for the golden run.
     torch.set_float32_matmul_precision("highest")
+    only = sys.argv[1:]
+    if only:                      # e.g. `make_golden.py vep_model`: regenerate selected fixtures only
+        for name in only:
+            if name in FIXTURES:
+                run_fixture(name, FIXTURES[name])
+            else:
+                globals()[f"{name}_fixture"]()
+        return
     for name, fx in FIXTURES.items():
         run_fixture(name, fx)
+    vep_model_fixture()
     bpe_fixture()
     misc_fixture()
     vep_fixture()

@@ -1,0 +1,300 @@
+"""BASELINE.json configurations other than the bench workload, the flash-attn-compatible operator seam, and the
+VEP token-position outputs, on a real MI355X through the C ABI.
+
+  cfg 1  single gene, 128 kb window, 1 tissue   (N=40, C=178, T=1)          full depth vs oracle
+  cfg 3  256 ragged genes of one donor, sharded by LPT over 8 ranks, batches of <= 8  full depth; oracle on a subset,
+         shard / batch independence on all, reassembly in query order
+  cfg 4  paired ref / alt 1 Mb windows                                                 full size: delta vs oracle delta
+  seam   MHA.__call__ / FlashAttLayer.forward, packed and padded, self and cross       vs oracle.mha_self / mha_cross
+  VEP    variant_prediction token-position outputs                                     vs the reference's own outputs
+
+Error metric for new assertions: element-wise |a-b| / (|b| + rms(b)) (not max-norm), so that small elements count.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vf_oracle as O
+from tests.conftest import load_vep_model_fixture
+from tests.helpers import SEQ2REG_512, build_model, seq2gene_kw, state_dict_cpu
+from variantformer_amd.dist import gene_cost, shard_batch, shard_genes_lpt
+from variantformer_amd.utils.synthetic import TISSUES_54, cfg3_gene_sizes, make_batch, make_vep_batch
+
+pytestmark = pytest.mark.gpu
+
+NORTH_STAR_RTOL = 1e-3
+
+
+def erel(a, b):
+    """max over elements of |a-b| / (|b| + rms(b))."""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float((np.abs(a - b) / (np.abs(b) + np.sqrt((b * b).mean()) + 1e-30)).max())
+
+
+@pytest.fixture(scope="module")
+def full_model():
+    import bench
+    model, hp, kw = bench.build_model(torch.device("cuda", 0))
+    return model, hp, kw, state_dict_cpu(model)
+
+
+def _oracle(batch, sd, hp, kw, rounding="bf16"):
+    import bench
+    shp = O.Seq2RegHP.from_hparams(hp)
+    torch.set_num_threads(min(16, bench.host_threads()))
+    return O.predict_step(batch, sd, shp, shp, O.Seq2GeneHP.from_kwargs(kw), rounding=rounding, share_cre_stream=True)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def test_cfg1_single_gene_128kb_one_tissue(full_model):
+    """BASELINE configs[0] geometry (SURVEY 8d cfg 1): N = 40 cCRE windows, C = 178 gene chunks, T = 1 tissue, the full
+    25-layer / 6-layer architecture.  HIP vs the same-rounding oracle and vs the pure-fp32 oracle."""
+    model, hp, kw, sd = full_model
+    batch = make_batch(1281, [40], [178], [[33]], 200)
+    out = model.predict_step(batch, 0)
+    assert out["pred_gene_exp"][0].shape == (1, 1) and out["embeddings"][0].shape == (1, 1536)
+    orc = _oracle(batch, sd, hp, kw)
+    assert erel(out["pred_gene_exp"][0], orc["pred_gene_exp"][0]) < NORTH_STAR_RTOL
+    assert erel(out["embeddings"][0], orc["embeddings"][0]) < 5e-3
+    f32 = _oracle(batch, sd, hp, kw, rounding=None)
+    e_pred, e_emb = erel(out["pred_gene_exp"][0], f32["pred_gene_exp"][0]), erel(out["embeddings"][0], f32["embeddings"][0])
+    print(f"[cfg1] HIP(bf16 operands) vs fp32 oracle, full depth: expression {e_pred:.2e}, embedding {e_emb:.2e} (element-wise)")
+    assert e_pred < 1e-2 and e_emb < 5e-2            # bf16-operand deviation from fp32 arithmetic, stated not hidden
+
+
+def test_cfg3_256_ragged_genes_lpt_shards(full_model):
+    """BASELINE configs[2]: 256 genes of one donor (N ~ lognormal(600, 0.6) in [40, 2048], C ~ U{20..200}, 54 tissues),
+    LPT-sharded over 8 ranks, each rank running batches of <= 8 genes; the expression matrix is reassembled in query
+    order.  On one GPU the 8 shards run one after the other (the RCCL gather itself is covered by tests/test_dist_cpu.py
+    and bench.py --workload cfg3).  Checks: (1) the three cheapest genes against the oracle, (2) every gene's result is
+    independent of its shard / batch neighbours: a second pass with a different partition (round-robin, batches of 5)
+    reproduces the matrix, (3) the matrix is finite, positive (Softplus) and in query order."""
+    model, hp, kw, sd = full_model
+    n_genes, T = 256, 54
+    n, c = cfg3_gene_sizes(n_genes)
+    costs = [gene_cost(int(a), int(b), T) for a, b in zip(n, c)]
+    owned = shard_genes_lpt(costs, 8)
+
+    def gene_batch(ids):
+        return make_batch_by_gene(ids, n, c)
+
+    def run(partition, bs):
+        expr = np.full((n_genes, T), np.nan, np.float32)
+        for shard in partition:
+            for s in range(0, len(shard), bs):
+                ids = shard[s:s + bs]
+                out = model.predict_step(gene_batch(ids), 0)
+                for j, g in enumerate(ids):
+                    expr[g] = out["pred_gene_exp"][j][:, 0]
+        return expr
+
+    a = run(owned, 8)
+    assert np.isfinite(a).all() and (a > 0).all()
+    rr = [list(range(r, n_genes, 8)) for r in range(8)]
+    b = run(rr, 5)
+    np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-6)
+    cheapest = sorted(range(n_genes), key=lambda i: costs[i])[:3]
+    orc = _oracle(gene_batch(cheapest), sd, hp, kw)
+    for j, g in enumerate(cheapest):
+        assert erel(a[g], orc["pred_gene_exp"][j][:, 0]) < NORTH_STAR_RTOL, (g, int(n[g]), int(c[g]))
+    loads = [sum(costs[i] for i in o) for o in owned]
+    print(f"[cfg3] LPT imbalance max/mean = {max(loads) / (sum(loads) / 8):.4f}; genes per rank {[len(o) for o in owned]}")
+
+
+def make_batch_by_gene(ids, n, c):
+    """collate of the cfg-3 genes `ids`: gene g is always built from seed (20251205, g), whatever batch it lands in."""
+    from variantformer_amd.utils.synthetic import collate, make_gene
+    return collate([make_gene(20251205 * 1000003 + int(g), int(n[g]), int(c[g]), TISSUES_54, 200) for g in ids])
+
+
+def test_cfg4_paired_ref_alt_full_size(full_model):
+    """BASELINE configs[3] (snp_indel_predictions geometry): two full-size 1 Mb genes (N = 1024, C = 200, T = 54) that
+    differ in 5 cCRE windows and 5 gene chunks.  The variant-effect delta = alt - ref of the HIP path must follow the
+    oracle's delta; the ref half must not notice the alt half (pair vs alone), and the VEP window de-duplication must
+    reproduce the plain evaluation bit for bit at this size."""
+    model, hp, kw, sd = full_model
+    ref = make_batch(40404, [1024], [200], [TISSUES_54], 200)
+    pair = {k: (v + [t.clone() for t in v] if isinstance(v, list) else v.repeat(2, 1)) for k, v in ref.items()}
+    rng = np.random.default_rng(7)
+    for w in rng.choice(1024, 5, replace=False):
+        valid = int((~pair["cre_attention_masks"][1][w, 0]).sum())
+        pos = rng.choice(valid, 3, replace=False)
+        pair["cre_sequences"][1][w, 0, pos] = torch.from_numpy(rng.integers(4, 18, 3))
+    for w in rng.choice(200, 5, replace=False):
+        valid = int((~pair["gene_attention_masks"][1][w, 0]).sum())
+        pos = rng.choice(valid, 3, replace=False)
+        pair["gene_embeddings"][1][w, 0, pos] = torch.from_numpy(rng.integers(4, 18, 3))
+    both = model.predict_step(pair, 0)
+    alone = model.predict_step(ref, 0)
+    np.testing.assert_allclose(both["pred_gene_exp"][0], alone["pred_gene_exp"][0], rtol=1e-5, atol=1e-6)
+    with torch.no_grad():
+        plain = model.forward_prepared(model.prepare_batch(pair))
+        dd = model.prepare_batch(pair, dedupe_windows=True)
+        assert dd.cre_ids.shape[0] == 1024 + 5 and dd.gene_ids.shape[0] == 200 + 5
+        dedup = model.forward_prepared(dd)
+    assert torch.equal(plain[0], dedup[0]) and torch.equal(plain[1], dedup[1])
+    delta = both["pred_gene_exp"][1] - both["pred_gene_exp"][0]
+    assert np.abs(delta).max() > 0
+    # oracle on both halves (2 x ~18 TFLOP on the host cores)
+    orc = _oracle(pair, sd, hp, kw)
+    for i in range(2):
+        assert erel(both["pred_gene_exp"][i], orc["pred_gene_exp"][i]) < NORTH_STAR_RTOL
+    d_orc = orc["pred_gene_exp"][1] - orc["pred_gene_exp"][0]
+    # the delta is a difference of two numbers each good to 1e-3 relative: compare on the scale of the expression
+    scale = np.abs(orc["pred_gene_exp"][0]).max()
+    err = np.abs(delta - d_orc).max() / scale
+    print(f"[cfg4] max |delta| {np.abs(d_orc).max():.3e} on expression scale {scale:.3f}; |delta_hip - delta_oracle| / scale = {err:.2e}")
+    assert err < NORTH_STAR_RTOL
+    log2fc_h = np.log2(both["pred_gene_exp"][1] / both["pred_gene_exp"][0])
+    log2fc_o = np.log2(orc["pred_gene_exp"][1] / orc["pred_gene_exp"][0])
+    assert np.abs(log2fc_h - log2fc_o).max() < 1e-3          # the reference's own VEP tolerance (tests/test_vep.py atol 1e-3)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def _mha_sd(mha, prefix=""):
+    return {prefix + k: v.detach().cpu().float() for k, v in mha.state_dict().items()}
+
+
+@pytest.mark.parametrize("D,H,alibi", [(1536, 32, True), (512, 8, False), (128, 4, True)])
+def test_mha_seam_self_packed_and_padded(D, H, alibi):
+    """flash_attn.modules.mha.MHA call contract (reference seq2gene/modules/layers.py:437-439,465,482-487;
+    seq2reg/modules.py:167): __call__(x, cu_seqlens=, max_seqlen=) on packed [tokens, D], and the padded [B, S, D]
+    call without keyword arguments; through FlashAttLayer.forward as well (unpad_info and key-padding-mask forms)."""
+    from variantformer_amd.seq2gene.modules.layers import MHA, FlashAttLayer
+    from variantformer_amd.utils.synthetic import fill_state_dict
+    rnd = O.Rounding("bf16")
+    layer = FlashAttLayer(D, H, use_alibi=alibi, cross_attn=False)
+    fill_state_dict(layer, 17)
+    sd = _mha_sd(layer.MHA)
+    layer = layer.cuda()
+    mha: MHA = layer.MHA
+    lens = [37, 1, 64, 130]
+    cu = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int32)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(sum(lens), D, generator=g)
+    slopes = torch.tensor(O.alibi_slopes(H), dtype=torch.float32) if alibi else None
+    want = O.mha_self(rnd.r(x), sd, "", H, cu, slopes, rnd)
+    got = mha(x.cuda(), cu_seqlens=cu.cuda(), max_seqlen=max(lens))
+    assert got.dtype == torch.float32 and got.shape == x.shape
+    assert erel(got.cpu().numpy(), want.numpy()) < 3e-3
+    got_l = layer(x.cuda(), unpad_info={"cu_seqlens": cu.cuda(), "max_seqlen": max(lens)})
+    assert torch.equal(got_l, got)
+    # bf16 in -> bf16 out, like the original module under autocast
+    got_b = mha(x.cuda().bfloat16(), cu_seqlens=cu.cuda(), max_seqlen=max(lens))
+    assert got_b.dtype == torch.bfloat16
+    assert erel(got_b.float().cpu().numpy(), want.numpy()) < 1.5e-2
+    # padded [B, S, D] without kwargs: every row is a key (no masking), seq2gene/modules/layers.py:487
+    B, S = 3, 40
+    xp = torch.randn(B, S, D, generator=g)
+    cu_p = torch.arange(0, B + 1, dtype=torch.int32) * S
+    want_p = O.mha_self(rnd.r(xp.reshape(B * S, D)), sd, "", H, cu_p, slopes, rnd).view(B, S, D)
+    got_p = mha(xp.cuda())
+    assert got_p.shape == (B, S, D)
+    assert erel(got_p.cpu().numpy(), want_p.numpy()) < 3e-3
+    # padded + key padding mask through FlashAttLayer (pack, run, scatter back, zeros on the pad rows)
+    mask = torch.zeros(B, S, dtype=torch.bool)
+    mask[0, 25:] = True
+    mask[2, 1:] = True
+    keep = ~mask
+    cu_m = torch.tensor(np.concatenate([[0], np.cumsum(keep.sum(1).numpy())]), dtype=torch.int32)
+    want_m = O.mha_self(rnd.r(xp[keep]), sd, "", H, cu_m, slopes, rnd)
+    got_m = layer(xp.cuda(), src_key_padding_mask=mask.cuda())
+    assert erel(got_m.cpu()[keep].numpy(), want_m.numpy()) < 3e-3
+    assert float(got_m.cpu()[mask].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("D,H", [(1536, 32), (128, 4)])
+def test_mha_seam_cross_packed_and_padded(D, H):
+    """Cross form: __call__(x, x_kv, cu_seqlens=, max_seqlen=, cu_seqlens_k=, max_seqlen_k=) and the padded call
+    (reference seq2gene/modules/layers.py:437-439, 482-483)."""
+    from variantformer_amd.seq2gene.modules.layers import FlashAttLayer
+    from variantformer_amd.utils.synthetic import fill_state_dict
+    rnd = O.Rounding("bf16")
+    layer = FlashAttLayer(D, H, use_alibi=False, cross_attn=True)
+    fill_state_dict(layer, 23)
+    sd = _mha_sd(layer.MHA)
+    layer = layer.cuda()
+    q_lens, k_lens = [5, 201, 64], [300, 17, 1]
+    cu_q = torch.tensor(np.concatenate([[0], np.cumsum(q_lens)]), dtype=torch.int32)
+    cu_k = torch.tensor(np.concatenate([[0], np.cumsum(k_lens)]), dtype=torch.int32)
+    g = torch.Generator().manual_seed(5)
+    x, ctx = torch.randn(sum(q_lens), D, generator=g), torch.randn(sum(k_lens), D, generator=g)
+    want = O.mha_cross(rnd.r(x), rnd.r(ctx), sd, "", H, cu_q, cu_k, rnd)
+    got = layer.MHA(x.cuda(), ctx.cuda(), cu_seqlens=cu_q.cuda(), max_seqlen=max(q_lens), cu_seqlens_k=cu_k.cuda(),
+                    max_seqlen_k=max(k_lens))
+    assert erel(got.cpu().numpy(), want.numpy()) < 3e-3
+    got_l = layer(x.cuda(), ctx.cuda(), unpad_info={"cu_seqlens": cu_q.cuda(), "max_seqlen": max(q_lens)},
+                  context_unpad_info={"cu_seqlens": cu_k.cuda(), "max_seqlen": max(k_lens)})
+    assert torch.equal(got_l, got)
+    B, S, Sk = 2, 33, 70
+    xp, cp = torch.randn(B, S, D, generator=g), torch.randn(B, Sk, D, generator=g)
+    want_p = O.mha_cross(rnd.r(xp.reshape(-1, D)), rnd.r(cp.reshape(-1, D)), sd, "", H,
+                         torch.arange(0, B + 1, dtype=torch.int32) * S, torch.arange(0, B + 1, dtype=torch.int32) * Sk, rnd)
+    got_p = layer.MHA(xp.cuda(), cp.cuda())
+    assert got_p.shape == (B, S, D)
+    assert erel(got_p.cpu().numpy(), want_p.view(B, S, D).numpy()) < 3e-3
+    with pytest.raises(AssertionError, match="context_key_padding_mask"):
+        layer(xp.cuda(), cp.cuda(), src_key_padding_mask=torch.zeros(B, S, dtype=torch.bool).cuda())
+
+
+def test_attention_rows_without_keys_are_zero():
+    """A query sequence whose key sequence is empty gets zero rows (flash-attn's convention), not uninitialised memory."""
+    from variantformer_amd import ops
+    H, dh = 4, 48
+    q = torch.randn(70, H * dh, device="cuda").bfloat16()
+    kv = torch.randn(30, 2 * H * dh, device="cuda").bfloat16()
+    cu_q = torch.tensor([0, 20, 70], dtype=torch.int32, device="cuda")
+    cu_k = torch.tensor([0, 30, 30], dtype=torch.int32, device="cuda")
+    out = torch.full((70, H * dh), float("nan"), device="cuda").bfloat16()
+    ops.attn_varlen(q, kv[:, :H * dh], kv[:, H * dh:], cu_q, cu_k, 50, 30, H, dh, out=out)
+    assert torch.isfinite(out[:20].float()).all() and float(out[:20].float().abs().max()) > 0
+    assert float(out[20:].float().abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def test_variant_prediction_vs_reference_golden():
+    """pred_gene_exp, embd, gene_token_embedding and cre_token_embedding of the HIP path against
+    the outputs of the reference's own variant_prediction (tests/golden/vep_model.*, fp32 CPU run) and against the
+    same-rounding oracle; NaN positions give zero token embeddings."""
+    meta, arrays, sd, vb = load_vep_model_fixture()
+    model = build_model(meta["seq2reg"], meta["seq2gene"], sd).cuda()
+    model.vep = True
+    hp = O.Seq2RegHP.from_hparams(meta["seq2reg"])
+    ghp = O.Seq2GeneHP.from_kwargs(meta["seq2gene"])
+    out = model.predict_step(vb, 0)
+    orc = O.variant_prediction(vb, sd, hp, hp, ghp, rounding="bf16", share_cre_stream=True)
+    assert out["variant_type"] == meta["variant_type"]
+    for i in range(3):
+        assert erel(out["pred_gene_exp"][i], arrays[f"pos.pred_gene_exp_{i}"]) < NORTH_STAR_RTOL
+        assert erel(out["pred_gene_exp"][i], orc["pred_gene_exp"][i]) < NORTH_STAR_RTOL
+        for k, ref_tol in (("embd", 1e-2), ("gene_token_embedding", 1e-2), ("cre_token_embedding", 1e-2)):
+            got = out[k][i]
+            assert got.shape == arrays[f"pos.{k}_{i}"].shape
+            assert erel(got, arrays[f"pos.{k}_{i}"]) < ref_tol, (k, i)          # bf16 operands vs the fp32 reference run
+            assert erel(got, orc[k][i]) < 3e-3, (k, i)                         # same rounding points
+    # the three genotypes really differ at the variant's windows
+    assert np.abs(out["cre_token_embedding"][1] - out["cre_token_embedding"][0]).max() > 1e-3
+    assert np.abs(out["gene_token_embedding"][2] - out["gene_token_embedding"][0]).max() > 1e-3
+    nan_b = dict(vb, cre_token_position=torch.full((3, 1), float("nan")), gene_token_position=torch.full((3, 1), float("nan")))
+    out_nan = model.predict_step(nan_b, 0)
+    for i in range(3):
+        assert float(np.abs(out_nan["gene_token_embedding"][i]).max()) == 0.0
+        assert float(np.abs(out_nan["cre_token_embedding"][i]).max()) == 0.0
+        np.testing.assert_array_equal(out_nan["pred_gene_exp"][i], out["pred_gene_exp"][i])
+
+
+def test_variant_prediction_production_width_vs_oracle():
+    """Same outputs at production widths (D = 1536, H = 32, seq2reg d = 512), 3 modulator layers, 200-token windows."""
+    kw = seq2gene_kw(layers=3)
+    model = build_model(SEQ2REG_512, kw, seed=77)
+    sd = state_dict_cpu(model)
+    model = model.cuda()
+    model.vep = True
+    vb = make_vep_batch(515, 9, 6, TISSUES_54[:3], 200, cre_index=4, gene_index=(2, 2, 3))
+    out = model.predict_step(vb, 0)
+    hp = O.Seq2RegHP.from_hparams(SEQ2REG_512)
+    orc = O.variant_prediction(vb, sd, hp, hp, O.Seq2GeneHP.from_kwargs(kw), rounding="bf16", share_cre_stream=True)
+    for i in range(3):
+        assert erel(out["pred_gene_exp"][i], orc["pred_gene_exp"][i]) < NORTH_STAR_RTOL
+        for k in ("embd", "gene_token_embedding", "cre_token_embedding"):
+            assert erel(out[k][i], orc[k][i]) < 5e-3, (k, i)

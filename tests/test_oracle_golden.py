@@ -134,3 +134,25 @@ def test_oracle_matches_reference_with_non_shipped_options(name):
     np.testing.assert_allclose(col["first_cre_layer_out"].numpy(), arrays["first_cre_layer_out"], rtol=RTOL, atol=ATOL)
     with pytest.raises(AssertionError, match="de-duplicated"):
         O.predict_step(batch, sd, cre_hp, gene_hp, hp, share_cre_stream=True)
+
+
+@pytest.mark.parametrize("share", [False, True])
+def test_oracle_variant_prediction_matches_reference(share):
+    """VEP token-position outputs: the oracle's variant_prediction against the reference's own
+    variant_prediction run on CPU (tests/golden/vep_model.*), with positions and with NaN positions."""
+    from tests.conftest import load_vep_model_fixture
+    meta, arrays, sd, vb = load_vep_model_fixture()
+    hp = O.Seq2RegHP.from_hparams(meta["seq2reg"])
+    ghp = O.Seq2GeneHP.from_kwargs(meta["seq2gene"])
+    for tag, batch in (("pos", vb), ("nan", dict(vb, cre_token_position=torch.full((3, 1), float("nan")),
+                                                 gene_token_position=torch.full((3, 1), float("nan"))))):
+        out = O.variant_prediction(batch, sd, hp, hp, ghp, rounding=None, share_cre_stream=share)
+        assert out["variant_type"] == meta["variant_type"]
+        for k in ("pred_gene_exp", "embd", "gene_token_embedding", "cre_token_embedding"):
+            for i in range(3):
+                want = arrays[f"{tag}.{k}_{i}"]
+                assert out[k][i].shape == want.shape == (len(meta["tissues"]), want.shape[1])
+                np.testing.assert_allclose(out[k][i], want, rtol=2e-5, atol=2e-5)
+    # the gathers really moved: het / hom rows differ from ref at the variant's window, and the NaN run is all zeros
+    assert np.abs(arrays["pos.cre_token_embedding_1"] - arrays["pos.cre_token_embedding_0"]).max() > 1e-3
+    assert np.abs(arrays["nan.gene_token_embedding_2"]).max() == 0.0

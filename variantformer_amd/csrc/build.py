@@ -29,18 +29,29 @@ def _stale() -> bool:
     return any(os.path.getmtime(os.path.join(HERE, f)) > t for f in SOURCES + HEADERS)
 
 
-def build_lib(force: bool = False, verbose: bool = False) -> str:
+TUNING_LIB = os.path.join(HERE, "libvf_hip_tuning.so")
+
+
+def build_lib(force: bool = False, verbose: bool = False, tuning: bool = False) -> str:
+    """tuning=True builds libvf_hip_tuning.so with -DVF_TUNING: the diagnostic kernel variants and the tile sweep of
+    scripts/ (results of the diagnostic variants are meaningless).  The product library never contains them."""
+    if tuning:
+        return _build(TUNING_LIB, ["-DVF_TUNING"], verbose, "tuning_")
     if not force and not _stale():
         return LIB
+    return _build(LIB, [], verbose, "")
+
+
+def _build(LIB: str, defines: list, verbose: bool, obj_prefix: str) -> str:
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libvf_hip.so")
     objs = []
     procs = []
     for src in SOURCES:
-        obj = os.path.join(HERE, os.path.splitext(src)[0] + ".o")
+        obj = os.path.join(HERE, obj_prefix + os.path.splitext(src)[0] + ".o")
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result",
-               "-mllvm", "-amdgpu-mfma-vgpr-form=1"] + EXTRA_FLAGS.get(src, []) + \
+               "-mllvm", "-amdgpu-mfma-vgpr-form=1"] + defines + EXTRA_FLAGS.get(src, []) + \
               ["-c", os.path.join(HERE, src), "-o", obj]
         if verbose:
             cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
@@ -61,4 +72,4 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build_lib(force="--force" in sys.argv, verbose="-v" in sys.argv))
+    print(build_lib(force="--force" in sys.argv, verbose="-v" in sys.argv, tuning="--tuning" in sys.argv))

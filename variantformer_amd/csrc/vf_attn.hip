@@ -90,6 +90,15 @@ __device__ __forceinline__ bool block_coords(const AttnParams& P, int& seq, int&
     return true;
 }
 
+// out[tok0 .. tok0+n)[head h] = 0 (sequences without keys)
+template <int DH>
+__device__ __forceinline__ void zero_rows(const AttnParams& P, int tok0, int n, int h) {
+    constexpr int CPR = DH / 4;                       // 8-byte pieces (the output is only 8-byte aligned)
+    for (int i = threadIdx.x; i < n * CPR; i += blockDim.x)
+        *reinterpret_cast<u32x2_t*>(P.out + (int64_t)(tok0 + i / CPR) * P.o_stride + h * DH + (i % CPR) * 4) =
+            (u32x2_t){0u, 0u};
+}
+
 __device__ __forceinline__ s16x4_t lds_tr_read(const char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
 }
@@ -251,17 +260,23 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P) {
     const int q_tok0 = P.cu_q[seq], len_q = P.cu_q[seq + 1] - q_tok0;
     const int k_tok0 = P.cu_k[seq], len_k = P.cu_k[seq + 1] - k_tok0;
     const int qb0 = qblk * BQ;
-    if (qb0 >= len_q || len_k <= 0) return;           // block-uniform
+    if (qb0 >= len_q) return;                         // block-uniform
+    if (len_k <= 0) {                                 // no keys: the output rows are zeros (flash-attn convention)
+        zero_rows<DH>(P, q_tok0 + qb0, (len_q - qb0) < BQ ? (len_q - qb0) : BQ, h);
+        return;
+    }
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
 
     // ---- zero the K pad chunks (d >= DH) of both stages once; loads never touch them
-    if (CPR < 8) {
-        constexpr int PADC = 8 - CPR;
+    // (chunk CPR is the mask slot and belongs to write_lds alone: zeroing it here as well would race with the mask
+    // write of tile 0, which is issued by another wave without a barrier in between)
+    if (CPR < 7) {
+        constexpr int PADC = 7 - CPR;
         for (int i = tid; i < 2 * BKV * PADC; i += 256) {
             const int st = i / (BKV * PADC), rem = i % (BKV * PADC);
-            const int row = rem / PADC, c = CPR + rem % PADC;
+            const int row = rem / PADC, c = CPR + 1 + rem % PADC;
             *reinterpret_cast<u32x4_t*>(smem + st * STAGE + row * K_ROW_BYTES + ((c ^ ((row >> 1) & 7)) << 4)) =
                 (u32x4_t){0u, 0u, 0u, 0u};
         }
@@ -401,7 +416,11 @@ __global__ __launch_bounds__(256, (QG >= 2 ? 2 : 4)) void attn_short_kernel(Attn
     if (!block_coords(P, seq, h, qblk)) return;
     const int q_tok0 = P.cu_q[seq], len_q = P.cu_q[seq + 1] - q_tok0;
     const int k_tok0 = P.cu_k[seq], len_k = P.cu_k[seq + 1] - k_tok0;
-    if (len_q <= 0 || len_k <= 0) return;
+    if (len_q <= 0) return;
+    if (len_k <= 0) {
+        zero_rows<DH>(P, q_tok0, len_q, h);
+        return;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
     const int nkv = (len_k + BKV - 1) / BKV;
@@ -503,15 +522,16 @@ int launch_short(AttnParams P, int n_seq, int max_k, hipStream_t st) {
     const int k_rows = ((max_k + BKV - 1) / BKV) * BKV;
     const int lds = k_rows * (K_ROW_BYTES + VLayout<DH>::ROW);
     auto kern = attn_short_kernel<DH, QG, ALIBI>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[VF_MAX_DEVICES] = {};    // the attribute is per device (and per instantiation)
+    const int dev = vf_current_device();
+    if (dev < 0 || !attr_set[dev]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 256 * (K_ROW_BYTES + VLayout<DH>::ROW)) != hipSuccess) {
             (void)hipGetLastError();
             vf_set_error("vf_attn_varlen_fwd: cannot reserve LDS");
             return VF_ERR_LAUNCH;
         }
-        attr_set = true;
+        if (dev >= 0) attr_set[dev] = true;
     }
     const unsigned nblk = set_grid(P, n_seq, 1);
     hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), lds, st, P, k_rows);
@@ -535,18 +555,21 @@ int launch_attn(AttnParams P, int n_seq, int max_q, int max_k, hipStream_t st) {
     // 15% faster with 64-query blocks; the 10^4-query gene->CRE cross attention is 17% faster with 128-query blocks)
     if (max_q > 256 && (long)n_seq * P.H * ((max_q + 127) / 128) >= 1024) {
         const dim3 grid(set_grid(P, n_seq, (max_q + 127) / 128));
-        if (DH == 48 && !ALIBI) {                  // diagnostic builds (VF_ATTN_DBG=1..4), never used otherwise
+#ifdef VF_TUNING                                   // libvf_hip_tuning.so only (scripts/): ceiling-finding builds whose results are meaningless
+        if (DH == 48 && !ALIBI) {
             static const int dbg = getenv("VF_ATTN_DBG") ? atoi(getenv("VF_ATTN_DBG")) : 0;
-            if (dbg == 1) { hipLaunchKernelGGL((attn_fwd_kernel<48, 2, false, 1>), grid, dim3(256), 0, st, P); return VF_OK; }
-            if (dbg == 2) { hipLaunchKernelGGL((attn_fwd_kernel<48, 2, false, 2>), grid, dim3(256), 0, st, P); return VF_OK; }
-            if (dbg == 3) { hipLaunchKernelGGL((attn_fwd_kernel<48, 2, false, 3>), grid, dim3(256), 0, st, P); return VF_OK; }
-            if (dbg == 4) { hipLaunchKernelGGL((attn_fwd_kernel<48, 2, false, 4>), grid, dim3(256), 0, st, P); return VF_OK; }
+            if (dbg == 1) { hipLaunchKernelGGL((attn_fwd_kernel<48, 2, false, 1>), grid, dim3(256), 0, st, P); VF_CHECK_LAUNCH("vf_attn_varlen_fwd"); return VF_OK; }
+            if (dbg == 2) { hipLaunchKernelGGL((attn_fwd_kernel<48, 2, false, 2>), grid, dim3(256), 0, st, P); VF_CHECK_LAUNCH("vf_attn_varlen_fwd"); return VF_OK; }
+            if (dbg == 3) { hipLaunchKernelGGL((attn_fwd_kernel<48, 2, false, 3>), grid, dim3(256), 0, st, P); VF_CHECK_LAUNCH("vf_attn_varlen_fwd"); return VF_OK; }
+            if (dbg == 4) { hipLaunchKernelGGL((attn_fwd_kernel<48, 2, false, 4>), grid, dim3(256), 0, st, P); VF_CHECK_LAUNCH("vf_attn_varlen_fwd"); return VF_OK; }
         }
+#endif
         // 4 query groups per wave (256-query blocks) once that still leaves >= 8 blocks per CU: every K/V fragment read
         // feeds 4 MFMAs (gene->CRE cross attention at 8 genes: 948 vs 993 us; no gain at one gene, 1376 blocks)
         if (DH == 48 && !ALIBI && (long)n_seq * P.H * ((max_q + 255) / 256) >= 2048) {
             const dim3 grid4(set_grid(P, n_seq, (max_q + 255) / 256));
             hipLaunchKernelGGL((attn_fwd_kernel<48, 4, false>), grid4, dim3(256), 0, st, P);
+            VF_CHECK_LAUNCH("vf_attn_varlen_fwd");
             return VF_OK;
         }
         hipLaunchKernelGGL((attn_fwd_kernel<DH, 2, ALIBI>), grid, dim3(256), 0, st, P);

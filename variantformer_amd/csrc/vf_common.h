@@ -15,6 +15,15 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 
 void vf_set_error(const char* fmt, ...);
 
+// Per-device launch state (dynamic-LDS attributes) is indexed by the current HIP device; -1 = out of range / error,
+// in which case the caller simply redoes the (idempotent) setup.
+#define VF_MAX_DEVICES 64
+static inline int vf_current_device() {
+    int d = -1;
+    if (hipGetDevice(&d) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    return (d >= 0 && d < VF_MAX_DEVICES) ? d : -1;
+}
+
 #define VF_REQUIRE(cond, ...)                        \
     do {                                             \
         if (!(cond)) {                               \

@@ -411,6 +411,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_mfma_kernel(const unsigned
     }
 }
 
+#ifdef VF_TUNING   // measured without gain; kept for scripts/ in libvf_hip_tuning.so only
 // Persistent variant (BK = 64): a block walks output tiles bid, bid + grid, ... (same XCD-grouped order) and the
 // LDS-DMA ring runs straight across tile boundaries, so the first K-tiles of the next output tile are already in
 // flight while the current tile's last MFMAs and its epilogue execute.  Hides the per-tile prologue latency, which
@@ -589,6 +590,8 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_persist_kernel(const unsig
     }
 }
 
+#endif  // VF_TUNING
+
 // Shape-generic fallback (any K % 8 == 0): 64x64 tile, fp32 FMA out of LDS.  Same lane->output
 // ownership as the MFMA kernel so the epilogues are shared.  Only small/odd shapes come here.
 template <int EPI>
@@ -645,30 +648,34 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(const unsigned short*
     }
 }
 
+// The product library instantiates only the configurations pick_variant() can select.
 using CfgA = Cfg<128, 128, 2, 2, 2>;       // 64 KiB, 4 waves, 2 blocks/CU
 using CfgB = Cfg<256, 256, 2, 4, 2>;       // 128 KiB, 8 waves, wave tile 128x64
+using CfgE = Cfg<64, 64, 2, 2, 4>;         // 64 KiB, small-M shapes, 2 blocks/CU
+using CfgJ = Cfg<128, 128, 2, 2, 3, 32>;   // 48 KiB, 4 waves, BK=32, 2 tiles in flight, 3 blocks/CU
+#ifdef VF_TUNING                            // tile sweep of scripts/gemm_bench.py (all measured equal or slower)
 using CfgC = Cfg<256, 128, 4, 2, 3>;       // 144 KiB, 8 waves, wave tile 64x64, 2 tiles in flight
 using CfgD = Cfg<256, 256, 2, 4, 4, 32>;   // 128 KiB, 8 waves, BK=32, 3 tiles in flight
-using CfgE = Cfg<64, 64, 2, 2, 4>;         // 64 KiB, small-M shapes, 2 blocks/CU
 using CfgF = Cfg<128, 256, 2, 4, 3>;       // 144 KiB, 8 waves, wave tile 64x64
 using CfgG = Cfg<128, 128, 2, 2, 4, 32>;   // 64 KiB, 4 waves, BK=32, 3 tiles in flight, 2 blocks/CU
 using CfgH = Cfg<256, 128, 2, 2, 3, 32>;   // 72 KiB, 4 waves (wave tile 128x64), BK=32, 2 blocks/CU
 using CfgI = Cfg<128, 256, 2, 2, 3, 32>;   // 72 KiB, 4 waves (wave tile 64x128), BK=32, 2 blocks/CU
-using CfgJ = Cfg<128, 128, 2, 2, 3, 32>;   // 48 KiB, 4 waves, BK=32, 2 tiles in flight, 3 blocks/CU
+#endif
 
 template <class C, int EPI, int DBG = 0>
 int launch_cfg(const void* A, int64_t lda, const void* W, const float* bias, const float* res, int64_t ldr, void* out,
                int64_t ldo, int M, int N, int K, hipStream_t st) {
-    static bool attr_set = false;                 // per (config, epilogue) instantiation
+    static bool attr_set[VF_MAX_DEVICES] = {};    // per (config, epilogue) instantiation AND per device
     auto kern = gemm_mfma_kernel<C, EPI, DBG>;
-    if (!attr_set) {
+    const int dev = vf_current_device();
+    if (dev < 0 || !attr_set[dev]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 C::LDS_BYTES) != hipSuccess) {
             (void)hipGetLastError();
             vf_set_error("vf_gemm_bf16: cannot reserve %d bytes of LDS", C::LDS_BYTES);
             return VF_ERR_LAUNCH;
         }
-        attr_set = true;
+        if (dev >= 0) attr_set[dev] = true;
     }
     const int tiles_m = (M + C::BM - 1) / C::BM, tiles_n = (N + C::BN - 1) / C::BN;
     const int n_blocks = tiles_m * tiles_n;
@@ -679,6 +686,7 @@ int launch_cfg(const void* A, int64_t lda, const void* W, const float* bias, con
     return VF_OK;
 }
 
+#ifdef VF_TUNING
 template <class C, int EPI>
 int launch_persist(const void* A, int64_t lda, const void* W, const float* bias, const float* res, int64_t ldr, void* out,
                    int64_t ldo, int M, int N, int K, hipStream_t st) {
@@ -703,13 +711,13 @@ int launch_persist(const void* A, int64_t lda, const void* W, const float* bias,
     return VF_OK;
 }
 
-// Tile choice (measured on MI355X, scripts/gemm_bench.py, random data): the grouped 128x128 kernel wins or ties on
-// every large shape of this model (it sits at the LDS-DMA fill ceiling, ~13 TB/s chip-wide); grids with fewer than
-// one 128x128 tile per CU slot use 64x64 tiles so that all 256 CUs get work.  variant 0 = automatic; 1..9 force a
-// configuration (tuning / tests).
-// The persistent form (ring running across output tiles) is 5-9 % faster for the bf16 / GeGLU epilogues on grids of
-// more than two waves of tiles and slower for the fp32-residual epilogue (its prefetched residual loads and stores
-// share the vmcnt queue with the next tile's LDS-DMA).
+#endif  // VF_TUNING
+
+// Tile choice (measured on MI355X, scripts/gemm_bench.py, random data; the cost model inside reproduces every measured
+// ordering): grids with fewer than 256 128x128 tiles use 64x64 tiles so that all 256 CUs get work; otherwise 256x256
+// (one 8-wave block per CU, half the L2 -> LDS bytes per flop) against 128x128 (two 4-wave blocks per CU) by whole
+// waves of tiles; the K = 512 GeGLU of seq2reg takes a BK = 32 ring with three blocks per CU.
+// variant 0 = automatic; 1 / 2 / 5 / 12 force a configuration (tests).  Other numbers exist only under VF_TUNING.
 int pick_variant(int M, int N, int K, int epilogue) {
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
@@ -744,14 +752,15 @@ int launch_gemm(const void* A, int64_t lda, const void* W, const float* bias, co
     switch (variant) {
         case 1: return launch_cfg<CfgA, EPI>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
         case 2: return launch_cfg<CfgB, EPI>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
+        case 5: return launch_cfg<CfgE, EPI>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
+        case 12: return launch_cfg<CfgJ, EPI>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
+#ifdef VF_TUNING
         case 3: return launch_cfg<CfgC, EPI>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
         case 4: return launch_cfg<CfgD, EPI>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
-        case 5: return launch_cfg<CfgE, EPI>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
         case 6: return launch_cfg<CfgF, EPI>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
         case 7: return launch_cfg<CfgG, EPI>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
         case 8: return launch_cfg<CfgH, EPI>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
         case 9: return launch_cfg<CfgI, EPI>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
-        case 12: return launch_cfg<CfgJ, EPI>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
         case 104: if (EPI == VF_EPI_BF16) return launch_cfg<CfgA, VF_EPI_BF16, 4>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st); break;
         case 103: if (EPI == VF_EPI_BF16) return launch_cfg<CfgA, VF_EPI_BF16, 3>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st); break;
         case 204: if (EPI == VF_EPI_BF16) return launch_cfg<CfgB, VF_EPI_BF16, 4>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st); break;
@@ -764,6 +773,7 @@ int launch_gemm(const void* A, int64_t lda, const void* W, const float* bias, co
         case 402: if (EPI == VF_EPI_BF16) return launch_cfg<CfgD, VF_EPI_BF16, 2>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st); break;
         case 10: return launch_persist<CfgA, EPI>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
         case 11: return launch_persist<CfgE, EPI>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
+#endif  // VF_TUNING
         default: break;
     }
     vf_set_error("vf_gemm_bf16_ex: unknown variant %d", variant);

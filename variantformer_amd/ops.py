@@ -26,20 +26,28 @@ class KernelTimer:
         self.records = {}
         self.detail = detail          # also key records by launch geometry (scripts/shape_breakdown.py)
 
-    def time(self, name: str, flops: float, nbytes: float, launch, geometry: str = ""):
+    def time(self, name: str, flops, nbytes: float, launch, geometry: str = "", family: str = ""):
+        """flops: a number, or a zero-argument callable evaluated in summary() (attention: the per-sequence lengths
+        live on the device, and reading them here would put a host sync between the launches being timed)."""
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         out = launch()
         b.record()
-        self.records.setdefault(name, []).append((a, b, flops, nbytes))
+        rec = [a, b, flops, nbytes]
+        self.records.setdefault(name, []).append(rec)
+        if family:
+            self.records.setdefault(f"{name}:{family}", []).append(rec)
         if self.detail and geometry:
-            self.records.setdefault(f"{name}[{geometry}]", []).append((a, b, flops, nbytes))
+            self.records.setdefault(f"{name}[{geometry}]", []).append(rec)
         return out
 
     def summary(self) -> dict:
         torch.cuda.synchronize()
         out = {}
         for name, recs in self.records.items():
+            for r in recs:
+                if callable(r[2]):
+                    r[2] = float(r[2]())
             ms = sum(a.elapsed_time(b) for a, b, _, _ in recs)
             out[name] = {"launches": len(recs), "total_ms": ms, "flops": sum(r[2] for r in recs),
                          "bytes": sum(r[3] for r in recs)}
@@ -47,12 +55,39 @@ class KernelTimer:
 
 
 TIMER: KernelTimer | None = None
+_SCOPE = ""          # default family label of launches made inside a `scope(...)` block (timer bookkeeping only)
+
+
+class scope:
+    """with ops.scope("seq2reg"): ...  -- launches without an explicit family are recorded under this label."""
+
+    def __init__(self, name: str):
+        self.name = name
+
+    def __enter__(self):
+        global _SCOPE
+        self.prev, _SCOPE = _SCOPE, self.name
+
+    def __exit__(self, *exc):
+        global _SCOPE
+        _SCOPE = self.prev
+        return False
 
 
 def _dev(*ts):
+    """Every tensor must live on the CURRENT device: the C ABI launches on torch's current stream and never switches
+    devices (one process per GPU; use torch.cuda.set_device / torch.cuda.device(...) around calls otherwise)."""
+    cur = None
     for t in ts:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise _lib.VFError("variantformer_amd ops need tensors on the GPU (no CPU fallback)")
+        if cur is None:
+            cur = torch.cuda.current_device()
+        if t.device.index != cur:
+            raise _lib.VFError(f"tensor on cuda:{t.device.index} but the current device is cuda:{cur}: "
+                               "libvf_hip launches on the current device's stream (wrap the call in torch.cuda.device)")
 
 
 def _ptr(t):
@@ -68,7 +103,8 @@ def _dt(dtype) -> int:
 
 
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None, epilogue: int,
-         residual: torch.Tensor | None = None, out: torch.Tensor | None = None, variant: int = 0) -> torch.Tensor:
+         residual: torch.Tensor | None = None, out: torch.Tensor | None = None, variant: int = 0,
+         family: str = "") -> torch.Tensor:
     """out = epilogue(a[M,K] @ w[N,K]^T + bias).  a, w bf16 (a may be a row-strided view).
     variant != 0 forces a tile configuration (vf_gemm_bf16_ex; tuning / tests only)."""
     _dev(a, w, bias, residual, out)
@@ -100,7 +136,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None, epilogue: 
                                    ldo, M, N, K, epilogue, _stream()), "vf_gemm_bf16")
     if TIMER is not None:
         nbytes = 2.0 * (M * K + N * K) + out.numel() * out.element_size() + (0 if residual is None else 4.0 * M * N)
-        TIMER.time("gemm", 2.0 * M * N * K, nbytes, launch, f"M={M} N={N} K={K} epi={epilogue}")
+        TIMER.time("gemm", 2.0 * M * N * K, nbytes, launch, f"M={M} N={N} K={K} epi={epilogue}", family or _SCOPE)
     else:
         launch()
     return out
@@ -119,7 +155,8 @@ def pack_geglu_rows(w: torch.Tensor, bias: torch.Tensor | None):
 
 def attn_varlen(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_q: torch.Tensor, cu_k: torch.Tensor | None,
                 max_q: int, max_k: int, n_heads: int, head_dim: int, slopes: torch.Tensor | None = None,
-                scale: float | None = None, out: torch.Tensor | None = None, q_at_start: bool = False) -> torch.Tensor:
+                scale: float | None = None, out: torch.Tensor | None = None, q_at_start: bool = False,
+                family: str = "") -> torch.Tensor:
     """q [tq, >=H*dh] / k, v [tk, >=H*dh] bf16 row-strided views whose first H*dh columns are the heads.
     q_at_start: ALiBi positions of the queries count from the start of the key sequence (default: flash-attn's
     end alignment)."""
@@ -141,8 +178,12 @@ def attn_varlen(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_q: torch.T
                                              cu_q.numel() - 1, int(max_q), int(max_k), n_heads, head_dim, _ptr(slopes),
                                              float(scale), _stream()), "vf_attn_varlen_fwd")
     if TIMER is not None:
-        # flops need the per-sequence lengths; the caller may attach them (attn_work), else a bound from max lengths
-        TIMER.time("attn", 0.0, 2.0 * D * (2 * q.shape[0] + 2 * k.shape[0]), launch)
+        def flops():       # 4 * sum_seq(len_q * len_k) * H * dh (QK^T and PV), evaluated after the timed replay
+            lq = (cu_q[1:] - cu_q[:-1]).double()
+            lk = lq if cu_k is None else (cu_k[1:] - cu_k[:-1]).double()
+            return 4.0 * float((lq * lk).sum().item()) * D
+        TIMER.time("attn", flops, 2.0 * D * (2 * q.shape[0] + 2 * k.shape[0]), launch,
+                   f"H={n_heads} dh={head_dim} max_q={int(max_q)} max_k={int(max_k)}", family or _SCOPE)
     else:
         launch()
     return out
@@ -155,8 +196,14 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out_dtyp
     rows, D = x.shape
     if out is None:
         out = torch.empty((rows, D), dtype=out_dtype, device=x.device)
-    check(_lib.load().vf_layernorm(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), rows, D, eps,
-                                   _dt(out.dtype), int(gelu), _stream()), "vf_layernorm")
+
+    def launch():
+        check(_lib.load().vf_layernorm(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), rows, D, eps,
+                                       _dt(out.dtype), int(gelu), _stream()), "vf_layernorm")
+    if TIMER is not None:
+        TIMER.time("layernorm", 0.0, float(rows) * D * (4 + out.element_size()), launch, f"D={D}", _SCOPE)
+    else:
+        launch()
     return out
 
 

@@ -119,8 +119,9 @@ def modulator_forward_packed(ctx_embedding, cre_layers, gene_layers, cre_x, gene
     side = _side_stream(cre_x.device) if overlap else None
     if overlap:
         side.wait_stream(main)                      # inputs (cre_x, labels, cu arrays) were produced on `main`
-    gene = gene_layers[0].forward_packed(gene, cu_gene_self, max_gene, context=cre, cu_ctx=ck, max_ctx=max_cre,
-                                         cu_cross_q=cq, max_cross_q=mq)
+    with ops.scope("gene_stream"):
+        gene = gene_layers[0].forward_packed(gene, cu_gene_self, max_gene, context=cre, cu_ctx=ck, max_ctx=max_cre,
+                                             cu_cross_q=cq, max_cross_q=mq)
     if use_res:                                     # gene-stream input added back after every gene layer (:253-254)
         gene = ops.add_rows(gene, gene_x)
     for i in range(n - 1):
@@ -133,18 +134,20 @@ def modulator_forward_packed(ctx_embedding, cre_layers, gene_layers, cre_x, gene
             cre.record_stream(main)                 # allocated on `side`, read by the gene layer on `main`
             main.wait_event(done)
         else:
-            kv = None if ctx_embedding is None else ops.gather_rows_bf16(_context_kv_table(ctx_embedding, cre_layers[i]), labels)
-            cre = cre_layers[i].forward_packed(cre, cu_cre, max_cre, context_kv=kv, cu_ctx=cu_cre, max_ctx=max_cre)
-        if final_rows is not None and i + 1 == n - 1:
-            # last gene layer: only the registry rows are consumed downstream -> compact [R, D] result
-            rows, cu_rows, cu_cross_rows, max_cross_rows = final_rows
-            gene = gene_layers[i + 1].forward_packed_rows(gene, cu_gene_self, max_gene, rows, cu_rows, cre, ck, max_cre,
-                                                          cu_cross_rows, max_cross_rows)
-        else:
-            gene = gene_layers[i + 1].forward_packed(gene, cu_gene_self, max_gene, context=cre, cu_ctx=ck,
-                                                     max_ctx=max_cre, cu_cross_q=cq, max_cross_q=mq)
-            if use_res:                             # :284-285
-                gene = ops.add_rows(gene, gene_x)
+            with ops.scope("cre_stream"):
+                kv = None if ctx_embedding is None else ops.gather_rows_bf16(_context_kv_table(ctx_embedding, cre_layers[i]), labels)
+                cre = cre_layers[i].forward_packed(cre, cu_cre, max_cre, context_kv=kv, cu_ctx=cu_cre, max_ctx=max_cre)
+        with ops.scope("gene_stream"):
+            if final_rows is not None and i + 1 == n - 1:
+                # last gene layer: only the registry rows are consumed downstream -> compact [R, D] result
+                rows, cu_rows, cu_cross_rows, max_cross_rows = final_rows
+                gene = gene_layers[i + 1].forward_packed_rows(gene, cu_gene_self, max_gene, rows, cu_rows, cre, ck, max_cre,
+                                                              cu_cross_rows, max_cross_rows)
+            else:
+                gene = gene_layers[i + 1].forward_packed(gene, cu_gene_self, max_gene, context=cre, cu_ctx=ck,
+                                                         max_ctx=max_cre, cu_cross_q=cq, max_cross_q=mq)
+                if use_res:                             # :284-285
+                    gene = ops.add_rows(gene, gene_x)
     return gene, cre
 
 
@@ -175,6 +178,12 @@ class CombinedModulator(nn.Module):
             cross_alibi=cross_alibi, flash_attn_3=flash_attn_3)
         self.cre_layers = nn.ModuleList([mk_cre() for _ in range(num_layers - 1)])
         self.gene_layers = nn.ModuleList([mk() for _ in range(num_layers)])
+        for stream, layers in (("cre", self.cre_layers), ("gene", self.gene_layers)):     # KernelTimer families
+            for l in layers:
+                if hasattr(l, "mixer"):
+                    l.mixer.MHA.family = f"{stream}_self"
+                if hasattr(l, "crossMHA"):
+                    l.crossMHA.MHA.family = "cre_ctx_cross" if stream == "cre" else "gene_cre_cross"
 
     def forward_packed(self, cre_x, gene_x, labels, cu_cre, max_cre, cu_gene_self, max_gene, cu_gene_cross=None,
                        max_gene_cross=None, cu_cre_for_gene=None, final_rows=None):

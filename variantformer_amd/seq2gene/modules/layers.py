@@ -100,6 +100,7 @@ class MHA(nn.Module):
         else:
             self.Wqkv = nn.Linear(embed_dim, 3 * embed_dim)
         self.out_proj = nn.Linear(embed_dim, embed_dim)
+        self.family = "cross" if cross_attn else "self"      # label of this module's launches in ops.KernelTimer
         if use_alibi:
             self.register_buffer("alibi_slopes", get_alibi_slopes(num_heads).float(), persistent=False)
         else:
@@ -118,11 +119,11 @@ class MHA(nn.Module):
             w, b = packed_linear(self.Wq)
             q = ops.gemm(x_bf16, w, b, ops.EPI_BF16)
             return ops.attn_varlen(q, kv_bf16[:, :D], kv_bf16[:, D:], cu_q, cu_k, max_q, max_k, self.num_heads,
-                                   self.head_dim, self.alibi_slopes)
+                                   self.head_dim, self.alibi_slopes, family=self.family)
         w, b = packed_linear(self.Wqkv)
         qkv = ops.gemm(x_bf16, w, b, ops.EPI_BF16)
         return ops.attn_varlen(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], cu_q, None, max_q, max_q,
-                               self.num_heads, self.head_dim, self.alibi_slopes)
+                               self.num_heads, self.head_dim, self.alibi_slopes, family=self.family)
 
     def fused(self, x_bf16, residual_f32, cu_q, max_q, kv_bf16=None, cu_k=None, max_k=None) -> torch.Tensor:
         """fp32 [tokens, D] = out_proj(attention(x)) + residual (one GEMM epilogue)."""
@@ -252,7 +253,7 @@ class ContextFlashAttentionEncoderLayer(nn.Module):
         hq = ops.gather_rows_bf16(h, rows)
         q = ops.gemm(hq, w[:D], None if b is None else b[:D], ops.EPI_BF16)             # [R, D]
         a = ops.attn_varlen(q, kv[:, :D], kv[:, D:], cu_rows, cu_src, 1, max_src, mha.num_heads, mha.head_dim,
-                            mha.alibi_slopes, q_at_start=True)
+                            mha.alibi_slopes, q_at_start=True, family=mha.family + "_registry_rows")
         src_rows = ops.gather_rows_f32(src, None, rows)
         wo, bo = packed_linear(mha.out_proj)
         x1 = ops.gemm(a, wo, bo, ops.EPI_RES_F32, residual=src_rows)

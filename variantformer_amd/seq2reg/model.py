@@ -88,11 +88,12 @@ class Seq2RegPredictor(nn.Module):
         W, L = ids.shape
         if 0 < max_len < L:
             L = max_len
-        cu = ops.mask_to_cu_seqlens(pad)
-        x = ops.embed_pack(ids, pad, cu, self.token_embedding.weight, self._pos_table(ids.device), n_tokens)
-        for layer in self.transformer_encoder:
-            x = layer.forward_packed(x, cu, L)
-        return ops.segment_mean(x, cu, out_dtype)
+        with ops.scope("seq2reg"):
+            cu = ops.mask_to_cu_seqlens(pad)
+            x = ops.embed_pack(ids, pad, cu, self.token_embedding.weight, self._pos_table(ids.device), n_tokens)
+            for layer in self.transformer_encoder:
+                x = layer.forward_packed(x, cu, L)
+            return ops.segment_mean(x, cu, out_dtype)
 
     def forward(self, x, padding_mask, tissue_vector=None, context=None, only_embed=False, precision=torch.float32):
         """x int64 [b, strands, L]; padding_mask bool [b, strands, L] (True = pad) -> fp32 [b, strands, d]

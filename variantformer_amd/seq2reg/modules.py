@@ -19,6 +19,7 @@ class FlashTransformerLayer(nn.Module):
     def __init__(self, d_model, nhead, hidden_dim=2048, dropout=0.1, use_alibi=False, mlp_dout=0.1):
         super().__init__()
         self.MHA = MHA(d_model, nhead, dropout=dropout, use_flash_attn=True, use_alibi=use_alibi)
+        self.MHA.family = "seq2reg_self"
         self.norm1 = nn.LayerNorm(d_model)
         self.norm2 = nn.LayerNorm(d_model)
         self.linear_geglu_1 = nn.Linear(d_model, hidden_dim)

@@ -170,6 +170,34 @@ def make_batch(seed: int, n_cres, n_chunks, tissues_per_gene, token_length: int 
     return collate(genes)
 
 
+def make_vep_batch(seed: int, n_cre: int, n_chunks: int, tissues, token_length: int = 200, cre_index: int = 2,
+                   gene_index=(1, 1, 2), **kw) -> dict:
+    """ref / het / hom batch in the layout the reference's VEPDataset.load_data returns
+    (datasets/vepdataset.py:765-799): three samples of one gene that differ in the CRE window `cre_index` and in the
+    gene chunks `gene_index[g]` (a few token ids changed, as an IUPAC substitution does after re-tokenisation), plus
+    `cre_token_position` / `gene_token_position` float tensors [3, 1] (create_batch, :335-336)."""
+    base = make_gene(seed * 1000003, n_cre, n_chunks, tissues, token_length, **kw)
+    genes = []
+    for g in range(3):
+        s = {k: v.clone() for k, v in base.items()}
+        if g > 0:
+            cre_valid = int((~s["cre_attention_masks"][cre_index, 0]).sum())
+            for j, pos in enumerate(randint(2, 0, max(1, cre_valid), seed, 20 + g)):
+                s["cre_sequences"][cre_index, 0, int(pos)] = FIRST_REAL_TOKEN + (7 * g + 3 * j) % 14
+            gi = gene_index[g]
+            g_valid = int((~s["gene_attention_masks"][gi, 0]).sum())
+            for j, pos in enumerate(randint(2, 0, max(1, g_valid), seed, 30 + g)):
+                s["gene_embeddings"][gi, 0, int(pos)] = FIRST_REAL_TOKEN + (5 * g + j) % 14
+        genes.append(s)
+    b = collate(genes)
+    return {"cre_sequences": b["cre_sequences"], "cre_attention_masks": b["cre_attention_masks"],
+            "tissue_context": b["tissue_context"], "ref_labels": b["ref_cre_labels"], "strand": b["strand_val"],
+            "gene_embeddings": b["gene_embeddings"], "gene_attention_masks": b["gene_attention_masks"],
+            "cre_token_position": torch.tensor([[float(cre_index)]] * 3),
+            "gene_token_position": torch.tensor([[float(i)] for i in gene_index]),
+            "variant_type": "SNP"}
+
+
 def cfg3_gene_sizes(n_genes: int, seed: int = 20251205):
     """SURVEY §8d cfg 3: N ~ lognormal(median 600, sigma 0.6) clipped [40, 2048],
     C ~ U{20..200}."""
