@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define VF_ABI_VERSION 1
+#define VF_ABI_VERSION 2
 
 enum vf_status {
     VF_OK = 0,
@@ -31,7 +31,7 @@ enum vf_status {
     VF_ERR_LAUNCH = 2         /* hipGetLastError() after the launch was not hipSuccess */
 };
 
-enum vf_dtype { VF_F32 = 0, VF_BF16 = 1 };
+enum vf_dtype { VF_F32 = 0, VF_BF16 = 1, VF_F16 = 2 };   /* VF_F16 = IEEE half (torch.float16) */
 
 /* Epilogues of vf_gemm_bf16 (acc = fp32 accumulator of A @ W^T, + bias[n] always) */
 enum vf_epilogue {
@@ -60,12 +60,23 @@ int vf_gemm_bf16(const void* A, int64_t lda, const void* W, const float* bias,
                  int M, int N, int K, int epilogue, void* stream);
 
 /* Same as vf_gemm_bf16 with an explicit tile configuration (tuning and tests): variant 0 = automatic
- * choice (what vf_gemm_bf16 does), 1..7 = fixed configurations (see vf_gemm.hip, CfgA..CfgG). */
+ * choice (what vf_gemm_bf16 does); 1 = 128x128, 5 = 64x64, 20 = two-group 256x256 tile (see vf_gemm.hip). */
 int vf_gemm_bf16_ex(const void* A, int64_t lda, const void* W, const float* bias,
                     const float* residual, int64_t ldr, void* out, int64_t ldo,
                     int M, int N, int K, int epilogue, int variant, void* stream);
 
-/* Permute rows of a [2F, K] bf16 weight (and its fp32 bias, may be NULL) into the VF_EPI_GEGLU_BF16
+/* fp16-operand twins (IEEE half in / out where the bf16 entry has bf16, fp32 accumulation, same tiles, same MFMA rate):
+ * the reference's `16-mixed` / fp16 flash-attn path (seq2gene/modules/layers.py:102-125 casts the MHA modules and
+ * their inputs to fp16 when precision is fp32; utils/functions.py:12-32 maps "16-mixed" to fp16 autocast;
+ * BASELINE.json configs[4] "fp16 with fp32 accumulate"). */
+int vf_gemm_f16(const void* A, int64_t lda, const void* W, const float* bias,
+                const float* residual, int64_t ldr, void* out, int64_t ldo,
+                int M, int N, int K, int epilogue, void* stream);
+int vf_gemm_f16_ex(const void* A, int64_t lda, const void* W, const float* bias,
+                   const float* residual, int64_t ldr, void* out, int64_t ldo,
+                   int M, int N, int K, int epilogue, int variant, void* stream);
+
+/* Permute rows of a [2F, K] 16-bit (bf16 or fp16) weight (and its fp32 bias, may be NULL) into the VF_EPI_GEGLU_BF16
  * layout (one-time weight repack at checkpoint load). */
 int vf_pack_geglu_rows(const void* W, const float* bias, void* W_out, float* bias_out,
                        int two_f, int K, void* stream);
@@ -78,8 +89,8 @@ int vf_pack_geglu_rows(const void* W, const float* bias, void* W_out, float* bia
  * q/k/v point at the first head of token 0 (so a packed [tokens,3,H,dh] buffer is passed as
  * q=base, k=base+H*dh, v=base+2*H*dh with row stride 3*H*dh).  bf16 in/out, fp32 softmax and
  * accumulation.  dh in {32, 48, 64}.  cu_seqlens_*: int32 [n_seq+1] device arrays.
- * alibi_slopes: fp32 [H] device array or NULL.  Sequences with 0 queries or 0 keys are skipped
- * (their output rows are left untouched). */
+ * alibi_slopes: fp32 [H] device array or NULL.  Sequences with 0 queries are skipped; the rows of
+ * queries whose key sequence is empty are written as zeros (flash-attn's convention). */
 int vf_attn_varlen_fwd(const void* q, const void* k, const void* v, void* out,
                        int64_t q_stride, int64_t k_stride, int64_t v_stride, int64_t o_stride,
                        const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k,
@@ -96,8 +107,20 @@ int vf_attn_varlen_fwd_qstart(const void* q, const void* k, const void* v, void*
                               int n_seq, int max_seqlen_q, int max_seqlen_k,
                               int H, int dh, const float* alibi_slopes, float scale, void* stream);
 
+/* fp16 twins of the two attention entries (Q, K, V, P and the output in IEEE half; fp32 scores / softmax). */
+int vf_attn_varlen_fwd_f16(const void* q, const void* k, const void* v, void* out,
+                           int64_t q_stride, int64_t k_stride, int64_t v_stride, int64_t o_stride,
+                           const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k,
+                           int n_seq, int max_seqlen_q, int max_seqlen_k,
+                           int H, int dh, const float* alibi_slopes, float scale, void* stream);
+int vf_attn_varlen_fwd_qstart_f16(const void* q, const void* k, const void* v, void* out,
+                                  int64_t q_stride, int64_t k_stride, int64_t v_stride, int64_t o_stride,
+                                  const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k,
+                                  int n_seq, int max_seqlen_q, int max_seqlen_k,
+                                  int H, int dh, const float* alibi_slopes, float scale, void* stream);
+
 /* y = LayerNorm(x) * gamma + beta over the last dim (eps inside sqrt, biased variance), optional
- * exact-erf GELU, output bf16 or fp32.  x fp32 [rows, D], D % 4 == 0, D <= 8192.
+ * exact-erf GELU, output fp32, bf16 or fp16 (out_dtype = vf_dtype).  x fp32 [rows, D], D % 4 == 0, D <= 8192.
  * Replaces nn.LayerNorm (seq2reg/modules.py:143-144, layers.py:75-77, head layers.py:1080-1081). */
 int vf_layernorm(const float* x, const float* gamma, const float* beta, void* out,
                  int64_t rows, int D, float eps, int out_dtype, int gelu, void* stream);
@@ -118,18 +141,18 @@ int vf_embed_pack(const int64_t* ids, const uint8_t* pad, const int32_t* cu,
 int vf_mask_to_cu_seqlens(const uint8_t* pad, int32_t* cu, int W, int L, void* stream);
 
 /* Masked mean over each window's packed tokens: out[w,:] = mean(x[cu[w]:cu[w+1], :]) (NaN if the
- * window is empty, as the reference's 0/0).  x fp32 [n_tok, d]; out bf16 or fp32 [W, d].
+ * window is empty, as the reference's 0/0).  x fp32 [n_tok, d]; out fp32, bf16 or fp16 [W, d].
  * Replaces seq2reg/model.py:263-267. */
 int vf_segment_mean(const float* x, const int32_t* cu, void* out, int W, int d, int out_dtype, void* stream);
 
 /* Row gather from two fp32 sources: out[i,:] = idx[i] >= 0 ? a[idx[i],:] : b[-idx[i]-1,:].
- * out fp32 or bf16 [n, d].  Replaces MultiRegistry/prepare_input concat (layers.py:508-521,
+ * out fp32, bf16 or fp16 [n, d].  Replaces MultiRegistry/prepare_input concat (layers.py:508-521,
  * model_combined_modulator.py:357-366), nn.Embedding lookups (:166-168), pool_outputs row 0
  * (:391-392) and pad_input/unpad_input row moves [3p]. */
 int vf_gather_rows_f32(const float* a, const float* b, const int64_t* idx, void* out,
                        int64_t n, int d, int out_dtype, void* stream);
 
-/* bf16 row gather: out[i,:] = src[idx[i],:], ld in elements. */
+/* 16-bit (bf16 or fp16) row gather: out[i,:] = src[idx[i],:], ld in elements. */
 int vf_gather_rows_bf16(const void* src, int64_t ld_src, const int64_t* idx, void* out, int64_t ld_out,
                         int64_t n, int d, void* stream);
 
@@ -146,8 +169,9 @@ int vf_segment_max(const float* x, const int32_t* cu_seqlens, float* out, int W,
 int vf_add_rows_f32(const float* a, const int64_t* idx_a, const float* b, const int64_t* idx_b, float* out, int64_t n,
                     int d, void* stream);
 
-/* fp32 -> bf16 (round to nearest even), n elements. */
+/* fp32 -> bf16 / fp16 (round to nearest even), n elements. */
 int vf_cast_f32_bf16(const float* x, void* out, int64_t n, void* stream);
+int vf_cast_f32_f16(const float* x, void* out, int64_t n, void* stream);
 
 /* ---- host-side (CPU) byte-pair encoder: SURVEY.md section 8f row 1 ------------------------------------------
  * Replaces the HuggingFace `tokenizers` BPE model (Rust, third party) as used by utils/seq.py:BPEEncoder.encode

@@ -26,6 +26,8 @@ Two arithmetic modes:
                    rounded to bf16 exactly where the HIP kernels round them (DESIGN.md
                    "Rounding points").  This is the checker for the GPU path: kernels and
                    oracle then differ only by accumulation order and exp/erf ulps.
+  rounding="fp16"  the same rounding points with IEEE half (the kernels' fp16-operand mode,
+                   the reference's 16-mixed / fp16 flash-attn path).
 """
 from __future__ import annotations
 
@@ -94,13 +96,13 @@ class Rounding:
     """Rounding policy: where the HIP kernels store bf16, the oracle rounds to bf16."""
 
     def __init__(self, mode: str | None):
-        assert mode in (None, "bf16")
+        assert mode in (None, "bf16", "fp16")
         self.mode = mode
 
     def r(self, x: torch.Tensor) -> torch.Tensor:
         if self.mode is None:
             return x
-        return x.to(torch.bfloat16).to(torch.float32)
+        return x.to(torch.bfloat16 if self.mode == "bf16" else torch.float16).to(torch.float32)
 
 
 def linear(x, w, b, rnd: Rounding):

@@ -2,7 +2,10 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from variantformer_amd import ops
+from variantformer_amd import ops, _lib
+if os.environ.get("VF_TUNING_LIB"):          # diagnostic / sweep variants live in libvf_hip_tuning.so only
+    from variantformer_amd.csrc.build import TUNING_LIB
+    _lib.load(TUNING_LIB)
 
 SHAPES = [  # (name, M, N, K, epilogue)
     ("gene Wqkv", 10854, 4608, 1536, ops.EPI_BF16), ("gene out_proj", 10854, 1536, 1536, ops.EPI_RES_F32),
@@ -21,7 +24,7 @@ SHAPES = [  # (name, M, N, K, epilogue)
     ("cre kv", 1024, 3072, 1536, ops.EPI_BF16), ("cre geglu2", 1024, 1536, 1024, ops.EPI_RES_F32),
     ("cre8 Wqkv", 8192, 4608, 1536, ops.EPI_BF16), ("cre8 out_proj", 8192, 1536, 1536, ops.EPI_RES_F32),
 ]
-variants = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else "1,2,3,4,5,6,7".split(","))]
+variants = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else "1,2,20".split(","))]
 rounds = 5
 only = sys.argv[2] if len(sys.argv) > 2 else None
 print("%-14s %7s %5s %5s | " % ("shape", "M", "N", "K") + " ".join("v%d TF/s" % v for v in variants))

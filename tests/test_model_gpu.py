@@ -328,3 +328,47 @@ def test_run_to_run_determinism_and_sequence_permutation():
     c = model.predict_step(pb, 0)
     for new, old in enumerate(perm):
         np.testing.assert_allclose(c["pred_gene_exp"][new], a["pred_gene_exp"][old], rtol=1e-5, atol=1e-6)
+
+
+def test_fp16_operand_mode_vs_oracle_and_reference_golden(golden):
+    """precision "16-mixed" (BASELINE configs[4]: fp16 operands, fp32 accumulation; reference utils/functions.py:12-32,
+    seq2gene/modules/layers.py:102-125): HIP vs the oracle with fp16 rounding points and vs the reference's fp32 fixture
+    (fp16 carries 3 more mantissa bits than bf16, so it must sit closer to the fp32 run than the bf16 mode does)."""
+    import types
+    meta, arrays, sd, batch = golden
+    model = build_model(meta["seq2reg"], meta["seq2gene"], sd).cuda()
+    bf = model.predict_step(batch, 0)
+    model.trainer = types.SimpleNamespace(precision="16-mixed")
+    assert model.operand_dtype() == torch.float16
+    out = model.predict_step(batch, 0)
+    cre_hp, gene_hp, hp = _hps(meta)
+    orc = O.predict_step(batch, sd, cre_hp, gene_hp, hp, rounding="fp16", share_cre_stream=True)
+    e16 = ebf = 0.0
+    for i in range(len(meta["n_cres"])):
+        assert _erel(out["pred_gene_exp"][i], orc["pred_gene_exp"][i]) < NORTH_STAR_RTOL
+        assert _erel(out["embeddings"][i], orc["embeddings"][i]) < 3 * NORTH_STAR_RTOL
+        assert _erel(out["pred_gene_exp"][i], arrays[f"pred_gene_exp_{i}"]) < NORTH_STAR_RTOL
+        e16 = max(e16, _erel(out["embeddings"][i], arrays[f"embeddings_{i}"]))
+        ebf = max(ebf, _erel(bf["embeddings"][i], arrays[f"embeddings_{i}"]))
+    print(f"[fp16 mode] embedding error vs the reference fp32 fixture: fp16 operands {e16:.2e}, bf16 operands {ebf:.2e}")
+    assert e16 < ebf
+    model.trainer = types.SimpleNamespace(precision="bf16-mixed")
+    again = model.predict_step(batch, 0)
+    assert np.array_equal(again["pred_gene_exp"][0], bf["pred_gene_exp"][0])     # weight repack follows the precision
+
+
+def test_fp16_operand_mode_production_width_vs_oracle():
+    kw = seq2gene_kw(layers=3)
+    model = build_model(SEQ2REG_512, kw, seed=4242)
+    sd = state_dict_cpu(model)
+    model = model.cuda()
+    model.precision = "16-mixed"
+    batch = make_batch(99, [7, 40, 1], [3, 9, 2], [[7], TISSUES_54[:5], [62, 10]], 200)
+    out = model.predict_step(batch, 3)
+    hp = O.Seq2RegHP.from_hparams(SEQ2REG_512)
+    orc = O.predict_step(batch, sd, hp, hp, O.Seq2GeneHP.from_kwargs(kw), rounding="fp16", share_cre_stream=True)
+    f32 = O.predict_step(batch, sd, hp, hp, O.Seq2GeneHP.from_kwargs(kw), rounding=None, share_cre_stream=True)
+    for i in range(3):
+        assert _erel(out["pred_gene_exp"][i], orc["pred_gene_exp"][i]) < NORTH_STAR_RTOL
+        assert _erel(out["embeddings"][i], orc["embeddings"][i]) < 3 * NORTH_STAR_RTOL
+        assert _erel(out["pred_gene_exp"][i], f32["pred_gene_exp"][i]) < NORTH_STAR_RTOL      # fp16 operands vs pure fp32

@@ -302,7 +302,7 @@ def test_rowdot_softplus(ops):
 # GEMM tile configurations at ragged edges (the automatic choice depends on the grid size, so every configuration the
 # pipeline can select is also forced here on shapes whose M / N are not multiples of any tile)
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("variant", [1, 2, 5, 12])
+@pytest.mark.parametrize("variant", [1, 5, 20])
 @pytest.mark.parametrize("epi", ["bf16", "res", "f32"])
 def test_gemm_forced_tile_configs_ragged(ops, variant, epi):
     M, N, K = 515, 776, 192
@@ -319,7 +319,7 @@ def test_gemm_forced_tile_configs_ragged(ops, variant, epi):
     np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), **tol)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 12])
+@pytest.mark.parametrize("variant", [1, 20])
 def test_gemm_geglu_forced_tile_configs_ragged(ops, variant):
     M, F2, K = 515, 1056, 192
     a = _bf(_rand((M, K), 41))
@@ -358,3 +358,145 @@ def test_gemm_auto_selection_at_batch_size(ops, epi):
     torch.cuda.synchronize()
     tol = dict(rtol=2e-5, atol=2e-5 * math.sqrt(K)) if epi == "res" else dict(rtol=2 ** -8, atol=2e-3)
     np.testing.assert_allclose(out[rows.cuda()].float().cpu().numpy(), ref.numpy(), **tol)
+
+
+@pytest.mark.parametrize("K", [64, 128, 192, 1536])
+@pytest.mark.parametrize("epi", ["bf16", "res", "gelu_f32"])
+def test_gemm_8phase_short_and_odd_k_loops(ops, K, epi):
+    """The two-group 256x256 kernel (variant 20) with 1, 2, 3 (odd) and 24 K-tiles: prologue / drain paths of its
+    prefetch stream, ragged M and N, every accumulator checked."""
+    M, N = 700, 520
+    a = _bf(_rand((M, K), 51))
+    w = _bf(_rand((N, K), 52, 1.0 / math.sqrt(K)))
+    b = _rand((N,), 53, 0.5)
+    res = _rand((M, N), 54)
+    ref = a @ w.t() + b
+    if epi == "res":
+        ref = ref + res
+    if epi == "gelu_f32":
+        ref = F.gelu(ref)
+    code = {"bf16": ops.EPI_BF16, "res": ops.EPI_RES_F32, "gelu_f32": ops.EPI_GELU_F32}[epi]
+    out = ops.gemm(a.cuda().bfloat16(), w.cuda().bfloat16(), b.cuda(), code, residual=res.cuda() if epi == "res" else None,
+                   variant=20)
+    torch.cuda.synchronize()
+    tol = dict(rtol=2 ** -8, atol=2e-3) if epi == "bf16" else dict(rtol=2e-5, atol=2e-5 * math.sqrt(K))
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), **tol)
+
+
+def test_gemm_8phase_race_screen(ops):
+    """Exact-integer operands (every product and sum exact in fp32) on a grid of several waves of tiles, repeated: any
+    LDS hazard in the staggered two-group schedule (a fragment read before its LDS-DMA landed, a half-tile overwritten
+    before its last read) shows up as a wrong integer.  Results must also be identical from launch to launch."""
+    M, N, K = 256 * 37 + 19, 256 * 9, 1536
+    g = torch.Generator().manual_seed(5)
+    a = torch.randint(-3, 4, (M, K), generator=g).float()
+    w = torch.randint(-3, 4, (N, K), generator=g).float()
+    ab, wb = a.cuda().bfloat16(), w.cuda().bfloat16()
+    ref = (a.cuda() @ w.cuda().t())
+    first = None
+    for it in range(6):
+        out = ops.gemm(ab, wb, None, ops.EPI_F32, variant=20)
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref), f"iteration {it}: {(out != ref).sum().item()} wrong elements"
+        first = out if first is None else first
+        assert torch.equal(out, first)
+
+
+# ---------------------------------------------------------------------------------------------
+# fp16-operand twins (BASELINE configs[4]: "fp16 with fp32 accumulate"; reference 16-mixed / fp16 flash path)
+# ---------------------------------------------------------------------------------------------
+def _h(x):
+    return x.to(torch.float16).to(torch.float32)
+
+
+@pytest.mark.parametrize("M,N,K,variant", [(257, 576, 192, 0), (1000, 1536, 512, 0), (513, 4608, 1536, 0), (77, 40, 72, 0),
+                                           (700, 520, 192, 20), (515, 776, 192, 1), (300, 192, 192, 5)])
+@pytest.mark.parametrize("epi", ["f16", "f32", "res", "gelu_f32"])
+def test_gemm_fp16_operands(ops, M, N, K, variant, epi):
+    if variant and K % 64:
+        pytest.skip("forced tile configurations need K % 64 == 0")
+    a = _h(_rand((M, K), 61))
+    w = _h(_rand((N, K), 62, 1.0 / math.sqrt(K)))
+    b = _rand((N,), 63, 0.5)
+    res = _rand((M, N), 64)
+    ref = a @ w.t() + b
+    if epi == "res":
+        ref = ref + res
+    if epi == "gelu_f32":
+        ref = F.gelu(ref)
+    code = {"f16": ops.EPI_BF16, "f32": ops.EPI_F32, "res": ops.EPI_RES_F32, "gelu_f32": ops.EPI_GELU_F32}[epi]
+    out = ops.gemm(a.cuda().half(), w.cuda().half(), b.cuda(), code, residual=res.cuda() if epi == "res" else None,
+                   variant=variant)
+    torch.cuda.synchronize()
+    if epi == "f16":
+        assert out.dtype == torch.float16
+        np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), rtol=2 ** -11, atol=3e-4)   # half an fp16 ulp
+    else:
+        assert out.dtype == torch.float32
+        np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=2e-5, atol=2e-5 * math.sqrt(K))
+
+
+def test_gemm_geglu_fp16(ops):
+    M, F2, K = 515, 1056, 192
+    a = _h(_rand((M, K), 71))
+    w = _h(_rand((F2, K), 72, 1.0 / math.sqrt(K)))
+    b = _rand((F2,), 73, 0.5)
+    x, gate = (a @ w.t() + b).chunk(2, dim=-1)
+    wp, bp = ops.pack_geglu_rows(w.cuda().half(), b.cuda())
+    for variant in (0, 1, 20):
+        out = ops.gemm(a.cuda().half(), wp, bp, ops.EPI_GEGLU_BF16, variant=variant)
+        torch.cuda.synchronize()
+        assert out.dtype == torch.float16
+        np.testing.assert_allclose(out.float().cpu().numpy(), (x * F.gelu(gate)).numpy(), rtol=2 ** -10, atol=3e-4)
+
+
+def test_gemm_mixed_operand_types_are_rejected(ops):
+    a = torch.zeros((4, 64), dtype=torch.float16, device="cuda")
+    w = torch.zeros((8, 64), dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(AssertionError):
+        ops.gemm(a, w, None, ops.EPI_F32)
+
+
+@pytest.mark.parametrize("dh,H,ql,kl,alibi", [ATTN_CASES[i] for i in (1, 2, 3, 4, 5, 6, 9, 12)])
+def test_attention_fp16_matches_oracle(ops, dh, H, ql, kl, alibi):
+    self_attn = kl is None
+    kl = ql if self_attn else kl
+    D = H * dh
+    tq, tk = sum(ql), sum(kl)
+    cu_q = torch.tensor([0] + list(np.cumsum(ql)), dtype=torch.int32)
+    cu_k = torch.tensor([0] + list(np.cumsum(kl)), dtype=torch.int32)
+    slopes = torch.tensor(O.alibi_slopes(H), dtype=torch.float32) if alibi else None
+    q = _h(_rand((tq, D), 22, 2.0))
+    kv = _h(_rand((tk, 2 * D), 23, 2.0))
+    k, v = kv[:, :D], kv[:, D:]
+    rnd = O.Rounding("fp16")
+    ref = torch.zeros(tq, D)
+    for b in range(len(ql)):
+        a, e, ka, ke = int(cu_q[b]), int(cu_q[b + 1]), int(cu_k[b]), int(cu_k[b + 1])
+        ref[a:e] = O.attention(q[a:e].view(-1, H, dh), k[ka:ke].view(-1, H, dh), v[ka:ke].view(-1, H, dh), slopes,
+                               rnd).reshape(e - a, D)
+    dkv = kv.cuda().half()
+    out = ops.attn_varlen(q.cuda().half(), dkv[:, :D], dkv[:, D:], cu_q.cuda(), cu_k.cuda(), max(ql), max(kl), H, dh,
+                          slopes.cuda() if alibi else None)
+    torch.cuda.synchronize()
+    assert out.dtype == torch.float16
+    # fp16 output (2^-12) + fp16 P rounding at a different running max than the oracle's final max
+    np.testing.assert_allclose(out.float().cpu().numpy(), _h(ref).numpy(), rtol=2 ** -9, atol=1.5e-3)
+
+
+def test_layernorm_cast_pool_fp16_outputs(ops):
+    x = _rand((37, 512), 81, 3.0)
+    g, b = 1 + 0.1 * _rand((512,), 82), 0.1 * _rand((512,), 83)
+    ref = F.layer_norm(x, (512,), g, b, 1e-5)
+    out = ops.layernorm(x.cuda(), g.cuda(), b.cuda(), torch.float16)
+    assert out.dtype == torch.float16
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), rtol=2 ** -11, atol=1e-3)
+    c = ops.cast16(x.cuda(), torch.float16)
+    assert torch.equal(c.cpu(), x.half())                          # round to nearest even, bit exact
+    with ops.compute_dtype(torch.float16):
+        assert ops.cast16(x.cuda()).dtype == torch.float16 and ops.layernorm(x.cuda(), g.cuda(), b.cuda()).dtype == torch.float16
+    assert ops.cdt() == torch.bfloat16
+    cu = torch.tensor([0, 5, 5, 37], dtype=torch.int32)
+    m = ops.segment_mean(x.cuda(), cu.cuda(), torch.float16)
+    np.testing.assert_allclose(m[0].float().cpu().numpy(), x[:5].mean(0).numpy(), rtol=2 ** -11, atol=1e-3)
+    np.testing.assert_allclose(m[2].float().cpu().numpy(), x[5:].mean(0).numpy(), rtol=2 ** -11, atol=1e-3)

@@ -13,9 +13,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libvf_hip.so")
 
 # enums of include/vf_hip.h
-VF_F32, VF_BF16 = 0, 1
+VF_F32, VF_BF16, VF_F16 = 0, 1, 2
 EPI_BF16, EPI_F32, EPI_RES_F32, EPI_GEGLU_BF16, EPI_GELU_F32, EPI_GELU_BF16 = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -25,9 +25,13 @@ SIGNATURES = {
     "vf_last_error": [],
     "vf_gemm_bf16": [_p, _l, _p, _p, _p, _l, _p, _l, _i, _i, _i, _i, _p],
     "vf_gemm_bf16_ex": [_p, _l, _p, _p, _p, _l, _p, _l, _i, _i, _i, _i, _i, _p],
+    "vf_gemm_f16": [_p, _l, _p, _p, _p, _l, _p, _l, _i, _i, _i, _i, _p],
+    "vf_gemm_f16_ex": [_p, _l, _p, _p, _p, _l, _p, _l, _i, _i, _i, _i, _i, _p],
     "vf_pack_geglu_rows": [_p, _p, _p, _p, _i, _i, _p],
     "vf_attn_varlen_fwd": [_p, _p, _p, _p, _l, _l, _l, _l, _p, _p, _i, _i, _i, _i, _i, _p, _f, _p],
     "vf_attn_varlen_fwd_qstart": [_p, _p, _p, _p, _l, _l, _l, _l, _p, _p, _i, _i, _i, _i, _i, _p, _f, _p],
+    "vf_attn_varlen_fwd_f16": [_p, _p, _p, _p, _l, _l, _l, _l, _p, _p, _i, _i, _i, _i, _i, _p, _f, _p],
+    "vf_attn_varlen_fwd_qstart_f16": [_p, _p, _p, _p, _l, _l, _l, _l, _p, _p, _i, _i, _i, _i, _i, _p, _f, _p],
     "vf_layernorm": [_p, _p, _p, _p, _l, _i, _f, _i, _i, _p],
     "vf_embed_pack": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "vf_mask_to_cu_seqlens": [_p, _p, _i, _i, _p],
@@ -36,6 +40,7 @@ SIGNATURES = {
     "vf_gather_rows_bf16": [_p, _l, _p, _p, _l, _l, _i, _p],
     "vf_rowdot_softplus": [_p, _p, _p, _p, _l, _i, _i, _p],
     "vf_cast_f32_bf16": [_p, _p, _l, _p],
+    "vf_cast_f32_f16": [_p, _p, _l, _p],
     "vf_segment_max": [_p, _p, _p, _i, _i, _p],
     "vf_add_rows_f32": [_p, _p, _p, _p, _p, _l, _i, _p],
     "vf_bpe_create": [_p, _i, _p, _i],

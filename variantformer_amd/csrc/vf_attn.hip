@@ -40,8 +40,8 @@ struct VLayout {
 // d = dh, K carries 0 (valid key) or -32768 (row past the sequence end) there.  Valid scores get exactly +0.0, masked
 // scores ~ -7e3 after scaling -> exp2 underflows to 0.  dh = 64 has no spare slot and masks on the VALU.
 template <int DH> struct HwMask { static constexpr bool value = DH < 64; };
-__device__ __forceinline__ u32x4_t mask_chunk(bool valid) { return (u32x4_t){valid ? 0u : 0xC700u, 0u, 0u, 0u}; }
-__device__ __forceinline__ u32x4_t q_pad_chunk(int d0, int dh) { return (u32x4_t){d0 == dh ? 0x3F80u : 0u, 0u, 0u, 0u}; }
+template <int DT> __device__ __forceinline__ u32x4_t mask_chunk(bool valid) { return (u32x4_t){valid ? 0u : Op16<DT>::NEG_BIG, 0u, 0u, 0u}; }
+template <int DT> __device__ __forceinline__ u32x4_t q_pad_chunk(int d0, int dh) { return (u32x4_t){d0 == dh ? Op16<DT>::ONE : 0u, 0u, 0u, 0u}; }
 
 // max over the lanes {l, l^16, l^32, l^48} (the four key sub-blocks g of one query) without LDS round trips:
 // v_permlane16_swap / v_permlane32_swap exchange 16- / 32-lane rows on the VALU (lane semantics checked by
@@ -107,11 +107,12 @@ __device__ __forceinline__ s16x4_t lds_tr_read(const char* p) {
 // sK / sV point at the tile's first key row in LDS.  All state is per lane (r = query, g = key sub-block).
 // DBGT (diagnostic builds of the long-stream kernel only): 1 = no softmax VALU work (P = S), 2 = additionally no LDS
 // fragment reads (operands reused), used to locate the binding ceiling; results are meaningless.
-template <int DH, int QG, bool ALIBI, int DBGT = 0>
+template <int DH, int QG, bool ALIBI, int DT, int DBGT = 0>
 __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, int kb0, int len_k, int r, int g, float c,
-                                          float slope2, const bf16x8_t (&qf)[QG][2], const float (&q_pos)[QG],
+                                          float slope2, const typename Op16<DT>::frag (&qf)[QG][2], const float (&q_pos)[QG],
                                           f32x4_t (&o)[QG][DH / 16], float (&m_run)[QG], f32x4_t (&l_acc)[QG]) {
-    constexpr int DT = DH / 16;
+    using frag_t = typename Op16<DT>::frag;
+    constexpr int NDT = DH / 16;
     constexpr int VROW = VLayout<DH>::ROW;
     // ---- S^T = K . Q^T : 4 key tiles x 2 k-steps, K fragments shared by the QG query groups
     f32x4_t s[QG][4];
@@ -122,21 +123,21 @@ __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, int kb
     // all 8 K fragments of the tile are requested before the first MFMA and the V fragments of the first 32-key
     // block right after, so LDS latency overlaps the MFMAs and the softmax arithmetic instead of preceding every
     // MFMA pair (diagnostic builds: just-in-time fragment reads cost ~70 of 150 us on the gene->CRE shape)
-    bf16x8_t kf[4][2];
+    frag_t kf[4][2];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
-            kf[kt][ks] = DBGT >= 2 ? qf[0][ks] : *reinterpret_cast<const bf16x8_t*>(
+            kf[kt][ks] = DBGT >= 2 ? qf[0][ks] : *reinterpret_cast<const frag_t*>(
                 sK + (16 * kt + r) * K_ROW_BYTES + (((4 * ks + g) ^ (r >> 1)) << 4));
-    auto read_v = [&](int kb, bf16x8_t(&vf)[DT]) {
+    auto read_v = [&](int kb, frag_t(&vf)[NDT]) {
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
+        for (int dt = 0; dt < NDT; ++dt) {
             const char* vp = sV + (32 * kb + 4 * g + (r >> 2)) * VROW + 32 * dt + 8 * (r & 3);
             if (DBGT >= 2) { vf[dt] = qf[0][0]; continue; }
             const s16x4_t lo = lds_tr_read(vp);
             const s16x4_t hi = lds_tr_read(vp + 16 * VROW);
-            vf[dt] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            vf[dt] = __builtin_bit_cast(frag_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
         }
     };
 #pragma unroll
@@ -145,12 +146,12 @@ __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, int kb
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int qg = 0; qg < QG; ++qg)
-                s[qg][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt][ks], qf[qg][ks], s[qg][kt], 0, 0, 0);
-    bf16x8_t vf0[DT], vf1[DT];
+                s[qg][kt] = Op16<DT>::mfma(kf[kt][ks], qf[qg][ks], s[qg][kt]);
+    frag_t vf0[NDT], vf1[NDT];
     read_v(0, vf0);
 
     // ---- online softmax per query group (lane (r,g): query r, keys kb0 + 16kt + 4g + e)
-    bf16x8_t pf[QG][2];
+    frag_t pf[QG][2];
     const bool tail = kb0 + BKV > len_k;           // wave-uniform: only the last (ragged) key tile masks keys
     const int klim = len_k - kb0 - 4 * g;          // key 16kt+e of this lane is valid iff 16kt+e < klim
     const float k_pos0 = (float)(kb0 + 4 * g);
@@ -160,11 +161,11 @@ __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, int kb
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
                 u32x4_t pk;
-                pk[0] = pack2bf(s[qg][2 * kb][0], s[qg][2 * kb][1]);
-                pk[1] = pack2bf(s[qg][2 * kb][2], s[qg][2 * kb][3]);
-                pk[2] = pack2bf(s[qg][2 * kb + 1][0], s[qg][2 * kb + 1][1]);
-                pk[3] = pack2bf(s[qg][2 * kb + 1][2], s[qg][2 * kb + 1][3]);
-                pf[qg][kb] = *reinterpret_cast<bf16x8_t*>(&pk);
+                pk[0] = Op16<DT>::pack2(s[qg][2 * kb][0], s[qg][2 * kb][1]);
+                pk[1] = Op16<DT>::pack2(s[qg][2 * kb][2], s[qg][2 * kb][3]);
+                pk[2] = Op16<DT>::pack2(s[qg][2 * kb + 1][0], s[qg][2 * kb + 1][1]);
+                pk[3] = Op16<DT>::pack2(s[qg][2 * kb + 1][2], s[qg][2 * kb + 1][3]);
+                pf[qg][kb] = *reinterpret_cast<frag_t*>(&pk);
             }
             l_acc[qg] = (f32x4_t){1.f, 1.f, 1.f, 1.f};
             continue;
@@ -202,16 +203,16 @@ __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, int kb
             const float alpha = __builtin_amdgcn_exp2f(ALIBI ? (m_old - m_new) : (m_old - m_new) * c);
             l_acc[qg] *= alpha;
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) o[qg][dt] *= alpha;
+            for (int dt = 0; dt < NDT; ++dt) o[qg][dt] *= alpha;
         }
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             u32x4_t pk;
-            pk[0] = pack2bf(s[qg][2 * kb][0], s[qg][2 * kb][1]);
-            pk[1] = pack2bf(s[qg][2 * kb][2], s[qg][2 * kb][3]);
-            pk[2] = pack2bf(s[qg][2 * kb + 1][0], s[qg][2 * kb + 1][1]);
-            pk[3] = pack2bf(s[qg][2 * kb + 1][2], s[qg][2 * kb + 1][3]);
-            pf[qg][kb] = *reinterpret_cast<bf16x8_t*>(&pk);
+            pk[0] = Op16<DT>::pack2(s[qg][2 * kb][0], s[qg][2 * kb][1]);
+            pk[1] = Op16<DT>::pack2(s[qg][2 * kb][2], s[qg][2 * kb][3]);
+            pk[2] = Op16<DT>::pack2(s[qg][2 * kb + 1][0], s[qg][2 * kb + 1][1]);
+            pk[3] = Op16<DT>::pack2(s[qg][2 * kb + 1][2], s[qg][2 * kb + 1][3]);
+            pf[qg][kb] = *reinterpret_cast<frag_t*>(&pk);
         }
     }
 
@@ -219,36 +220,38 @@ __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, int kb
     // under block 0's MFMAs
     read_v(1, vf1);
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
+    for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
         for (int qg = 0; qg < QG; ++qg)
-            o[qg][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf0[dt], pf[qg][0], o[qg][dt], 0, 0, 0);
+            o[qg][dt] = Op16<DT>::mfma(vf0[dt], pf[qg][0], o[qg][dt]);
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
+    for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
         for (int qg = 0; qg < QG; ++qg)
-            o[qg][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf1[dt], pf[qg][1], o[qg][dt], 0, 0, 0);
+            o[qg][dt] = Op16<DT>::mfma(vf1[dt], pf[qg][1], o[qg][dt]);
     // ---- softmax denominators on the matrix pipe: a V^T fragment of ones gives l[q] += sum_k P[q][k] in every
     // accumulator row, i.e. each lane ends up with the complete row sum of its query (no per-element v_add_f32 --
     // the softmax is VALU-issue bound -- and no cross-lane reduction at the end).  The sum runs over the bf16 P the
     // PV product uses, so O / l is an exact convex combination of the V rows.
     if (DBGT == 0) {
-        const u32x4_t ones_bits = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
-        const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_bits);
+        constexpr unsigned int one2 = Op16<DT>::ONE * 0x10001u;
+        const u32x4_t ones_bits = {one2, one2, one2, one2};
+        const frag_t ones = __builtin_bit_cast(frag_t, ones_bits);
 #pragma unroll
         for (int qg = 0; qg < QG; ++qg) {
-            l_acc[qg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[qg][0], l_acc[qg], 0, 0, 0);
-            l_acc[qg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[qg][1], l_acc[qg], 0, 0, 0);
+            l_acc[qg] = Op16<DT>::mfma(ones, pf[qg][0], l_acc[qg]);
+            l_acc[qg] = Op16<DT>::mfma(ones, pf[qg][1], l_acc[qg]);
         }
     }
 }
 
-template <int DH, int QG, bool ALIBI, int DBG = 0>
+template <int DH, int QG, bool ALIBI, int DT = VF_BF16, int DBG = 0>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P) {
+    using frag_t = typename Op16<DT>::frag;
     constexpr int CPR = DH / 8;                       // 16-byte chunks per K/V row
     constexpr int NCHUNK = BKV * CPR;                 // chunks per tile
     constexpr int NLD = (NCHUNK + 255) / 256;         // chunk loads per thread per operand
-    constexpr int DT = DH / 16;                       // output d-tiles
+    constexpr int NDT = DH / 16;                       // output d-tiles
     constexpr int VROW = VLayout<DH>::ROW;
     constexpr int STAGE = K_TILE_BYTES + VLayout<DH>::TILE;
     constexpr int BQ = 4 * QG * 16;
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P) {
     }
 
     // ---- Q fragments (B operand): lane (r,g) holds Q[q = r][d = 32ks + 8g .. +7]
-    bf16x8_t qf[QG][2];
+    frag_t qf[QG][2];
     int q_abs[QG];
 #pragma unroll
     for (int qg = 0; qg < QG; ++qg) {
@@ -293,9 +296,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int d0 = 32 * ks + 8 * g;
-            u32x4_t raw = q_pad_chunk(d0, DH);
+            u32x4_t raw = q_pad_chunk<DT>(d0, DH);
             if (d0 < DH) raw = *reinterpret_cast<const u32x4_t*>(qp + d0);
-            qf[qg][ks] = *reinterpret_cast<bf16x8_t*>(&raw);
+            qf[qg][ks] = *reinterpret_cast<frag_t*>(&raw);
         }
     }
 
@@ -307,7 +310,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P) {
 #pragma unroll
     for (int qg = 0; qg < QG; ++qg) q_pos[qg] = (float)(q_abs[qg] + (P.q_at_start ? 0 : len_k - len_q));
 
-    f32x4_t o[QG][DT];
+    f32x4_t o[QG][NDT];
     float m_run[QG];
     f32x4_t l_acc[QG];
 #pragma unroll
@@ -315,7 +318,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P) {
         m_run[qg] = -INFINITY;
         l_acc[qg] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) o[qg][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int dt = 0; dt < NDT; ++dt) o[qg][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     }
 
     // ---- K/V tile staging: global -> registers -> LDS.  The tile's K chunks and V chunks form ONE list of 2*NCHUNK
@@ -353,7 +356,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P) {
         }
         if (HwMask<DH>::value && tid < BKV)          // pad slot d = DH of every key row: 0 or the mask value
             *reinterpret_cast<u32x4_t*>(sK + tid * K_ROW_BYTES + ((CPR ^ ((tid >> 1) & 7)) << 4)) =
-                mask_chunk(t * BKV + tid < len_k);
+                mask_chunk<DT>(t * BKV + tid < len_k);
     };
 
     const int nkv = (len_k + BKV - 1) / BKV;
@@ -367,7 +370,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P) {
     for (int t = 0; t + 1 < nkv; ++t) {
         if (DBG < 3) load_regs(t + 1);
         const char* sK = smem + (t & 1) * STAGE;
-        attn_tile<DH, QG, ALIBI, (DBG > 2 ? 0 : DBG)>(sK, sK + K_TILE_BYTES, t * BKV, len_k, r, g, c, slope2, qf, q_pos,
+        attn_tile<DH, QG, ALIBI, DT, (DBG > 2 ? 0 : DBG)>(sK, sK + K_TILE_BYTES, t * BKV, len_k, r, g, c, slope2, qf, q_pos,
                                                        o, m_run, l_acc);
         if (DBG < 3) write_lds((t + 1) & 1, t + 1);
         if (DBG < 4) __syncthreads();
@@ -375,7 +378,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P) {
     {
         const int t = nkv - 1;
         const char* sK = smem + (t & 1) * STAGE;
-        attn_tile<DH, QG, ALIBI, (DBG > 2 ? 0 : DBG)>(sK, sK + K_TILE_BYTES, t * BKV, len_k, r, g, c, slope2, qf, q_pos,
+        attn_tile<DH, QG, ALIBI, DT, (DBG > 2 ? 0 : DBG)>(sK, sK + K_TILE_BYTES, t * BKV, len_k, r, g, c, slope2, qf, q_pos,
                                                        o, m_run, l_acc);
     }
 
@@ -387,10 +390,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P) {
         if (q_abs[qg] < len_q) {
             unsigned short* op = P.out + (int64_t)(q_tok0 + q_abs[qg]) * P.o_stride + h * DH + 4 * g;
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
+            for (int dt = 0; dt < NDT; ++dt) {
                 u32x2_t pk;
-                pk[0] = pack2bf(o[qg][dt][0] * inv, o[qg][dt][1] * inv);
-                pk[1] = pack2bf(o[qg][dt][2] * inv, o[qg][dt][3] * inv);
+                pk[0] = Op16<DT>::pack2(o[qg][dt][0] * inv, o[qg][dt][1] * inv);
+                pk[1] = Op16<DT>::pack2(o[qg][dt][2] * inv, o[qg][dt][3] * inv);
                 *reinterpret_cast<u32x2_t*>(op + 16 * dt) = pk;
             }
         }
@@ -402,10 +405,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P) {
 // no per-tile barriers) and is fetched once per (sequence, head) instead of once per 64-query block.
 // Wave w owns the query groups w, w+4, ... (16 queries each), QG = ceil(max_seqlen_q / 64) of them, processed
 // together so that every K / V fragment read from LDS feeds QG MFMAs.
-template <int DH, int QG, bool ALIBI>
+template <int DH, int QG, bool ALIBI, int DT = VF_BF16>
 __global__ __launch_bounds__(256, (QG >= 2 ? 2 : 4)) void attn_short_kernel(AttnParams P, int k_rows) {
+    using frag_t = typename Op16<DT>::frag;
     constexpr int CPR = DH / 8;
-    constexpr int DT = DH / 16;
+    constexpr int NDT = DH / 16;
     constexpr int VROW = VLayout<DH>::ROW;
     constexpr int MAXIT = 8;                                      // 256 rows x 8 chunk slots / 256 threads
     extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
@@ -427,7 +431,7 @@ __global__ __launch_bounds__(256, (QG >= 2 ? 2 : 4)) void attn_short_kernel(Attn
     const int nchunks = nkv * BKV * 8;
 
     // ---- Q fragments of this wave's query groups (issued before the K/V loads so that both are in flight together)
-    bf16x8_t qf[QG][2];
+    frag_t qf[QG][2];
     int q_abs[QG];
     float q_pos[QG];
 #pragma unroll
@@ -438,9 +442,9 @@ __global__ __launch_bounds__(256, (QG >= 2 ? 2 : 4)) void attn_short_kernel(Attn
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int d0 = 32 * ks + 8 * g;
-            u32x4_t raw = q_pad_chunk(d0, DH);
+            u32x4_t raw = q_pad_chunk<DT>(d0, DH);
             if (d0 < DH) raw = *reinterpret_cast<const u32x4_t*>(qp + d0);
-            qf[qg][ks] = *reinterpret_cast<bf16x8_t*>(&raw);
+            qf[qg][ks] = *reinterpret_cast<frag_t*>(&raw);
         }
         q_pos[qg] = (float)(q_abs[qg] + (P.q_at_start ? 0 : len_k - len_q));
     }
@@ -453,7 +457,7 @@ __global__ __launch_bounds__(256, (QG >= 2 ? 2 : 4)) void attn_short_kernel(Attn
         for (int it = 0; it < MAXIT; ++it) {
             const int ci = tid + 256 * it;
             const int row = ci >> 3, cc = ci & 7;
-            kbuf[it] = (HwMask<DH>::value && cc == CPR) ? mask_chunk(row < len_k) : (u32x4_t){0u, 0u, 0u, 0u};
+            kbuf[it] = (HwMask<DH>::value && cc == CPR) ? mask_chunk<DT>(row < len_k) : (u32x4_t){0u, 0u, 0u, 0u};
             vbuf[it] = (u32x4_t){0u, 0u, 0u, 0u};
             if (ci < nchunks && cc < CPR) {
                 const int key = row < len_k ? row : len_k - 1;
@@ -474,7 +478,7 @@ __global__ __launch_bounds__(256, (QG >= 2 ? 2 : 4)) void attn_short_kernel(Attn
 
     const float c = P.scale_log2;
     const float slope2 = ALIBI ? P.slopes[h] * 1.4426950408889634f : 0.f;
-    f32x4_t o[QG][DT];
+    f32x4_t o[QG][NDT];
     float m_run[QG];
     f32x4_t l_acc[QG];
 #pragma unroll
@@ -482,13 +486,13 @@ __global__ __launch_bounds__(256, (QG >= 2 ? 2 : 4)) void attn_short_kernel(Attn
         m_run[qg] = -INFINITY;
         l_acc[qg] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) o[qg][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int dt = 0; dt < NDT; ++dt) o[qg][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     }
     __syncthreads();
     if (wave * 16 >= len_q) return;                                // this wave owns no valid query (wave-uniform)
 
     for (int t = 0; t < nkv; ++t)
-        attn_tile<DH, QG, ALIBI>(sK0 + t * BKV * K_ROW_BYTES, sV0 + t * BKV * VROW, t * BKV, len_k, r, g, c, slope2, qf,
+        attn_tile<DH, QG, ALIBI, DT>(sK0 + t * BKV * K_ROW_BYTES, sV0 + t * BKV * VROW, t * BKV, len_k, r, g, c, slope2, qf,
                                  q_pos, o, m_run, l_acc);
 
 #pragma unroll
@@ -498,10 +502,10 @@ __global__ __launch_bounds__(256, (QG >= 2 ? 2 : 4)) void attn_short_kernel(Attn
         if (q_abs[qg] < len_q) {
             unsigned short* op = P.out + (int64_t)(q_tok0 + q_abs[qg]) * P.o_stride + h * DH + 4 * g;
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
+            for (int dt = 0; dt < NDT; ++dt) {
                 u32x2_t pk;
-                pk[0] = pack2bf(o[qg][dt][0] * inv, o[qg][dt][1] * inv);
-                pk[1] = pack2bf(o[qg][dt][2] * inv, o[qg][dt][3] * inv);
+                pk[0] = Op16<DT>::pack2(o[qg][dt][0] * inv, o[qg][dt][1] * inv);
+                pk[1] = Op16<DT>::pack2(o[qg][dt][2] * inv, o[qg][dt][3] * inv);
                 *reinterpret_cast<u32x2_t*>(op + 16 * dt) = pk;
             }
         }
@@ -517,11 +521,11 @@ static unsigned set_grid(AttnParams& P, int n_seq, int nqb) {
     return 8u * (unsigned)P.chunk;
 }
 
-template <int DH, int QG, bool ALIBI>
+template <int DH, int QG, bool ALIBI, int DT>
 int launch_short(AttnParams P, int n_seq, int max_k, hipStream_t st) {
     const int k_rows = ((max_k + BKV - 1) / BKV) * BKV;
     const int lds = k_rows * (K_ROW_BYTES + VLayout<DH>::ROW);
-    auto kern = attn_short_kernel<DH, QG, ALIBI>;
+    auto kern = attn_short_kernel<DH, QG, ALIBI, DT>;
     static bool attr_set[VF_MAX_DEVICES] = {};    // the attribute is per device (and per instantiation)
     const int dev = vf_current_device();
     if (dev < 0 || !attr_set[dev]) {
@@ -539,15 +543,15 @@ int launch_short(AttnParams P, int n_seq, int max_k, hipStream_t st) {
     return VF_OK;
 }
 
-template <int DH, bool ALIBI>
+template <int DH, bool ALIBI, int DT>
 int launch_attn(AttnParams P, int n_seq, int max_q, int max_k, hipStream_t st) {
     // Measured on MI355X (scripts/attn_bench.py, 8 genes): the one-block-per-(sequence, head) kernel wins for the gene
     // stream (201-token sequences, dh 48: 396 vs 485 us); for seq2reg windows / chunks (dh 64, <= 200 tokens) the tiled
     // kernel with 64-query blocks is faster (460 vs 613 us on 200-token chunks: more blocks in flight, fewer registers;
     // the K/V re-reads of its query blocks hit the XCD's L2 thanks to block_coords).
     if (DH <= 48 && max_q > 128 && max_q <= 256 && max_k <= 256) {
-        if (max_q <= 192) return launch_short<DH, 3, ALIBI>(P, n_seq, max_k, st);
-        return launch_short<DH, 4, ALIBI>(P, n_seq, max_k, st);
+        if (max_q <= 192) return launch_short<DH, 3, ALIBI, DT>(P, n_seq, max_k, st);
+        return launch_short<DH, 4, ALIBI, DT>(P, n_seq, max_k, st);
     }
     // long query streams: 2 query groups per wave (halves K/V LDS traffic per MFMA);
     // short ones (seq2reg windows, gene stream): 64-query blocks to limit tail waste.
@@ -556,26 +560,26 @@ int launch_attn(AttnParams P, int n_seq, int max_q, int max_k, hipStream_t st) {
     if (max_q > 256 && (long)n_seq * P.H * ((max_q + 127) / 128) >= 1024) {
         const dim3 grid(set_grid(P, n_seq, (max_q + 127) / 128));
 #ifdef VF_TUNING                                   // libvf_hip_tuning.so only (scripts/): ceiling-finding builds whose results are meaningless
-        if (DH == 48 && !ALIBI) {
+        if (DH == 48 && !ALIBI && DT == VF_BF16) {
             static const int dbg = getenv("VF_ATTN_DBG") ? atoi(getenv("VF_ATTN_DBG")) : 0;
-            if (dbg == 1) { hipLaunchKernelGGL((attn_fwd_kernel<48, 2, false, 1>), grid, dim3(256), 0, st, P); VF_CHECK_LAUNCH("vf_attn_varlen_fwd"); return VF_OK; }
-            if (dbg == 2) { hipLaunchKernelGGL((attn_fwd_kernel<48, 2, false, 2>), grid, dim3(256), 0, st, P); VF_CHECK_LAUNCH("vf_attn_varlen_fwd"); return VF_OK; }
-            if (dbg == 3) { hipLaunchKernelGGL((attn_fwd_kernel<48, 2, false, 3>), grid, dim3(256), 0, st, P); VF_CHECK_LAUNCH("vf_attn_varlen_fwd"); return VF_OK; }
-            if (dbg == 4) { hipLaunchKernelGGL((attn_fwd_kernel<48, 2, false, 4>), grid, dim3(256), 0, st, P); VF_CHECK_LAUNCH("vf_attn_varlen_fwd"); return VF_OK; }
+            if (dbg == 1) { hipLaunchKernelGGL((attn_fwd_kernel<48, 2, false, VF_BF16, 1>), grid, dim3(256), 0, st, P); VF_CHECK_LAUNCH("vf_attn_varlen_fwd"); return VF_OK; }
+            if (dbg == 2) { hipLaunchKernelGGL((attn_fwd_kernel<48, 2, false, VF_BF16, 2>), grid, dim3(256), 0, st, P); VF_CHECK_LAUNCH("vf_attn_varlen_fwd"); return VF_OK; }
+            if (dbg == 3) { hipLaunchKernelGGL((attn_fwd_kernel<48, 2, false, VF_BF16, 3>), grid, dim3(256), 0, st, P); VF_CHECK_LAUNCH("vf_attn_varlen_fwd"); return VF_OK; }
+            if (dbg == 4) { hipLaunchKernelGGL((attn_fwd_kernel<48, 2, false, VF_BF16, 4>), grid, dim3(256), 0, st, P); VF_CHECK_LAUNCH("vf_attn_varlen_fwd"); return VF_OK; }
         }
 #endif
         // 4 query groups per wave (256-query blocks) once that still leaves >= 8 blocks per CU: every K/V fragment read
         // feeds 4 MFMAs (gene->CRE cross attention at 8 genes: 948 vs 993 us; no gain at one gene, 1376 blocks)
         if (DH == 48 && !ALIBI && (long)n_seq * P.H * ((max_q + 255) / 256) >= 2048) {
             const dim3 grid4(set_grid(P, n_seq, (max_q + 255) / 256));
-            hipLaunchKernelGGL((attn_fwd_kernel<48, 4, false>), grid4, dim3(256), 0, st, P);
+            hipLaunchKernelGGL((attn_fwd_kernel<48, 4, false, DT>), grid4, dim3(256), 0, st, P);
             VF_CHECK_LAUNCH("vf_attn_varlen_fwd");
             return VF_OK;
         }
-        hipLaunchKernelGGL((attn_fwd_kernel<DH, 2, ALIBI>), grid, dim3(256), 0, st, P);
+        hipLaunchKernelGGL((attn_fwd_kernel<DH, 2, ALIBI, DT>), grid, dim3(256), 0, st, P);
     } else {
         const dim3 grid(set_grid(P, n_seq, (max_q + 63) / 64));
-        hipLaunchKernelGGL((attn_fwd_kernel<DH, 1, ALIBI>), grid, dim3(256), 0, st, P);
+        hipLaunchKernelGGL((attn_fwd_kernel<DH, 1, ALIBI, DT>), grid, dim3(256), 0, st, P);
     }
     VF_CHECK_LAUNCH("vf_attn_varlen_fwd");
     return VF_OK;
@@ -583,6 +587,7 @@ int launch_attn(AttnParams P, int n_seq, int max_q, int max_k, hipStream_t st) {
 
 }  // namespace
 
+template <int DT>
 static int attn_dispatch(const void* q, const void* k, const void* v, void* out, int64_t q_stride,
                          int64_t k_stride, int64_t v_stride, int64_t o_stride, const int32_t* cu_seqlens_q,
                          const int32_t* cu_seqlens_k, int n_seq, int max_seqlen_q, int max_seqlen_k, int H,
@@ -606,9 +611,9 @@ static int attn_dispatch(const void* q, const void* k, const void* v, void* out,
     hipStream_t st = (hipStream_t)stream;
     const bool alibi = alibi_slopes != nullptr;
     switch (dh) {
-        case 32: return alibi ? launch_attn<32, true>(P, n_seq, max_seqlen_q, max_seqlen_k, st) : launch_attn<32, false>(P, n_seq, max_seqlen_q, max_seqlen_k, st);
-        case 48: return alibi ? launch_attn<48, true>(P, n_seq, max_seqlen_q, max_seqlen_k, st) : launch_attn<48, false>(P, n_seq, max_seqlen_q, max_seqlen_k, st);
-        default: return alibi ? launch_attn<64, true>(P, n_seq, max_seqlen_q, max_seqlen_k, st) : launch_attn<64, false>(P, n_seq, max_seqlen_q, max_seqlen_k, st);
+        case 32: return alibi ? launch_attn<32, true, DT>(P, n_seq, max_seqlen_q, max_seqlen_k, st) : launch_attn<32, false, DT>(P, n_seq, max_seqlen_q, max_seqlen_k, st);
+        case 48: return alibi ? launch_attn<48, true, DT>(P, n_seq, max_seqlen_q, max_seqlen_k, st) : launch_attn<48, false, DT>(P, n_seq, max_seqlen_q, max_seqlen_k, st);
+        default: return alibi ? launch_attn<64, true, DT>(P, n_seq, max_seqlen_q, max_seqlen_k, st) : launch_attn<64, false, DT>(P, n_seq, max_seqlen_q, max_seqlen_k, st);
     }
 }
 
@@ -616,7 +621,7 @@ extern "C" int vf_attn_varlen_fwd(const void* q, const void* k, const void* v, v
                                   int64_t k_stride, int64_t v_stride, int64_t o_stride, const int32_t* cu_seqlens_q,
                                   const int32_t* cu_seqlens_k, int n_seq, int max_seqlen_q, int max_seqlen_k, int H,
                                   int dh, const float* alibi_slopes, float scale, void* stream) {
-    return attn_dispatch(q, k, v, out, q_stride, k_stride, v_stride, o_stride, cu_seqlens_q, cu_seqlens_k, n_seq,
+    return attn_dispatch<VF_BF16>(q, k, v, out, q_stride, k_stride, v_stride, o_stride, cu_seqlens_q, cu_seqlens_k, n_seq,
                          max_seqlen_q, max_seqlen_k, H, dh, alibi_slopes, scale, 0, stream);
 }
 
@@ -625,6 +630,23 @@ extern "C" int vf_attn_varlen_fwd_qstart(const void* q, const void* k, const voi
                                          const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k, int n_seq,
                                          int max_seqlen_q, int max_seqlen_k, int H, int dh, const float* alibi_slopes,
                                          float scale, void* stream) {
-    return attn_dispatch(q, k, v, out, q_stride, k_stride, v_stride, o_stride, cu_seqlens_q, cu_seqlens_k, n_seq,
+    return attn_dispatch<VF_BF16>(q, k, v, out, q_stride, k_stride, v_stride, o_stride, cu_seqlens_q, cu_seqlens_k, n_seq,
                          max_seqlen_q, max_seqlen_k, H, dh, alibi_slopes, scale, 1, stream);
+}
+
+extern "C" int vf_attn_varlen_fwd_f16(const void* q, const void* k, const void* v, void* out, int64_t q_stride,
+                                      int64_t k_stride, int64_t v_stride, int64_t o_stride, const int32_t* cu_seqlens_q,
+                                      const int32_t* cu_seqlens_k, int n_seq, int max_seqlen_q, int max_seqlen_k, int H,
+                                      int dh, const float* alibi_slopes, float scale, void* stream) {
+    return attn_dispatch<VF_F16>(q, k, v, out, q_stride, k_stride, v_stride, o_stride, cu_seqlens_q, cu_seqlens_k, n_seq,
+                                 max_seqlen_q, max_seqlen_k, H, dh, alibi_slopes, scale, 0, stream);
+}
+
+extern "C" int vf_attn_varlen_fwd_qstart_f16(const void* q, const void* k, const void* v, void* out, int64_t q_stride,
+                                             int64_t k_stride, int64_t v_stride, int64_t o_stride,
+                                             const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k, int n_seq,
+                                             int max_seqlen_q, int max_seqlen_k, int H, int dh, const float* alibi_slopes,
+                                             float scale, void* stream) {
+    return attn_dispatch<VF_F16>(q, k, v, out, q_stride, k_stride, v_stride, o_stride, cu_seqlens_q, cu_seqlens_k, n_seq,
+                                 max_seqlen_q, max_seqlen_k, H, dh, alibi_slopes, scale, 1, stream);
 }

@@ -58,6 +58,41 @@ __device__ __forceinline__ unsigned int pack2bf(float lo, float hi) {
 __device__ __forceinline__ float bf2f(unsigned short b) {
     return __uint_as_float(((unsigned int)b) << 16);
 }
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+// two fp32 -> packed IEEE half pair, round to nearest even
+__device__ __forceinline__ unsigned int pack2h(float lo, float hi) {
+    const f32x2_t v = {lo, hi};
+    const f16x2_t h = __builtin_convertvector(v, f16x2_t);
+    return __builtin_bit_cast(unsigned int, h);
+}
+__device__ __forceinline__ float h2f(unsigned short b) {
+    return (float)__builtin_bit_cast(_Float16, b);
+}
+
+// The 16-bit operand type of the MFMA kernels: VF_BF16 (the reference's bf16-mixed path) or VF_F16 (its 16-mixed /
+// fp16 flash-attn path, seq2gene/modules/layers.py:102-125, utils/functions.py:12-32); fp32 accumulation in both,
+// same MFMA shape and rate.  ONE / NEG_BIG are the bit patterns of 1.0 and -32768.0 (attention key masking).
+template <int DT> struct Op16;
+template <> struct Op16<VF_BF16> {
+    using frag = bf16x8_t;
+    static __device__ __forceinline__ f32x4_t mfma(frag a, frag b, f32x4_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ unsigned int pack2(float lo, float hi) { return pack2bf(lo, hi); }
+    static __device__ __forceinline__ float to_f32(unsigned short b) { return bf2f(b); }
+    static constexpr unsigned int ONE = 0x3F80u, NEG_BIG = 0xC700u;
+};
+template <> struct Op16<VF_F16> {
+    using frag = f16x8_t;
+    static __device__ __forceinline__ f32x4_t mfma(frag a, frag b, f32x4_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ unsigned int pack2(float lo, float hi) { return pack2h(lo, hi); }
+    static __device__ __forceinline__ float to_f32(unsigned short b) { return h2f(b); }
+    static constexpr unsigned int ONE = 0x3C00u, NEG_BIG = 0xF800u;
+};
+
 // exact (erf) GELU, as nn.GELU() / F.gelu default
 __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));

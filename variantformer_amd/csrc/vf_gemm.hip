@@ -43,7 +43,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 // Epilogue for 4 consecutive n (n_base .. n_base+3) of row m.  For GEGLU `v` is the `a` half and
 // `gate` the gate half; n_out is the output column of v[0].
-template <int EPI>
+template <int EPI, int DT = VF_BF16>
 __device__ __forceinline__ void epilogue_store(f32x4_t v, f32x4_t gate, int64_t m, int n_bias, int n_bias_gate,
                                                int n_out, const float* __restrict__ bias,
                                                const float* __restrict__ res, int64_t ldr, void* out, int64_t ldo,
@@ -66,8 +66,8 @@ __device__ __forceinline__ void epilogue_store(f32x4_t v, f32x4_t gate, int64_t 
         *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(out) + m * ldo + n_out) = v;
     } else {
         u32x2_t p;
-        p[0] = pack2bf(v[0], v[1]);
-        p[1] = pack2bf(v[2], v[3]);
+        p[0] = Op16<DT>::pack2(v[0], v[1]);
+        p[1] = Op16<DT>::pack2(v[2], v[3]);
         *reinterpret_cast<u32x2_t*>(reinterpret_cast<unsigned short*>(out) + m * ldo + n_out) = p;
     }
 }
@@ -92,7 +92,7 @@ struct Cfg {
 
 // DBG (diagnostic builds only, never selected automatically): 1 = no global loads (fragment reads + MFMA ceiling),
 // 2 = no fragment reads / MFMA (LDS-DMA fill ceiling).  Results are meaningless in both.
-template <class C, int EPI, int DBG = 0>
+template <class C, int EPI, int DT = VF_BF16, int DBG = 0>
 __global__ __launch_bounds__(C::THREADS, 2) void gemm_mfma_kernel(const unsigned short* __restrict__ A, int64_t lda,
                                                               const unsigned short* __restrict__ W,
                                                               const float* __restrict__ bias,
@@ -100,6 +100,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_mfma_kernel(const unsigned
                                                               int64_t ldo, int M, int N, int K, int tiles_n, int n_blocks,
                                                               int GROUP_M) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    using frag_t = typename Op16<DT>::frag;
     constexpr int BM = C::BM, BN = C::BN, TM = C::TM, TN = C::TN, STAGES = C::STAGES, LPT = C::LPT;
     constexpr int BK = C::BK, ROW_BYTES = C::ROW_BYTES, CPR = C::CPR, RPP = C::ROWS_PER_PIECE;
 
@@ -163,13 +164,13 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_mfma_kernel(const unsigned
     const int offW = C::A_BYTES + (wn * (BN / C::WN) + r) * ROW_BYTES;
     const int offA = (wm * (BM / C::WM) + r) * ROW_BYTES;
 
-    auto read_frags = [&](int stage, int ks, bf16x8_t(&wf)[TN], bf16x8_t(&af)[TM]) {
+    auto read_frags = [&](int stage, int ks, frag_t(&wf)[TN], frag_t(&af)[TM]) {
         if (DBG == 2) return;
         const char* base = smem + stage * C::STAGE_BYTES + (((4 * ks + g) ^ sw) << 4);
 #pragma unroll
-        for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const bf16x8_t*>(base + offW + i * 16 * ROW_BYTES);
+        for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const frag_t*>(base + offW + i * 16 * ROW_BYTES);
 #pragma unroll
-        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(base + offA + i * 16 * ROW_BYTES);
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const frag_t*>(base + offA + i * 16 * ROW_BYTES);
     };
     auto issue_piece = [&](int kt, int stage, int i) {       // i in [0, LPT): one LDS-DMA wave-instruction
         if (i < C::PA) glds16(srcA[i] + kt * BK, ldsA_piece + stage * C::STAGE_BYTES + i * 1024);
@@ -177,13 +178,13 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_mfma_kernel(const unsigned
     };
     // MFMAs of one sub-step with the LDS-DMA pieces of K-tile `kt_issue` spread between them (one piece every
     // TN*TM/LPT MFMAs) instead of a burst right after the barrier
-    auto mma_spread = [&](const bf16x8_t(&wf)[TN], const bf16x8_t(&af)[TM], int kt_issue, int stage_issue, bool do_issue) {
+    auto mma_spread = [&](const frag_t(&wf)[TN], const frag_t(&af)[TM], int kt_issue, int stage_issue, bool do_issue) {
         constexpr int EVERY = 3;       // measured on 256x256: every 3 MFMAs 1203, every 4 1194, every 2 1195, burst 1161 (1133 before)
 #pragma unroll
         for (int in = 0; in < TN; ++in)
 #pragma unroll
             for (int im = 0; im < TM; ++im) {
-                acc[in][im] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[in], af[im], acc[in][im], 0, 0, 0);
+                acc[in][im] = Op16<DT>::mfma(wf[in], af[im], acc[in][im]);
                 const int idx = in * TM + im;
                 if (idx % EVERY == EVERY - 1 && idx / EVERY < LPT) {
                     if (do_issue) issue_piece(kt_issue, stage_issue, idx / EVERY);
@@ -191,13 +192,13 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_mfma_kernel(const unsigned
                 }
             }
     };
-    auto mma = [&](const bf16x8_t(&wf)[TN], const bf16x8_t(&af)[TM]) {
+    auto mma = [&](const frag_t(&wf)[TN], const frag_t(&af)[TM]) {
         if (DBG == 2) return;
 #pragma unroll
         for (int in = 0; in < TN; ++in)
 #pragma unroll
             for (int im = 0; im < TM; ++im)
-                acc[in][im] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[in], af[im], acc[in][im], 0, 0, 0);
+                acc[in][im] = Op16<DT>::mfma(wf[in], af[im], acc[in][im]);
     };
     // wait until at most `ahead` younger K-tiles of this wave's LDS-DMA are still in flight
     auto wait_tiles = [&](int ahead) {
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_mfma_kernel(const unsigned
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
-    bf16x8_t wf0[TN], af0[TM], wf1[TN], af1[TM];
+    frag_t wf0[TN], af0[TM], wf1[TN], af1[TM];
     read_frags(0, 0, wf0, af0);
     int stage = 0;
     // cross from tile t (in `stage`) to tile t+1
@@ -345,6 +346,20 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_mfma_kernel(const unsigned
     const int nw0 = n0 + wn * WT_N;
     load_res_pass(0, rbuf[0]);
     __syncthreads();                     // every wave's last fragments are in registers: the ring is free
+    // bias of the wave's columns: ONE branch and one batch of loads (a per-element `if (bias) v += load` makes hipcc
+    // branch around every load and drain vmcnt(0) behind each: 32 dependent L2 round trips per wave)
+    f32x4_t bvec[TN];
+    if (bias) {
+#pragma unroll
+        for (int in = 0; in < TN; ++in) {
+            int nb = (EPI == VF_EPI_GEGLU_BF16) ? nw0 + (in >> 1) * 32 + (in & 1) * 16 + 4 * g : nw0 + in * 16 + 4 * g;
+            nb = nb < N ? nb : 0;
+            bvec[in] = *reinterpret_cast<const f32x4_t*>(bias + nb);
+        }
+    } else {
+#pragma unroll
+        for (int in = 0; in < TN; ++in) bvec[in] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
     char* const region = smem + wave * REGION;
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
@@ -358,25 +373,16 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_mfma_kernel(const unsigned
                 if (EPI == VF_EPI_GEGLU_BF16) {
 #pragma unroll
                     for (int ip = 0; ip < TN / 2; ++ip) {
-                        f32x4_t v = acc[2 * ip][im], gt = acc[2 * ip + 1][im];
-                        int nb = nw0 + ip * 32 + 4 * g;
-                        nb = nb < N ? nb : 0;
-                        if (bias) {
-                            v += *reinterpret_cast<const f32x4_t*>(bias + nb);
-                            gt += *reinterpret_cast<const f32x4_t*>(bias + nb + 16);
-                        }
+                        const f32x4_t v = acc[2 * ip][im] + bvec[2 * ip], gt = acc[2 * ip + 1][im] + bvec[2 * ip + 1];
                         u32x2_t pk;
-                        pk[0] = pack2bf(v[0] * gelu_erf(gt[0]), v[1] * gelu_erf(gt[1]));
-                        pk[1] = pack2bf(v[2] * gelu_erf(gt[2]), v[3] * gelu_erf(gt[3]));
+                        pk[0] = Op16<DT>::pack2(v[0] * gelu_erf(gt[0]), v[1] * gelu_erf(gt[1]));
+                        pk[1] = Op16<DT>::pack2(v[2] * gelu_erf(gt[2]), v[3] * gelu_erf(gt[3]));
                         *reinterpret_cast<u32x2_t*>(rowp + (ip * 16 + 4 * g) * 2) = pk;
                     }
                 } else {
 #pragma unroll
                     for (int in = 0; in < TN; ++in) {
-                        f32x4_t v = acc[in][im];
-                        int nb = nw0 + in * 16 + 4 * g;
-                        nb = nb < N ? nb : 0;
-                        if (bias) v += *reinterpret_cast<const f32x4_t*>(bias + nb);
+                        f32x4_t v = acc[in][im] + bvec[in];
                         if (EPI == VF_EPI_GELU_F32 || EPI == VF_EPI_GELU_BF16) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
@@ -385,8 +391,8 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_mfma_kernel(const unsigned
                             *reinterpret_cast<f32x4_t*>(rowp + (in * 16 + 4 * g) * 4) = v;
                         } else {
                             u32x2_t pk;
-                            pk[0] = pack2bf(v[0], v[1]);
-                            pk[1] = pack2bf(v[2], v[3]);
+                            pk[0] = Op16<DT>::pack2(v[0], v[1]);
+                            pk[1] = Op16<DT>::pack2(v[2], v[3]);
                             *reinterpret_cast<u32x2_t*>(rowp + (in * 16 + 4 * g) * 2) = pk;
                         }
                     }
@@ -394,18 +400,27 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_mfma_kernel(const unsigned
             }
         }
         // (2) read the slice back row-wise (same wave: LDS operations are in order) and store whole rows
+        constexpr int KB = (EPI == VF_EPI_RES_F32) ? 4 : NI;     // read-back batch (fewer spare registers with a residual)
 #pragma unroll
-        for (int k = 0; k < NI; ++k) {
-            const int row = k * RI + ep_row;
-            const int64_t m = mw0 + ps * RP + row;
-            if (ps * RP + row < WT_M && m < M && ep_col < n_out_total) {
-                u32x4_t d = *reinterpret_cast<const u32x4_t*>(region + row * PITCH + (lane % CR) * 16);
+        for (int k0 = 0; k0 < NI; k0 += KB) {
+            u32x4_t dd[KB];
+#pragma unroll
+            for (int k = 0; k < KB; ++k)
+                if (k0 + k < NI)
+                    dd[k] = *reinterpret_cast<const u32x4_t*>(region + ((k0 + k) * RI + ep_row) * PITCH + (lane % CR) * 16);
+#pragma unroll
+            for (int k = 0; k < KB; ++k) {
+                if (k0 + k >= NI) continue;
+                const int row = (k0 + k) * RI + ep_row;
+                const int64_t m = mw0 + ps * RP + row;
+                u32x4_t d = dd[k];
                 if (EPI == VF_EPI_RES_F32) {
                     f32x4_t f = __builtin_bit_cast(f32x4_t, d);
-                    f += RES_PRE ? resv[RES_PRE ? ps : 0][RES_PRE ? k : 0] : rbuf[ps & 1][RES_PIPE ? k : 0];
+                    f += RES_PRE ? resv[RES_PRE ? ps : 0][RES_PRE ? k0 + k : 0] : rbuf[ps & 1][RES_PIPE ? k0 + k : 0];
                     d = __builtin_bit_cast(u32x4_t, f);
                 }
-                *reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(out) + (m * ldo + ep_col) * ES) = d;
+                if (ps * RP + row < WT_M && m < M && ep_col < n_out_total)
+                    *reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(out) + (m * ldo + ep_col) * ES) = d;
             }
         }
     }
@@ -416,13 +431,14 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_mfma_kernel(const unsigned
 // LDS-DMA ring runs straight across tile boundaries, so the first K-tiles of the next output tile are already in
 // flight while the current tile's last MFMAs and its epilogue execute.  Hides the per-tile prologue latency, which
 // is what limits the K = 512 (seq2reg) shapes: 8 K-tiles per output tile.
-template <class C, int EPI>
+template <class C, int EPI, int DT = VF_BF16>
 __global__ __launch_bounds__(C::THREADS, 2) void gemm_persist_kernel(const unsigned short* __restrict__ A, int64_t lda,
                                                                  const unsigned short* __restrict__ W,
                                                                  const float* __restrict__ bias,
                                                                  const float* __restrict__ res, int64_t ldr, void* out,
                                                                  int64_t ldo, int M, int N, int K, int tiles_n, int n_tiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    using frag_t = typename Op16<DT>::frag;
     constexpr int BM = C::BM, BN = C::BN, TM = C::TM, TN = C::TN, STAGES = C::STAGES, LPT = C::LPT;
     constexpr int BK = C::BK, ROW_BYTES = C::ROW_BYTES, CPR = C::CPR, RPP = C::ROWS_PER_PIECE;
     static_assert(C::KS == 2, "persistent kernel is written for BK = 64");
@@ -489,12 +505,12 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_persist_kernel(const unsig
     const int sw = swz<BK>(r);
     const int offW = C::A_BYTES + (wn * (BN / C::WN) + r) * ROW_BYTES;
     const int offA = (wm * (BM / C::WM) + r) * ROW_BYTES;
-    auto read_frags = [&](int stage, int ks, bf16x8_t(&wf)[TN], bf16x8_t(&af)[TM]) {
+    auto read_frags = [&](int stage, int ks, frag_t(&wf)[TN], frag_t(&af)[TM]) {
         const char* base = smem + stage * C::STAGE_BYTES + (((4 * ks + g) ^ sw) << 4);
 #pragma unroll
-        for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const bf16x8_t*>(base + offW + i * 16 * ROW_BYTES);
+        for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const frag_t*>(base + offW + i * 16 * ROW_BYTES);
 #pragma unroll
-        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(base + offA + i * 16 * ROW_BYTES);
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const frag_t*>(base + offA + i * 16 * ROW_BYTES);
     };
     auto wait_tiles = [&](int ahead) {
         if (STAGES >= 5 && ahead >= 3) wait_vmcnt<3 * LPT>();
@@ -522,7 +538,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_persist_kernel(const unsig
         stage = stage + 1 == STAGES ? 0 : stage + 1;
     };
 
-    bf16x8_t wf0[TN], af0[TM], wf1[TN], af1[TM];
+    frag_t wf0[TN], af0[TM], wf1[TN], af1[TM];
     constexpr bool RES_PRE = (EPI == VF_EPI_RES_F32) && (TN * TM <= 16);
     for (int tl = 0; tl < my_tiles; ++tl) {
         int m0, n0;
@@ -553,14 +569,14 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_persist_kernel(const unsig
             for (int in = 0; in < TN; ++in)
 #pragma unroll
                 for (int im = 0; im < TM; ++im)
-                    acc[in][im] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[in], af0[im], acc[in][im], 0, 0, 0);
+                    acc[in][im] = Op16<DT>::mfma(wf0[in], af0[im], acc[in][im]);
             if (j + 1 < total) boundary();
             if (kt + 1 < nkt) read_frags(stage, 0, wf0, af0);
 #pragma unroll
             for (int in = 0; in < TN; ++in)
 #pragma unroll
                 for (int im = 0; im < TM; ++im)
-                    acc[in][im] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[in], af1[im], acc[in][im], 0, 0, 0);
+                    acc[in][im] = Op16<DT>::mfma(wf1[in], af1[im], acc[in][im]);
             ++j;
         }
         // ---- epilogue of this tile (the ring already holds / is fetching the next tile's first K-tiles)
@@ -574,7 +590,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_persist_kernel(const unsig
                 for (int ip = 0; ip < TN / 2; ++ip) {
                     const int nb = nw0 + ip * 32 + 4 * g;
                     if (nb >= N) continue;
-                    epilogue_store<EPI>(acc[2 * ip][im], acc[2 * ip + 1][im], m, nb, nb + 16, nw0 / 2 + ip * 16 + 4 * g, bias,
+                    epilogue_store<EPI, DT>(acc[2 * ip][im], acc[2 * ip + 1][im], m, nb, nb + 16, nw0 / 2 + ip * 16 + 4 * g, bias,
                                         res, ldr, out, ldo);
                 }
             } else {
@@ -582,7 +598,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_persist_kernel(const unsig
                 for (int in = 0; in < TN; ++in) {
                     const int nb = nw0 + in * 16 + 4 * g;
                     if (nb >= N) continue;
-                    epilogue_store<EPI>(acc[in][im], acc[in][im], m, nb, nb, nb, bias, res, ldr, out, ldo,
+                    epilogue_store<EPI, DT>(acc[in][im], acc[in][im], m, nb, nb, nb, bias, res, ldr, out, ldo,
                                         RES_PRE ? &resv[RES_PRE ? in : 0][RES_PRE ? im : 0] : nullptr);
                 }
             }
@@ -592,9 +608,317 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_persist_kernel(const unsig
 
 #endif  // VF_TUNING
 
+// ======================================================================================================================
+// 256 x 256 x 64 tile, 8 waves, two wave groups running half a phase apart ("8-phase" schedule: 4 phases per K-tile,
+// two K-tiles per LDS double buffer; cdna_hip_programming.md section 5, re-derived here for this operand layout).
+//
+// Waves 0-3 (group 0) and 4-7 (group 1) sit pairwise on the 4 SIMDs.  A phase of one wave is
+//     [LDS fragment reads + 2 LDS-DMA pieces of the prefetch stream]  s_barrier  [16 MFMAs]  s_barrier
+// and group 1 runs one barrier behind group 0, so on every SIMD one wave issues MFMAs while its partner reads
+// fragments and issues the prefetch: the matrix pipe never waits for LDS and the LDS never waits for the matrix pipe.
+//
+// Wave (wm = wave / 4, wn = wave % 4) owns the contiguous 128 (m) x 64 (n) block of the tile, computed as four
+// quadrants of 64 x 32 (16 MFMAs of 16x16x32 over the K-tile's 64 deep slice each):
+//     P1: (m-lo, n-lo)   reads W-lo (4 x b128, first), A-lo (8)      P2: (m-lo, n-hi)   reads W-hi (4)
+//     P3: (m-hi, n-hi)   reads A-hi (8)                              P4: (m-hi, n-lo)   W-lo kept in registers
+// A K-tile lives in LDS as four 16 KiB half-tiles  WL | AL | WH | AH  (128 rows x 128 B each, XOR-swizzled like the
+// other configurations).  Half-tile XL holds, for every wave row / column group, the FIRST half of that group's rows
+// (LDS row i of AL <-> m = m0 + (i / 64) * 128 + i % 64, of WL <-> n = n0 + (i / 32) * 64 + i % 32), XH the second: the
+// LDS-DMA source address is per lane, so the split costs nothing and every wave tile stays contiguous in memory.
+//
+// Prefetch stream: one half-tile (2 LDS-DMA wave-instructions per wave) per phase, in the order WL, AL, WH, AH, running
+// one K-tile plus three half-tiles ahead of the consumer; the only wait is a counted vmcnt(6) in P4 (three half-tiles
+// stay in flight across every barrier, vmcnt never reaches 0 inside the loop).
+//   RAW  a half-tile is read at the earliest one phase after the P4 wait that retired it (both groups have passed a
+//        barrier behind their own wait by then).
+//   WAR  half-tile X of K-tile t+2 overwrites X of K-tile t.  WL: last read P1, rewritten P2 -- one phase later, legal
+//        only because the four W-lo reads are issued first and retired (lgkmcnt(8)) BEFORE P1's first barrier, i.e.
+//        before the other group, half a phase ahead, can issue the rewrite.  AL: read P1, rewritten P3; WH: read P2,
+//        rewritten P4; AH: read P3, rewritten P1 of the next tile -- two phases, safe for any stagger of one barrier.
+// ======================================================================================================================
+struct Cfg8 {
+    static constexpr int BM = 256, BN = 256, BK = 64, WM = 2, WN = 4, NW = 8, THREADS = 512;
+    static constexpr int TM = 8, TN = 4;                        // 16x16 tiles per wave: 128 x 64
+    static constexpr int HALF_BYTES = 128 * 128;                // one half-tile: 128 rows x 64 bf16
+    static constexpr int TILE_BYTES = 4 * HALF_BYTES;           // WL | AL | WH | AH
+    static constexpr int LDS_BYTES = 2 * TILE_BYTES;            // 128 KiB
+    enum { WL = 0, AL = 1, WH = 2, AH = 3 };
+};
+
+template <int EPI, int DT = VF_BF16>
+__global__ __launch_bounds__(512, 2) void gemm8_kernel(const unsigned short* __restrict__ A, int64_t lda,
+                                                       const unsigned short* __restrict__ W,
+                                                       const float* __restrict__ bias, const float* __restrict__ res,
+                                                       int64_t ldr, void* out, int64_t ldo, int M, int N, int K,
+                                                       int tiles_n, int n_blocks, int GROUP_M) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using frag_t = typename Op16<DT>::frag;
+    using C = Cfg8;
+    constexpr int BM = C::BM, BN = C::BN, TM = C::TM, TN = C::TN, BK = C::BK;
+
+    // XCD-aware bijective remap + grouped order (same as gemm_mfma_kernel)
+    const int bid = blockIdx.x;
+    const int q8 = n_blocks >> 3, r8 = n_blocks & 7, xcd = bid & 7, loc = bid >> 3;
+    const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+    const int tiles_m = n_blocks / tiles_n;
+    const int per_group = GROUP_M * tiles_n;
+    const int grp = wg / per_group, in_grp = wg - grp * per_group;
+    const int first_m = grp * GROUP_M;
+    const int gsz = (tiles_m - first_m) < GROUP_M ? (tiles_m - first_m) : GROUP_M;
+    const int m0 = (first_m + in_grp % gsz) * BM, n0 = (in_grp / gsz) * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int r = lane & 15, g = lane >> 4;
+
+    // ---- LDS-DMA sources: wave w fills rows 16w .. 16w+15 of every half-tile (two 8-row pieces)
+    const unsigned short* src[4][2];
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi) {
+        const int i = 16 * wave + 8 * pi + (lane >> 3);                       // LDS row inside the half-tile
+        const int c = (lane & 7) ^ ((i >> 1) & 7);                            // logical (source) chunk of this lane
+        const int am = m0 + (i >> 6) * 128 + (i & 63);
+        const int wn_row = n0 + (i >> 5) * 64 + (i & 31);
+        int v;
+        v = am;           v = v < M ? v : M - 1;  src[C::AL][pi] = A + (int64_t)v * lda + c * 8;
+        v = am + 64;      v = v < M ? v : M - 1;  src[C::AH][pi] = A + (int64_t)v * lda + c * 8;
+        v = wn_row;       v = v < N ? v : N - 1;  src[C::WL][pi] = W + (int64_t)v * K + c * 8;
+        v = wn_row + 32;  v = v < N ? v : N - 1;  src[C::WH][pi] = W + (int64_t)v * K + c * 8;
+    }
+    char* const lds_piece = smem + wave * 2048;                               // + buf * TILE + type * HALF + pi * 1024
+    auto issue = [&](int kt, int type) {                                      // one half-tile of K-tile kt
+        char* dst = lds_piece + (kt & 1) * C::TILE_BYTES + type * C::HALF_BYTES;
+        glds16(src[type][0] + kt * BK, dst);
+        glds16(src[type][1] + kt * BK, dst + 1024);
+    };
+
+    f32x4_t acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    // ---- fragment addresses (bytes inside a K-tile buffer): row * 128 + ((4 ks + g) ^ swz(r)) * 16
+    const int sw = (r >> 1) & 7;
+    const int ck0 = ((g) ^ sw) << 4, ck1 = ((4 + g) ^ sw) << 4;
+    const int offW = (wn * 32 + r) * 128;            // + {WL, WH} * HALF + in_local * 2048
+    const int offA = (wm * 64 + r) * 128;            // + {AL, AH} * HALF + im_local * 2048
+    frag_t wlo[2][2], whi[2][2], af[4][2];         // [fragment][k-step]
+    auto read_w = [&](const char* buf, int type, frag_t (&f)[2][2]) {
+        const char* b = buf + type * C::HALF_BYTES + offW;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            f[i][0] = *reinterpret_cast<const frag_t*>(b + i * 2048 + ck0);
+            f[i][1] = *reinterpret_cast<const frag_t*>(b + i * 2048 + ck1);
+        }
+    };
+    auto read_a = [&](const char* buf, int type) {
+        const char* b = buf + type * C::HALF_BYTES + offA;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            af[i][0] = *reinterpret_cast<const frag_t*>(b + i * 2048 + ck0);
+            af[i][1] = *reinterpret_cast<const frag_t*>(b + i * 2048 + ck1);
+        }
+    };
+    // first barrier of a phase, then the fragment reads must be back, then the MFMA cluster, then the second barrier.
+    // sched_barrier(0) keeps hipcc from moving MFMAs or LDS reads across the phase structure; the priority flips keep
+    // the cluster together (cdna_hip_programming.md T5).
+#define VF_G8_SYNC_IN()                                          \
+    do {                                                         \
+        asm volatile("" ::: "memory");                           \
+        __builtin_amdgcn_sched_barrier(0);                       \
+        __builtin_amdgcn_s_barrier();                            \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       \
+        __builtin_amdgcn_sched_barrier(0);                       \
+        __builtin_amdgcn_s_setprio(1);                           \
+    } while (0)
+#define VF_G8_SYNC_OUT()                                         \
+    do {                                                         \
+        __builtin_amdgcn_s_setprio(0);                           \
+        __builtin_amdgcn_sched_barrier(0);                       \
+        __builtin_amdgcn_s_barrier();                            \
+        asm volatile("" ::: "memory");                           \
+        __builtin_amdgcn_sched_barrier(0);                       \
+    } while (0)
+#define VF_G8_MMA(WF, IN0, IM0)                                                                                      \
+    do {                                                                                                             \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                             \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                            \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                        \
+                    acc[IN0 + i][IM0 + j] =                                                                          \
+                        Op16<DT>::mfma(WF[i][ks], af[j][ks], acc[IN0 + i][IM0 + j]); \
+    } while (0)
+
+    // ---- prologue: K-tile 0 complete, the first three half-tiles of K-tile 1 in flight
+    const int nkt = K / BK;
+    issue(0, C::WL); issue(0, C::AL); issue(0, C::WH); issue(0, C::AH);
+    if (nkt > 1) {
+        issue(1, C::WL); issue(1, C::AL); issue(1, C::WH);
+        wait_vmcnt<6>();
+    } else {
+        wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (wm == 1) __builtin_amdgcn_s_barrier();       // group 1 runs one barrier behind (matched after the loop)
+
+    for (int t = 0; t < nkt; ++t) {
+        const char* buf = smem + (t & 1) * C::TILE_BYTES;
+        const bool pre1 = t + 1 < nkt, pre2 = t + 2 < nkt;       // wave-uniform
+        // ---- P1: (m-lo, n-lo)
+        read_w(buf, C::WL, wlo);
+        __builtin_amdgcn_sched_barrier(0);                       // W-lo reads are issued first ...
+        read_a(buf, C::AL);
+        if (pre1) issue(t + 1, C::AH);
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");       // ... and retired before the barrier (WAR on WL)
+        VF_G8_SYNC_IN();
+        VF_G8_MMA(wlo, 0, 0);
+        VF_G8_SYNC_OUT();
+        // ---- P2: (m-lo, n-hi)
+        read_w(buf, C::WH, whi);
+        if (pre2) issue(t + 2, C::WL);
+        VF_G8_SYNC_IN();
+        VF_G8_MMA(whi, 2, 0);
+        VF_G8_SYNC_OUT();
+        // ---- P3: (m-hi, n-hi)
+        read_a(buf, C::AH);
+        if (pre2) issue(t + 2, C::AL);
+        VF_G8_SYNC_IN();
+        VF_G8_MMA(whi, 2, 4);
+        VF_G8_SYNC_OUT();
+        // ---- P4: (m-hi, n-lo); retire K-tile t+1 (all but the three youngest half-tiles)
+        if (pre2) {
+            issue(t + 2, C::WH);
+            wait_vmcnt<6>();
+        } else {
+            wait_vmcnt<0>();
+        }
+        VF_G8_SYNC_IN();
+        VF_G8_MMA(wlo, 0, 4);
+        VF_G8_SYNC_OUT();
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();       // matches group 1's extra barrier: every wave is past its last MFMA
+    asm volatile("" ::: "memory");
+#undef VF_G8_SYNC_IN
+#undef VF_G8_SYNC_OUT
+#undef VF_G8_MMA
+
+    // ---- epilogue: each wave stages its 128 x 64 block through its own 16 KiB slice of the (now free) ring and
+    // writes whole rows, 16 bytes per lane; the fp32 residual rows of pass p+1 are requested while pass p goes through
+    // LDS (same scheme as gemm_mfma_kernel, see the comments there).
+    constexpr bool OUT_F32 = (EPI == VF_EPI_F32 || EPI == VF_EPI_RES_F32 || EPI == VF_EPI_GELU_F32);
+    constexpr int ES = OUT_F32 ? 4 : 2;
+    constexpr int WT_M = 128, WT_N = 64;
+    constexpr int WT_NO = (EPI == VF_EPI_GEGLU_BF16) ? WT_N / 2 : WT_N;
+    constexpr int PITCH = WT_NO * ES + 16;
+    constexpr int REGION = C::LDS_BYTES / C::NW;
+    constexpr int RP = (((REGION / PITCH) < WT_M ? (REGION / PITCH) : WT_M) / 16) * 16;
+    constexpr int IMP = RP / 16, NPASS = (TM + IMP - 1) / IMP;
+    constexpr int CR = WT_NO * ES / 16, RI = 64 / CR, NI = RP / RI;
+    static_assert(RP >= 16 && CR >= 1 && CR <= 64 && 64 % CR == 0, "epilogue geometry");
+    constexpr bool RES = (EPI == VF_EPI_RES_F32);
+    const int n_out_total = (EPI == VF_EPI_GEGLU_BF16) ? N / 2 : N;
+    const int64_t mw0 = m0 + wm * WT_M;
+    const int nw0 = n0 + wn * WT_N;
+    const int no0 = (EPI == VF_EPI_GEGLU_BF16) ? nw0 / 2 : nw0;
+    const int ep_row = lane / CR, ep_col = no0 + (lane % CR) * (16 / ES);
+    f32x4_t rbuf[2][RES ? NI : 1];
+    auto load_res_pass = [&](int ps, f32x4_t (&dst)[RES ? NI : 1]) {
+        if (RES) {
+#pragma unroll
+            for (int k = 0; k < NI; ++k) {
+                int64_t m = mw0 + ps * RP + k * RI + ep_row;
+                m = m < M ? m : M - 1;
+                const int col = ep_col < N ? ep_col : N - 4;
+                dst[RES ? k : 0] = *reinterpret_cast<const f32x4_t*>(res + m * ldr + col);
+            }
+        }
+    };
+    load_res_pass(0, rbuf[0]);
+    // bias of the wave's columns: ONE branch and one batch of loads (a per-element `if (bias) v += load` makes hipcc
+    // branch around every load and drain vmcnt(0) behind each: 32 dependent L2 round trips per wave)
+    f32x4_t bvec[TN];
+    if (bias) {
+#pragma unroll
+        for (int in = 0; in < TN; ++in) {
+            int nb = (EPI == VF_EPI_GEGLU_BF16) ? nw0 + (in >> 1) * 32 + (in & 1) * 16 + 4 * g : nw0 + in * 16 + 4 * g;
+            nb = nb < N ? nb : 0;
+            bvec[in] = *reinterpret_cast<const f32x4_t*>(bias + nb);
+        }
+    } else {
+#pragma unroll
+        for (int in = 0; in < TN; ++in) bvec[in] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
+    char* const region = smem + wave * REGION;
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        if (ps + 1 < NPASS) load_res_pass(ps + 1, rbuf[(ps + 1) & 1]);
+#pragma unroll
+        for (int iml = 0; iml < IMP; ++iml) {
+            const int im = ps * IMP + iml;
+            if (im < TM) {
+                char* rowp = region + (iml * 16 + r) * PITCH;
+                if (EPI == VF_EPI_GEGLU_BF16) {
+#pragma unroll
+                    for (int ip = 0; ip < TN / 2; ++ip) {
+                        const f32x4_t v = acc[2 * ip][im] + bvec[2 * ip], gt = acc[2 * ip + 1][im] + bvec[2 * ip + 1];
+                        u32x2_t pk;
+                        pk[0] = Op16<DT>::pack2(v[0] * gelu_erf(gt[0]), v[1] * gelu_erf(gt[1]));
+                        pk[1] = Op16<DT>::pack2(v[2] * gelu_erf(gt[2]), v[3] * gelu_erf(gt[3]));
+                        *reinterpret_cast<u32x2_t*>(rowp + (ip * 16 + 4 * g) * 2) = pk;
+                    }
+                } else {
+#pragma unroll
+                    for (int in = 0; in < TN; ++in) {
+                        f32x4_t v = acc[in][im] + bvec[in];
+                        if (EPI == VF_EPI_GELU_F32 || EPI == VF_EPI_GELU_BF16) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                        }
+                        if (OUT_F32) {
+                            *reinterpret_cast<f32x4_t*>(rowp + (in * 16 + 4 * g) * 4) = v;
+                        } else {
+                            u32x2_t pk;
+                            pk[0] = Op16<DT>::pack2(v[0], v[1]);
+                            pk[1] = Op16<DT>::pack2(v[2], v[3]);
+                            *reinterpret_cast<u32x2_t*>(rowp + (in * 16 + 4 * g) * 2) = pk;
+                        }
+                    }
+                }
+            }
+        }
+        // (2) read the slice back row-wise: all LDS reads first (unconditional: every row lies inside the slice), then
+        // the predicated stores, so that no store waits behind a per-row ds_read round trip
+        constexpr int KB = RES ? 4 : NI;          // read-back batch (the residual epilogue has fewer registers to spare)
+#pragma unroll
+        for (int k0 = 0; k0 < NI; k0 += KB) {
+            u32x4_t dd[KB];
+#pragma unroll
+            for (int k = 0; k < KB; ++k)
+                if (k0 + k < NI)
+                    dd[k] = *reinterpret_cast<const u32x4_t*>(region + ((k0 + k) * RI + ep_row) * PITCH + (lane % CR) * 16);
+#pragma unroll
+            for (int k = 0; k < KB; ++k) {
+                if (k0 + k >= NI) continue;
+                const int row = (k0 + k) * RI + ep_row;
+                const int64_t m = mw0 + ps * RP + row;
+                u32x4_t d = dd[k];
+                if (RES) {
+                    f32x4_t f = __builtin_bit_cast(f32x4_t, d);
+                    f += rbuf[ps & 1][RES ? k0 + k : 0];
+                    d = __builtin_bit_cast(u32x4_t, f);
+                }
+                if (ps * RP + row < WT_M && m < M && ep_col < n_out_total)
+                    *reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(out) + (m * ldo + ep_col) * ES) = d;
+            }
+        }
+    }
+}
+
 // Shape-generic fallback (any K % 8 == 0): 64x64 tile, fp32 FMA out of LDS.  Same lane->output
 // ownership as the MFMA kernel so the epilogues are shared.  Only small/odd shapes come here.
-template <int EPI>
+template <int EPI, int DT = VF_BF16>
 __global__ __launch_bounds__(256) void gemm_generic_kernel(const unsigned short* __restrict__ A, int64_t lda,
                                                           const unsigned short* __restrict__ W,
                                                           const float* __restrict__ bias,
@@ -615,8 +939,8 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(const unsigned short*
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int k = k0 + kc + e;
-            sA[row][kc + e] = k < K ? bf2f(A[(int64_t)gm * lda + k]) : 0.f;
-            sW[row][kc + e] = k < K ? bf2f(W[(int64_t)gn * K + k]) : 0.f;
+            sA[row][kc + e] = k < K ? Op16<DT>::to_f32(A[(int64_t)gm * lda + k]) : 0.f;
+            sW[row][kc + e] = k < K ? Op16<DT>::to_f32(W[(int64_t)gn * K + k]) : 0.f;
         }
         __syncthreads();
 #pragma unroll 8
@@ -636,24 +960,24 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(const unsigned short*
         for (int ip = 0; ip < 2; ++ip) {
             const int nb = n0 + ip * 32 + 4 * ng;
             if (nb >= N) continue;
-            epilogue_store<EPI>(acc[2 * ip], acc[2 * ip + 1], m, nb, nb + 16, n0 / 2 + ip * 16 + 4 * ng, bias, res, ldr, out, ldo);
+            epilogue_store<EPI, DT>(acc[2 * ip], acc[2 * ip + 1], m, nb, nb + 16, n0 / 2 + ip * 16 + 4 * ng, bias, res, ldr, out, ldo);
         }
     } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int nb = n0 + 16 * j + 4 * ng;
             if (nb >= N) continue;
-            epilogue_store<EPI>(acc[j], acc[j], m, nb, nb, nb, bias, res, ldr, out, ldo);
+            epilogue_store<EPI, DT>(acc[j], acc[j], m, nb, nb, nb, bias, res, ldr, out, ldo);
         }
     }
 }
 
 // The product library instantiates only the configurations pick_variant() can select.
 using CfgA = Cfg<128, 128, 2, 2, 2>;       // 64 KiB, 4 waves, 2 blocks/CU
-using CfgB = Cfg<256, 256, 2, 4, 2>;       // 128 KiB, 8 waves, wave tile 128x64
 using CfgE = Cfg<64, 64, 2, 2, 4>;         // 64 KiB, small-M shapes, 2 blocks/CU
-using CfgJ = Cfg<128, 128, 2, 2, 3, 32>;   // 48 KiB, 4 waves, BK=32, 2 tiles in flight, 3 blocks/CU
 #ifdef VF_TUNING                            // tile sweep of scripts/gemm_bench.py (all measured equal or slower)
+using CfgB = Cfg<256, 256, 2, 4, 2>;       // 128 KiB, 8 waves, wave tile 128x64, one barrier per K-tile (round 1's big tile)
+using CfgJ = Cfg<128, 128, 2, 2, 3, 32>;   // 48 KiB, 4 waves, BK=32, 2 tiles in flight, 3 blocks/CU
 using CfgC = Cfg<256, 128, 4, 2, 3>;       // 144 KiB, 8 waves, wave tile 64x64, 2 tiles in flight
 using CfgD = Cfg<256, 256, 2, 4, 4, 32>;   // 128 KiB, 8 waves, BK=32, 3 tiles in flight
 using CfgF = Cfg<128, 256, 2, 4, 3>;       // 144 KiB, 8 waves, wave tile 64x64
@@ -662,11 +986,11 @@ using CfgH = Cfg<256, 128, 2, 2, 3, 32>;   // 72 KiB, 4 waves (wave tile 128x64)
 using CfgI = Cfg<128, 256, 2, 2, 3, 32>;   // 72 KiB, 4 waves (wave tile 64x128), BK=32, 2 blocks/CU
 #endif
 
-template <class C, int EPI, int DBG = 0>
+template <class C, int EPI, int DT = VF_BF16, int DBG = 0>
 int launch_cfg(const void* A, int64_t lda, const void* W, const float* bias, const float* res, int64_t ldr, void* out,
                int64_t ldo, int M, int N, int K, hipStream_t st) {
     static bool attr_set[VF_MAX_DEVICES] = {};    // per (config, epilogue) instantiation AND per device
-    auto kern = gemm_mfma_kernel<C, EPI, DBG>;
+    auto kern = gemm_mfma_kernel<C, EPI, DT, DBG>;
     const int dev = vf_current_device();
     if (dev < 0 || !attr_set[dev]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -687,11 +1011,11 @@ int launch_cfg(const void* A, int64_t lda, const void* W, const float* bias, con
 }
 
 #ifdef VF_TUNING
-template <class C, int EPI>
+template <class C, int EPI, int DT = VF_BF16>
 int launch_persist(const void* A, int64_t lda, const void* W, const float* bias, const float* res, int64_t ldr, void* out,
                    int64_t ldo, int M, int N, int K, hipStream_t st) {
     static bool attr_set = false;
-    auto kern = gemm_persist_kernel<C, EPI>;
+    auto kern = gemm_persist_kernel<C, EPI, DT>;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 C::LDS_BYTES) != hipSuccess) {
@@ -713,66 +1037,86 @@ int launch_persist(const void* A, int64_t lda, const void* W, const float* bias,
 
 #endif  // VF_TUNING
 
+template <int EPI, int DT = VF_BF16>
+int launch_gemm8(const void* A, int64_t lda, const void* W, const float* bias, const float* res, int64_t ldr, void* out,
+                 int64_t ldo, int M, int N, int K, hipStream_t st) {
+    static bool attr_set[VF_MAX_DEVICES] = {};
+    auto kern = gemm8_kernel<EPI, DT>;
+    const int dev = vf_current_device();
+    if (dev < 0 || !attr_set[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                Cfg8::LDS_BYTES) != hipSuccess) {
+            (void)hipGetLastError();
+            vf_set_error("vf_gemm_bf16: cannot reserve %d bytes of LDS", Cfg8::LDS_BYTES);
+            return VF_ERR_LAUNCH;
+        }
+        if (dev >= 0) attr_set[dev] = true;
+    }
+    const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256;
+    const int n_blocks = tiles_m * tiles_n;
+    hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(512), Cfg8::LDS_BYTES, st, (const unsigned short*)A, lda,
+                       (const unsigned short*)W, bias, res, ldr, out, ldo, M, N, K, tiles_n, n_blocks, 8);
+    VF_CHECK_LAUNCH("vf_gemm_bf16");
+    return VF_OK;
+}
+
 // Tile choice (measured on MI355X, scripts/gemm_bench.py, random data; the cost model inside reproduces every measured
 // ordering): grids with fewer than 256 128x128 tiles use 64x64 tiles so that all 256 CUs get work; otherwise 256x256
 // (one 8-wave block per CU, half the L2 -> LDS bytes per flop) against 128x128 (two 4-wave blocks per CU) by whole
-// waves of tiles; the K = 512 GeGLU of seq2reg takes a BK = 32 ring with three blocks per CU.
-// variant 0 = automatic; 1 / 2 / 5 / 12 force a configuration (tests).  Other numbers exist only under VF_TUNING.
+// waves of tiles.
+// // variant 0 = automatic; 1 / 5 / 20 force a configuration (tests).  Other numbers exist only under VF_TUNING.
 int pick_variant(int M, int N, int K, int epilogue) {
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
     if (t128 < 256) return 5;
-    const bool big_ok = epilogue == VF_EPI_BF16 || epilogue == VF_EPI_GEGLU_BF16 || epilogue == VF_EPI_RES_F32;
-    if (!big_ok) return (K >= 4096 && t256 >= 256) ? 2 : 1;
-    // seq2reg GeGLU (K = 512): BK = 32 ring, 48 KiB -> 3 blocks per CU hide the short main loop's fill (772 vs 641 / 699)
-    if (K <= 512 && epilogue == VF_EPI_GEGLU_BF16 && t128 >= 4096) return 12;
-    // 128x128 (2 blocks per CU, 512 slots) vs 256x256 (1 block per CU, 256 slots, 4x the work per tile): whole waves
-    // of tiles are what a launch pays for, so compare ceil(tiles / slots) x work per wave, with the measured per-flop
-    // advantage of the big tile (half the L2 -> LDS bytes per flop): 1.13x for the bf16 / GeGLU epilogues (gene Wqkv
-    // 1098 vs 975, Wq 1117 vs 970, GeGLU 1027 vs 942 TFLOP/s), 1.06x for the fp32-residual epilogue (783 vs 719 with the
-    // pipelined residual prefetch), more at long K (1380 vs 1170 at 8192^3).  Reproduces every measured ordering of
-    // profiles/r01_g_gemm_sweep_b8.log and of the one-gene shapes (e.g. M = 10854, N = 1536: 258 big tiles = 2 waves
-    // for 1.01 waves of work -> 128x128 wins, 664 vs 468; M = 8192, N = 2048: exactly one wave -> 256x256, 884 vs 781).
+    // 128x128 (2 blocks per CU, 512 slots) vs the two-group 256x256 kernel (1 block per CU, 256 slots, 4x the work per
+    // tile): whole waves of tiles are what a launch pays for, so compare ceil(tiles / slots) x work per wave with the
+    // measured per-flop advantage of the big tile (gpurun_out/r2b/gemm_bench.log, 8 genes per step, TFLOP/s 256x256 vs
+    // 128x128: gene Wqkv 1312 vs 1121, Wq 1227 vs 982, GeGLU 1127 vs 942, fp32-residual out_proj 940 vs 808 and
+    // K = 1024 down-projection 784 vs 692, seq2reg K = 512 Wqkv 985 vs 765, 8192^3 1520 vs 1186).  The same rule keeps
+    // the one-gene shapes (M = 10854: 258 big tiles = 2 waves for 1.01 waves of work) and the CRE stream on 128x128.
+    (void)K;
     const long waves_small = (t128 + 511) / 512, waves_big = (t256 + 255) / 256;
-    const double gain = K >= 4096 ? 1.18 : (epilogue == VF_EPI_RES_F32 ? 1.06 : 1.13);
-    return (double)waves_big * 2.0 / gain < (double)waves_small ? 2 : 1;
+    const double gain = epilogue == VF_EPI_RES_F32 ? 1.14 : 1.2;
+    return (double)waves_big * 2.0 / gain < (double)waves_small ? 20 : 1;
 }
 
-template <int EPI>
+template <int EPI, int DT>
 int launch_gemm(const void* A, int64_t lda, const void* W, const float* bias, const float* res, int64_t ldr, void* out,
                 int64_t ldo, int M, int N, int K, int variant, hipStream_t st) {
     if (K % 64 != 0) {
         dim3 grid((N + 63) / 64, (M + 63) / 64);
-        hipLaunchKernelGGL(gemm_generic_kernel<EPI>, grid, dim3(256), 0, st, (const unsigned short*)A, lda,
+        hipLaunchKernelGGL((gemm_generic_kernel<EPI, DT>), grid, dim3(256), 0, st, (const unsigned short*)A, lda,
                            (const unsigned short*)W, bias, res, ldr, out, ldo, M, N, K);
         VF_CHECK_LAUNCH("vf_gemm_bf16");
         return VF_OK;
     }
     if (variant == 0) variant = pick_variant(M, N, K, EPI);
     switch (variant) {
-        case 1: return launch_cfg<CfgA, EPI>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
-        case 2: return launch_cfg<CfgB, EPI>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
-        case 5: return launch_cfg<CfgE, EPI>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
-        case 12: return launch_cfg<CfgJ, EPI>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
+        case 1: return launch_cfg<CfgA, EPI, DT>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
+        case 5: return launch_cfg<CfgE, EPI, DT>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
+        case 20: return launch_gemm8<EPI, DT>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
 #ifdef VF_TUNING
-        case 3: return launch_cfg<CfgC, EPI>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
-        case 4: return launch_cfg<CfgD, EPI>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
-        case 6: return launch_cfg<CfgF, EPI>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
-        case 7: return launch_cfg<CfgG, EPI>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
-        case 8: return launch_cfg<CfgH, EPI>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
-        case 9: return launch_cfg<CfgI, EPI>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
-        case 104: if (EPI == VF_EPI_BF16) return launch_cfg<CfgA, VF_EPI_BF16, 4>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st); break;
-        case 103: if (EPI == VF_EPI_BF16) return launch_cfg<CfgA, VF_EPI_BF16, 3>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st); break;
-        case 204: if (EPI == VF_EPI_BF16) return launch_cfg<CfgB, VF_EPI_BF16, 4>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st); break;
-        case 203: if (EPI == VF_EPI_BF16) return launch_cfg<CfgB, VF_EPI_BF16, 3>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st); break;
-        case 101: if (EPI == VF_EPI_BF16) return launch_cfg<CfgA, VF_EPI_BF16, 1>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st); break;
-        case 102: if (EPI == VF_EPI_BF16) return launch_cfg<CfgA, VF_EPI_BF16, 2>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st); break;
-        case 201: if (EPI == VF_EPI_BF16) return launch_cfg<CfgB, VF_EPI_BF16, 1>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st); break;
-        case 202: if (EPI == VF_EPI_BF16) return launch_cfg<CfgB, VF_EPI_BF16, 2>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st); break;
-        case 401: if (EPI == VF_EPI_BF16) return launch_cfg<CfgD, VF_EPI_BF16, 1>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st); break;
-        case 402: if (EPI == VF_EPI_BF16) return launch_cfg<CfgD, VF_EPI_BF16, 2>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st); break;
-        case 10: return launch_persist<CfgA, EPI>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
-        case 11: return launch_persist<CfgE, EPI>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
+        case 2: return launch_cfg<CfgB, EPI, DT>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
+        case 12: return launch_cfg<CfgJ, EPI, DT>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
+        case 3: return launch_cfg<CfgC, EPI, DT>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
+        case 4: return launch_cfg<CfgD, EPI, DT>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
+        case 6: return launch_cfg<CfgF, EPI, DT>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
+        case 7: return launch_cfg<CfgG, EPI, DT>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
+        case 8: return launch_cfg<CfgH, EPI, DT>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
+        case 9: return launch_cfg<CfgI, EPI, DT>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
+        case 104: if (EPI == VF_EPI_BF16 && DT == VF_BF16) return launch_cfg<CfgA, VF_EPI_BF16, VF_BF16, 4>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st); break;
+        case 103: if (EPI == VF_EPI_BF16 && DT == VF_BF16) return launch_cfg<CfgA, VF_EPI_BF16, VF_BF16, 3>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st); break;
+        case 204: if (EPI == VF_EPI_BF16 && DT == VF_BF16) return launch_cfg<CfgB, VF_EPI_BF16, VF_BF16, 4>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st); break;
+        case 203: if (EPI == VF_EPI_BF16 && DT == VF_BF16) return launch_cfg<CfgB, VF_EPI_BF16, VF_BF16, 3>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st); break;
+        case 101: if (EPI == VF_EPI_BF16 && DT == VF_BF16) return launch_cfg<CfgA, VF_EPI_BF16, VF_BF16, 1>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st); break;
+        case 102: if (EPI == VF_EPI_BF16 && DT == VF_BF16) return launch_cfg<CfgA, VF_EPI_BF16, VF_BF16, 2>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st); break;
+        case 201: if (EPI == VF_EPI_BF16 && DT == VF_BF16) return launch_cfg<CfgB, VF_EPI_BF16, VF_BF16, 1>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st); break;
+        case 202: if (EPI == VF_EPI_BF16 && DT == VF_BF16) return launch_cfg<CfgB, VF_EPI_BF16, VF_BF16, 2>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st); break;
+        case 401: if (EPI == VF_EPI_BF16 && DT == VF_BF16) return launch_cfg<CfgD, VF_EPI_BF16, VF_BF16, 1>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st); break;
+        case 402: if (EPI == VF_EPI_BF16 && DT == VF_BF16) return launch_cfg<CfgD, VF_EPI_BF16, VF_BF16, 2>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st); break;
+        case 10: return launch_persist<CfgA, EPI, DT>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
+        case 11: return launch_persist<CfgE, EPI, DT>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
 #endif  // VF_TUNING
         default: break;
     }
@@ -792,44 +1136,56 @@ __global__ void pack_geglu_rows_kernel(const unsigned short* __restrict__ W, con
 
 }  // namespace
 
+template <int DT>
 static int gemm_dispatch(const void* A, int64_t lda, const void* W, const float* bias, const float* residual,
                          int64_t ldr, void* out, int64_t ldo, int M, int N, int K, int epilogue, int variant, void* stream) {
-    VF_REQUIRE(A && W && out, "vf_gemm_bf16: null pointer");
-    VF_REQUIRE(M >= 0 && N > 0 && K > 0, "vf_gemm_bf16: bad shape M=%d N=%d K=%d", M, N, K);
-    VF_REQUIRE(K % 8 == 0 && N % 8 == 0, "vf_gemm_bf16: K and N must be multiples of 8 (K=%d N=%d)", K, N);
-    VF_REQUIRE(lda % 8 == 0 && lda >= K, "vf_gemm_bf16: lda=%lld must be >= K and a multiple of 8", (long long)lda);
+    VF_REQUIRE(A && W && out, "vf_gemm: null pointer");
+    VF_REQUIRE(M >= 0 && N > 0 && K > 0, "vf_gemm: bad shape M=%d N=%d K=%d", M, N, K);
+    VF_REQUIRE(K % 8 == 0 && N % 8 == 0, "vf_gemm: K and N must be multiples of 8 (K=%d N=%d)", K, N);
+    VF_REQUIRE(lda % 8 == 0 && lda >= K, "vf_gemm: lda=%lld must be >= K and a multiple of 8", (long long)lda);
     VF_REQUIRE(ldo % 8 == 0 || (ldo % 4 == 0 && (epilogue == VF_EPI_F32 || epilogue == VF_EPI_RES_F32 || epilogue == VF_EPI_GELU_F32)),
-               "vf_gemm_bf16: ldo=%lld must keep rows 16-byte aligned (multiple of 8 for bf16, 4 for fp32 outputs)", (long long)ldo);
+               "vf_gemm: ldo=%lld must keep rows 16-byte aligned (multiple of 8 for 16-bit, 4 for fp32 outputs)", (long long)ldo);
     VF_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)W % 16 == 0) && ((uintptr_t)out % 16 == 0),
-               "vf_gemm_bf16: pointers must be 16-byte aligned");
-    VF_REQUIRE(variant >= 0 && variant <= 999, "vf_gemm_bf16_ex: variant %d out of range", variant);
+               "vf_gemm: pointers must be 16-byte aligned");
+    VF_REQUIRE(variant >= 0 && variant <= 999, "vf_gemm_ex: variant %d out of range", variant);
     if (M == 0) return VF_OK;
     hipStream_t st = (hipStream_t)stream;
     switch (epilogue) {
-        case VF_EPI_BF16: return launch_gemm<VF_EPI_BF16>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, variant, st);
-        case VF_EPI_F32: return launch_gemm<VF_EPI_F32>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, variant, st);
+        case VF_EPI_BF16: return launch_gemm<VF_EPI_BF16, DT>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, variant, st);
+        case VF_EPI_F32: return launch_gemm<VF_EPI_F32, DT>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, variant, st);
         case VF_EPI_RES_F32:
-            VF_REQUIRE(residual && ldr % 4 == 0 && ((uintptr_t)residual % 16 == 0), "vf_gemm_bf16: residual epilogue needs an aligned residual");
-            return launch_gemm<VF_EPI_RES_F32>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, variant, st);
+            VF_REQUIRE(residual && ldr % 4 == 0 && ((uintptr_t)residual % 16 == 0), "vf_gemm: residual epilogue needs an aligned residual");
+            return launch_gemm<VF_EPI_RES_F32, DT>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, variant, st);
         case VF_EPI_GEGLU_BF16:
-            VF_REQUIRE(N % 32 == 0, "vf_gemm_bf16: GEGLU epilogue needs N %% 32 == 0 (N=%d)", N);
-            return launch_gemm<VF_EPI_GEGLU_BF16>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, variant, st);
-        case VF_EPI_GELU_F32: return launch_gemm<VF_EPI_GELU_F32>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, variant, st);
-        case VF_EPI_GELU_BF16: return launch_gemm<VF_EPI_GELU_BF16>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, variant, st);
-        default: VF_REQUIRE(false, "vf_gemm_bf16: unknown epilogue %d", epilogue);
+            VF_REQUIRE(N % 32 == 0, "vf_gemm: GEGLU epilogue needs N %% 32 == 0 (N=%d)", N);
+            return launch_gemm<VF_EPI_GEGLU_BF16, DT>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, variant, st);
+        case VF_EPI_GELU_F32: return launch_gemm<VF_EPI_GELU_F32, DT>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, variant, st);
+        case VF_EPI_GELU_BF16: return launch_gemm<VF_EPI_GELU_BF16, DT>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, variant, st);
+        default: VF_REQUIRE(false, "vf_gemm: unknown epilogue %d", epilogue);
     }
     return VF_OK;
 }
 
 extern "C" int vf_gemm_bf16(const void* A, int64_t lda, const void* W, const float* bias, const float* residual,
                             int64_t ldr, void* out, int64_t ldo, int M, int N, int K, int epilogue, void* stream) {
-    return gemm_dispatch(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, epilogue, 0, stream);
+    return gemm_dispatch<VF_BF16>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, epilogue, 0, stream);
 }
 
 extern "C" int vf_gemm_bf16_ex(const void* A, int64_t lda, const void* W, const float* bias, const float* residual,
                                int64_t ldr, void* out, int64_t ldo, int M, int N, int K, int epilogue, int variant,
                                void* stream) {
-    return gemm_dispatch(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, epilogue, variant, stream);
+    return gemm_dispatch<VF_BF16>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, epilogue, variant, stream);
+}
+
+extern "C" int vf_gemm_f16(const void* A, int64_t lda, const void* W, const float* bias, const float* residual,
+                           int64_t ldr, void* out, int64_t ldo, int M, int N, int K, int epilogue, void* stream) {
+    return gemm_dispatch<VF_F16>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, epilogue, 0, stream);
+}
+
+extern "C" int vf_gemm_f16_ex(const void* A, int64_t lda, const void* W, const float* bias, const float* residual,
+                              int64_t ldr, void* out, int64_t ldo, int M, int N, int K, int epilogue, int variant,
+                              void* stream) {
+    return gemm_dispatch<VF_F16>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, epilogue, variant, stream);
 }
 
 extern "C" int vf_pack_geglu_rows(const void* W, const float* bias, void* W_out, float* bias_out, int two_f, int K,

@@ -21,6 +21,11 @@ extern "C" const char* vf_last_error(void) { return g_err; }
 
 namespace {
 
+// runtime 16-bit output type (VF_BF16 / VF_F16): uniform per launch
+__device__ __forceinline__ unsigned int pack2_dt(float lo, float hi, int dt) {
+    return dt == VF_F16 ? pack2h(lo, hi) : pack2bf(lo, hi);
+}
+
 // ---------------------------------------------------------------------------------------------
 // LayerNorm: one wave per row, row held in registers (two-pass mean / variance like ATen),
 // float4 loads, bf16x4 or float4 stores.
@@ -28,7 +33,7 @@ namespace {
 template <int MAXC>   // MAXC float4 chunks per lane: D <= 256*MAXC
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, void* __restrict__ out,
-                                                        int64_t rows, int D, float eps, int out_bf16, int gelu) {
+                                                        int64_t rows, int D, float eps, int out_dt, int gelu) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -69,10 +74,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                 y[e] = (v[c][e] - mean) * rstd * gg[e] + bb[e];
                 if (gelu) y[e] = gelu_erf(y[e]);
             }
-            if (out_bf16) {
+            if (out_dt != VF_F32) {
                 u32x2_t p;
-                p[0] = pack2bf(y[0], y[1]);
-                p[1] = pack2bf(y[2], y[3]);
+                p[0] = pack2_dt(y[0], y[1], out_dt);
+                p[1] = pack2_dt(y[2], y[3], out_dt);
                 reinterpret_cast<u32x2_t*>(reinterpret_cast<unsigned short*>(out) + row * D)[i] = p;
             } else {
                 reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(out) + row * D)[i] = y;
@@ -165,7 +170,7 @@ __global__ __launch_bounds__(256) void embed_pack_kernel(const int64_t* __restri
 // segment mean (masked mean pool): one block per window, threads over float4 columns
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void segment_mean_kernel(const float* __restrict__ x, const int32_t* __restrict__ cu,
-                                                          void* __restrict__ out, int d, int out_bf16) {
+                                                          void* __restrict__ out, int d, int out_dt) {
     const int w = blockIdx.x;
     const int a = cu[w], e = cu[w + 1];
     const int n4 = d >> 2;
@@ -174,10 +179,10 @@ __global__ __launch_bounds__(256) void segment_mean_kernel(const float* __restri
         f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         for (int t = a; t < e; ++t) acc += reinterpret_cast<const f32x4_t*>(x + (int64_t)t * d)[c];
         acc *= inv;
-        if (out_bf16) {
+        if (out_dt != VF_F32) {
             u32x2_t p;
-            p[0] = pack2bf(acc[0], acc[1]);
-            p[1] = pack2bf(acc[2], acc[3]);
+            p[0] = pack2_dt(acc[0], acc[1], out_dt);
+            p[1] = pack2_dt(acc[2], acc[3], out_dt);
             reinterpret_cast<u32x2_t*>(reinterpret_cast<unsigned short*>(out) + (int64_t)w * d)[c] = p;
         } else {
             reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(out) + (int64_t)w * d)[c] = acc;
@@ -222,7 +227,7 @@ __global__ __launch_bounds__(256) void add_rows_kernel(const float* __restrict__
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gather_rows_f32_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                              const int64_t* __restrict__ idx, void* __restrict__ out,
-                                                             int64_t n, int d, int out_bf16) {
+                                                             int64_t n, int d, int out_dt) {
     const int n4 = d >> 2;
     const int64_t total = n * n4;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -231,10 +236,10 @@ __global__ __launch_bounds__(256) void gather_rows_f32_kernel(const float* __res
         const int64_t j = idx[row];
         const float* src = j >= 0 ? a + j * d : b + (-j - 1) * d;
         const f32x4_t v = reinterpret_cast<const f32x4_t*>(src)[c];
-        if (out_bf16) {
+        if (out_dt != VF_F32) {
             u32x2_t p;
-            p[0] = pack2bf(v[0], v[1]);
-            p[1] = pack2bf(v[2], v[3]);
+            p[0] = pack2_dt(v[0], v[1], out_dt);
+            p[1] = pack2_dt(v[2], v[3], out_dt);
             reinterpret_cast<u32x2_t*>(reinterpret_cast<unsigned short*>(out) + row * d)[c] = p;
         } else {
             reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(out) + row * d)[c] = v;
@@ -279,17 +284,18 @@ __global__ __launch_bounds__(256) void rowdot_softplus_kernel(const float* __res
     }
 }
 
-__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ out,
-                                                           int64_t n) {
+__global__ __launch_bounds__(256) void cast_f32_16_kernel(const float* __restrict__ x, unsigned short* __restrict__ out,
+                                                         int64_t n, int out_dt) {
     const int64_t n4 = n >> 2;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         const f32x4_t v = reinterpret_cast<const f32x4_t*>(x)[i];
         u32x2_t p;
-        p[0] = pack2bf(v[0], v[1]);
-        p[1] = pack2bf(v[2], v[3]);
+        p[0] = pack2_dt(v[0], v[1], out_dt);
+        p[1] = pack2_dt(v[2], v[3], out_dt);
         reinterpret_cast<u32x2_t*>(out)[i] = p;
     }
-    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) out[(n4 << 2) + threadIdx.x] = f2bf(x[(n4 << 2) + threadIdx.x]);
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3))
+        out[(n4 << 2) + threadIdx.x] = (unsigned short)(pack2_dt(x[(n4 << 2) + threadIdx.x], 0.f, out_dt) & 0xFFFFu);
 }
 
 inline int stream_grid(int64_t work_items) {
@@ -305,11 +311,11 @@ extern "C" int vf_layernorm(const float* x, const float* gamma, const float* bet
                             float eps, int out_dtype, int gelu, void* stream) {
     VF_REQUIRE(x && gamma && beta && out, "vf_layernorm: null pointer");
     VF_REQUIRE(D > 0 && D % 4 == 0 && D <= 8192, "vf_layernorm: D=%d must be a multiple of 4 and <= 8192", D);
-    VF_REQUIRE(out_dtype == VF_F32 || out_dtype == VF_BF16, "vf_layernorm: bad out_dtype %d", out_dtype);
+    VF_REQUIRE(out_dtype == VF_F32 || out_dtype == VF_BF16 || out_dtype == VF_F16, "vf_layernorm: bad out_dtype %d", out_dtype);
     if (rows <= 0) return VF_OK;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)((rows + 3) / 4));
-    const int bf = out_dtype == VF_BF16;
+    const int bf = out_dtype;
     if (D <= 512) hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, st, x, gamma, beta, out, rows, D, eps, bf, gelu);
     else if (D <= 2048) hipLaunchKernelGGL(layernorm_kernel<8>, grid, dim3(256), 0, st, x, gamma, beta, out, rows, D, eps, bf, gelu);
     else hipLaunchKernelGGL(layernorm_kernel<32>, grid, dim3(256), 0, st, x, gamma, beta, out, rows, D, eps, bf, gelu);
@@ -338,9 +344,9 @@ extern "C" int vf_embed_pack(const int64_t* ids, const uint8_t* pad, const int32
 
 extern "C" int vf_segment_mean(const float* x, const int32_t* cu, void* out, int W, int d, int out_dtype, void* stream) {
     VF_REQUIRE(x && cu && out && d > 0 && d % 4 == 0, "vf_segment_mean: bad arguments (d=%d)", d);
-    VF_REQUIRE(out_dtype == VF_F32 || out_dtype == VF_BF16, "vf_segment_mean: bad out_dtype %d", out_dtype);
+    VF_REQUIRE(out_dtype == VF_F32 || out_dtype == VF_BF16 || out_dtype == VF_F16, "vf_segment_mean: bad out_dtype %d", out_dtype);
     if (W <= 0) return VF_OK;
-    hipLaunchKernelGGL(segment_mean_kernel, dim3(W), dim3(256), 0, (hipStream_t)stream, x, cu, out, d, out_dtype == VF_BF16);
+    hipLaunchKernelGGL(segment_mean_kernel, dim3(W), dim3(256), 0, (hipStream_t)stream, x, cu, out, d, out_dtype);
     VF_CHECK_LAUNCH("vf_segment_mean");
     return VF_OK;
 }
@@ -366,10 +372,10 @@ extern "C" int vf_add_rows_f32(const float* a, const int64_t* idx_a, const float
 extern "C" int vf_gather_rows_f32(const float* a, const float* b, const int64_t* idx, void* out, int64_t n, int d,
                                   int out_dtype, void* stream) {
     VF_REQUIRE(a && idx && out && d > 0 && d % 4 == 0, "vf_gather_rows_f32: bad arguments (d=%d)", d);
-    VF_REQUIRE(out_dtype == VF_F32 || out_dtype == VF_BF16, "vf_gather_rows_f32: bad out_dtype %d", out_dtype);
+    VF_REQUIRE(out_dtype == VF_F32 || out_dtype == VF_BF16 || out_dtype == VF_F16, "vf_gather_rows_f32: bad out_dtype %d", out_dtype);
     if (n <= 0) return VF_OK;
     hipLaunchKernelGGL(gather_rows_f32_kernel, dim3(stream_grid(n * (d / 4))), dim3(256), 0, (hipStream_t)stream, a,
-                       b ? b : a, idx, out, n, d, out_dtype == VF_BF16);
+                       b ? b : a, idx, out, n, d, out_dtype);
     VF_CHECK_LAUNCH("vf_gather_rows_f32");
     return VF_OK;
 }
@@ -395,12 +401,15 @@ extern "C" int vf_rowdot_softplus(const float* x, const float* w, const float* b
     return VF_OK;
 }
 
-extern "C" int vf_cast_f32_bf16(const float* x, void* out, int64_t n, void* stream) {
-    VF_REQUIRE(x && out && n >= 0, "vf_cast_f32_bf16: bad arguments");
-    VF_REQUIRE(((uintptr_t)x % 16 == 0) && ((uintptr_t)out % 8 == 0), "vf_cast_f32_bf16: misaligned pointer");
+static int cast_f32_16(const float* x, void* out, int64_t n, int dt, void* stream) {
+    VF_REQUIRE(x && out && n >= 0, "vf_cast_f32_*: bad arguments");
+    VF_REQUIRE(((uintptr_t)x % 16 == 0) && ((uintptr_t)out % 8 == 0), "vf_cast_f32_*: misaligned pointer");
     if (n == 0) return VF_OK;
-    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(stream_grid(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, x,
-                       (unsigned short*)out, n);
-    VF_CHECK_LAUNCH("vf_cast_f32_bf16");
+    hipLaunchKernelGGL(cast_f32_16_kernel, dim3(stream_grid(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, x,
+                       (unsigned short*)out, n, dt);
+    VF_CHECK_LAUNCH("vf_cast_f32_*");
     return VF_OK;
 }
+
+extern "C" int vf_cast_f32_bf16(const float* x, void* out, int64_t n, void* stream) { return cast_f32_16(x, out, n, VF_BF16, stream); }
+extern "C" int vf_cast_f32_f16(const float* x, void* out, int64_t n, void* stream) { return cast_f32_16(x, out, n, VF_F16, stream); }

@@ -11,7 +11,38 @@ import torch
 
 from . import _lib
 from ._lib import (EPI_BF16, EPI_F32, EPI_GEGLU_BF16, EPI_GELU_BF16, EPI_GELU_F32, EPI_RES_F32, VF_BF16,  # noqa: F401
-                   VF_F32, check)
+                   VF_F16, VF_F32, check)
+
+# The 16-bit operand type of the GEMM / attention kernels: torch.bfloat16 (the reference's shipped `bf16-mixed`) or
+# torch.float16 (its `16-mixed` / fp16 flash-attn path; BASELINE configs[4]).  fp32 accumulation either way.  The
+# "*_BF16" epilogue names mean "16-bit output in the operand type".
+_CDT = torch.bfloat16
+
+
+class compute_dtype:
+    """with ops.compute_dtype(torch.float16): ...  -- 16-bit tensors created inside (LayerNorm outputs, casts, packed
+    weights) use this operand type; kernels themselves follow the dtype of the tensors they are handed."""
+
+    def __init__(self, dtype):
+        assert dtype in (torch.bfloat16, torch.float16), dtype
+        self.dtype = dtype
+
+    def __enter__(self):
+        global _CDT
+        self.prev, _CDT = _CDT, self.dtype
+
+    def __exit__(self, *exc):
+        global _CDT
+        _CDT = self.prev
+        return False
+
+
+def cdt():
+    return _CDT
+
+
+def _is16(dtype) -> bool:
+    return dtype in (torch.bfloat16, torch.float16)
 
 
 def _stream() -> int:
@@ -99,21 +130,23 @@ def _dt(dtype) -> int:
         return VF_F32
     if dtype == torch.bfloat16:
         return VF_BF16
+    if dtype == torch.float16:
+        return VF_F16
     raise _lib.VFError(f"unsupported dtype {dtype}")
 
 
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None, epilogue: int,
          residual: torch.Tensor | None = None, out: torch.Tensor | None = None, variant: int = 0,
          family: str = "") -> torch.Tensor:
-    """out = epilogue(a[M,K] @ w[N,K]^T + bias).  a, w bf16 (a may be a row-strided view).
-    variant != 0 forces a tile configuration (vf_gemm_bf16_ex; tuning / tests only)."""
+    """out = epilogue(a[M,K] @ w[N,K]^T + bias).  a, w both bf16 or both fp16 (a may be a row-strided view); 16-bit
+    outputs come back in the operand type.  variant != 0 forces a tile configuration (vf_gemm_*_ex; tests only)."""
     _dev(a, w, bias, residual, out)
-    assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and a.dim() == 2 and w.dim() == 2
+    assert _is16(a.dtype) and w.dtype == a.dtype and a.dim() == 2 and w.dim() == 2
     assert a.stride(1) == 1 and w.is_contiguous() and a.shape[1] == w.shape[1]
     M, K = a.shape
     N = w.shape[0]
     n_out = N // 2 if epilogue == EPI_GEGLU_BF16 else N
-    odt = torch.float32 if epilogue in (EPI_F32, EPI_RES_F32, EPI_GELU_F32) else torch.bfloat16
+    odt = torch.float32 if epilogue in (EPI_F32, EPI_RES_F32, EPI_GELU_F32) else a.dtype
     if out is None:
         out = torch.empty((M, n_out), dtype=odt, device=a.device)
     assert out.dtype == odt and out.shape == (M, n_out) and out.stride(1) == 1
@@ -128,12 +161,15 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None, epilogue: 
     def launch():
         lda = a.stride(0) if M > 1 else max(a.stride(0), K)
         ldo = out.stride(0) if M > 1 else max(out.stride(0), n_out)
+        f16 = a.dtype == torch.float16
         if variant:
-            check(lib.vf_gemm_bf16_ex(a.data_ptr(), lda, w.data_ptr(), _ptr(bias), _ptr(residual), ldr, out.data_ptr(),
-                                      ldo, M, N, K, epilogue, variant, _stream()), "vf_gemm_bf16_ex")
+            fn = lib.vf_gemm_f16_ex if f16 else lib.vf_gemm_bf16_ex
+            check(fn(a.data_ptr(), lda, w.data_ptr(), _ptr(bias), _ptr(residual), ldr, out.data_ptr(),
+                     ldo, M, N, K, epilogue, variant, _stream()), "vf_gemm_ex")
         else:
-            check(lib.vf_gemm_bf16(a.data_ptr(), lda, w.data_ptr(), _ptr(bias), _ptr(residual), ldr, out.data_ptr(),
-                                   ldo, M, N, K, epilogue, _stream()), "vf_gemm_bf16")
+            fn = lib.vf_gemm_f16 if f16 else lib.vf_gemm_bf16
+            check(fn(a.data_ptr(), lda, w.data_ptr(), _ptr(bias), _ptr(residual), ldr, out.data_ptr(),
+                     ldo, M, N, K, epilogue, _stream()), "vf_gemm")
     if TIMER is not None:
         nbytes = 2.0 * (M * K + N * K) + out.numel() * out.element_size() + (0 if residual is None else 4.0 * M * N)
         TIMER.time("gemm", 2.0 * M * N * K, nbytes, launch, f"M={M} N={N} K={K} epi={epilogue}", family or _SCOPE)
@@ -143,9 +179,9 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None, epilogue: 
 
 
 def pack_geglu_rows(w: torch.Tensor, bias: torch.Tensor | None):
-    """Permute a [2F,K] bf16 weight (+ fp32 bias) into the GEGLU-epilogue row order."""
+    """Permute a [2F,K] 16-bit weight (+ fp32 bias) into the GEGLU-epilogue row order."""
     _dev(w, bias)
-    assert w.dtype == torch.bfloat16 and w.is_contiguous()
+    assert _is16(w.dtype) and w.is_contiguous()
     wo = torch.empty_like(w)
     bo = torch.empty_like(bias) if bias is not None else None
     check(_lib.load().vf_pack_geglu_rows(w.data_ptr(), _ptr(bias), wo.data_ptr(), _ptr(bo), w.shape[0], w.shape[1],
@@ -162,17 +198,21 @@ def attn_varlen(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_q: torch.T
     end alignment)."""
     _dev(q, k, v, cu_q, cu_k, slopes, out)
     for t in (q, k, v):
-        assert t.dtype == torch.bfloat16 and t.dim() == 2 and t.stride(1) == 1
+        assert _is16(t.dtype) and t.dtype == q.dtype and t.dim() == 2 and t.stride(1) == 1
     assert cu_q.dtype == torch.int32 and (cu_k is None or cu_k.dtype == torch.int32)
     D = n_heads * head_dim
     if out is None:
-        out = torch.empty((q.shape[0], D), dtype=torch.bfloat16, device=q.device)
+        out = torch.empty((q.shape[0], D), dtype=q.dtype, device=q.device)
     if scale is None:
         scale = 1.0 / math.sqrt(head_dim)
     if slopes is not None:
         assert slopes.dtype == torch.float32 and slopes.numel() == n_heads
     def launch():
-        fn = _lib.load().vf_attn_varlen_fwd_qstart if q_at_start else _lib.load().vf_attn_varlen_fwd
+        lib = _lib.load()
+        if q.dtype == torch.float16:
+            fn = lib.vf_attn_varlen_fwd_qstart_f16 if q_at_start else lib.vf_attn_varlen_fwd_f16
+        else:
+            fn = lib.vf_attn_varlen_fwd_qstart if q_at_start else lib.vf_attn_varlen_fwd
         check(fn(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), q.stride(0),
                                              k.stride(0), v.stride(0), out.stride(0), cu_q.data_ptr(), _ptr(cu_k),
                                              cu_q.numel() - 1, int(max_q), int(max_k), n_heads, head_dim, _ptr(slopes),
@@ -189,9 +229,11 @@ def attn_varlen(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_q: torch.T
     return out
 
 
-def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out_dtype=torch.bfloat16, gelu: bool = False,
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out_dtype=None, gelu: bool = False,
               eps: float = 1e-5, out: torch.Tensor | None = None) -> torch.Tensor:
+    """out_dtype None = the current compute dtype (ops.cdt())."""
     _dev(x, gamma, beta, out)
+    out_dtype = _CDT if out_dtype is None else out_dtype
     assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 2
     rows, D = x.shape
     if out is None:
@@ -232,8 +274,9 @@ def embed_pack(ids: torch.Tensor, pad: torch.Tensor, cu: torch.Tensor, table: to
     return out
 
 
-def segment_mean(x: torch.Tensor, cu: torch.Tensor, out_dtype=torch.bfloat16) -> torch.Tensor:
+def segment_mean(x: torch.Tensor, cu: torch.Tensor, out_dtype=None) -> torch.Tensor:
     _dev(x, cu)
+    out_dtype = _CDT if out_dtype is None else out_dtype
     assert x.dtype == torch.float32 and x.is_contiguous() and cu.dtype == torch.int32
     W = cu.numel() - 1
     out = torch.empty((W, x.shape[1]), dtype=out_dtype, device=x.device)
@@ -280,8 +323,8 @@ def gather_rows_f32(a: torch.Tensor, b: torch.Tensor | None, idx: torch.Tensor, 
 
 def gather_rows_bf16(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     _dev(src, idx)
-    assert src.dtype == torch.bfloat16 and src.stride(1) == 1 and idx.dtype == torch.int64
-    out = torch.empty((idx.numel(), src.shape[1]), dtype=torch.bfloat16, device=src.device)
+    assert _is16(src.dtype) and src.stride(1) == 1 and idx.dtype == torch.int64
+    out = torch.empty((idx.numel(), src.shape[1]), dtype=src.dtype, device=src.device)
     check(_lib.load().vf_gather_rows_bf16(src.data_ptr(), src.stride(0), idx.data_ptr(), out.data_ptr(), out.stride(0),
                                           idx.numel(), src.shape[1], _stream()), "vf_gather_rows_bf16")
     return out
@@ -296,9 +339,17 @@ def rowdot_softplus(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor | None, so
     return out
 
 
-def cast_bf16(x: torch.Tensor) -> torch.Tensor:
+def cast16(x: torch.Tensor, dtype=None) -> torch.Tensor:
+    """fp32 -> 16-bit operand type (default: the current compute dtype), round to nearest even."""
     _dev(x)
-    assert x.dtype == torch.float32 and x.is_contiguous()
-    out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
-    check(_lib.load().vf_cast_f32_bf16(x.data_ptr(), out.data_ptr(), x.numel(), _stream()), "vf_cast_f32_bf16")
+    dtype = _CDT if dtype is None else dtype
+    assert x.dtype == torch.float32 and x.is_contiguous() and _is16(dtype)
+    out = torch.empty(x.shape, dtype=dtype, device=x.device)
+    lib = _lib.load()
+    fn = lib.vf_cast_f32_f16 if dtype == torch.float16 else lib.vf_cast_f32_bf16
+    check(fn(x.data_ptr(), out.data_ptr(), x.numel(), _stream()), "vf_cast_f32_16")
     return out
+
+
+def cast_bf16(x: torch.Tensor) -> torch.Tensor:
+    return cast16(x, torch.bfloat16)

@@ -76,11 +76,11 @@ def _context_kv_table(ctx_embedding: nn.Embedding, layer) -> torch.Tensor:
     """bf16 [9, 2D] = Wkv_layer(context embedding table); constant per weights, cached on the layer."""
     tab = ctx_embedding.weight
     mha = layer.crossMHA.MHA
-    key = (tab.data_ptr(), tab._version, mha.Wkv.weight.data_ptr(), mha.Wkv.weight._version)
+    key = (tab.data_ptr(), tab._version, mha.Wkv.weight.data_ptr(), mha.Wkv.weight._version, ops.cdt())
     c = getattr(layer, "_vf_ctx_kv", None)
     if c is None or c[0] != key:
         with torch.no_grad():
-            c = (key, mha.project_kv(ops.cast_bf16(tab.detach().float().contiguous())))
+            c = (key, mha.project_kv(ops.cast16(tab.detach().float().contiguous())))
         layer._vf_ctx_kv = c
     return c[1]
 
@@ -304,10 +304,24 @@ class Seq2GenePredictorCombinedModulator(nn.Module):
     def device(self):
         return self.gene_map.weight.device
 
+    def operand_dtype(self):
+        """16-bit operand type of the GEMM / attention kernels for the trainer's precision string (reference
+        utils/functions.py:12-32 + model_combined_modulator.py:736-744 + layers.py:102-125):
+          "bf16-mixed" (shipped, configs/vf_model.yaml:37) -> bf16 operands, fp32 accumulation;
+          "16-mixed" / "16"                                -> fp16 operands, fp32 accumulation (autocast fp16);
+          "32" / "32-true"                                 -> the reference keeps fp32 outside the MHA modules and runs
+                                                              those in fp16; here every GEMM takes fp16 operands (10-bit
+                                                              mantissa, the closest MFMA type) with fp32 accumulation.
+        No trainer attached -> the shipped bf16.  `self.precision` (a string) overrides the trainer."""
+        p = self.precision if isinstance(self.precision, str) else getattr(self.trainer, "precision", None)
+        if p is None:
+            return torch.bfloat16
+        return torch.bfloat16 if precision2dtype(str(p)) == torch.bfloat16 else torch.float16
+
     def _precision_branch(self):
         """Reference :736-744: bf16/fp16-mixed -> None (autocast path), anything else -> fp32 (which the
-        reference then runs through an fp16 flash-attn round trip).  Both branches run the same bf16-operand
-        / fp32-accumulate kernels here; the value is only reported."""
+        reference then runs through an fp16 flash-attn round trip).  The value is what transform_with_batching
+        returns; the operand type the kernels use comes from operand_dtype()."""
         try:
             p = precision2dtype(self.trainer.precision)
         except Exception:
@@ -386,6 +400,10 @@ class Seq2GenePredictorCombinedModulator(nn.Module):
     def forward_prepared(self, pb: PreparedBatch, return_cre: bool = False):
         """The hot path: everything below runs as HIP kernels on the current stream.
         Returns (pred fp32 [sum T, 1], emb fp32 [sum T, D])."""
+        with ops.compute_dtype(self.operand_dtype()):
+            return self._forward_prepared(pb, return_cre)
+
+    def _forward_prepared(self, pb: PreparedBatch, return_cre: bool = False):
         # seq2reg over every CRE window / gene chunk of the batch (HOT LOOP A, SURVEY §3.1)
         cre_tok = self.cre_tokenizer.embed_packed(pb.cre_ids, pb.cre_pad, pb.cre_tokens, max_len=pb.cre_max_len)        # bf16 [sum N, d]
         gene_tokenizer = self.gene_tokenizer if self.gene_tokenizer is not None else self.cre_tokenizer

@@ -38,16 +38,17 @@ def get_alibi_slopes(n: int) -> torch.Tensor:
 # weight packing (fp32 master parameters -> bf16 kernel operands), cached per parameter version
 # ---------------------------------------------------------------------------------------------
 def packed_linear(lin: nn.Linear, geglu: bool = False):
-    """(bf16 weight [N,K], fp32 bias [N]) for vf_gemm_bf16; `geglu` applies the GEGLU row interleave.
-    Rebuilt whenever the parameter is modified in place (load_state_dict) or moved."""
+    """(16-bit weight [N,K] in the current compute dtype, fp32 bias [N]) for vf_gemm_*; `geglu` applies the GEGLU row
+    interleave.  Rebuilt whenever the parameter is modified in place (load_state_dict), moved, or the compute dtype
+    changes (one cached copy per module: a model runs in one precision at a time)."""
     w = lin.weight
-    key = (w.data_ptr(), w._version, str(w.device), geglu,
+    key = (w.data_ptr(), w._version, str(w.device), geglu, ops.cdt(),
            None if lin.bias is None else (lin.bias.data_ptr(), lin.bias._version))
     cache = getattr(lin, "_vf_packed", None)
     if cache is not None and cache[0] == key:
         return cache[1], cache[2]
     with torch.no_grad():
-        wb = ops.cast_bf16(w.detach().float().contiguous())
+        wb = ops.cast16(w.detach().float().contiguous())
         b = None if lin.bias is None else lin.bias.detach().float().contiguous()
         if geglu:
             wb, b = ops.pack_geglu_rows(wb, b)
@@ -142,11 +143,16 @@ class MHA(nn.Module):
                 Sk = x_kv.shape[1]
                 cu_seqlens_k, max_seqlen_k = _cu_from_padded(B, Sk, x.device), Sk
                 x_kv = x_kv.reshape(B * Sk, -1)
-        xb = x if x.dtype == torch.bfloat16 else ops.cast_bf16(x.float().contiguous())
+        cd = x.dtype if x.dtype in (torch.bfloat16, torch.float16) else ops.cdt()     # 16-bit inputs pick the operand type
+        with ops.compute_dtype(cd):
+            return self._forward_cd(x, x_kv, cu_seqlens, max_seqlen, cu_seqlens_k, max_seqlen_k, in_dtype, in_shape, cd)
+
+    def _forward_cd(self, x, x_kv, cu_seqlens, max_seqlen, cu_seqlens_k, max_seqlen_k, in_dtype, in_shape, cd):
+        xb = x if x.dtype == cd else ops.cast16(x.float().contiguous())
         kv = None
         if self.cross_attn:
             src = x_kv if x_kv is not None else x
-            kv = self.project_kv(src if src.dtype == torch.bfloat16 else ops.cast_bf16(src.float().contiguous()))
+            kv = self.project_kv(src if src.dtype == cd else ops.cast16(src.float().contiguous()))
             if cu_seqlens_k is None:
                 cu_seqlens_k, max_seqlen_k = cu_seqlens, max_seqlen
         a = self.attend(xb, kv, cu_seqlens, max_seqlen, cu_seqlens_k, max_seqlen_k)
@@ -226,7 +232,7 @@ class ContextFlashAttentionEncoderLayer(nn.Module):
         x1 = self.mixer.MHA.fused(h, src, cu_src, max_src)
         h = ops.layernorm(x1, self.norm2.weight, self.norm2.bias)
         if context_kv is None:
-            context_kv = self.crossMHA.MHA.project_kv(ops.cast_bf16(context))
+            context_kv = self.crossMHA.MHA.project_kv(ops.cast16(context))
         cq = cu_src if cu_cross_q is None else cu_cross_q
         mq = max_src if max_cross_q is None else max_cross_q
         x2 = self.crossMHA.MHA.fused(h, x1, cq, mq, context_kv, cu_ctx, max_ctx)
@@ -258,7 +264,7 @@ class ContextFlashAttentionEncoderLayer(nn.Module):
         wo, bo = packed_linear(mha.out_proj)
         x1 = ops.gemm(a, wo, bo, ops.EPI_RES_F32, residual=src_rows)
         h = ops.layernorm(x1, self.norm2.weight, self.norm2.bias)
-        ckv = self.crossMHA.MHA.project_kv(ops.cast_bf16(context))
+        ckv = self.crossMHA.MHA.project_kv(ops.cast16(context))
         x2 = self.crossMHA.MHA.fused(h, x1, cu_cross_rows, max_cross_rows, ckv, cu_ctx, max_ctx)
         h = ops.layernorm(x2, self.norm3.weight, self.norm3.bias)
         w1, b1 = packed_linear(self.linear_geglu_1, geglu=True)
@@ -268,8 +274,16 @@ class ContextFlashAttentionEncoderLayer(nn.Module):
 
     def forward(self, src, context, src_key_padding_mask=None, context_padding_mask=None, precision=torch.float32,
                 unpad_info=None, context_unpad_info=None, gene_unpad_info=None):
-        """Reference signature.  `precision` is accepted and ignored: operands are always bf16 with fp32
-        accumulation (the reference's bf16-mixed path); there is no fp16 round trip."""
+        """Reference signature.  `precision` (a torch dtype or None, as the reference passes it, layers.py:94-125):
+        torch.float16 / torch.float32 select fp16 operands (the reference's fp16 flash path), torch.bfloat16 bf16
+        operands, None the ambient compute dtype (ops.cdt(), bf16 unless the model's precision says otherwise)."""
+        cd = {torch.float16: torch.float16, torch.float32: torch.float16, torch.bfloat16: torch.bfloat16}.get(precision, ops.cdt())
+        with ops.compute_dtype(cd):
+            return self._forward_ref(src, context, src_key_padding_mask, context_padding_mask, unpad_info,
+                                     context_unpad_info, gene_unpad_info)
+
+    def _forward_ref(self, src, context, src_key_padding_mask, context_padding_mask, unpad_info, context_unpad_info,
+                     gene_unpad_info):
         if context_padding_mask is None and src_key_padding_mask is not None:
             context_padding_mask = src_key_padding_mask.clone()
         info = gene_unpad_info if gene_unpad_info is not None else unpad_info
@@ -343,7 +357,7 @@ class ContextFlashCrossAttentionEncoderLayer(nn.Module):
         assert not self.make_data_kv
         h = ops.layernorm(src, self.norm1.weight, self.norm1.bias)
         if context_kv is None:
-            context_kv = self.crossMHA.MHA.project_kv(ops.cast_bf16(context))
+            context_kv = self.crossMHA.MHA.project_kv(ops.cast16(context))
         cq = cu_src if cu_cross_q is None else cu_cross_q
         mq = max_src if max_cross_q is None else max_cross_q
         x1 = self.crossMHA.MHA.fused(h, src, cq, mq, context_kv, cu_ctx, max_ctx)
@@ -432,14 +446,14 @@ class TissueExpressionHeads(nn.Module):
         """One head on fp32 rows [n, D] -> fp32 [n, 1]."""
         if self.kind == "linear":
             return ops.rowdot_softplus(g_exp, te[0].weight.reshape(-1).contiguous(), te[0].bias, self.softplus)
-        x = ops.cast_bf16(g_exp)
+        x = ops.cast16(g_exp)
         if self.kind == "mlp_small":
             w0, b0 = packed_linear(te[0])
             h = ops.gemm(x, w0, b0, ops.EPI_GELU_F32)
             return ops.rowdot_softplus(h, te[2].weight.reshape(-1).contiguous(), te[2].bias, self.softplus)
         w0, b0 = packed_linear(te[0])
         h = ops.gemm(x, w0, b0, ops.EPI_F32)
-        h = ops.layernorm(h, te[1].weight, te[1].bias, torch.bfloat16, gelu=True)
+        h = ops.layernorm(h, te[1].weight, te[1].bias, gelu=True)
         w4, b4 = packed_linear(te[4])
         h = ops.gemm(h, w4, b4, ops.EPI_GELU_F32)
         return ops.rowdot_softplus(h, te[6].weight.reshape(-1).contiguous(), te[6].bias, self.softplus)

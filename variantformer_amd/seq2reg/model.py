@@ -80,7 +80,7 @@ class Seq2RegPredictor(nn.Module):
             self._pe_dev = self.position_encoding.to(device).contiguous()
         return self._pe_dev
 
-    def embed_packed(self, ids: torch.Tensor, pad: torch.Tensor, n_tokens: int, out_dtype=torch.bfloat16,
+    def embed_packed(self, ids: torch.Tensor, pad: torch.Tensor, n_tokens: int, out_dtype=None,
                      max_len: int = 0):
         """ids int64 [W, L], pad bool/u8 [W, L] (True = pad) on the GPU -> pooled [W, d].
         n_tokens = number of valid tokens (host-known; sizes the packed buffers); max_len = longest window in valid
