@@ -13,6 +13,12 @@ over one batch of `--genes-per-step` genes whose token ids / masks are already r
 N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), genes shard across ranks (weak scaling: every
 rank runs `--genes-per-step` genes per step) and one all-gather reassembles the expression matrix each step.
 
+`--workload cfg3` is BASELINE.json configs[2]: 256 ragged genes of one donor (N ~ lognormal(600, 0.6) in
+[40, 2048] cCREs, C ~ U{20..200} chunks, 54 tissues).  A step is then ONE PASS OVER ALL 256 GENES: the genes are dealt to
+the ranks by LPT on the FLOP model, every rank runs its shard in batches of <= `--genes-per-step` genes, and one
+all-gather reassembles the [256, 54] expression matrix -- strong scaling (total work fixed as N grows); the line also
+carries each rank's busy time (load imbalance).  `--dtype fp16` runs the fp16-operand path (BASELINE configs[4]).
+
 Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
@@ -146,6 +152,84 @@ def cpu_baseline(model, hp, kw, executed_full: float, threads: int, budget_s: fl
                       f"executes per full-size gene"}
 
 
+def run_cfg3(args, model, hp, kw, dev, rank, world, use_dist):
+    """BASELINE configs[2]: 256 ragged genes, LPT-sharded, batches of <= genes_per_step, one gather per pass."""
+    import torch.distributed as dist
+    from variantformer_amd.dist import all_gather_expression, gene_cost, shard_genes_lpt
+    from variantformer_amd.utils.flops import batch_flops
+    from variantformer_amd.utils.synthetic import TISSUES_54, cfg3_gene_sizes, collate, make_gene
+    n_genes, T = 256, args.tissues
+    tissues = TISSUES_54[:T]
+    n, c = cfg3_gene_sizes(n_genes)
+    costs = [gene_cost(int(a), int(b), T) for a, b in zip(n, c)]
+    owned = shard_genes_lpt(costs, world)
+    mine = owned[rank]
+    bs = args.genes_per_step
+    flops_all = 0.0
+    with torch.no_grad():
+        pbs = []
+        for s0 in range(0, len(mine), bs):          # inputs resident in HBM before the timed region
+            ids = mine[s0:s0 + bs]
+            batch = collate([make_gene(20251205 * 1000003 + g, int(n[g]), int(c[g]), tissues, 200) for g in ids])
+            flops_all += batch_flops(batch, hp["embedding_dim"], hp["num_layers"], kw["emb_dim"], kw["num_layers"])
+            pbs.append(model.prepare_batch(batch))
+
+        def one_pass():
+            t0 = time.perf_counter()
+            parts = [model.forward_prepared(pb)[0].view(pb.n_genes, T) for pb in pbs]
+            local = torch.cat(parts) if parts else torch.empty((0, T), device=dev)
+            torch.cuda.synchronize()
+            busy = time.perf_counter() - t0
+            expr = all_gather_expression(local, owned, n_genes) if use_dist else all_gather_expression(local, [mine], n_genes)
+            return expr.cpu(), busy
+
+        for _ in range(args.warmup):
+            one_pass()
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        busy = 0.0
+        for _ in range(args.steps):
+            expr, b = one_pass()
+            busy += b
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        busies = [busy]
+        if use_dist:
+            t = torch.tensor([dt, busy, flops_all], device=dev, dtype=torch.float64)
+            allt = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(allt, t)
+            dt = float(max(float(x[0]) for x in allt))
+            busies = [float(x[1]) for x in allt]
+            flops_all = float(sum(float(x[2]) for x in allt))
+        assert torch.isfinite(expr).all() and tuple(expr.shape) == (n_genes, T)
+    if rank == 0:
+        loads = [sum(costs[i] for i in o) for o in owned]
+        print(json.dumps({
+            "metric": "genes/sec/node (54-tissue expr) at 1 Mb cis-window", "value": round(n_genes * args.steps / dt, 4),
+            "unit": "genes/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: 256 ragged genes of one donor (N ~ lognormal(600, 0.6) in [40, 2048] "
+                                   "cCRE windows, C ~ U{20..200} gene chunks, %d tissues), full 1.2B-architecture network, "
+                                   "random-init weights; one step = one pass over all 256 genes, LPT gene shards, one "
+                                   "all-gather of the [256, %d] expression matrix" % (T, T),
+                       "genes": n_genes, "batch_genes_per_launch": bs, "tissues": T, "parallelism": f"gene-shard (LPT) x{world}"},
+            "algorithmic_tflop_per_pass": round(flops_all / 1e12, 2),
+            "achieved_algorithmic_tflops_whole_step": round(flops_all * args.steps / dt / 1e12, 1),
+            "rank_busy_seconds_per_pass": [round(b / args.steps, 4) for b in busies],
+            "busy_imbalance_max_over_mean": round(max(busies) / (sum(busies) / len(busies)), 4),
+            "lpt_cost_imbalance_max_over_mean": round(max(loads) / (sum(loads) / len(loads)), 4),
+            "genes_per_rank": [len(o) for o in owned], "source_sha": source_sha()}))
+    if use_dist:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -157,6 +241,10 @@ def main():
     ap.add_argument("--n-chunks", type=int, default=200)
     ap.add_argument("--tissues", type=int, default=54)
     ap.add_argument("--layers", type=int, default=None, help="override modulator depth (debug only; invalidates the number)")
+    ap.add_argument("--workload", choices=["cfg2", "cfg3"], default="cfg2",
+                    help="cfg2 = the headline 1 Mb / 54-tissue gene (weak scaling); cfg3 = 256 ragged genes, LPT shards, "
+                         "strong scaling")
+    ap.add_argument("--dtype", choices=["bf16", "fp16"], default="bf16", help="16-bit operand type (fp32 accumulation)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -180,6 +268,10 @@ def main():
     from variantformer_amd.utils.synthetic import TISSUES_54, make_batch
 
     model, hp, kw = build_model(dev, args.layers)
+    if args.dtype == "fp16":
+        model.precision = "16-mixed"               # reference utils/functions.py:12-32: fp16 operands
+    if args.workload == "cfg3":
+        return run_cfg3(args, model, hp, kw, dev, rank, world, use_dist)
     G = args.genes_per_step
     tissues = TISSUES_54[: args.tissues]
     batch = make_batch(20251205 + rank, [args.n_cre] * G, [args.n_chunks] * G, [tissues] * G, 200)
@@ -265,7 +357,7 @@ def main():
         out = {
             "metric": "genes/sec/node (54-tissue expr) at 1 Mb cis-window", "value": round(value, 4), "unit": "genes/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": ("BASELINE configs[1]: full 1.2B-architecture network (%d modulator layers, width %d, %d "
                                     "heads; seq2reg width 512, 8 heads, 6 layers, assumed), random-init weights, 1 Mb "
                                     "cis-window, %d tissues, 1 donor" % (kw["num_layers"], kw["emb_dim"], kw["num_heads"],

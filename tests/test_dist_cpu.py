@@ -74,3 +74,71 @@ def test_all_gather_single_process_path():
     local = torch.tensor([[2.0], [0.0], [1.0]])
     out = all_gather_expression(local, owned, 3)
     assert out.ravel().tolist() == [0.0, 1.0, 2.0]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# sharded vcf2exp driver: LPT shards, per-rank batches, ragged tissue lists, embeddings, reassembly in query order
+# ---------------------------------------------------------------------------------------------------------------------
+class _ToyGenes(torch.utils.data.Dataset):
+    """n items with ragged sizes; item i asks for T_i = 1 + i % 4 'tissues'."""
+
+    def __init__(self, n):
+        self.n = n
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        return {"gene": i, "tissues": [10 * i + t for t in range(1 + i % 4)]}
+
+
+def _toy_collate(items):
+    return {"gene": [it["gene"] for it in items], "tissues": [it["tissues"] for it in items]}
+
+
+def _toy_predict(batch, batch_idx):
+    """predict_step's contract: per gene pred [T, 1] and embeddings [T, D]; values identify (gene, tissue)."""
+    preds = [np.array([[g * 1000.0 + t] for t in ts], dtype=np.float32) for g, ts in zip(batch["gene"], batch["tissues"])]
+    embs = [np.array([[g + 0.5, t, -1.0] for t in ts], dtype=np.float32) for g, ts in zip(batch["gene"], batch["tissues"])]
+    return {"pred_gene_exp": preds, "embeddings": embs}
+
+
+def _sharded_worker(rank, world, port, n, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from variantformer_amd.dist import predict_sharded
+        costs = [float((i * 5) % 7 + 1) for i in range(n)]
+        res, busy = predict_sharded(_toy_predict, _ToyGenes(n), _toy_collate, costs=costs, batch_size=3, device="cpu")
+        q.put((rank, [p.tolist() for p in res["pred_gene_exp"]], [e.shape for e in res["embeddings"]], busy))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_predict_sharded_world2_ragged_query_order():
+    world, n = 2, 11
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ds = _ToyGenes(n)
+    want = [[[i * 1000.0 + t] for t in ds[i]["tissues"]] for i in range(n)]
+    for rank, preds, emb_shapes, busy in res:
+        assert preds == want                                             # every rank holds all genes, in query order
+        assert [tuple(s) for s in emb_shapes] == [(1 + i % 4, 3) for i in range(n)]
+        assert busy >= 0.0
+
+
+def test_predict_sharded_single_process_and_empty_shard():
+    from variantformer_amd.dist import all_gather_ragged, predict_sharded
+    res, _ = predict_sharded(_toy_predict, _ToyGenes(5), _toy_collate, batch_size=2)
+    assert [p.shape for p in res["pred_gene_exp"]] == [(1, 1), (2, 1), (3, 1), (4, 1), (1, 1)]
+    assert res["embeddings"][3][2].tolist() == [3.5, 32.0, -1.0]
+    out = all_gather_ragged([np.ones((2, 4), np.float32)], [[0]], 1, "cpu")
+    assert out[0].shape == (2, 4)

@@ -142,6 +142,12 @@ ATTN_CASES = [
     (48, 32, [201] * 6, None, True),                         # gene stream shape
     # >= 2048 blocks of 256 queries -> 4 query groups per wave (batched gene -> CRE cross attention), ragged
     (48, 32, [1300, 257, 600, 1024, 999, 256, 255, 1, 770, 512, 1100, 300], [300, 64, 100, 1, 129, 200, 65, 77, 256, 31, 128, 90], False),
+    # head dims a tokenizer checkpoint may carry (d = 768 / 8 heads, d = 1024 / 8 heads): 256-byte K rows, 3 / 4 k-steps
+    (96, 4, [70, 200, 33, 1], None, False),
+    (96, 2, [300, 64], [77, 500], False),
+    (96, 8, [125, 99], None, True),
+    (128, 2, [130, 64, 1, 200], None, True),
+    (128, 4, [257], [1000], False),
 ]
 
 
@@ -457,7 +463,7 @@ def test_gemm_mixed_operand_types_are_rejected(ops):
         ops.gemm(a, w, None, ops.EPI_F32)
 
 
-@pytest.mark.parametrize("dh,H,ql,kl,alibi", [ATTN_CASES[i] for i in (1, 2, 3, 4, 5, 6, 9, 12)])
+@pytest.mark.parametrize("dh,H,ql,kl,alibi", [ATTN_CASES[i] for i in (1, 2, 3, 4, 5, 6, 9, 12, 13, 16)])
 def test_attention_fp16_matches_oracle(ops, dh, H, ql, kl, alibi):
     self_attn = kl is None
     kl = ql if self_attn else kl

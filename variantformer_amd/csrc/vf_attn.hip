@@ -25,8 +25,19 @@
 namespace {
 
 constexpr int BKV = 64;
-constexpr int K_ROW_BYTES = 128;                 // 64 (padded dh) bf16
-constexpr int K_TILE_BYTES = BKV * K_ROW_BYTES;  // 8 KiB
+
+// K tile: one row per key, the head dimension padded to 64 (dh <= 64: 128-byte rows, 8 chunks of 16 bytes) or to 128
+// (dh = 96 / 128: 256-byte rows, 16 chunks).  Chunk c of row `row` is stored at chunk c ^ swz(row), which makes the
+// ds_read_b128 of a 16-lane group (rows r = 0..15, same logical chunk) hit 16 distinct 16-byte bank slots:
+// 128-byte rows alternate between the two halves of the 256-byte bank row, so 8 XOR values suffice; 256-byte rows all
+// start on the same bank and need all 16.
+template <int DH>
+struct KLayout {
+    static constexpr int ROW = DH <= 64 ? 128 : 256;
+    static constexpr int TILE = BKV * ROW;
+    static constexpr int KS = DH <= 64 ? 2 : DH / 32;            // 32-deep MFMA steps of the QK^T contraction
+    static __device__ __forceinline__ int swz(int row) { return ROW == 128 ? (row >> 1) & 7 : row & 15; }
+};
 
 template <int DH>
 struct VLayout {
@@ -109,11 +120,12 @@ __device__ __forceinline__ s16x4_t lds_tr_read(const char* p) {
 // fragment reads (operands reused), used to locate the binding ceiling; results are meaningless.
 template <int DH, int QG, bool ALIBI, int DT, int DBGT = 0>
 __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, int kb0, int len_k, int r, int g, float c,
-                                          float slope2, const typename Op16<DT>::frag (&qf)[QG][2], const float (&q_pos)[QG],
+                                          float slope2, const typename Op16<DT>::frag (&qf)[QG][KLayout<DH>::KS], const float (&q_pos)[QG],
                                           f32x4_t (&o)[QG][DH / 16], float (&m_run)[QG], f32x4_t (&l_acc)[QG]) {
     using frag_t = typename Op16<DT>::frag;
     constexpr int NDT = DH / 16;
     constexpr int VROW = VLayout<DH>::ROW;
+    constexpr int KS = KLayout<DH>::KS, K_ROW_BYTES = KLayout<DH>::ROW;
     // ---- S^T = K . Q^T : 4 key tiles x 2 k-steps, K fragments shared by the QG query groups
     f32x4_t s[QG][4];
 #pragma unroll
@@ -123,13 +135,13 @@ __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, int kb
     // all 8 K fragments of the tile are requested before the first MFMA and the V fragments of the first 32-key
     // block right after, so LDS latency overlaps the MFMAs and the softmax arithmetic instead of preceding every
     // MFMA pair (diagnostic builds: just-in-time fragment reads cost ~70 of 150 us on the gene->CRE shape)
-    frag_t kf[4][2];
+    frag_t kf[4][KS];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < KS; ++ks)
             kf[kt][ks] = DBGT >= 2 ? qf[0][ks] : *reinterpret_cast<const frag_t*>(
-                sK + (16 * kt + r) * K_ROW_BYTES + (((4 * ks + g) ^ (r >> 1)) << 4));
+                sK + (16 * kt + r) * K_ROW_BYTES + (((4 * ks + g) ^ KLayout<DH>::swz(r)) << 4));
     auto read_v = [&](int kb, frag_t(&vf)[NDT]) {
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) {
@@ -143,7 +155,7 @@ __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, int kb
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int qg = 0; qg < QG; ++qg)
                 s[qg][kt] = Op16<DT>::mfma(kf[kt][ks], qf[qg][ks], s[qg][kt]);
@@ -253,10 +265,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P) {
     constexpr int NLD = (NCHUNK + 255) / 256;         // chunk loads per thread per operand
     constexpr int NDT = DH / 16;                       // output d-tiles
     constexpr int VROW = VLayout<DH>::ROW;
+    constexpr int KS = KLayout<DH>::KS, K_ROW_BYTES = KLayout<DH>::ROW, K_TILE_BYTES = KLayout<DH>::TILE;
     constexpr int STAGE = K_TILE_BYTES + VLayout<DH>::TILE;
     constexpr int BQ = 4 * QG * 16;
 
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+    extern __shared__ __attribute__((aligned(16))) char smem[];       // 2 * STAGE bytes (attn_fwd_lds<DH>())
 
     int seq, h, qblk;
     if (!block_coords(P, seq, h, qblk)) return;
@@ -275,7 +288,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P) {
     // ---- zero the K pad chunks (d >= DH) of both stages once; loads never touch them
     // (chunk CPR is the mask slot and belongs to write_lds alone: zeroing it here as well would race with the mask
     // write of tile 0, which is issued by another wave without a barrier in between)
-    if (CPR < 7) {
+    if (CPR < 7) {                                    // dh = 32 / 48 only (dh >= 64 has no pad chunks that are read)
         constexpr int PADC = 7 - CPR;
         for (int i = tid; i < 2 * BKV * PADC; i += 256) {
             const int st = i / (BKV * PADC), rem = i % (BKV * PADC);
@@ -286,7 +299,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P) {
     }
 
     // ---- Q fragments (B operand): lane (r,g) holds Q[q = r][d = 32ks + 8g .. +7]
-    frag_t qf[QG][2];
+    frag_t qf[QG][KS];
     int q_abs[QG];
 #pragma unroll
     for (int qg = 0; qg < QG; ++qg) {
@@ -294,7 +307,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P) {
         const int row = q_abs[qg] < len_q ? q_abs[qg] : len_q - 1;
         const unsigned short* qp = P.q + (int64_t)(q_tok0 + row) * P.q_stride + h * DH;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
             const int d0 = 32 * ks + 8 * g;
             u32x4_t raw = q_pad_chunk<DT>(d0, DH);
             if (d0 < DH) raw = *reinterpret_cast<const u32x4_t*>(qp + d0);
@@ -351,7 +364,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P) {
             const int ci = is_v ? item - NCHUNK : item;
             const int row = ci / CPR, c = ci % CPR;
             const int off = is_v ? K_TILE_BYTES + row * VROW + (c << 4)
-                                 : row * K_ROW_BYTES + ((c ^ ((row >> 1) & 7)) << 4);
+                                 : row * K_ROW_BYTES + ((c ^ KLayout<DH>::swz(row)) << 4);
             *reinterpret_cast<u32x4_t*>(sK + off) = kvreg[i];
         }
         if (HwMask<DH>::value && tid < BKV)          // pad slot d = DH of every key row: 0 or the mask value
@@ -411,6 +424,8 @@ __global__ __launch_bounds__(256, (QG >= 2 ? 2 : 4)) void attn_short_kernel(Attn
     constexpr int CPR = DH / 8;
     constexpr int NDT = DH / 16;
     constexpr int VROW = VLayout<DH>::ROW;
+    constexpr int K_ROW_BYTES = KLayout<DH>::ROW, KS = KLayout<DH>::KS;
+    static_assert(K_ROW_BYTES == 128, "the short-sequence kernel is written for dh <= 64");
     constexpr int MAXIT = 8;                                      // 256 rows x 8 chunk slots / 256 threads
     extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
     char* const sK0 = smem_dyn;
@@ -431,7 +446,7 @@ __global__ __launch_bounds__(256, (QG >= 2 ? 2 : 4)) void attn_short_kernel(Attn
     const int nchunks = nkv * BKV * 8;
 
     // ---- Q fragments of this wave's query groups (issued before the K/V loads so that both are in flight together)
-    frag_t qf[QG][2];
+    frag_t qf[QG][KS];
     int q_abs[QG];
     float q_pos[QG];
 #pragma unroll
@@ -521,16 +536,41 @@ static unsigned set_grid(AttnParams& P, int n_seq, int nqb) {
     return 8u * (unsigned)P.chunk;
 }
 
+// dynamic LDS of the tiled kernel: two (K tile + V tile) stages
+template <int DH> constexpr int attn_fwd_lds() { return 2 * (KLayout<DH>::TILE + VLayout<DH>::TILE); }
+
+template <int DH, int QG, bool ALIBI, int DT, int DBG = 0>
+int launch_fwd(const AttnParams& P, dim3 grid, hipStream_t st) {
+    auto kern = attn_fwd_kernel<DH, QG, ALIBI, DT, DBG>;
+    constexpr int lds = attn_fwd_lds<DH>();
+    if (lds > 65536) {                             // dh = 128 only: above the default dynamic-LDS limit
+        static bool attr_set[VF_MAX_DEVICES] = {};
+        const int dev = vf_current_device();
+        if (dev < 0 || !attr_set[dev]) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
+                hipSuccess) {
+                (void)hipGetLastError();
+                vf_set_error("vf_attn_varlen_fwd: cannot reserve %d bytes of LDS", lds);
+                return VF_ERR_LAUNCH;
+            }
+            if (dev >= 0) attr_set[dev] = true;
+        }
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, P);
+    VF_CHECK_LAUNCH("vf_attn_varlen_fwd");
+    return VF_OK;
+}
+
 template <int DH, int QG, bool ALIBI, int DT>
 int launch_short(AttnParams P, int n_seq, int max_k, hipStream_t st) {
     const int k_rows = ((max_k + BKV - 1) / BKV) * BKV;
-    const int lds = k_rows * (K_ROW_BYTES + VLayout<DH>::ROW);
+    const int lds = k_rows * (KLayout<DH>::ROW + VLayout<DH>::ROW);
     auto kern = attn_short_kernel<DH, QG, ALIBI, DT>;
     static bool attr_set[VF_MAX_DEVICES] = {};    // the attribute is per device (and per instantiation)
     const int dev = vf_current_device();
     if (dev < 0 || !attr_set[dev]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                256 * (K_ROW_BYTES + VLayout<DH>::ROW)) != hipSuccess) {
+                                256 * (KLayout<DH>::ROW + VLayout<DH>::ROW)) != hipSuccess) {
             (void)hipGetLastError();
             vf_set_error("vf_attn_varlen_fwd: cannot reserve LDS");
             return VF_ERR_LAUNCH;
@@ -549,40 +589,39 @@ int launch_attn(AttnParams P, int n_seq, int max_q, int max_k, hipStream_t st) {
     // stream (201-token sequences, dh 48: 396 vs 485 us); for seq2reg windows / chunks (dh 64, <= 200 tokens) the tiled
     // kernel with 64-query blocks is faster (460 vs 613 us on 200-token chunks: more blocks in flight, fewer registers;
     // the K/V re-reads of its query blocks hit the XCD's L2 thanks to block_coords).
-    if (DH <= 48 && max_q > 128 && max_q <= 256 && max_k <= 256) {
-        if (max_q <= 192) return launch_short<DH, 3, ALIBI, DT>(P, n_seq, max_k, st);
-        return launch_short<DH, 4, ALIBI, DT>(P, n_seq, max_k, st);
+    if constexpr (DH <= 48) {
+        if (max_q > 128 && max_q <= 256 && max_k <= 256) {
+            if (max_q <= 192) return launch_short<DH, 3, ALIBI, DT>(P, n_seq, max_k, st);
+            return launch_short<DH, 4, ALIBI, DT>(P, n_seq, max_k, st);
+        }
     }
     // long query streams: 2 query groups per wave (halves K/V LDS traffic per MFMA);
     // short ones (seq2reg windows, gene stream): 64-query blocks to limit tail waste.
     // 2 query groups per wave only when that still leaves >= 4 blocks per CU (measured: CRE stream, 256 blocks, is
-    // 15% faster with 64-query blocks; the 10^4-query gene->CRE cross attention is 17% faster with 128-query blocks)
-    if (max_q > 256 && (long)n_seq * P.H * ((max_q + 127) / 128) >= 1024) {
-        const dim3 grid(set_grid(P, n_seq, (max_q + 127) / 128));
+    // 15% faster with 64-query blocks; the 10^4-query gene->CRE cross attention is 17% faster with 128-query blocks).
+    // dh = 96 / 128 (not a shape of the shipped model) always take one query group per wave.
+    if constexpr (DH <= 64) {
+        if (max_q > 256 && (long)n_seq * P.H * ((max_q + 127) / 128) >= 1024) {
+            const dim3 grid(set_grid(P, n_seq, (max_q + 127) / 128));
 #ifdef VF_TUNING                                   // libvf_hip_tuning.so only (scripts/): ceiling-finding builds whose results are meaningless
-        if (DH == 48 && !ALIBI && DT == VF_BF16) {
-            static const int dbg = getenv("VF_ATTN_DBG") ? atoi(getenv("VF_ATTN_DBG")) : 0;
-            if (dbg == 1) { hipLaunchKernelGGL((attn_fwd_kernel<48, 2, false, VF_BF16, 1>), grid, dim3(256), 0, st, P); VF_CHECK_LAUNCH("vf_attn_varlen_fwd"); return VF_OK; }
-            if (dbg == 2) { hipLaunchKernelGGL((attn_fwd_kernel<48, 2, false, VF_BF16, 2>), grid, dim3(256), 0, st, P); VF_CHECK_LAUNCH("vf_attn_varlen_fwd"); return VF_OK; }
-            if (dbg == 3) { hipLaunchKernelGGL((attn_fwd_kernel<48, 2, false, VF_BF16, 3>), grid, dim3(256), 0, st, P); VF_CHECK_LAUNCH("vf_attn_varlen_fwd"); return VF_OK; }
-            if (dbg == 4) { hipLaunchKernelGGL((attn_fwd_kernel<48, 2, false, VF_BF16, 4>), grid, dim3(256), 0, st, P); VF_CHECK_LAUNCH("vf_attn_varlen_fwd"); return VF_OK; }
-        }
+            if constexpr (DH == 48 && !ALIBI && DT == VF_BF16) {
+                static const int dbg = getenv("VF_ATTN_DBG") ? atoi(getenv("VF_ATTN_DBG")) : 0;
+                if (dbg == 1) return launch_fwd<48, 2, false, VF_BF16, 1>(P, grid, st);
+                if (dbg == 2) return launch_fwd<48, 2, false, VF_BF16, 2>(P, grid, st);
+                if (dbg == 3) return launch_fwd<48, 2, false, VF_BF16, 3>(P, grid, st);
+                if (dbg == 4) return launch_fwd<48, 2, false, VF_BF16, 4>(P, grid, st);
+            }
 #endif
-        // 4 query groups per wave (256-query blocks) once that still leaves >= 8 blocks per CU: every K/V fragment read
-        // feeds 4 MFMAs (gene->CRE cross attention at 8 genes: 948 vs 993 us; no gain at one gene, 1376 blocks)
-        if (DH == 48 && !ALIBI && (long)n_seq * P.H * ((max_q + 255) / 256) >= 2048) {
-            const dim3 grid4(set_grid(P, n_seq, (max_q + 255) / 256));
-            hipLaunchKernelGGL((attn_fwd_kernel<48, 4, false, DT>), grid4, dim3(256), 0, st, P);
-            VF_CHECK_LAUNCH("vf_attn_varlen_fwd");
-            return VF_OK;
+            // 4 query groups per wave (256-query blocks) once that still leaves >= 8 blocks per CU: every K/V fragment
+            // read feeds 4 MFMAs (gene->CRE cross attention at 8 genes: 948 vs 993 us; no gain at one gene, 1376 blocks)
+            if constexpr (DH == 48 && !ALIBI) {
+                if ((long)n_seq * P.H * ((max_q + 255) / 256) >= 2048)
+                    return launch_fwd<48, 4, false, DT>(P, dim3(set_grid(P, n_seq, (max_q + 255) / 256)), st);
+            }
+            return launch_fwd<DH, 2, ALIBI, DT>(P, grid, st);
         }
-        hipLaunchKernelGGL((attn_fwd_kernel<DH, 2, ALIBI, DT>), grid, dim3(256), 0, st, P);
-    } else {
-        const dim3 grid(set_grid(P, n_seq, (max_q + 63) / 64));
-        hipLaunchKernelGGL((attn_fwd_kernel<DH, 1, ALIBI, DT>), grid, dim3(256), 0, st, P);
     }
-    VF_CHECK_LAUNCH("vf_attn_varlen_fwd");
-    return VF_OK;
+    return launch_fwd<DH, 1, ALIBI, DT>(P, dim3(set_grid(P, n_seq, (max_q + 63) / 64)), st);
 }
 
 }  // namespace
@@ -593,7 +632,8 @@ static int attn_dispatch(const void* q, const void* k, const void* v, void* out,
                          const int32_t* cu_seqlens_k, int n_seq, int max_seqlen_q, int max_seqlen_k, int H,
                          int dh, const float* alibi_slopes, float scale, int q_at_start, void* stream) {
     VF_REQUIRE(q && k && v && out && cu_seqlens_q, "vf_attn_varlen_fwd: null pointer");
-    VF_REQUIRE(dh == 32 || dh == 48 || dh == 64, "vf_attn_varlen_fwd: head_dim %d not supported (32/48/64)", dh);
+    VF_REQUIRE(dh == 32 || dh == 48 || dh == 64 || dh == 96 || dh == 128,
+               "vf_attn_varlen_fwd: head_dim %d not supported (32/48/64/96/128)", dh);
     VF_REQUIRE(H > 0 && H <= 65535 && n_seq >= 0, "vf_attn_varlen_fwd: H=%d n_seq=%d out of range", H, n_seq);
     VF_REQUIRE((long)n_seq * H * ((max_seqlen_q + 63) / 64) < (1L << 31) - 8,
                "vf_attn_varlen_fwd: n_seq * H * ceil(max_seqlen_q / 64) exceeds the grid limit");
@@ -613,7 +653,9 @@ static int attn_dispatch(const void* q, const void* k, const void* v, void* out,
     switch (dh) {
         case 32: return alibi ? launch_attn<32, true, DT>(P, n_seq, max_seqlen_q, max_seqlen_k, st) : launch_attn<32, false, DT>(P, n_seq, max_seqlen_q, max_seqlen_k, st);
         case 48: return alibi ? launch_attn<48, true, DT>(P, n_seq, max_seqlen_q, max_seqlen_k, st) : launch_attn<48, false, DT>(P, n_seq, max_seqlen_q, max_seqlen_k, st);
-        default: return alibi ? launch_attn<64, true, DT>(P, n_seq, max_seqlen_q, max_seqlen_k, st) : launch_attn<64, false, DT>(P, n_seq, max_seqlen_q, max_seqlen_k, st);
+        case 64: return alibi ? launch_attn<64, true, DT>(P, n_seq, max_seqlen_q, max_seqlen_k, st) : launch_attn<64, false, DT>(P, n_seq, max_seqlen_q, max_seqlen_k, st);
+        case 96: return alibi ? launch_attn<96, true, DT>(P, n_seq, max_seqlen_q, max_seqlen_k, st) : launch_attn<96, false, DT>(P, n_seq, max_seqlen_q, max_seqlen_k, st);
+        default: return alibi ? launch_attn<128, true, DT>(P, n_seq, max_seqlen_q, max_seqlen_k, st) : launch_attn<128, false, DT>(P, n_seq, max_seqlen_q, max_seqlen_k, st);
     }
 }
 

@@ -66,3 +66,76 @@ def shard_batch(batch: dict, gene_ids: list[int]) -> dict:
         else:
             out[k] = v[torch.as_tensor(gene_ids, dtype=torch.long)]
     return out
+
+
+def all_gather_ragged(rows: list, owned: list[list[int]], n_items: int, device, group=None) -> list:
+    """rows[j]: numpy / tensor [T_j, ...] (fp32) for this rank's item owned[rank][j]; the leading length T_j may differ
+    per item (genes queried with different tissue lists), trailing dims are common.  Returns the list of n_items arrays
+    in query order on every rank.  ONE padded all-gather of the values plus one of the lengths (RCCL over xGMI with the
+    "nccl" backend): blocks are padded to the largest shard and the longest item."""
+    import numpy as np
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    assert len(rows) == len(owned[rank])
+    rows = [torch.as_tensor(r, dtype=torch.float32) for r in rows]
+    trail = tuple(rows[0].shape[1:]) if rows else ()
+    if dist.is_initialized():                       # agree on trailing dims / longest item even if a shard is empty
+        meta = torch.tensor([max([r.shape[0] for r in rows], default=0)] + list(trail) + [-1] * (4 - len(trail)),
+                            dtype=torch.int64, device=device)
+        allmeta = [torch.empty_like(meta) for _ in range(world)]
+        dist.all_gather(allmeta, meta, group=group)
+        t_max = int(max(int(m[0]) for m in allmeta))
+        full = [m for m in allmeta if int(m[0]) > 0]
+        if not trail and full:
+            trail = tuple(int(v) for v in full[0][1:] if int(v) >= 0)
+    else:
+        t_max = max([r.shape[0] for r in rows], default=0)
+    max_rows = max(len(o) for o in owned)
+    vals = torch.zeros((max_rows, t_max) + trail, dtype=torch.float32, device=device)
+    lens = torch.zeros((max_rows,), dtype=torch.int64, device=device)
+    for j, r in enumerate(rows):
+        vals[j, : r.shape[0]] = r.to(device)
+        lens[j] = r.shape[0]
+    if dist.is_initialized():
+        g_vals = torch.empty((world * max_rows, t_max) + trail, dtype=torch.float32, device=device)
+        g_lens = torch.empty((world * max_rows,), dtype=torch.int64, device=device)
+        dist.all_gather_into_tensor(g_vals, vals, group=group)
+        dist.all_gather_into_tensor(g_lens, lens, group=group)
+    else:
+        g_vals, g_lens = vals, lens
+    g_vals, g_lens = g_vals.cpu().numpy(), g_lens.cpu().numpy()
+    out = [None] * n_items
+    for r in range(world):
+        for j, item in enumerate(owned[r]):
+            out[item] = np.ascontiguousarray(g_vals[r * max_rows + j, : g_lens[r * max_rows + j]])
+    return out
+
+
+def predict_sharded(predict_batch, dataset, collate_fn, costs=None, batch_size: int = 8, device="cpu", group=None,
+                    loader_kwargs: dict | None = None):
+    """vcf2exp over the ranks of the default process group: genes (dataset items) are dealt by LPT on
+    `costs` (None: equal costs), each rank runs `predict_batch(batch, batch_idx) -> {"pred_gene_exp": [...],
+    "embeddings": [...]}` (predict_step's contract) over ITS genes in batches of `batch_size`, and one padded gather per
+    output reassembles the per-gene results in dataset order on every rank.  Without an initialised process group this
+    is the single-process loop.  Returns ({"pred_gene_exp": [n items], "embeddings": [n items]}, busy_seconds)."""
+    import time
+
+    from torch.utils.data import DataLoader, Subset
+    n = len(dataset)
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    owned = shard_genes_lpt([1.0] * n if costs is None else costs, world)
+    mine = owned[rank]
+    preds, embs = [], []
+    t0 = time.perf_counter()
+    if mine:
+        loader = DataLoader(Subset(dataset, mine), batch_size=batch_size, shuffle=False, collate_fn=collate_fn,
+                            **(loader_kwargs or {}))
+        for i, batch in enumerate(loader):
+            out = predict_batch(batch, i)
+            preds.extend(out["pred_gene_exp"])
+            embs.extend(out["embeddings"])
+    busy = time.perf_counter() - t0
+    assert len(preds) == len(mine)
+    return {"pred_gene_exp": all_gather_ragged(preds, owned, n, device, group),
+            "embeddings": all_gather_ragged(embs, owned, n, device, group)}, busy

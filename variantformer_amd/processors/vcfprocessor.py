@@ -136,6 +136,29 @@ class VCFProcessor:
         predictions = trainer.predict(model, dataloader, ckpt_path=checkpoint_path)
         return self.format_output(vcf_dataset.query_df, predictions)
 
+    def predict_distributed(self, model, checkpoint_path, trainer, vcf_dataset, batch_size: int | None = None, costs=None,
+                            **loader_kwargs):
+        """Multi-GPU vcf2exp (the reference is single-device, vcfprocessor.py:252-258): call from every rank
+        of a torch.distributed job (one process per GPU, launched with `python -m torch.distributed.run` BEFORE anything
+        touches the GPU; scripts/vcf2exp_dist.py shows the launcher).  The rows of `vcf_dataset.query_df` are dealt to
+        the ranks by LPT on `costs` (default: `vcf_dataset.gene_costs()` when the dataset offers it, else equal),
+        every rank runs the single-GPU path over its rows, and one padded all-gather per output (RCCL over xGMI)
+        returns the complete frame, in query order, on every rank."""
+        from ..dist import predict_sharded
+        model.trainer = trainer
+        model.eval()
+        if costs is None and hasattr(vcf_dataset, "gene_costs"):
+            costs = vcf_dataset.gene_costs()
+        bs = batch_size or int(self.vcf_loader_config.dataloader.get("batch_size", 8))
+
+        def run(batch, i):
+            with torch.no_grad():
+                return model.predict_step(batch, i)
+        results, busy = predict_sharded(run, vcf_dataset, collate_fn_batching, costs=costs, batch_size=bs,
+                                        device=model.device, loader_kwargs=loader_kwargs)
+        self.last_busy_seconds = busy
+        return self.format_output(vcf_dataset.query_df, [results])
+
     def format_output(self, df, predictions):
         pred_exp, embd = [], []
         for p in predictions:
