@@ -169,6 +169,18 @@ int vf_segment_max(const float* x, const int32_t* cu_seqlens, float* out, int W,
 int vf_add_rows_f32(const float* a, const int64_t* idx_a, const float* b, const int64_t* idx_b, float* out, int64_t n,
                     int d, void* stream);
 
+/* "linear" sequence pooling of seq2reg (seq2reg/model.py:183-184,268-272: nn.Linear(token_length, 1) over the token axis
+ * of the zero-masked window): out[w,:] = sum over the valid positions p of window w of lin_w[p] * x[row(w,p),:] + lin_b[0],
+ * on the packed stream (row(w,p) = cu[w] + rank of p among the valid positions).  pad u8 [W, L]; out fp32 / bf16 / fp16. */
+int vf_segment_linear(const float* x, const int32_t* cu_seqlens, const uint8_t* pad, const float* lin_w,
+                      const float* lin_b, void* out, int W, int L, int d, int out_dtype, void* stream);
+
+/* out[i,:] = src[idx[i],:] * (scale ? scale[i] : 1) + (shift ? shift[i] : 0), fp32 [n, d]: the per-token context rows of a
+ * use_context tokenizer (seq2reg/model.py:222-245: context_embedding(label) repeated over the tokens, or expanded per
+ * position by expand_context = nn.Linear(1, token_length)). */
+int vf_affine_rows_f32(const float* src, const int64_t* idx, const float* scale, const float* shift, float* out,
+                       int64_t n, int d, void* stream);
+
 /* fp32 -> bf16 / fp16 (round to nearest even), n elements. */
 int vf_cast_f32_bf16(const float* x, void* out, int64_t n, void* stream);
 int vf_cast_f32_f16(const float* x, void* out, int64_t n, void* stream);

@@ -185,11 +185,14 @@ class Seq2RegHP:
     token_length: int
     positional_encoding: str = "sinusoidal"
     seq_pool: str = "mean"
+    use_context: bool = False
+    expand_context: bool = False
 
     @classmethod
     def from_hparams(cls, hp: dict):
         return cls(hp["embedding_dim"], hp["num_heads"], hp["num_layers"], hp["token_length"],
-                   hp.get("positional_encoding", "sinusoidal"), hp.get("seq_pool", "mean"))
+                   hp.get("positional_encoding", "sinusoidal"), hp.get("seq_pool", "mean"),
+                   hp.get("use_context", False), hp.get("expand_context", False))
 
 
 def seq2reg_layer(x, cu, sd, pfx, hp: Seq2RegHP, slopes, rnd: Rounding):
@@ -203,9 +206,21 @@ def seq2reg_layer(x, cu, sd, pfx, hp: Seq2RegHP, slopes, rnd: Rounding):
     return geglu_ffn(h, sd, pfx, rnd) + x                            # :188  x += res_long (= layer input)
 
 
-def seq2reg_embed(ids, pad_mask, sd, pfx, hp: Seq2RegHP, rnd: Rounding):
+def seq2reg_context_layer(x, ctx, cu, sd, pfx, hp: Seq2RegHP, slopes, rnd: Rounding):
+    """seq2reg's ContextFlashAttentionEncoderLayer.forward (seq2reg/modules.py:72-126), make_data_kv false: LN1 ->
+    self-MHA -> +src -> LN2 -> cross-MHA(q = x, kv = context rows of the same window, no ALiBi, same key padding as the
+    tokens :105-112) -> +res_short -> LN3 -> GeGLU -> + src."""
+    h = rnd.r(layer_norm(x, sd[pfx + "norm1.weight"], sd[pfx + "norm1.bias"]))
+    x1 = mha_self(h, sd, pfx + "mixer.MHA.", hp.num_heads, cu, slopes, rnd) + x
+    h = rnd.r(layer_norm(x1, sd[pfx + "norm2.weight"], sd[pfx + "norm2.bias"]))
+    x2 = mha_cross(h, ctx, sd, pfx + "crossMHA.MHA.", hp.num_heads, cu, cu, rnd) + x1
+    h = rnd.r(layer_norm(x2, sd[pfx + "norm3.weight"], sd[pfx + "norm3.bias"]))
+    return geglu_ffn(h, sd, pfx, rnd) + x
+
+
+def seq2reg_embed(ids, pad_mask, sd, pfx, hp: Seq2RegHP, rnd: Rounding, context=None):
     """Seq2RegPredictor.forward(only_embed=True) (seq2reg/model.py:193-279).
-    ids int64 [b,1,L], pad_mask bool [b,1,L] (True = pad) -> [b,1,d]."""
+    ids int64 [b,1,L], pad_mask bool [b,1,L] (True = pad), context int64 [b] (use_context) -> [b,1,d]."""
     b, ns, L = ids.shape
     ids = ids.reshape(b * ns, L)
     pad = pad_mask.reshape(b * ns, L)
@@ -216,9 +231,20 @@ def seq2reg_embed(ids, pad_mask, sd, pfx, hp: Seq2RegHP, rnd: Rounding):
     else:
         slopes = torch.tensor(alibi_slopes(hp.num_heads), dtype=torch.float32)
     xp, idx, cu, _, lens = unpad_input(x, ~pad)
-    for l in range(hp.num_layers):
-        xp = seq2reg_layer(xp, cu, sd, f"{pfx}transformer_encoder.{l}.", hp, slopes, rnd)
     d = hp.embedding_dim
+    if hp.use_context:                                                # :222-245
+        c = sd[pfx + "context_embedding.weight"][context.long().reshape(-1)].repeat_interleave(ns, dim=0)   # [b*ns, d]
+        if hp.expand_context:       # Linear(1, token_length) on every embedding element: context[w, p, :] = c * W[p] + B[p]
+            We, Be = sd[pfx + "expand_context.weight"][:, 0], sd[pfx + "expand_context.bias"]
+            cfull = c[:, None, :] * We[None, :, None] + Be[None, :, None]
+        else:
+            cfull = c[:, None, :].expand(b * ns, L, d)
+        ctx = cfull.reshape(b * ns * L, d)[idx]                       # context rows of the valid tokens
+        for l in range(hp.num_layers):
+            xp = seq2reg_context_layer(xp, ctx, cu, sd, f"{pfx}transformer_encoder.{l}.", hp, slopes, rnd)
+    else:
+        for l in range(hp.num_layers):
+            xp = seq2reg_layer(xp, cu, sd, f"{pfx}transformer_encoder.{l}.", hp, slopes, rnd)
     if hp.seq_pool == "mean":                                         # :263-267
         out = torch.zeros(b * ns, d)
         for w in range(b * ns):
@@ -230,8 +256,9 @@ def seq2reg_embed(ids, pad_mask, sd, pfx, hp: Seq2RegHP, rnd: Rounding):
             a, e = int(cu[w]), int(cu[w + 1])
             if e > a:
                 out[w] = xp[a:e].max(dim=0).values
-    else:
-        raise NotImplementedError("seq_pool='linear' needs the padded positions; not used by shipped configs")
+    else:                                                             # "linear" :268-272: Linear(token_length, 1) over the
+        full = pad_input(xp, idx, b * ns, L)                          # token axis of the zero-masked window
+        out = torch.einsum("wpd,p->wd", full, sd[pfx + "linear.weight"][0]) + sd[pfx + "linear.bias"][0]
     return out.view(b, ns, d)
 
 

@@ -57,6 +57,25 @@ def load_vep_model_fixture():
     return meta, arrays, sd, vb
 
 
+def load_s2r_opts():
+    """{name: (hparams, reference output [9,1,d], state_dict, gene sample)} of tests/golden/s2r_opts.*: the reference's
+    own Seq2RegPredictor(only_embed=True) for the non-shipped tokenizer options."""
+    from variantformer_amd.utils.synthetic import make_gene, make_tensor
+    from oracle.vf_oracle import alibi_slopes
+    with open(os.path.join(GOLDEN, "s2r_opts.json")) as f:
+        meta = json.load(f)["cases"]
+    arrays = dict(np.load(os.path.join(GOLDEN, "s2r_opts.npz")))
+    out = {}
+    for name, m in meta.items():
+        sd = {k: (torch.tensor(alibi_slopes(shape[0]), dtype=torch.float32) if k.endswith(".m")
+                  else torch.from_numpy(make_tensor(k, shape, m["seed"]))) for k, shape in m["state_dict_shapes"].items()}
+        chk = float(sum(float(v.double().abs().sum()) for v in sd.values()))
+        assert abs(chk - m["weight_abs_sum"]) <= 1e-6 * m["weight_abs_sum"], "weight regeneration drifted"
+        g = make_gene(m["seed"], m["n_windows"], 2, [7], m["hparams"]["token_length"], cre_len_range=tuple(m["cre_len_range"]))
+        out[name] = (m["hparams"], arrays[name], sd, g)
+    return out
+
+
 @pytest.fixture(params=["small_sin", "small_alibi"])
 def golden(request):
     return load_fixture(request.param)

@@ -355,6 +355,46 @@ def vep_model_fixture():
           "nan ->", float(np.abs(arrays["nan.gene_token_embedding_0"]).max()))
 
 
+S2R_OPTS = {
+    # name: (overrides of the small_sin seq2reg hparams, seed)
+    "ctx_max": (dict(use_context=True, expand_context=False, seq_pool="max"), 911),
+    "ctx_expand_linear_alibi": (dict(use_context=True, expand_context=True, seq_pool="linear", positional_encoding="alibi"), 912),
+    "linear": (dict(seq_pool="linear"), 913),
+    "dh96": (dict(embedding_dim=192, num_heads=2), 914),
+    "dh128_alibi": (dict(embedding_dim=256, num_heads=2, positional_encoding="alibi", seq_pool="max"), 915),
+}
+
+
+def s2r_opts_fixture():
+    """The reference's own Seq2RegPredictor.forward(only_embed=True) (seq2reg/model.py:193-279) for the tokenizer
+    options the shipped checkpoint may or may not use: context embedding with / without expand_context
+    (seq2reg/modules.py:40-126), max / linear sequence pooling, head dims 96 / 128."""
+    from seq2reg.model import Seq2RegPredictor
+    from variantformer_amd.utils.synthetic import fill_state_dict, make_gene
+    base = FIXTURES["small_sin"]["seq2reg"]
+    arrays, meta = {}, {}
+    for name, (over, seed) in S2R_OPTS.items():
+        hp = dict(base, **over)
+        torch.manual_seed(0)
+        m = Seq2RegPredictor(**hp)
+        fill_state_dict(m, seed)
+        m.eval()
+        g = make_gene(seed, 9, 2, [7], hp["token_length"], cre_len_range=(3, 41))
+        with torch.no_grad():
+            out = m(g["cre_sequences"], g["cre_attention_masks"], None, context=g["ref_cre_labels"], only_embed=True,
+                    precision=None)
+        arrays[name] = out.numpy()
+        sd = m.state_dict()
+        meta[name] = dict(hparams=hp, seed=seed, n_windows=9, cre_len_range=[3, 41],
+                          state_dict_shapes={k: list(v.shape) for k, v in sd.items()},
+                          weight_abs_sum=float(sum(float(v.double().abs().sum()) for v in sd.values() if torch.is_floating_point(v))))
+        print(f"[golden] s2r_opts {name}: {tuple(out.shape)} {out.ravel()[:3].numpy()}")
+    np.savez_compressed(os.path.join(HERE, "s2r_opts.npz"), **arrays)
+    with open(os.path.join(HERE, "s2r_opts.json"), "w") as f:
+        json.dump(dict(cases=meta, generated_by="tests/golden/make_golden.py: reference seq2reg.model.Seq2RegPredictor "
+                                                "(fp32, CPU, stubbed flash_attn)"), f, indent=1, sort_keys=True)
+
+
 def bpe_fixture():
     """Token-id golden vectors from the reference's BPEEncoder (utils/seq.py:8-62)."""
     from utils.seq import BPEEncoder
@@ -538,6 +578,7 @@ def main():
     for name, fx in FIXTURES.items():
         run_fixture(name, fx)
     vep_model_fixture()
+    s2r_opts_fixture()
     bpe_fixture()
     misc_fixture()
     vep_fixture()

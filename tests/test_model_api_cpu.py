@@ -62,9 +62,9 @@ def test_unsupported_configurations_fail_loudly():
     with pytest.raises(ValueError, match="Invalid head type"):
         build_model(meta["seq2reg"], kw)
     hp = dict(meta["seq2reg"])
-    hp["use_context"] = True
-    with pytest.raises(NotImplementedError):
-        build_model(hp, meta["seq2gene"])
+    hp["use_context"] = True                   # builds (a CRE tokenizer may read the cCRE labels); the gene branch of the
+    m = build_model(hp, meta["seq2gene"])      # reference hands a float zero tensor as context and fails at run time
+    assert m.cre_tokenizer.use_context and "cre_tokenizer.context_embedding.weight" in m.state_dict()
 
 
 def test_non_shipped_options_build_with_reference_state_dict_names():
@@ -178,3 +178,15 @@ def test_trainer_pipelines_host_preparation_with_the_forward():
     v = Fake()
     v.vep = True
     assert [o["value"] for o in Trainer().predict(v, [4, 5])] == [4, 5] and v.log == [("step", 4, 0), ("step", 5, 1)]
+
+
+def test_seq2reg_option_state_dicts_match_reference():
+    """Module tree / state-dict keys of the tokenizer options (context embedding, expand_context, linear pooling) equal
+    the reference's (tests/golden/s2r_opts.json records its state_dict inventory), so such a checkpoint loads strictly."""
+    from tests.conftest import load_s2r_opts
+    from variantformer_amd.seq2reg.model import Seq2RegPredictor
+    for name, (hp, _, sd, _) in load_s2r_opts().items():
+        m = Seq2RegPredictor(**hp)
+        mine = {k: list(v.shape) for k, v in m.state_dict().items()}
+        assert mine == {k: list(v.shape) for k, v in sd.items()}, name
+        m.load_state_dict(sd, strict=True)

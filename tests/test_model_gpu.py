@@ -372,3 +372,24 @@ def test_fp16_operand_mode_production_width_vs_oracle():
         assert _erel(out["pred_gene_exp"][i], orc["pred_gene_exp"][i]) < NORTH_STAR_RTOL
         assert _erel(out["embeddings"][i], orc["embeddings"][i]) < 3 * NORTH_STAR_RTOL
         assert _erel(out["pred_gene_exp"][i], f32["pred_gene_exp"][i]) < NORTH_STAR_RTOL      # fp16 operands vs pure fp32
+
+
+def test_seq2reg_options_vs_reference_golden():
+    """seq_pool max / linear, use_context (with and without expand_context), head dims 96 / 128 on the HIP path: vs the
+    reference's own Seq2RegPredictor outputs (fp32 fixture) and vs the same-rounding oracle."""
+    from tests.conftest import load_s2r_opts
+    from variantformer_amd.seq2reg.model import Seq2RegPredictor
+    for name, (hp, want, sd, g) in load_s2r_opts().items():
+        m = Seq2RegPredictor(**hp)
+        m.load_state_dict(sd, strict=True)
+        m = m.cuda().eval()
+        got = m(g["cre_sequences"], g["cre_attention_masks"], None, context=g["ref_cre_labels"], only_embed=True)
+        assert got.shape == want.shape and got.dtype == torch.float32
+        orc = O.seq2reg_embed(g["cre_sequences"], g["cre_attention_masks"], sd, "", O.Seq2RegHP.from_hparams(hp),
+                              O.Rounding("bf16"), context=g["ref_cre_labels"])
+        assert _erel(got.cpu().numpy(), orc.numpy()) < 1e-2, name            # bf16 flips on max-pooled / summed rows
+        assert _erel(got.cpu().numpy(), want) < BF16_VS_FP32, name
+    # a use_context tokenizer without integer labels fails like the reference's nn.Embedding does
+    with pytest.raises(NotImplementedError, match="integer cCRE labels"):
+        m_ctx = Seq2RegPredictor(**load_s2r_opts()["ctx_max"][0]).cuda()
+        m_ctx(g["cre_sequences"], g["cre_attention_masks"], None, context=torch.zeros(9), only_embed=True)

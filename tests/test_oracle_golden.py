@@ -156,3 +156,15 @@ def test_oracle_variant_prediction_matches_reference(share):
     # the gathers really moved: het / hom rows differ from ref at the variant's window, and the NaN run is all zeros
     assert np.abs(arrays["pos.cre_token_embedding_1"] - arrays["pos.cre_token_embedding_0"]).max() > 1e-3
     assert np.abs(arrays["nan.gene_token_embedding_2"]).max() == 0.0
+
+
+def test_oracle_seq2reg_options_match_reference():
+    """Tokenizer options outside the shipped configuration (seq_pool max / linear, use_context with and
+    without expand_context, head dims 96 / 128): oracle vs the reference's own Seq2RegPredictor."""
+    from tests.conftest import load_s2r_opts
+    for name, (hp, want, sd, g) in load_s2r_opts().items():
+        ohp = O.Seq2RegHP.from_hparams(hp)
+        got = O.seq2reg_embed(g["cre_sequences"], g["cre_attention_masks"], sd, "", ohp, O.Rounding(None),
+                              context=g["ref_cre_labels"])
+        assert got.shape == want.shape
+        np.testing.assert_allclose(got.numpy(), want, rtol=2e-5, atol=2e-5, err_msg=name)

@@ -42,6 +42,8 @@ SIGNATURES = {
     "vf_cast_f32_bf16": [_p, _p, _l, _p],
     "vf_cast_f32_f16": [_p, _p, _l, _p],
     "vf_segment_max": [_p, _p, _p, _i, _i, _p],
+    "vf_segment_linear": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "vf_affine_rows_f32": [_p, _p, _p, _p, _p, _l, _i, _p],
     "vf_add_rows_f32": [_p, _p, _p, _p, _p, _l, _i, _p],
     "vf_bpe_create": [_p, _i, _p, _i],
     "vf_bpe_destroy": [_p],

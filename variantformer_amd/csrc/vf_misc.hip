@@ -190,6 +190,60 @@ __global__ __launch_bounds__(256) void segment_mean_kernel(const float* __restri
     }
 }
 
+// "linear" pooling of seq2reg (reference seq2reg/model.py:268-272): out[w, c] = sum_p lin_w[p] * x[w, p, c] * valid(p)
+// + lin_b, on the packed stream: the k-th valid token of window w sits at row cu[w] + k and at position vpos[k].
+__global__ __launch_bounds__(256) void segment_linear_kernel(const float* __restrict__ x, const int32_t* __restrict__ cu,
+                                                            const uint8_t* __restrict__ pad,
+                                                            const float* __restrict__ lin_w, const float* __restrict__ lin_b,
+                                                            void* __restrict__ out, int L, int d, int out_dt) {
+    extern __shared__ float wsel[];                  // [L] weight of the k-th valid token
+    __shared__ int nvalid_s;
+    const int w = blockIdx.x, tid = threadIdx.x;
+    if (tid < 64) {
+        int base = 0;
+        for (int p0 = 0; p0 < L; p0 += 64) {
+            const int p = p0 + tid;
+            const bool valid = p < L && pad[(int64_t)w * L + p] == 0;
+            const unsigned long long bal = __ballot(valid);
+            if (valid) wsel[base + __popcll(bal & ((1ull << tid) - 1ull))] = lin_w[p];
+            base += __popcll(bal);
+        }
+        if (tid == 0) nvalid_s = base;
+    }
+    __syncthreads();
+    const int nvalid = nvalid_s;
+    const int64_t row0 = cu[w];
+    const int n4 = d >> 2;
+    const float bias = lin_b ? lin_b[0] : 0.f;
+    for (int c = tid; c < n4; c += 256) {
+        f32x4_t acc = (f32x4_t){bias, bias, bias, bias};
+        for (int k = 0; k < nvalid; ++k) acc += wsel[k] * reinterpret_cast<const f32x4_t*>(x + (row0 + k) * d)[c];
+        if (out_dt != VF_F32) {
+            u32x2_t p;
+            p[0] = pack2_dt(acc[0], acc[1], out_dt);
+            p[1] = pack2_dt(acc[2], acc[3], out_dt);
+            reinterpret_cast<u32x2_t*>(reinterpret_cast<unsigned short*>(out) + (int64_t)w * d)[c] = p;
+        } else {
+            reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(out) + (int64_t)w * d)[c] = acc;
+        }
+    }
+}
+
+// out[i, :] = src[idx[i], :] * (scale ? scale[i] : 1) + (shift ? shift[i] : 0)   (fp32 rows; the per-token context rows of
+// a use_context seq2reg tokenizer: embedding row of the window's label, optionally expanded per position)
+__global__ __launch_bounds__(256) void affine_rows_kernel(const float* __restrict__ src, const int64_t* __restrict__ idx,
+                                                         const float* __restrict__ scale, const float* __restrict__ shift,
+                                                         float* __restrict__ out, int64_t n, int d) {
+    const int n4 = d >> 2;
+    const int64_t total = n * n4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / n4;
+        const int c = (int)(i - row * n4);
+        const float a = scale ? scale[row] : 1.f, b = shift ? shift[row] : 0.f;
+        reinterpret_cast<f32x4_t*>(out + row * d)[c] = reinterpret_cast<const f32x4_t*>(src + idx[row] * d)[c] * a + b;
+    }
+}
+
 // segment max (max pool over the tokens of a sequence): one block per window, threads over float4 columns
 __global__ __launch_bounds__(256) void segment_max_kernel(const float* __restrict__ x, const int32_t* __restrict__ cu,
                                                          float* __restrict__ out, int d) {
@@ -348,6 +402,28 @@ extern "C" int vf_segment_mean(const float* x, const int32_t* cu, void* out, int
     if (W <= 0) return VF_OK;
     hipLaunchKernelGGL(segment_mean_kernel, dim3(W), dim3(256), 0, (hipStream_t)stream, x, cu, out, d, out_dtype);
     VF_CHECK_LAUNCH("vf_segment_mean");
+    return VF_OK;
+}
+
+extern "C" int vf_segment_linear(const float* x, const int32_t* cu, const uint8_t* pad, const float* lin_w,
+                                 const float* lin_b, void* out, int W, int L, int d, int out_dtype, void* stream) {
+    VF_REQUIRE(x && cu && pad && lin_w && out && d > 0 && d % 4 == 0 && L > 0 && L <= 8192,
+               "vf_segment_linear: bad arguments (L=%d d=%d)", L, d);
+    VF_REQUIRE(out_dtype == VF_F32 || out_dtype == VF_BF16 || out_dtype == VF_F16, "vf_segment_linear: bad out_dtype %d", out_dtype);
+    if (W <= 0) return VF_OK;
+    hipLaunchKernelGGL(segment_linear_kernel, dim3(W), dim3(256), L * sizeof(float), (hipStream_t)stream, x, cu, pad, lin_w,
+                       lin_b, out, L, d, out_dtype);
+    VF_CHECK_LAUNCH("vf_segment_linear");
+    return VF_OK;
+}
+
+extern "C" int vf_affine_rows_f32(const float* src, const int64_t* idx, const float* scale, const float* shift, float* out,
+                                  int64_t n, int d, void* stream) {
+    VF_REQUIRE(src && idx && out && d > 0 && d % 4 == 0, "vf_affine_rows_f32: bad arguments (d=%d)", d);
+    if (n <= 0) return VF_OK;
+    hipLaunchKernelGGL(affine_rows_kernel, dim3(stream_grid(n * (d / 4))), dim3(256), 0, (hipStream_t)stream, src, idx,
+                       scale, shift, out, n, d);
+    VF_CHECK_LAUNCH("vf_affine_rows_f32");
     return VF_OK;
 }
 

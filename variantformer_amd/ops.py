@@ -295,6 +295,34 @@ def segment_max(x: torch.Tensor, cu: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def segment_linear(x: torch.Tensor, cu: torch.Tensor, pad: torch.Tensor, lin_w: torch.Tensor, lin_b: torch.Tensor | None,
+                   out_dtype=None) -> torch.Tensor:
+    """seq2reg "linear" pooling: out[w] = sum_p lin_w[p] * x[row(w, p)] over the valid positions p, + lin_b."""
+    _dev(x, cu, pad, lin_w, lin_b)
+    out_dtype = _CDT if out_dtype is None else out_dtype
+    pad = pad.view(torch.uint8) if pad.dtype == torch.bool else pad
+    assert x.dtype == torch.float32 and x.is_contiguous() and cu.dtype == torch.int32 and pad.dtype == torch.uint8
+    W, L = pad.shape
+    assert lin_w.dtype == torch.float32 and lin_w.numel() == L and lin_w.is_contiguous() and cu.numel() == W + 1
+    out = torch.empty((W, x.shape[1]), dtype=out_dtype, device=x.device)
+    check(_lib.load().vf_segment_linear(x.data_ptr(), cu.data_ptr(), pad.data_ptr(), lin_w.data_ptr(), _ptr(lin_b),
+                                        out.data_ptr(), W, L, x.shape[1], _dt(out_dtype), _stream()), "vf_segment_linear")
+    return out
+
+
+def affine_rows(src: torch.Tensor, idx: torch.Tensor, scale: torch.Tensor | None = None,
+                shift: torch.Tensor | None = None) -> torch.Tensor:
+    """out[i] = src[idx[i]] * scale[i] + shift[i] (fp32 rows; scale / shift optional per-row scalars)."""
+    _dev(src, idx, scale, shift)
+    assert src.dtype == torch.float32 and src.is_contiguous() and idx.dtype == torch.int64 and idx.is_contiguous()
+    for t in (scale, shift):
+        assert t is None or (t.dtype == torch.float32 and t.is_contiguous() and t.numel() == idx.numel())
+    out = torch.empty((idx.numel(), src.shape[1]), dtype=torch.float32, device=src.device)
+    check(_lib.load().vf_affine_rows_f32(src.data_ptr(), idx.data_ptr(), _ptr(scale), _ptr(shift), out.data_ptr(),
+                                         idx.numel(), src.shape[1], _stream()), "vf_affine_rows_f32")
+    return out
+
+
 def add_rows(a: torch.Tensor, b: torch.Tensor, idx_a: torch.Tensor | None = None, idx_b: torch.Tensor | None = None) -> torch.Tensor:
     """out[i] = a[idx_a[i]] + b[idx_b[i]] (identity where an index is None), fp32 rows."""
     _dev(a, b, idx_a, idx_b)

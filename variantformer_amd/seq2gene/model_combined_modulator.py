@@ -68,6 +68,8 @@ class PreparedBatch:
     max_tissues: int = 1
     cre_unique_inverse: torch.Tensor = None   # int64 [sum N]: row of each window in the de-duplicated cre_ids
     gene_unique_inverse: torch.Tensor = None
+    cre_ctx: torch.Tensor = None              # int64 [windows]: cCRE label of every (de-duplicated) CRE window, for a
+                                              # use_context CRE tokenizer (seq2reg/model.py:222-245); None otherwise
     cre_max_len: int = 0                      # longest CRE window / gene chunk in valid tokens (0: padded length);
     gene_max_len: int = 0                     # sizes the attention grid of seq2reg
 
@@ -329,9 +331,13 @@ class Seq2GenePredictorCombinedModulator(nn.Module):
         return None if p in (torch.float16, torch.bfloat16) else torch.float32
 
     @staticmethod
-    def _unique_windows(ids: torch.Tensor, pad: torch.Tensor):
-        """Rows of (ids, pad) that are byte-identical are embedded once (seq2reg sees windows independently)."""
-        key = np.concatenate([ids.numpy().astype(np.int16), pad.numpy().astype(np.int16)], axis=1)
+    def _unique_windows(ids: torch.Tensor, pad: torch.Tensor, extra: torch.Tensor | None = None):
+        """Rows of (ids, pad[, extra]) that are byte-identical are embedded once (seq2reg sees windows independently;
+        `extra` = the window's context label when the tokenizer reads it)."""
+        cols = [ids.numpy().astype(np.int16), pad.numpy().astype(np.int16)]
+        if extra is not None:
+            cols.append(extra.numpy().astype(np.int16).reshape(-1, 1))
+        key = np.concatenate(cols, axis=1)
         _, first, inverse = np.unique(key, axis=0, return_index=True, return_inverse=True)
         order = np.argsort(first)                       # keep first-occurrence order
         rank = np.empty_like(order)
@@ -358,8 +364,14 @@ class Seq2GenePredictorCombinedModulator(nn.Module):
         gene_pad = torch.cat([v[:, 0, :] for v in gm]).bool().contiguous()
         labels = torch.cat([v.reshape(-1) for v in batch["ref_cre_labels"]]).long().contiguous()
         cre_inv = gene_inv = None
+        cre_ctx = labels if getattr(self.cre_tokenizer, "use_context", False) else None
         if dedupe_windows:
-            cre_ids, cre_pad, cre_inv = self._unique_windows(cre_ids.cpu(), cre_pad.cpu())
+            n_before = cre_ids.shape[0]
+            cre_ids, cre_pad, cre_inv = self._unique_windows(cre_ids.cpu(), cre_pad.cpu(), None if cre_ctx is None else cre_ctx.cpu())
+            if cre_ctx is not None:            # label of the first occurrence of every kept window
+                first = torch.full((cre_ids.shape[0],), n_before, dtype=torch.long)
+                first.scatter_reduce_(0, cre_inv, torch.arange(n_before), reduce="amin")
+                cre_ctx = cre_ctx.cpu()[first]
             gene_ids, gene_pad, gene_inv = self._unique_windows(gene_ids.cpu(), gene_pad.cpu())
         cre_tokens = int((~cre_pad).sum())
         gene_tokens = int((~gene_pad).sum())
@@ -389,7 +401,7 @@ class Seq2GenePredictorCombinedModulator(nn.Module):
             labels=labels.to(dev), cu_cre=to(cu_cre), max_cre=max(n_cre), cu_gene_self=to(cu_self),
             max_gene=max(self_lens), cu_gene_cross=to(cu_cross), max_gene_cross=max(cross_lens),
             gene_stream_idx=to(np.concatenate(idx)), registry_rows=to(np.array(reg_rows, dtype=np.int64)),
-            cre_max_len=cre_max_len, gene_max_len=gene_max_len,
+            cre_max_len=cre_max_len, gene_max_len=gene_max_len, cre_ctx=None if cre_ctx is None else cre_ctx.to(dev),
             total_tissue_rows=len(reg_rows), registry_rows_host=np.array(reg_rows, dtype=np.int64), cu_cre_host=cu_cre,
             cu_registry=to(np.arange(len(reg_rows) + 1, dtype=np.int32)),
             cu_registry_cross=to(np.concatenate([[0], np.cumsum([len(t) for t in tissues])]).astype(np.int32)),
@@ -405,7 +417,8 @@ class Seq2GenePredictorCombinedModulator(nn.Module):
 
     def _forward_prepared(self, pb: PreparedBatch, return_cre: bool = False):
         # seq2reg over every CRE window / gene chunk of the batch (HOT LOOP A)
-        cre_tok = self.cre_tokenizer.embed_packed(pb.cre_ids, pb.cre_pad, pb.cre_tokens, max_len=pb.cre_max_len)        # bf16 [sum N, d]
+        cre_tok = self.cre_tokenizer.embed_packed(pb.cre_ids, pb.cre_pad, pb.cre_tokens, max_len=pb.cre_max_len,
+                                                  context=pb.cre_ctx)                                          # 16-bit [sum N, d]
         gene_tokenizer = self.gene_tokenizer if self.gene_tokenizer is not None else self.cre_tokenizer
         gene_tok = gene_tokenizer.embed_packed(pb.gene_ids, pb.gene_pad, pb.gene_tokens, max_len=pb.gene_max_len)        # bf16 [sum C, d]
         if pb.cre_unique_inverse is not None:            # de-duplicated windows -> one row per original window
@@ -527,7 +540,10 @@ class Seq2GenePredictorCombinedModulator(nn.Module):
         n = [int(v.shape[0]) for v in x]
         ids = torch.cat([v[:, 0, :] for v in x]).long().contiguous().to(dev)
         pad = torch.cat([v[:, 0, :] for v in attention_mask]).bool().contiguous().to(dev)
-        emb = embedder.embed_packed(ids, pad, int((~pad).sum().item()), torch.float32)
+        ctx = None
+        if getattr(embedder, "use_context", False):       # reference :778-785 hands the labels to the embedder
+            ctx = torch.cat([torch.as_tensor(v).reshape(-1) for v in ref_labels_tensor]).to(dev)
+        emb = embedder.embed_packed(ids, pad, int((~pad).sum().item()), torch.float32, context=ctx)
         maxn = max(n)
         X = torch.zeros((len(n), maxn, emb.shape[1]), dtype=torch.float32, device=dev)
         mask = torch.ones((len(n), maxn), dtype=torch.bool, device=dev)

@@ -49,26 +49,39 @@ class Seq2RegPredictor(nn.Module):
         assert use_flash, "Only Flash is supported"
         assert positional_encoding in ["sinusoidal", "alibi"], "Position encoding must be either 'sinusoidal' or 'alibi'"
         assert seq_pool in ["mean", "max", "linear"]
-        if use_context:
-            raise NotImplementedError(
-                "use_context=True tokenizers are not on the shipped path (the gene branch passes a float zero "
-                "tensor as context, model_combined_modulator.py:575-577, which only works with use_context=False)")
-        if seq_pool != "mean":
-            raise NotImplementedError("only seq_pool='mean' is implemented on the HIP path")
         self.token_embedding = nn.Embedding(vocab_size, embedding_dim)
         self.pos_encoding_type = positional_encoding
         self.seq_pool = seq_pool
         self.use_context = use_context
+        self.expand_context_type = expand_context
         self.strand_agg = strand_agg
         self.num_classes = num_classes
         self.tissues = tissues
         use_alibi = positional_encoding == "alibi"
+        if use_context:                       # reference seq2reg/model.py:90-95
+            from ..utils.constants import REF_CREs
+            self.context_embedding = nn.Embedding(len(REF_CREs), embedding_dim)
+            if expand_context:
+                self.expand_context = nn.Linear(1, token_length)
         if not use_alibi:
             # plain attribute like the reference (not in the state dict, :105); a device copy is cached
             self.position_encoding = positionalencoding1d(embedding_dim, token_length)
         self._pe_dev = None
-        self.transformer_encoder = nn.ModuleList(
-            [FlashTransformerLayer(d_model=embedding_dim, nhead=num_heads, use_alibi=use_alibi) for _ in range(num_layers)])
+        if use_context:
+            # same module tree as the reference's seq2reg ContextFlashAttentionEncoderLayer (seq2reg/modules.py:40-126):
+            # mixer.MHA / crossMHA.MHA / norm1-3 / linear_geglu_1-2 / buffer m -- and the same arithmetic as the seq2gene
+            # layer of that name (cross attention without ALiBi, q = tokens, k/v = the context rows)
+            from ..seq2gene.modules.layers import ContextFlashAttentionEncoderLayer
+            self.transformer_encoder = nn.ModuleList(
+                [ContextFlashAttentionEncoderLayer(d_model=embedding_dim, nhead=num_heads, batch_first=True,
+                                                   use_alibi=use_alibi, mlp_dout=mlp_dout) for _ in range(num_layers)])
+            for l in self.transformer_encoder:
+                l.mixer.MHA.family, l.crossMHA.MHA.family = "seq2reg_self", "seq2reg_ctx_cross"
+        else:
+            self.transformer_encoder = nn.ModuleList(
+                [FlashTransformerLayer(d_model=embedding_dim, nhead=num_heads, use_alibi=use_alibi) for _ in range(num_layers)])
+        if seq_pool == "linear":              # :183-184
+            self.linear = nn.Linear(token_length, 1)
         # kept only so that checkpoints load strictly; unused at inference
         in_f = embedding_dim * 2 if strand_agg == "concat" else embedding_dim
         self.tissue_classifiers = nn.ModuleDict({str(t): nn.Linear(in_f, num_classes) for t in range(num_tissues)})
@@ -81,23 +94,52 @@ class Seq2RegPredictor(nn.Module):
         return self._pe_dev
 
     def embed_packed(self, ids: torch.Tensor, pad: torch.Tensor, n_tokens: int, out_dtype=None,
-                     max_len: int = 0):
+                     max_len: int = 0, context: torch.Tensor | None = None):
         """ids int64 [W, L], pad bool/u8 [W, L] (True = pad) on the GPU -> pooled [W, d].
         n_tokens = number of valid tokens (host-known; sizes the packed buffers); max_len = longest window in valid
-        tokens when the host knows it (sizes the attention grid; 0 -> L, an upper bound)."""
+        tokens when the host knows it (sizes the attention grid; 0 -> L, an upper bound).
+        context int64 [W]: the window's reference-cCRE label, required by a use_context tokenizer (:222-245)."""
         W, L = ids.shape
-        if 0 < max_len < L:
-            L = max_len
+        Lmax = max_len if 0 < max_len < L else L
         with ops.scope("seq2reg"):
             cu = ops.mask_to_cu_seqlens(pad)
             x = ops.embed_pack(ids, pad, cu, self.token_embedding.weight, self._pos_table(ids.device), n_tokens)
-            for layer in self.transformer_encoder:
-                x = layer.forward_packed(x, cu, L)
-            return ops.segment_mean(x, cu, out_dtype)
+            if self.use_context:
+                if context is None or torch.is_floating_point(context):
+                    raise NotImplementedError(
+                        "a use_context tokenizer needs integer cCRE labels as context; the gene branch of the reference "
+                        "passes a float zero tensor (model_combined_modulator.py:575-577), which nn.Embedding rejects there too")
+                ctx = self._context_rows(pad, cu, context.to(ids.device).long().reshape(-1), n_tokens)
+                for layer in self.transformer_encoder:
+                    x = layer.forward_packed(x, cu, Lmax, context=ctx, cu_ctx=cu, max_ctx=Lmax)
+            else:
+                for layer in self.transformer_encoder:
+                    x = layer.forward_packed(x, cu, Lmax)
+            if self.seq_pool == "mean":                               # :263-267
+                return ops.segment_mean(x, cu, out_dtype)
+            if self.seq_pool == "max":                                # :257-261 (pads carry -inf there = valid tokens only)
+                m = ops.segment_max(x, cu)
+                od = ops.cdt() if out_dtype is None else out_dtype
+                return m if od == torch.float32 else ops.cast16(m, od)
+            return ops.segment_linear(x, cu, pad, self.linear.weight.reshape(-1).contiguous(), self.linear.bias, out_dtype)
+
+    def _context_rows(self, pad, cu, labels, n_tokens):
+        """fp32 [n_tokens, d]: context_embedding(label of the token's window), optionally expanded per position
+        (expand_context = nn.Linear(1, token_length) applied to each embedding element, :229-236:
+        context[p, :] = emb * W[p] + b[p]).  Index bookkeeping by torch, row arithmetic by vf_affine_rows_f32."""
+        lens = (cu[1:] - cu[:-1]).long()
+        tok_label = torch.repeat_interleave(labels, lens, output_size=n_tokens).contiguous()
+        table = self.context_embedding.weight.float().contiguous()
+        if not self.expand_context_type:
+            return ops.gather_rows_f32(table, None, tok_label)
+        pos = torch.nonzero(pad.view(torch.uint8) == 0)[:, 1]                                   # position of every packed token
+        scale = self.expand_context.weight[:, 0].float()[pos].contiguous()
+        shift = self.expand_context.bias.float()[pos].contiguous()
+        return ops.affine_rows(table, tok_label, scale, shift)
 
     def forward(self, x, padding_mask, tissue_vector=None, context=None, only_embed=False, precision=torch.float32):
-        """x int64 [b, strands, L]; padding_mask bool [b, strands, L] (True = pad) -> fp32 [b, strands, d]
-        (reference seq2reg/model.py:193-279 with only_embed=True)."""
+        """x int64 [b, strands, L]; padding_mask bool [b, strands, L] (True = pad); context int64 [b] (use_context)
+        -> fp32 [b, strands, d] (reference seq2reg/model.py:193-279 with only_embed=True)."""
         if not only_embed:
             raise NotImplementedError("only the embedding path (only_embed=True) is part of the inference hot path")
         b, ns, L = x.size()
@@ -105,4 +147,8 @@ class Seq2RegPredictor(nn.Module):
         ids = x.reshape(b * ns, L).to(dev).long().contiguous()
         pad = padding_mask.reshape(b * ns, L).to(dev).contiguous()
         n_tokens = int((~pad.bool()).sum().item())
-        return self.embed_packed(ids, pad, n_tokens, torch.float32).view(b, ns, -1)
+        ctx = None
+        if self.use_context and context is not None:
+            ctx = torch.as_tensor(context).to(dev).reshape(-1)
+            ctx = ctx if torch.is_floating_point(ctx) else ctx.long().repeat_interleave(ns)
+        return self.embed_packed(ids, pad, n_tokens, torch.float32, context=ctx).view(b, ns, -1)
