@@ -205,9 +205,10 @@ int64_t vf_bpe_encode(const void* bpe, const char* seq, int64_t len, int32_t* id
  * vf_vcf_open reads a plain / gzip / bgzip VCF once (genotypes of `sample`, NULL or "" = first sample column) and
  * returns a handle (NULL on I/O error or unknown sample).  vf_vcf_consensus writes the consensus of the 0-based
  * interval [start0, start0 + ref_len) of `chrom`, whose reference bases are `ref`, into `out` and returns its
- * length, or a negative VF_CONS_* code.  snp_only != 0 is the reference's "SNP" filter (TYPE="snp" records only);
- * indel_policy 0 refuses regions that hold a non-reference insertion / deletion genotype (VF_CONS_INDEL), 1 applies
- * the first genotype allele of such records. */
+ * length, or a negative VF_CONS_* code.  snp_only != 0 is the reference's "SNP" filter (records with a snp ALT only);
+ * indel_policy for records that are not single-base substitutions: 2 = bcftools' `-H I` rule (IUPAC codes for
+ * equal-length alleles, the first non-REF genotype allele otherwise: a het indel applies its ALT), 1 = the first
+ * genotype allele, 0 = refuse the region (VF_CONS_INDEL). */
 enum { VF_CONS_BAD_ARG = -1, VF_CONS_REF_MISMATCH = -2, VF_CONS_INDEL = -3, VF_CONS_BAD_GT = -4 };
 void* vf_vcf_open(const char* path, const char* sample);
 void vf_vcf_close(void* vcf);

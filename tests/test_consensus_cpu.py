@@ -95,11 +95,11 @@ def py_consensus(ref, start0, recs, snp_only=True):
             continue
         if len(r) != 1 or any(len(a) != 1 for a in alts):
             continue
-        al = gt.replace("|", "/").split("/")
-        if al[0] == ".":
+        al = [a for a in gt.replace("|", "/").split("/") if a != "."]      # missing alleles do not take part
+        if not al:
             continue
         a0 = int(al[0])
-        a1 = a0 if len(al) == 1 or al[1] == "." else int(al[1])
+        a1 = a0 if len(al) == 1 else int(al[1])
         if a0 == 0 and a1 == 0:
             continue
         if p <= frozen:
@@ -182,11 +182,49 @@ def test_ref_mismatch_and_indel_policy(tmp_path):
     h = dp.VCFHandle(vcf2)
     assert h.consensus("chr1", 0, ref, True) == ("AYGTACGTAC", 1)              # SNP mode ignores the indels
     with pytest.raises(dp.ConsensusError) as ei:
-        h.consensus("chr1", 0, ref, False)                                     # nothing guessed by default
+        h.consensus("chr1", 0, ref, False, "error")                            # strict mode: nothing guessed
     assert ei.value.code == -3
     assert h.consensus("chr1", 0, ref, False, "skip") == ("AYGTACGTAC", 1)
     # first genotype allele of a non-SNP record: insertion applied, deletion applied (1/0), 0/1 insertion not
     assert h.consensus("chr1", 0, ref, False, "first_allele") == ("AYGTGGACGAC", 3)
+    # default = bcftools' -H I rule: alleles of unequal length -> the first NON-REF genotype allele replaces REF, so the
+    # het insertion at 10 (0/1) and the het deletion at 7 (1/0) are both applied
+    assert dp.DEFAULT_INDEL_POLICY == "bcftools"
+    assert h.consensus("chr1", 0, ref, False) == ("AYGTGGACGACA", 4)
+
+
+def test_bcftools_iupac_rule_known_answers(tmp_path):
+    """`bcftools consensus -H I` as restated in vf_vcf.cpp (apply_variant, IUPAC branch): equal-length genotype alleles
+    are merged position by position into IUPAC codes, unequal lengths take the first non-REF genotype allele, alleles
+    with non-IUPAC characters ('*') do not take part, overlapping and edge-crossing records are skipped.
+    PARITY UNPINNED (no bcftools binary offline): these are the documented rules, not vectors from the tool."""
+    #      1234567890123456789012
+    ref = "ACGTACGTACGTACGTACGTAC"
+    recs = [(2, "C", ["T", "G"], "1/2"),        # multi-allelic het SNP -> code of {T, G} = K
+            (4, "TA", ["GC"], "0/1"),           # equal-length MNP, het -> per position: {T,G}=K, {A,C}=M
+            (7, "G", ["GTT", "GA"], "1/2"),     # two insertions of different length -> first genotype allele (GTT)
+            (9, "AC", ["A", "*"], "1/2"),       # '*' does not take part: one participating allele (A) -> deletion applied
+            (12, "T", ["C", "TAAA"], "0/2"),    # REF (len 1) vs insertion (len 4): unequal -> first non-REF allele = TAAA
+            (14, "CGT", ["C"], "1/1"),          # hom deletion
+            (15, "G", ["A"], "1/1"),            # starts inside the applied deletion -> skipped
+            (18, "C", ["T"], "./1"),            # half-missing genotype: the called allele -> T (hom by convention)
+            (21, "ACG", ["A"], "1/1")]          # REF runs past the region end -> skipped
+    vcf = str(tmp_path / "b.vcf")
+    write_vcf(vcf, {"chr1": recs})
+    h = dp.VCFHandle(vcf)
+    got, n = h.consensus("chr1", 0, ref, False)
+    #       A  K  G  KM  C  GTT  T  A    G  TAAA  A  C        A  T  G  T  AC
+    want = "A" "K" "G" "KM" "C" "GTT" "T" "A" "G" "TAAA" "A" "C" "A" "T" "G" "T" "AC"
+    assert got == want and n == 7
+    # SNP mode keeps a record as soon as ONE alt is a snp (bcftools TYPE!="snp" is false then): the mixed record at 12
+    # takes part (and applies its insertion allele, which is what the genotype names), the pure indels / MNPs do not --
+    # so the SNP at 15, no longer inside an applied deletion, is applied
+    got_snp, _ = h.consensus("chr1", 0, ref, True)
+    assert got_snp == "A" "K" "G" "TA" "C" "G" "T" "AC" "G" "TAAA" "A" "CAT" "A" "T" "G" "T" "AC"
+    # lower-case reference bases keep their case under same-length replacements
+    vcf2 = str(tmp_path / "c.vcf")
+    write_vcf(vcf2, {"chr1": [(2, "CG", ["TA"], "0/1")]})
+    assert dp.VCFHandle(vcf2).consensus("chr1", 0, "AcGT", False)[0] == "AyRT"
 
 
 def test_sample_selection_and_plain_text(world, tmp_path):
@@ -361,3 +399,53 @@ def test_create_vcf_from_variant_and_dataloader(world, tmp_path):
     assert batch["cre_sequences"][0].shape == (2, 1, 24) and batch["tissue_context"][0].tolist() == ds.query_df.iloc[0]["tissues"]
     with pytest.raises(ValueError, match="gene_cre_manifest"):
         VCFProcessor(config_dir=str(tmp_path / "configs"), require_gpu=False).create_data(merged, ds.query_df)
+
+
+def test_bgzf_fasta_with_fai_and_gzi(world, tmp_path):
+    """The shipped loader configs point at a bgzip-compressed genome (GRCh38...fasta.gz + .fai + .gzi): FastaReader
+    must read it block-wise like `samtools faidx`; plain gzip is refused with a clear message."""
+    import gzip
+    import struct
+    import zlib
+    raw = open(world["fasta"], "rb").read()
+    # write BGZF by hand: 1500-byte uncompressed blocks (each block = gzip member with the BC extra field) + EOF block
+    path = str(tmp_path / "g.fa.gz")
+    offsets = []
+    with open(path, "wb") as f:
+        u = 0
+        for a in range(0, len(raw), 1500):
+            chunk = raw[a:a + 1500]
+            comp = zlib.compressobj(6, zlib.DEFLATED, -15)
+            body = comp.compress(chunk) + comp.flush()
+            bsize = 18 + len(body) + 8
+            offsets.append((f.tell(), u))
+            f.write(b"\x1f\x8b\x08\x04" + b"\x00" * 4 + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize - 1))
+            f.write(body + struct.pack("<II", zlib.crc32(chunk), len(chunk)))
+            u += len(chunk)
+        f.write(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))      # the standard EOF block
+    assert gzip.open(path, "rb").read() == raw                       # it IS valid gzip
+    import shutil
+    shutil.copy(world["fasta"] + ".fai", path + ".fai") if os.path.exists(world["fasta"] + ".fai") else None
+    plain = dp.FastaReader(world["fasta"])
+    for with_gzi in (False, True):
+        if with_gzi:                                                 # samtools' .gzi: n, then (compressed, uncompressed) per block but the first
+            with open(path + ".gzi", "wb") as f:
+                f.write(struct.pack("<Q", len(offsets) - 1))
+                for c, uo in offsets[1:]:
+                    f.write(struct.pack("<QQ", c, uo))
+        z = dp.FastaReader(path)
+        assert z.bgzf and z.index == plain.index
+        for chrom, a, b in (("chr1", 0, 10), ("chr1", 1490, 1520), ("chr1", 2990, 6100), ("chr2", 7, 4000), ("chr2", 5000, 10 ** 9)):
+            assert z.fetch(chrom, a, b) == plain.fetch(chrom, a, b)
+    ex = dp.ExtractSeqFromBed(neighbour_hood=25, ref_fasta=path)
+    bed = pd.DataFrame({"chrom": ["chr1"], "start": [2000], "end": [2100], "cCRE": ["PLS"]})
+    df = ex.process_subject(vcf_file=world["vcf"], bed_regions=bed, variant_type="SNP")
+    assert df.iloc[0]["sequence"] == py_consensus(world["g1"][1975:2125], 1975, world["recs1"])
+    gz = str(tmp_path / "plain.fa.gz")
+    with gzip.open(gz, "wb") as f:
+        f.write(raw)
+    with pytest.raises(ValueError, match="not BGZF"):
+        dp.FastaReader(gz)
+    # a region on a chromosome the genome does not have: no rows, no crash
+    none = ex.process_subject(vcf_file=None, bed_regions=pd.DataFrame({"chrom": ["chrZ"], "start": [1], "end": [5], "cCRE": ["x"]}))
+    assert len(none) == 0 and list(none.columns) == ["chrom", "start_cre", "end_cre", "sequence", "cCRE"]

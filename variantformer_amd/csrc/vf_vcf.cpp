@@ -16,9 +16,25 @@
 //   * REF must equal the reference base (case-insensitive), else the whole region fails -- the reference then falls
 //     back to the unmodified reference sequence for that region (data_process.py:73-88), and so does the caller here;
 //   * a record that starts at or before the end of an already applied one is skipped ("overlaps with another variant").
-// Insertions / deletions (all-variants mode, `-e 'ALT~"<.*>"'`, the vcf2exp path): `indel_policy` 0 refuses the region
-// (VF_CONS_INDEL) so that nothing is guessed; 1 applies the FIRST genotype allele of a non-SNP record (bcftools 1.x
-// source as recalled, unverifiable here) -- callers must opt in.
+// All-variants mode (`-e 'ALT~"<.*>"'`, the vcf2exp path, utils/data_process.py:41-59) lets insertions, deletions and
+// MNPs through.  `indel_policy` selects what happens to a record that is not a single-base substitution:
+//   2 (default of the Python layer, "bcftools"): the `-H I` rule of bcftools consensus (consensus.c apply_variant, the
+//     PICK_IUPAC / iupac_GTs branch of bcftools 1.10 ... 1.21, restated from the published source as recalled -- the
+//     reference's Dockerfile builds htslib / bcftools 1.21):
+//       * the alleles named by the genotype are collected (missing ones skipped); `fallback` = the first of them that
+//         is not REF (REF if there is none);
+//       * alleles that hold a character outside the IUPAC alphabet ('*', '<...>') do not take part;
+//       * if all participating alleles have the SAME length the consensus allele is, position by position, the IUPAC
+//         code of the union of their bases (het SNP 0/1 -> code of {ref, alt}; 1/2 -> code of {alt1, alt2}; equal-length
+//         MNPs position-wise; hom 1/1 -> the alt itself);
+//       * otherwise (an insertion / deletion against REF or against the other allele) the `fallback` allele replaces
+//         REF as a whole: a het indel 0/1 APPLIES the ALT allele;
+//       * a same-length replacement keeps the case of the reference bases it overwrites;
+//   1 ("first_allele", round 1's opt-in guess): the first genotype allele of a non-SNP record, REF = no change;
+//   0 ("error"): refuses the region (VF_CONS_INDEL) so that nothing is guessed.
+// A record whose REF runs past the region end, or that starts inside the span of an applied record, is skipped, as
+// bcftools does for overlaps ("The site ... overlaps with another variant, skipping").  Still PARITY UNPINNED: no
+// bcftools binary exists offline to generate vectors from.
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -37,8 +53,9 @@ struct Rec {
     uint16_t ref_len;
     uint8_t n_alt;
     int8_t a0, a1;      // genotype allele indices; -1 missing
-    uint8_t symbolic;   // some ALT is <...> (or '*')
+    uint8_t symbolic;   // some ALT is <...> or a breakend
     uint8_t all_snp;    // REF and every ALT are a single base
+    uint8_t any_snp;    // some ALT differs from REF by exactly one base at equal length (bcftools TYPE has the snp bit)
 };
 struct Chrom {
     std::vector<Rec> recs;
@@ -58,6 +75,20 @@ char iupac_of(char a, char b) {
     auto idx = [](char c) { c = up(c); return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : -1; };
     const int i = idx(a), j = idx(b);
     return (i < 0 || j < 0) ? 'N' : T[i][j];
+}
+
+// IUPAC code <-> bit mask (A=1, C=2, G=4, T=8); -1 for a character outside the alphabet
+int iupac_mask(char c) {
+    switch (up(c)) {
+        case 'A': return 1; case 'C': return 2; case 'G': return 4; case 'T': case 'U': return 8;
+        case 'M': return 3; case 'R': return 5; case 'W': return 9; case 'S': return 6; case 'Y': return 10; case 'K': return 12;
+        case 'V': return 7; case 'H': return 11; case 'D': return 13; case 'B': return 14; case 'N': return 15;
+        default: return -1;
+    }
+}
+char mask_iupac(int m) {
+    static const char T[16] = {'N', 'A', 'C', 'M', 'G', 'R', 'S', 'V', 'T', 'W', 'Y', 'H', 'K', 'D', 'B', 'N'};
+    return T[m & 15];
 }
 
 // split a tab separated line in place; returns the number of fields
@@ -107,8 +138,13 @@ bool parse_line(Vcf& V, char* line, int sample_col) {
             char* comma = strchr(a, ',');
             if (comma) *comma = 0;
             const size_t al = strlen(a);
-            if (a[0] == '<' || a[0] == '*' || strchr(a, '[') || strchr(a, ']')) r.symbolic = 1;
+            if (a[0] == '<' || strchr(a, '[') || strchr(a, ']')) r.symbolic = 1;     // the filter is ALT~"<.*>": '*' alone passes it
             if (al != 1) r.all_snp = 0;
+            if (al == ref_len && a[0] != '<' && a[0] != '*') {
+                int diff = 0;
+                for (size_t k = 0; k < al; ++k) diff += up(a[k]) != up(ref[k]);
+                if (diff == 1) r.any_snp = 1;
+            }
             V.pool.insert(V.pool.end(), a, a + al + 1);
             if (r.n_alt < 255) ++r.n_alt;
             if (!comma) break;
@@ -149,8 +185,14 @@ bool parse_line(Vcf& V, char* line, int sample_col) {
                 r.a0 = r.a1 = -1;
             } else {
                 r.a0 = (int8_t)parse_allele(q);
-                if (*q == '/' || *q == '|') { ++q; r.a1 = (int8_t)parse_allele(q); if (r.a1 < 0) r.a1 = r.a0; }
-                else r.a1 = r.a0;           // haploid
+                if (*q == '/' || *q == '|') {
+                    ++q;
+                    r.a1 = (int8_t)parse_allele(q);
+                    if (r.a1 < 0) r.a1 = r.a0;                  // "1/." : the called allele
+                    else if (r.a0 < 0) r.a0 = r.a1;             // "./1" : likewise (bcftools skips missing alleles)
+                } else {
+                    r.a1 = r.a0;            // haploid
+                }
             }
         }
     } else if (n < 10) {
@@ -249,7 +291,7 @@ extern "C" int64_t vf_vcf_consensus(const void* h, const char* chrom, int64_t st
     const char* pool = V->pool.data();
     for (auto r = first; r != R.end() && r->pos <= hi1; ++r) {
         if (r->symbolic) continue;                                   // -e 'ALT~"<.*>"'
-        if (snp_only && !r->all_snp) continue;                       // ... || TYPE!="snp"
+        if (snp_only && !r->any_snp) continue;                       // ... || TYPE!="snp" (true when NO alt is a snp)
         if (r->a0 < 0) continue;                                     // missing genotype
         if (r->a0 > r->n_alt || r->a1 > r->n_alt) return VF_CONS_BAD_GT;
         if (r->a0 == 0 && r->a1 == 0) continue;                      // hom-ref
@@ -268,15 +310,51 @@ extern "C" int64_t vf_vcf_consensus(const void* h, const char* chrom, int64_t st
         const char* al1 = allele(r->a1);
         const bool single = r->ref_len == 1 && al0[1] == 0 && al1[1] == 0 && al0[0] && al1[0];
         std::string repl;
-        if (single) {
-            char c = r->a0 == r->a1 ? al0[0] : iupac_of(al0[0], al1[0]);
-            const char rb = ref[off];
-            if (rb >= 'a' && rb <= 'z' && c >= 'A' && c <= 'Z') c = (char)(c + 32);
-            repl.assign(1, c);
+        if (single && iupac_mask(al0[0]) >= 0 && iupac_mask(al1[0]) >= 0) {
+            repl.assign(1, mask_iupac(iupac_mask(al0[0]) | iupac_mask(al1[0])));
+        } else if (indel_policy == 2) {                              // bcftools consensus -H I
+            const int gt[2] = {r->a0, r->a1};
+            const int fallback = gt[0] > 0 ? gt[0] : gt[1];          // first non-REF genotype allele (REF if none)
+            auto iupac_ok = [](const char* a) {
+                if (!a[0]) return false;
+                for (const char* p = a; *p; ++p)
+                    if (iupac_mask(*p) < 0) return false;
+                return true;
+            };
+            const char* use[2];
+            int n_use = 0;
+            for (int k = 0; k < 2; ++k) {
+                const char* a = allele(gt[k]);
+                if (iupac_ok(a)) use[n_use++] = a;
+            }
+            if (n_use == 0) continue;
+            const size_t l0 = strlen(use[0]);
+            const bool same_len = n_use == 1 || strlen(use[1]) == l0;
+            if (same_len) {
+                repl.resize(l0);
+                for (size_t j = 0; j < l0; ++j) {
+                    int m = iupac_mask(use[0][j]);
+                    if (n_use == 2) m |= iupac_mask(use[1][j]);
+                    repl[j] = mask_iupac(m);
+                }
+            } else {
+                const char* fa = allele(fallback);
+                if (!iupac_ok(fa)) continue;
+                repl = fa;
+            }
         } else {
             if (indel_policy == 0) return VF_CONS_INDEL;
             if (r->a0 == 0) continue;                                // first allele is REF: nothing applied
             repl = al0;
+        }
+        if ((int64_t)repl.size() == r->ref_len) {                    // same length: keep the case of the overwritten bases
+            bool same = true;
+            for (int k = 0; k < r->ref_len; ++k) {
+                const char rb = ref[off + k];
+                if (rb >= 'a' && rb <= 'z' && repl[k] >= 'A' && repl[k] <= 'Z') repl[k] = (char)(repl[k] + 32);
+                same = same && up(repl[k]) == up(rb);
+            }
+            if (same) continue;                                      // the consensus allele IS the reference: no-op
         }
         // copy the untouched reference up to the record, then the replacement
         const int64_t need = (off - cur) + (int64_t)repl.size();

@@ -77,7 +77,7 @@ class VCFDataset(Dataset):
 
     def __init__(self, max_length: int, max_chunks: int, cre_neighbour_hood: int, gencode_v24, gene_cre_manifest,
                  gene_upstream_neighbour_hood: int, gene_downstream_neighbour_hood: int, query_df: pd.DataFrame,
-                 fasta_path: str, vcf_path: str = None, indel_policy: str = "error", sample: str = None):
+                 fasta_path: str, vcf_path: str = None, indel_policy: str = "bcftools", sample: str = None):
         self.bpe = BPEEncoder()
         self.bpe.load_vocabulary()
         self.vocab = self.bpe.vocab

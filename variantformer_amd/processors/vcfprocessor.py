@@ -25,7 +25,7 @@ from .trainer import Trainer
 
 class VCFProcessor:
     def __init__(self, model_class: str = "v4_pcg", config_dir: str | None = None, require_gpu: bool = True,
-                 gene_cre_manifest=None, indel_policy: str = "error"):
+                 gene_cre_manifest=None, indel_policy: str = "bcftools"):
         base_dir = Path(__file__).parent.parent.resolve()
         self.config_location = Path(config_dir) if config_dir else base_dir / "configs"
         self.model_config = load_yaml(str(self.config_location / "vf_model.yaml"))[model_class]

@@ -13,8 +13,14 @@ with a printed note (reference :73-88, :441-453).
 
 PARITY UNPINNED against bcftools itself (absent offline): see variantformer_amd/csrc/vf_vcf.cpp for the restated
 semantics.  `variant_type="SNP"` (the VEP loader's mode) touches single-base substitutions only and is fully specified
-there.  `variant_type=None` (the vcf2exp mode) lets insertions / deletions through in the reference; here that needs
-an explicit `indel_policy` ("first_allele" or "skip"), otherwise such a region raises -- nothing is guessed silently.
+there.  `variant_type=None` (the vcf2exp mode) lets insertions / deletions through in the reference.  `indel_policy` selects
+their treatment: "bcftools" (default) = the `-H I` rule of bcftools consensus restated in vf_vcf.cpp (IUPAC codes for
+equal-length alleles, the first non-REF genotype allele otherwise, i.e. a het indel applies its ALT), so a real donor
+VCF runs as it does in the reference; "error" refuses a region that holds such a genotype (strict mode: nothing is
+guessed), "skip" keeps substitutions only, "first_allele" is round 1's guess.
+
+The genome may be plain FASTA or bgzip-compressed FASTA (`.fa.gz` with its `.fai` and `.gzi`, which is what the shipped
+vcfloader.yaml / veploader.yaml point at, like `samtools faidx` reads it).
 """
 from __future__ import annotations
 
@@ -27,15 +33,30 @@ import pandas as pd
 
 from .. import _lib
 
-_INDEL_POLICIES = {"error": 0, "first_allele": 1, "skip": 2}
+_INDEL_POLICIES = {"error": 0, "first_allele": 1, "skip": 2, "bcftools": 3}
+DEFAULT_INDEL_POLICY = "bcftools"
 
 
 class FastaReader:
-    """Random access to a FASTA through its samtools .fai index (built in memory when the .fai is missing)."""
+    """Random access to a FASTA through its samtools .fai index (built in memory when the .fai is missing).
+    bgzip-compressed FASTA (BGZF: `.fa.gz` + `.fai` + `.gzi`, as `samtools faidx` writes them) is read block-wise: the
+    .fai offsets address the UNCOMPRESSED stream and the .gzi (or, when it is missing, one pass over the block headers)
+    maps them to BGZF blocks, each inflated with zlib on demand.  Plain gzip cannot be read randomly and is refused."""
 
     def __init__(self, path: str):
         self.path = path
         self.index = {}
+        with open(path, "rb") as f:
+            magic = f.read(18)
+        self.bgzf = magic[:2] == b"\x1f\x8b"
+        if self.bgzf and not (len(magic) == 18 and magic[3] & 4 and magic[12:14] == b"BC"):
+            raise ValueError(f"{path} is gzip but not BGZF: random access needs `bgzip` compression (or a plain FASTA); "
+                             "recompress with `bgzip` and index with `samtools faidx`")
+        if self.bgzf:
+            self._load_block_index()
+            self._block_cache = (-1, b"")
+        self._fh = open(path, "rb")
+        self._lock = threading.Lock()
         fai = path + ".fai"
         if os.path.exists(fai):
             with open(fai) as f:
@@ -45,12 +66,70 @@ class FastaReader:
                         self.index[p[0]] = tuple(int(v) for v in p[1:5])      # length, offset, linebases, linewidth
         else:
             self._scan()
-        self._fh = open(path, "rb")
-        self._lock = threading.Lock()
+
+    # -- BGZF ------------------------------------------------------------------------------------------
+    def _load_block_index(self):
+        """self._blk_c / self._blk_u: compressed / uncompressed start offset of every BGZF block (sorted)."""
+        import struct
+        gzi = self.path + ".gzi"
+        if os.path.exists(gzi):
+            with open(gzi, "rb") as f:
+                raw = f.read()
+            n = struct.unpack_from("<Q", raw, 0)[0]
+            vals = struct.unpack_from("<%dQ" % (2 * n), raw, 8)
+            self._blk_c, self._blk_u = [0] + list(vals[0::2]), [0] + list(vals[1::2])      # block 0 is implicit
+            return
+        self._blk_c, self._blk_u = [], []
+        c = u = 0
+        size = os.path.getsize(self.path)
+        with open(self.path, "rb") as f:
+            while c < size:
+                f.seek(c)
+                h = f.read(18)
+                if len(h) < 18 or h[:2] != b"\x1f\x8b" or h[12:14] != b"BC":
+                    raise ValueError(f"{self.path}: malformed BGZF block at offset {c}")
+                bsize = struct.unpack_from("<H", h, 16)[0] + 1
+                f.seek(c + bsize - 4)
+                isize = struct.unpack("<I", f.read(4))[0]
+                if isize:                       # the empty EOF block carries no data
+                    self._blk_c.append(c)
+                    self._blk_u.append(u)
+                c += bsize
+                u += isize
+
+    def _block(self, i: int) -> bytes:
+        import struct
+        import zlib
+        if self._block_cache[0] == i:
+            return self._block_cache[1]
+        self._fh.seek(self._blk_c[i])
+        h = self._fh.read(18)
+        bsize = struct.unpack_from("<H", h, 16)[0] + 1
+        xlen = struct.unpack_from("<H", h, 10)[0]
+        body = self._fh.read(bsize - 18)
+        data = zlib.decompress(body[xlen - 6: -8], -15)          # raw deflate between the header and CRC32 / ISIZE
+        self._block_cache = (i, data)
+        return data
+
+    def _read_uncompressed(self, first: int, last: int) -> bytes:
+        import bisect
+        i = bisect.bisect_right(self._blk_u, first) - 1
+        out = []
+        while first < last and i < len(self._blk_u):
+            data = self._block(i)
+            a = first - self._blk_u[i]
+            piece = data[a: a + (last - first)]
+            if not piece:
+                break
+            out.append(piece)
+            first += len(piece)
+            i += 1
+        return b"".join(out)
 
     def _scan(self):
+        import gzip
         name, length, offset, lb, lw, pos = None, 0, 0, 0, 0, 0
-        with open(self.path, "rb") as f:
+        with (gzip.open(self.path, "rb") if self.bgzf else open(self.path, "rb")) as f:
             for raw in f:
                 if raw.startswith(b">"):
                     if name is not None:
@@ -80,8 +159,11 @@ class FastaReader:
         first = offset + (start0 // lb) * lw + start0 % lb
         last = offset + ((end0 - 1) // lb) * lw + (end0 - 1) % lb + 1
         with self._lock:
-            self._fh.seek(first)
-            raw = self._fh.read(last - first)
+            if self.bgzf:
+                raw = self._read_uncompressed(first, last)
+            else:
+                self._fh.seek(first)
+                raw = self._fh.read(last - first)
         return raw.replace(b"\n", b"").replace(b"\r", b"").decode("ascii")
 
 
@@ -103,7 +185,7 @@ class VCFHandle:
     def num_records(self, chrom: str | None = None) -> int:
         return int(self._lib.vf_vcf_num_records(self._h, (chrom or "").encode()))
 
-    def consensus(self, chrom: str, start0: int, ref: str, snp_only: bool, indel_policy: str = "error"):
+    def consensus(self, chrom: str, start0: int, ref: str, snp_only: bool, indel_policy: str = DEFAULT_INDEL_POLICY):
         """(consensus string, n_applied); raises ConsensusError with .code on VF_CONS_* failures."""
         raw = ref.encode("ascii")
         cap = len(raw) + 4096
@@ -112,7 +194,7 @@ class VCFHandle:
             out = C.create_string_buffer(cap)
             n_applied = C.c_int64(0)
             n = self._lib.vf_vcf_consensus(self._h, chrom.encode(), int(start0), raw, len(raw), int(bool(snp_only)),
-                                           1 if policy == 1 else 0, out, cap, C.byref(n_applied))
+                                           {1: 1, 3: 2}.get(policy, 0), out, cap, C.byref(n_applied))
             if n == -1 and cap < 16 * (len(raw) + 4096):      # insertions overflowed the buffer
                 cap *= 4
                 continue
@@ -126,7 +208,7 @@ class VCFHandle:
 
 class ConsensusError(RuntimeError):
     MESSAGES = {-1: "bad argument", -2: "REF allele does not match the reference genome",
-                -3: "insertion / deletion genotype in the region and no indel_policy given",
+                -3: "insertion / deletion genotype in the region under indel_policy='error'",
                 -4: "genotype allele index beyond the ALT list"}
 
     def __init__(self, code: int, region: str):
@@ -156,7 +238,7 @@ def open_vcf(path: str, sample: str | None = None) -> VCFHandle:
 
 class ExtractSeqFromBed:
     def __init__(self, neighbour_hood: int, ref_fasta: str, upstream_neighbour_hood: int = None,
-                 indel_policy: str = "error", sample: str | None = None):
+                 indel_policy: str = DEFAULT_INDEL_POLICY, sample: str | None = None):
         self.neighbour_hood = neighbour_hood
         self.ref_fasta = ref_fasta
         self.upstream_neighbour_hood = upstream_neighbour_hood
@@ -206,8 +288,8 @@ class ExtractSeqFromBed:
             d, _ = self.process_region((region, vcf_file, self.ref_fasta, variant_type))
             if d:
                 rows.append(d)
-        df = pd.DataFrame(rows)
-        if not df["start_cre"].is_monotonic_increasing:
+        df = pd.DataFrame(rows, columns=["chrom", "start_cre", "end_cre", "sequence", "cCRE"])
+        if len(df) and not df["start_cre"].is_monotonic_increasing:
             df = df.sort_values(by=["chrom", "start_cre"], ascending=True).reset_index(drop=True)
         return df
 
