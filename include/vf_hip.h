@@ -216,6 +216,18 @@ int64_t vf_vcf_num_records(const void* vcf, const char* chrom);
 int64_t vf_vcf_consensus(const void* vcf, const char* chrom, int64_t start0, const char* ref, int64_t ref_len,
                          int snp_only, int indel_policy, char* out, int64_t out_cap, int64_t* n_applied);
 
+/* ---- host-side (CPU) batched sample builder: all cCRE windows of a gene in one call -----------------------------
+ * Replaces the per-window loop of the reference's sample builder (datasets/vcfdataset.py:219-283; one subprocess pair
+ * and one tokenizer call per window).  span_ref holds the reference bases of [span_start0, span_start0 + span_len) of
+ * `chrom`; window i = [starts0[i], ends0[i]) inside it: IUPAC consensus (vf_vcf_consensus; vcf NULL = reference only)
+ * -> reverse complement when revcomp != 0 -> vf_bpe_encode -> the first L token ids into ids_out[i*L ..] (pad_id
+ * beyond) and mask_out (1 = pad, the reference's convention).  status[i] (may be NULL): 0 consensus applied, 1 fell
+ * back to the reference bases (REF mismatch), VF_CONS_INDEL window refused under indel_policy 0.  Returns n or -1. */
+int64_t vf_build_windows(const void* vcf, const void* bpe, const char* chrom, int64_t span_start0, const char* span_ref,
+                         int64_t span_len, int64_t n, const int64_t* starts0, const int64_t* ends0, int snp_only,
+                         int indel_policy, int revcomp, int L, int64_t pad_id, int64_t* ids_out, uint8_t* mask_out,
+                         int32_t* status);
+
 #ifdef __cplusplus
 }
 #endif

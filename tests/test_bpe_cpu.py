@@ -66,3 +66,22 @@ def test_edge_cases(enc):
     long = "ACGTTGCA" * 40000                      # 320 kb: a whole gene body as ONE word
     ids, _, _, _ = enc.encode([long, "A"])
     assert enc.decode(ids) == long and len(ids) < len(long) / 2
+
+
+def test_live_cross_check_against_huggingface_tokenizers(enc):
+    """The reference tokenises with the third-party HuggingFace `tokenizers` BPE (utils/seq.py:14-16,43-50).  Where that
+    package is importable (the dev container; not required on the GPU box) the in-tree encoder is compared with it on
+    random and adversarial strings: long single words, runs of one base (overlapping same-rank pairs), IUPAC codes."""
+    tk = pytest.importorskip("tokenizers")
+    import numpy as np
+    from variantformer_amd.utils.seq import DEFAULT_VOCAB as VOCAB_FILE
+    ref = tk.Tokenizer.from_file(VOCAB_FILE)
+    rng = np.random.default_rng(12)
+    cases = ["A" * 1, "A" * 2, "A" * 3, "A" * 7, "A" * 64, "T" * 1001, "AC" * 500, "ACG" * 333, "AACCGGTT" * 200,
+             "AAACAAACAAAAC" * 50, "R" * 40 + "Y" * 41]
+    for n in (5, 33, 350, 351, 4097, 60000):
+        cases.append("".join(rng.choice(list("ACGT"), n)))
+        cases.append("".join(rng.choice(list("ACGTRYSWKM"), n, p=[.22, .22, .22, .22, .02, .02, .02, .02, .02, .02])))
+        cases.append("".join(rng.choice(list("AC"), n, p=[.9, .1])))              # long runs of one base
+    for s in cases:
+        assert enc.encode_forward(s).tolist() == ref.encode(s).ids, (len(s), s[:40])

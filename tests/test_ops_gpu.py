@@ -308,7 +308,7 @@ def test_rowdot_softplus(ops):
 # GEMM tile configurations at ragged edges (the automatic choice depends on the grid size, so every configuration the
 # pipeline can select is also forced here on shapes whose M / N are not multiples of any tile)
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("variant", [1, 5, 20])
+@pytest.mark.parametrize("variant", [1, 5, 20, 21])
 @pytest.mark.parametrize("epi", ["bf16", "res", "f32"])
 def test_gemm_forced_tile_configs_ragged(ops, variant, epi):
     M, N, K = 515, 776, 192
@@ -325,7 +325,7 @@ def test_gemm_forced_tile_configs_ragged(ops, variant, epi):
     np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), **tol)
 
 
-@pytest.mark.parametrize("variant", [1, 20])
+@pytest.mark.parametrize("variant", [1, 20, 21])
 def test_gemm_geglu_forced_tile_configs_ragged(ops, variant):
     M, F2, K = 515, 1056, 192
     a = _bf(_rand((M, K), 41))
@@ -366,11 +366,14 @@ def test_gemm_auto_selection_at_batch_size(ops, epi):
     np.testing.assert_allclose(out[rows.cuda()].float().cpu().numpy(), ref.numpy(), **tol)
 
 
+@pytest.mark.parametrize("variant", [20, 21])
 @pytest.mark.parametrize("K", [64, 128, 192, 1536])
 @pytest.mark.parametrize("epi", ["bf16", "res", "gelu_f32"])
-def test_gemm_8phase_short_and_odd_k_loops(ops, K, epi):
+def test_gemm_8phase_short_and_odd_k_loops(ops, K, epi, variant):
     """The two-group 256x256 kernel (variant 20) with 1, 2, 3 (odd) and 24 K-tiles: prologue / drain paths of its
     prefetch stream, ragged M and N, every accumulator checked."""
+    if variant == 21 and K < 128:
+        pytest.skip("the persistent form needs two K-tiles per output tile")
     M, N = 700, 520
     a = _bf(_rand((M, K), 51))
     w = _bf(_rand((N, K), 52, 1.0 / math.sqrt(K)))
@@ -383,13 +386,14 @@ def test_gemm_8phase_short_and_odd_k_loops(ops, K, epi):
         ref = F.gelu(ref)
     code = {"bf16": ops.EPI_BF16, "res": ops.EPI_RES_F32, "gelu_f32": ops.EPI_GELU_F32}[epi]
     out = ops.gemm(a.cuda().bfloat16(), w.cuda().bfloat16(), b.cuda(), code, residual=res.cuda() if epi == "res" else None,
-                   variant=20)
+                   variant=variant)
     torch.cuda.synchronize()
     tol = dict(rtol=2 ** -8, atol=2e-3) if epi == "bf16" else dict(rtol=2e-5, atol=2e-5 * math.sqrt(K))
     np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), **tol)
 
 
-def test_gemm_8phase_race_screen(ops):
+@pytest.mark.parametrize("variant", [20, 21])
+def test_gemm_8phase_race_screen(ops, variant):
     """Exact-integer operands (every product and sum exact in fp32) on a grid of several waves of tiles, repeated: any
     LDS hazard in the staggered two-group schedule (a fragment read before its LDS-DMA landed, a half-tile overwritten
     before its last read) shows up as a wrong integer.  Results must also be identical from launch to launch."""
@@ -401,7 +405,7 @@ def test_gemm_8phase_race_screen(ops):
     ref = (a.cuda() @ w.cuda().t())
     first = None
     for it in range(6):
-        out = ops.gemm(ab, wb, None, ops.EPI_F32, variant=20)
+        out = ops.gemm(ab, wb, None, ops.EPI_F32, variant=variant)
         torch.cuda.synchronize()
         assert torch.equal(out, ref), f"iteration {it}: {(out != ref).sum().item()} wrong elements"
         first = out if first is None else first
@@ -449,7 +453,7 @@ def test_gemm_geglu_fp16(ops):
     b = _rand((F2,), 73, 0.5)
     x, gate = (a @ w.t() + b).chunk(2, dim=-1)
     wp, bp = ops.pack_geglu_rows(w.cuda().half(), b.cuda())
-    for variant in (0, 1, 20):
+    for variant in (0, 1, 20, 21):
         out = ops.gemm(a.cuda().half(), wp, bp, ops.EPI_GEGLU_BF16, variant=variant)
         torch.cuda.synchronize()
         assert out.dtype == torch.float16

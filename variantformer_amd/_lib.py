@@ -52,10 +52,11 @@ SIGNATURES = {
     "vf_vcf_close": [_p],
     "vf_vcf_num_records": [_p, C.c_char_p],
     "vf_vcf_consensus": [_p, C.c_char_p, _l, C.c_char_p, _l, _i, _i, _p, _l, _p],
+    "vf_build_windows": [_p, _p, C.c_char_p, _l, C.c_char_p, _l, _l, _p, _p, _i, _i, _i, _i, _l, _p, _p, _p],
 }
 _RESTYPES = {"vf_last_error": C.c_char_p, "vf_bpe_create": C.c_void_p, "vf_bpe_destroy": None, "vf_bpe_encode": C.c_int64,
              "vf_vcf_open": C.c_void_p, "vf_vcf_close": None, "vf_vcf_num_records": C.c_int64,
-             "vf_vcf_consensus": C.c_int64}
+             "vf_vcf_consensus": C.c_int64, "vf_build_windows": C.c_int64}
 
 _lib = None
 

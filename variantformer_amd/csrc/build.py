@@ -13,7 +13,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["vf_gemm.hip", "vf_attn.hip", "vf_misc.hip", "vf_bpe.cpp", "vf_vcf.cpp"]
+SOURCES = ["vf_gemm.hip", "vf_attn.hip", "vf_misc.hip", "vf_bpe.cpp", "vf_vcf.cpp", "vf_host.cpp"]
 HEADERS = ["vf_common.h", os.path.join("..", "..", "include", "vf_hip.h")]
 LIB = os.path.join(HERE, "libvf_hip.so")
 ARCH = "gfx950"

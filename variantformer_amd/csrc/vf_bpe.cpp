@@ -8,7 +8,7 @@
 // tokenizers' `Word::merge_all`, restated here.  Token ids must be bit-exact (tests/golden/bpe_ids.json).
 #include <stdint.h>
 #include <stdlib.h>
-#include <queue>
+#include <algorithm>
 #include <vector>
 #include "../../include/vf_hip.h"
 
@@ -18,50 +18,95 @@ struct Bpe {
     int n_ids;
     std::vector<int32_t> rank;     // [n_ids * n_ids], -1 = no merge
     std::vector<int32_t> merged;   // [n_ids * n_ids] id of the merged token
+    std::vector<int16_t> rank16;   // the same ranks, 2 bytes each (500 KB for the shipped vocabulary: stays in the L2 of a
+                                   // host core; the merged id follows from the rank: new_id_of_rank)
+    std::vector<int32_t> new_id_of_rank;   // [n_rank] token produced by the merge of that rank
+    int n_rank = 0;
+    bool monotone = true;          // every rule that involves a merged token has a higher rank than the token's own rule
 };
 struct Sym { int32_t c, prev, next, len; };
-struct Merge { int32_t pos, rank, new_id; };
-struct Worse {                      // priority_queue keeps the "largest": smallest rank, then smallest pos
-    bool operator()(const Merge& a, const Merge& b) const { return a.rank != b.rank ? a.rank > b.rank : a.pos > b.pos; }
+
+// Reusable per-thread work space (a gene body is one 300 kb word: no allocation per call)
+struct Scratch {
+    std::vector<Sym> sym;
+    std::vector<std::vector<int32_t>> bucket;      // candidate positions per merge rank
+    std::vector<uint8_t> used;                     // rank has candidates (short words touch few of the ~480 ranks)
+    std::vector<int32_t> used_list;
 };
 
-// merge one word (a run of valid characters); appends ids and raw start offsets of the resulting tokens
-void encode_word(const Bpe& B, const char* s, int64_t n, int64_t raw0, std::vector<int32_t>& ids, std::vector<int64_t>& starts) {
-    std::vector<Sym> sym((size_t)n);
+// merge one word (a run of valid characters); appends ids and raw start offsets of the resulting tokens.
+//
+// tokenizers' Word::merge_all pops candidate pairs from a binary heap ordered by (rank, position) and validates
+// each against the current symbols.  A pair created by a merge of rank r contains the token that merge produced,
+// and every rule about that token was learned later, i.e. has a rank > r: candidates therefore only ever enter
+// HIGHER ranks than the one being processed, and the heap order equals "rank buckets in ascending order, positions
+// ascending inside a bucket".  Buckets of plain ints replace the heap (the heap was 75 % of the host time per gene);
+// the position order inside a bucket is reproduced without sorting (see the run walk below).
+void encode_word(const Bpe& B, Scratch& S, const char* s, int64_t n, int64_t raw0, std::vector<int32_t>& ids,
+                 std::vector<int64_t>& starts) {
+    std::vector<Sym>& sym = S.sym;
+    sym.resize((size_t)n);
     for (int64_t i = 0; i < n; ++i) {
         unsigned char ch = (unsigned char)s[i];
         if (ch >= 'a' && ch <= 'z') ch = (unsigned char)(ch - 32);
         sym[(size_t)i] = {B.char_id[ch], (int32_t)(i - 1), (int32_t)(i + 1 < n ? i + 1 : -1), 1};
     }
-    std::priority_queue<Merge, std::vector<Merge>, Worse> q;
     const int N = B.n_ids;
+    const int n_rank = B.n_rank;
+    const int16_t* R = B.rank16.data();
+    if ((int)S.bucket.size() < n_rank) { S.bucket.resize((size_t)n_rank); S.used.assign((size_t)n_rank, 0); }
+    auto push = [&](int32_t r, int32_t pos) {
+        if (!S.used[(size_t)r]) { S.used[(size_t)r] = 1; S.used_list.push_back(r); }
+        S.bucket[(size_t)r].push_back(pos);
+    };
     for (int64_t i = 0; i + 1 < n; ++i) {
-        const int32_t r = B.rank[(size_t)sym[(size_t)i].c * N + sym[(size_t)i + 1].c];
-        if (r >= 0) q.push({(int32_t)i, r, B.merged[(size_t)sym[(size_t)i].c * N + sym[(size_t)i + 1].c]});
+        const int32_t r = R[(size_t)sym[(size_t)i].c * N + sym[(size_t)i + 1].c];
+        if (r >= 0) push(r, (int32_t)i);
     }
-    while (!q.empty()) {
-        const Merge top = q.top();
-        q.pop();
-        Sym& cur = sym[(size_t)top.pos];
-        if (cur.len == 0 || cur.next == -1) continue;
-        const int32_t next_pos = cur.next;
-        const Sym right = sym[(size_t)next_pos];
-        const size_t key = (size_t)cur.c * N + right.c;
-        if (B.rank[key] < 0 || B.merged[key] != top.new_id) continue;      // expired queue entry
-        cur.c = top.new_id;
-        cur.len += right.len;
-        cur.next = right.next;
-        sym[(size_t)next_pos].len = 0;
-        if (right.next > -1) sym[(size_t)right.next].prev = top.pos;
-        if (cur.prev >= 0) {
-            const size_t k = (size_t)sym[(size_t)cur.prev].c * N + cur.c;
-            if (B.rank[k] >= 0) q.push({cur.prev, B.rank[k], B.merged[k]});
-        }
-        if (cur.next >= 0) {
-            const size_t k = (size_t)cur.c * N + sym[(size_t)cur.next].c;
-            if (B.rank[k] >= 0) q.push({top.pos, B.rank[k], B.merged[k]});
+    // ranks in ascending order (candidates only ever enter higher ranks); unused ranks cost one byte test each
+    for (int r = 0; r < n_rank; ++r) {
+        if (!S.used[(size_t)r]) continue;
+        // Candidates of one rank are applied WITHOUT sorting them by position: two rank-r pairs can only overlap when
+        // the rule is (a, a) and the text holds a run a a a ..., where the heap order means "leftmost pair first".  So
+        // from any candidate the walk first moves left to the start of such a run and then merges greedily rightwards;
+        // disjoint merges of one rank commute, and entries that went stale on the way fail the validation below.
+        std::vector<int32_t>& bk = S.bucket[(size_t)r];
+        const int32_t new_id = B.new_id_of_rank[(size_t)r];
+        for (size_t e = 0; e < bk.size(); ++e) {
+            int32_t pos = bk[e];
+            {
+                const Sym& c0 = sym[(size_t)pos];
+                if (c0.len == 0 || c0.next == -1) continue;
+                if (R[(size_t)c0.c * N + sym[(size_t)c0.next].c] != r) continue;      // expired candidate
+            }
+            while (sym[(size_t)pos].prev >= 0 &&
+                   R[(size_t)sym[(size_t)sym[(size_t)pos].prev].c * N + sym[(size_t)pos].c] == r)
+                pos = sym[(size_t)pos].prev;
+            while (pos >= 0) {
+                Sym& cur = sym[(size_t)pos];
+                if (cur.next == -1) break;
+                const int32_t next_pos = cur.next;
+                const Sym right = sym[(size_t)next_pos];
+                if (R[(size_t)cur.c * N + right.c] != r) break;
+                cur.c = new_id;
+                cur.len += right.len;
+                cur.next = right.next;
+                sym[(size_t)next_pos].len = 0;
+                if (right.next > -1) sym[(size_t)right.next].prev = pos;
+                if (cur.prev >= 0) {
+                    const int32_t rr = R[(size_t)sym[(size_t)cur.prev].c * N + cur.c];
+                    if (rr >= 0) push(rr, cur.prev);
+                }
+                if (cur.next >= 0) {
+                    const int32_t rr = R[(size_t)cur.c * N + sym[(size_t)cur.next].c];
+                    if (rr >= 0) push(rr, pos);
+                }
+                pos = cur.next;                                                        // next pair of the run, if any
+            }
         }
     }
+    for (int32_t u : S.used_list) { S.bucket[(size_t)u].clear(); S.used[(size_t)u] = 0; }
+    S.used_list.clear();
     int64_t off = raw0;
     for (int32_t i = 0; i >= 0 && i < n; i = sym[(size_t)i].next) {
         ids.push_back(sym[(size_t)i].c);
@@ -85,6 +130,23 @@ extern "C" void* vf_bpe_create(const int32_t* char_ids, int n_ids, const int32_t
         const size_t k = (size_t)a * n_ids + b;
         if (B->rank[k] < 0) { B->rank[k] = r; B->merged[k] = c; }
     }
+    B->n_rank = n_merges;
+    if (n_merges > 32767) { delete B; return nullptr; }
+    B->rank16.resize(B->rank.size());
+    for (size_t k = 0; k < B->rank.size(); ++k) B->rank16[k] = (int16_t)B->rank[k];
+    B->new_id_of_rank.assign((size_t)(n_merges > 0 ? n_merges : 1), -1);
+    // rank at which every token is created (characters: -1); the bucket algorithm needs rank(rule) > creation rank of
+    // both of its operands, which holds for any vocabulary learned by BPE training
+    std::vector<int32_t> born((size_t)n_ids, -1);
+    for (int r = 0; r < n_merges; ++r) {
+        const int32_t a = merges[3 * r], b = merges[3 * r + 1], c = merges[3 * r + 2];
+        const size_t k = (size_t)a * n_ids + b;
+        if (B->rank[k] != r) continue;                       // a later duplicate of an earlier rule never fires
+        B->new_id_of_rank[(size_t)r] = c;
+        if (born[(size_t)a] >= r || born[(size_t)b] >= r) B->monotone = false;
+        if (born[(size_t)c] < 0) born[(size_t)c] = r;
+    }
+    if (!B->monotone) { delete B; return nullptr; }          // not a BPE-trained merge list: refuse rather than mis-tokenise
     return B;
 }
 
@@ -94,10 +156,11 @@ extern "C" int64_t vf_bpe_encode(const void* h, const char* seq, int64_t len, in
                                  int64_t capacity) {
     if (!h || (!seq && len > 0) || len < 0) return -1;
     const Bpe& B = *static_cast<const Bpe*>(h);
-    std::vector<int32_t> ids;
-    std::vector<int64_t> starts;
-    ids.reserve((size_t)(len / 2 + 8));
-    starts.reserve((size_t)(len / 2 + 8));
+    static thread_local Scratch S;
+    static thread_local std::vector<int32_t> ids;
+    static thread_local std::vector<int64_t> starts;
+    ids.clear();
+    starts.clear();
     int64_t i = 0;
     while (i < len) {
         auto valid = [&](int64_t j) {
@@ -108,7 +171,7 @@ extern "C" int64_t vf_bpe_encode(const void* h, const char* seq, int64_t len, in
         while (i < len && !valid(i)) ++i;
         int64_t j = i;
         while (j < len && valid(j)) ++j;
-        if (j > i) encode_word(B, seq + i, j - i, i, ids, starts);
+        if (j > i) encode_word(B, S, seq + i, j - i, i, ids, starts);
         i = j;
     }
     const int64_t n = (int64_t)ids.size();

@@ -916,6 +916,294 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const unsigned short* __r
     }
 }
 
+// ----------------------------------------------------------------------------------------------------------------------
+// Persistent form of the two-group kernel: one 8-wave block per CU walks the output tiles bid, bid + grid, ... (same
+// XCD-grouped order) and the prefetch stream of half-tiles runs STRAIGHT ACROSS output-tile boundaries -- to the stream
+// the next output tile's K-tile 0 is simply "K-tile nkt".  When a tile's last MFMA retires, K-tile 0 of the next tile
+// has landed and K-tile 1 is in flight: the ~2-3 us of first-fill latency per tile (a quarter of a K = 512 tile) and the
+// block launch are gone.  The ring is therefore never free, so the epilogue stages each wave's block through a
+// private 4 KiB slice of the 32 KiB that remain of the 160 KiB LDS (XOR-swizzled 16-byte chunks instead of padded
+// rows; 16 / 32 / 64 rows per pass for fp32 / 16-bit / GeGLU outputs).  Needs K >= 128 (two K-tiles per output tile).
+// ----------------------------------------------------------------------------------------------------------------------
+template <int EPI, int DT = VF_BF16>
+__global__ __launch_bounds__(512, 2) void gemm8p_kernel(const unsigned short* __restrict__ A, int64_t lda,
+                                                        const unsigned short* __restrict__ W,
+                                                        const float* __restrict__ bias, const float* __restrict__ res,
+                                                        int64_t ldr, void* out, int64_t ldo, int M, int N, int K,
+                                                        int tiles_n, int n_tiles, int GROUP_M) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using frag_t = typename Op16<DT>::frag;
+    using C = Cfg8;
+    constexpr int BM = C::BM, BN = C::BN, TM = C::TM, TN = C::TN, BK = C::BK;
+    constexpr int SCRATCH = 4096;                                // epilogue staging per wave, behind the ring
+
+    const int bid = blockIdx.x, grid = gridDim.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int r = lane & 15, g = lane >> 4;
+    const int nkt = K / BK;
+    const int my_tiles = (n_tiles - bid + grid - 1) / grid;
+
+    auto tile_origin = [&](int t, int& m0, int& n0) {            // XCD-contiguous runs, grouped order (see gemm_mfma_kernel)
+        const int q8 = n_tiles >> 3, r8 = n_tiles & 7, xcd = t & 7, loc = t >> 3;
+        const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+        const int tiles_m = n_tiles / tiles_n;
+        const int per_group = GROUP_M * tiles_n;
+        const int grp = wg / per_group, in_grp = wg - grp * per_group;
+        const int first_m = grp * GROUP_M;
+        const int gsz = (tiles_m - first_m) < GROUP_M ? (tiles_m - first_m) : GROUP_M;
+        m0 = (first_m + in_grp % gsz) * BM;
+        n0 = (in_grp / gsz) * BN;
+    };
+
+    // ---- prefetch stream: cursor (s_tile, s_kt) = the K-tile whose half-tiles are being requested; s_g = its global index
+    const unsigned short* src[4][2];
+    auto set_src = [&](int tile_seq) {
+        int m0, n0;
+        tile_origin(bid + tile_seq * grid, m0, n0);
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi) {
+            const int i = 16 * wave + 8 * pi + (lane >> 3);
+            const int c = (lane & 7) ^ ((i >> 1) & 7);
+            const int am = m0 + (i >> 6) * 128 + (i & 63);
+            const int wn_row = n0 + (i >> 5) * 64 + (i & 31);
+            int v;
+            v = am;           v = v < M ? v : M - 1;  src[C::AL][pi] = A + (int64_t)v * lda + c * 8;
+            v = am + 64;      v = v < M ? v : M - 1;  src[C::AH][pi] = A + (int64_t)v * lda + c * 8;
+            v = wn_row;       v = v < N ? v : N - 1;  src[C::WL][pi] = W + (int64_t)v * K + c * 8;
+            v = wn_row + 32;  v = v < N ? v : N - 1;  src[C::WH][pi] = W + (int64_t)v * K + c * 8;
+        }
+    };
+    int s_tile = 0, s_kt = 0, s_g = 0;
+    bool live = true;
+    char* const lds_piece = smem + wave * 2048;
+    auto issue = [&](int type) {                                 // half-tile `type` of the cursor's K-tile
+        char* dst = lds_piece + (s_g & 1) * C::TILE_BYTES + type * C::HALF_BYTES;
+        glds16(src[type][0] + s_kt * BK, dst);
+        glds16(src[type][1] + s_kt * BK, dst + 1024);
+    };
+    auto advance = [&]() {                                       // after the AH half-tile: next K-tile, maybe next output tile
+        ++s_g;
+        if (++s_kt == nkt) {
+            s_kt = 0;
+            live = ++s_tile < my_tiles;
+            if (live) set_src(s_tile);
+        }
+    };
+
+    const int sw = (r >> 1) & 7;
+    const int ck0 = ((g) ^ sw) << 4, ck1 = ((4 + g) ^ sw) << 4;
+    const int offW = (wn * 32 + r) * 128;
+    const int offA = (wm * 64 + r) * 128;
+    frag_t wlo[2][2], whi[2][2], af[4][2];
+    auto read_w = [&](const char* buf, int type, frag_t (&f)[2][2]) {
+        const char* b = buf + type * C::HALF_BYTES + offW;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            f[i][0] = *reinterpret_cast<const frag_t*>(b + i * 2048 + ck0);
+            f[i][1] = *reinterpret_cast<const frag_t*>(b + i * 2048 + ck1);
+        }
+    };
+    auto read_a = [&](const char* buf, int type) {
+        const char* b = buf + type * C::HALF_BYTES + offA;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            af[i][0] = *reinterpret_cast<const frag_t*>(b + i * 2048 + ck0);
+            af[i][1] = *reinterpret_cast<const frag_t*>(b + i * 2048 + ck1);
+        }
+    };
+#define VF_G8_SYNC_IN()                                          \
+    do {                                                         \
+        asm volatile("" ::: "memory");                           \
+        __builtin_amdgcn_sched_barrier(0);                       \
+        __builtin_amdgcn_s_barrier();                            \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       \
+        __builtin_amdgcn_sched_barrier(0);                       \
+        __builtin_amdgcn_s_setprio(1);                           \
+    } while (0)
+#define VF_G8_SYNC_OUT()                                         \
+    do {                                                         \
+        __builtin_amdgcn_s_setprio(0);                           \
+        __builtin_amdgcn_sched_barrier(0);                       \
+        __builtin_amdgcn_s_barrier();                            \
+        asm volatile("" ::: "memory");                           \
+        __builtin_amdgcn_sched_barrier(0);                       \
+    } while (0)
+#define VF_G8_MMA(WF, IN0, IM0)                                                                                      \
+    do {                                                                                                             \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                             \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                            \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                        \
+                    acc[IN0 + i][IM0 + j] =                                                                          \
+                        Op16<DT>::mfma(WF[i][ks], af[j][ks], acc[IN0 + i][IM0 + j]); \
+    } while (0)
+
+    // ---- prologue (K >= 128): K-tile 0 of the first output tile complete, three half-tiles of its K-tile 1 in flight
+    set_src(0);
+    issue(C::WL); issue(C::AL); issue(C::WH); issue(C::AH);
+    advance();
+    issue(C::WL); issue(C::AL); issue(C::WH);
+    wait_vmcnt<6>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (wm == 1) __builtin_amdgcn_s_barrier();       // group 1 runs one barrier behind (matched after the last tile)
+
+    // ---- epilogue geometry (per wave: 128 x 64 block, SCRATCH bytes of private LDS, chunk c of row q at c ^ (q % CR))
+    constexpr bool OUT_F32 = (EPI == VF_EPI_F32 || EPI == VF_EPI_RES_F32 || EPI == VF_EPI_GELU_F32);
+    constexpr int ES = OUT_F32 ? 4 : 2;
+    constexpr int WT_M = 128, WT_N = 64;
+    constexpr int WT_NO = (EPI == VF_EPI_GEGLU_BF16) ? WT_N / 2 : WT_N;
+    constexpr int RB = WT_NO * ES;                               // bytes per staged row: 256 / 128 / 64
+    constexpr int CR = RB / 16, RI = 64 / CR;                    // 16-byte chunks per row, rows per wave-instruction
+    constexpr int RP = SCRATCH / RB, IMP = RP / 16, NPASS = TM / IMP, NI = RP / RI;
+    static_assert(RP % 16 == 0 && TM % IMP == 0 && CR >= 4 && CR <= 16, "epilogue geometry");
+    constexpr bool RES = (EPI == VF_EPI_RES_F32);
+    const int n_out_total = (EPI == VF_EPI_GEGLU_BF16) ? N / 2 : N;
+    char* const region = smem + C::LDS_BYTES + wave * SCRATCH;
+    const int ep_row = lane / CR, ep_chunk = lane % CR;
+
+    int g_cons = 0;                                              // global index of the K-tile being consumed
+    for (int ti = 0; ti < my_tiles; ++ti) {
+        int m0, n0;
+        tile_origin(bid + ti * grid, m0, n0);
+        f32x4_t acc[TN][TM];
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+        for (int t = 0; t < nkt; ++t, ++g_cons) {
+            const char* buf = smem + (g_cons & 1) * C::TILE_BYTES;
+            // ---- P1: (m-lo, n-lo); the stream requests AH of the cursor's K-tile and moves on
+            read_w(buf, C::WL, wlo);
+            __builtin_amdgcn_sched_barrier(0);
+            read_a(buf, C::AL);
+            if (live) { issue(C::AH); advance(); }
+            asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");   // W-lo reads retired before the barrier (WAR on WL)
+            VF_G8_SYNC_IN();
+            VF_G8_MMA(wlo, 0, 0);
+            VF_G8_SYNC_OUT();
+            // ---- P2: (m-lo, n-hi)
+            read_w(buf, C::WH, whi);
+            if (live) issue(C::WL);
+            VF_G8_SYNC_IN();
+            VF_G8_MMA(whi, 2, 0);
+            VF_G8_SYNC_OUT();
+            // ---- P3: (m-hi, n-hi)
+            read_a(buf, C::AH);
+            if (live) issue(C::AL);
+            VF_G8_SYNC_IN();
+            VF_G8_MMA(whi, 2, 4);
+            VF_G8_SYNC_OUT();
+            // ---- P4: (m-hi, n-lo); retire the next K-tile (all but the three youngest half-tiles)
+            if (live) {
+                issue(C::WH);
+                wait_vmcnt<6>();
+            } else {
+                wait_vmcnt<0>();
+            }
+            VF_G8_SYNC_IN();
+            VF_G8_MMA(wlo, 0, 4);
+            VF_G8_SYNC_OUT();
+        }
+
+        // ---- epilogue of this tile (no barrier: private accumulators, private scratch; the stream keeps landing)
+        const int64_t mw0 = m0 + wm * WT_M;
+        const int nw0 = n0 + wn * WT_N;
+        const int no0 = (EPI == VF_EPI_GEGLU_BF16) ? nw0 / 2 : nw0;
+        const int ep_col = no0 + ep_chunk * (16 / ES);
+        f32x4_t bvec[TN];
+        if (bias) {
+#pragma unroll
+            for (int in = 0; in < TN; ++in) {
+                int nb = (EPI == VF_EPI_GEGLU_BF16) ? nw0 + (in >> 1) * 32 + (in & 1) * 16 + 4 * g : nw0 + in * 16 + 4 * g;
+                nb = nb < N ? nb : 0;
+                bvec[in] = *reinterpret_cast<const f32x4_t*>(bias + nb);
+            }
+        } else {
+#pragma unroll
+            for (int in = 0; in < TN; ++in) bvec[in] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        }
+        f32x4_t rbuf[2][RES ? NI : 1];
+        auto load_res_pass = [&](int ps, f32x4_t (&dst)[RES ? NI : 1]) {
+            if (RES) {
+#pragma unroll
+                for (int k = 0; k < NI; ++k) {
+                    int64_t m = mw0 + ps * RP + k * RI + ep_row;
+                    m = m < M ? m : M - 1;
+                    const int col = ep_col < N ? ep_col : N - 4;
+                    dst[RES ? k : 0] = *reinterpret_cast<const f32x4_t*>(res + m * ldr + col);
+                }
+            }
+        };
+        load_res_pass(0, rbuf[0]);
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            if (ps + 1 < NPASS) load_res_pass(ps + 1, rbuf[(ps + 1) & 1]);
+#pragma unroll
+            for (int iml = 0; iml < IMP; ++iml) {
+                const int im = ps * IMP + iml;
+                const int q = iml * 16 + r;                      // row inside the pass
+                char* rowp = region + q * RB;
+                const int sx = q & (CR - 1);
+                if (EPI == VF_EPI_GEGLU_BF16) {
+#pragma unroll
+                    for (int ip = 0; ip < TN / 2; ++ip) {
+                        const f32x4_t v = acc[2 * ip][im] + bvec[2 * ip], gt = acc[2 * ip + 1][im] + bvec[2 * ip + 1];
+                        u32x2_t pk;
+                        pk[0] = Op16<DT>::pack2(v[0] * gelu_erf(gt[0]), v[1] * gelu_erf(gt[1]));
+                        pk[1] = Op16<DT>::pack2(v[2] * gelu_erf(gt[2]), v[3] * gelu_erf(gt[3]));
+                        const int byte = (ip * 16 + 4 * g) * 2;                 // 8-byte piece inside the 64-byte row
+                        *reinterpret_cast<u32x2_t*>(rowp + ((((byte >> 4) ^ sx) << 4) | (byte & 8))) = pk;
+                    }
+                } else {
+#pragma unroll
+                    for (int in = 0; in < TN; ++in) {
+                        f32x4_t v = acc[in][im] + bvec[in];
+                        if (EPI == VF_EPI_GELU_F32 || EPI == VF_EPI_GELU_BF16) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                        }
+                        if (OUT_F32) {
+                            *reinterpret_cast<f32x4_t*>(rowp + (((in * 4 + g) ^ sx) << 4)) = v;
+                        } else {
+                            u32x2_t pk;
+                            pk[0] = Op16<DT>::pack2(v[0], v[1]);
+                            pk[1] = Op16<DT>::pack2(v[2], v[3]);
+                            const int byte = (in * 16 + 4 * g) * 2;
+                            *reinterpret_cast<u32x2_t*>(rowp + ((((byte >> 4) ^ sx) << 4) | (byte & 8))) = pk;
+                        }
+                    }
+                }
+            }
+            u32x4_t dd[NI];
+#pragma unroll
+            for (int k = 0; k < NI; ++k) {
+                const int q = k * RI + ep_row;
+                dd[k] = *reinterpret_cast<const u32x4_t*>(region + q * RB + ((ep_chunk ^ (q & (CR - 1))) << 4));
+            }
+#pragma unroll
+            for (int k = 0; k < NI; ++k) {
+                const int row = ps * RP + k * RI + ep_row;
+                const int64_t m = mw0 + row;
+                u32x4_t d = dd[k];
+                if (RES) {
+                    f32x4_t f = __builtin_bit_cast(f32x4_t, d);
+                    f += rbuf[ps & 1][RES ? k : 0];
+                    d = __builtin_bit_cast(u32x4_t, f);
+                }
+                if (m < M && ep_col < n_out_total)
+                    *reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(out) + (m * ldo + ep_col) * ES) = d;
+            }
+        }
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();       // matches group 1's extra barrier
+#undef VF_G8_SYNC_IN
+#undef VF_G8_SYNC_OUT
+#undef VF_G8_MMA
+}
+
 // Shape-generic fallback (any K % 8 == 0): 64x64 tile, fp32 FMA out of LDS.  Same lane->output
 // ownership as the MFMA kernel so the epilogues are shared.  Only small/odd shapes come here.
 template <int EPI, int DT = VF_BF16>
@@ -1060,6 +1348,31 @@ int launch_gemm8(const void* A, int64_t lda, const void* W, const float* bias, c
     return VF_OK;
 }
 
+template <int EPI, int DT = VF_BF16>
+int launch_gemm8p(const void* A, int64_t lda, const void* W, const float* bias, const float* res, int64_t ldr, void* out,
+                  int64_t ldo, int M, int N, int K, hipStream_t st) {
+    constexpr int LDS = Cfg8::LDS_BYTES + 8 * 4096;              // ring + per-wave epilogue scratch = 160 KiB
+    static bool attr_set[VF_MAX_DEVICES] = {};
+    auto kern = gemm8p_kernel<EPI, DT>;
+    const int dev = vf_current_device();
+    if (dev < 0 || !attr_set[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
+            hipSuccess) {
+            (void)hipGetLastError();
+            vf_set_error("vf_gemm: cannot reserve %d bytes of LDS", LDS);
+            return VF_ERR_LAUNCH;
+        }
+        if (dev >= 0) attr_set[dev] = true;
+    }
+    const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256;
+    const int n_tiles = tiles_m * tiles_n;
+    const int grid = n_tiles < 256 ? n_tiles : 256;              // one resident block per CU
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, st, (const unsigned short*)A, lda, (const unsigned short*)W, bias,
+                       res, ldr, out, ldo, M, N, K, tiles_n, n_tiles, 8);
+    VF_CHECK_LAUNCH("vf_gemm");
+    return VF_OK;
+}
+
 // Tile choice (measured on MI355X, scripts/gemm_bench.py, random data; the cost model inside reproduces every measured
 // ordering): grids with fewer than 256 128x128 tiles use 64x64 tiles so that all 256 CUs get work; otherwise 256x256
 // (one 8-wave block per CU, half the L2 -> LDS bytes per flop) against 128x128 (two 4-wave blocks per CU) by whole
@@ -1096,6 +1409,9 @@ int launch_gemm(const void* A, int64_t lda, const void* W, const float* bias, co
         case 1: return launch_cfg<CfgA, EPI, DT>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
         case 5: return launch_cfg<CfgE, EPI, DT>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
         case 20: return launch_gemm8<EPI, DT>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
+        case 21:
+            if (K < 128) break;
+            return launch_gemm8p<EPI, DT>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
 #ifdef VF_TUNING
         case 2: return launch_cfg<CfgB, EPI, DT>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
         case 12: return launch_cfg<CfgJ, EPI, DT>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
