@@ -20,12 +20,21 @@ launches = collections.defaultdict(set)
 for f in glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"]
-        m = re.search(r"(gemm_\w+|attn_\w+|layernorm_kernel|seq2reg_\w+)(<[^>]*(?:<[^>]*>[^>]*)*>)?", name)
+        m = re.search(r"(gemm\w+|attn_\w+|layernorm_kernel|seq2reg_\w+)(<[^>]*(?:<[^>]*>[^>]*)*>)?", name)
         if not m:
             continue
         key = (m.group(1) + (m.group(2) or ""))[:90]
         acc[key][r["Counter_Name"]] += float(r["Counter_Value"])
         launches[key].add((f, r["Dispatch_Id"]))
+# kernel durations of the same pass (--kernel-trace): MFMA-busy cycles per SIMD per microsecond, i.e. the matrix pipe's
+# busy time expressed as a clock rate (2400 = busy every cycle at the 2.4 GHz maximum clock; the chip holds ~1.9-2.1 GHz
+# under MFMA load, MI355X_MICROARCH.md "DVFS give-back")
+dur = collections.defaultdict(float)
+for f in glob.glob(os.path.join(src, "**", "*kernel_trace.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        m = re.search(r"(gemm\w+|attn_\w+|layernorm_kernel|seq2reg_\w+)(<[^>]*(?:<[^>]*>[^>]*)*>)?", r["Kernel_Name"])
+        if m:
+            dur[(m.group(1) + (m.group(2) or ""))[:90]] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3
 res = {}
 for k, c in sorted(acc.items()):
     n = len(launches[k])
@@ -33,8 +42,12 @@ for k, c in sorted(acc.items()):
     e.update({cn: v / n for cn, v in c.items()})
     busy = c.get("SQ_BUSY_CYCLES", 0.0)
     wave = c.get("SQ_WAVE_CYCLES", 0.0)
+    if dur.get(k):
+        e["avg_duration_us"] = dur[k] / n
+        e["mfma_busy_MHz_per_simd"] = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024.0 * dur[k])
+        e["mfma_busy_frac_of_2400MHz"] = e["mfma_busy_MHz_per_simd"] / 2400.0
     if busy:
-        e["mfma_busy_frac"] = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (busy * 16.0)
+        e["mfma_busy_over_sq_busy"] = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (busy * 16.0)
     if wave:
         e["wait_any_frac_of_wave_cycles"] = c.get("SQ_WAIT_ANY", 0.0) / wave
         e["wait_inst_any_frac_of_wave_cycles"] = c.get("SQ_WAIT_INST_ANY", 0.0) / wave
@@ -50,4 +63,4 @@ res["_method"] = ("rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WA
                   "--warmup 1 --no-cpu-baseline --no-kernel-timing; per-launch averages per kernel instantiation")
 json.dump(res, open(out_path, "w"), indent=1)
 print(json.dumps({k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()
-                      if "frac" in kk or kk == "launches"} for k, v in res.items() if isinstance(v, dict)}, indent=1))
+                      if "frac" in kk or kk in ("launches", "avg_duration_us", "mfma_busy_MHz_per_simd")} for k, v in res.items() if isinstance(v, dict)}, indent=1))

@@ -5,13 +5,15 @@
 TAG=${1:-x}
 O=gpurun_out/$TAG
 mkdir -p $O
-if [ "$2" != "--skip-tests" ]; then
+if [ "$2" != "--skip-tests" ] && [ "$2" != "--pmc-only" ]; then
   python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
   tail -3 $O/pytest_gpu.log
 fi
-python bench.py > $O/bench.json 2> $O/bench.err; cat $O/bench.json
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+if [ "$2" != "--pmc-only" ]; then
+python bench.py > $O/bench.json 2> $O/bench.err; cat $O/bench.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench.py --no-cpu-baseline > $O/bench_prof.json 2> $O/prof.err
+fi
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/${TAG}_pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > $O/pmc_fetch.json 2> $O/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/${TAG}_pmc_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > $O/pmc_write.json 2> $O/pmc_write.err
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d gpurun_out/${TAG}_pmc_sq -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing > $O/pmc_sq.json 2> $O/pmc_sq.err
