@@ -64,6 +64,13 @@ def test_vcfprocessor_flow(tmp_path, model_class):
     ref = direct.predict_step(collate_fn_batching([dataset[i] for i in range(3)]), 0)
     for i in range(3):
         np.testing.assert_allclose(out["predicted_expression"][i], ref["pred_gene_exp"][i], rtol=1e-5, atol=1e-6)
+    # the sharded driver (one rank here: no process group) returns the same frame, ragged tissue lists included
+    dataset2, _ = vp.create_data(None, query, dataset_factory=factory)
+    out2 = vp.predict_distributed(model, ckpt, trainer, dataset2, batch_size=2)
+    assert list(out2.columns) == list(out.columns) and vp.last_busy_seconds > 0
+    for i in range(3):
+        np.testing.assert_allclose(out2["predicted_expression"][i], out["predicted_expression"][i], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(out2["embeddings"][i], out["embeddings"][i], rtol=1e-5, atol=1e-5)
 
 
 def test_model_manager_rejects_missing_checkpoint_and_bad_class(tmp_path):
