@@ -76,6 +76,22 @@ int vf_gemm_f16_ex(const void* A, int64_t lda, const void* W, const float* bias,
                    const float* residual, int64_t ldr, void* out, int64_t ldo,
                    int M, int N, int K, int epilogue, int variant, void* stream);
 
+/* LayerNorm without a pass of its own: LN(x) . W^T = rstd * (x . (gamma (.) W)^T - mean * rowsum(gamma (.) W))
+ * + (W . beta + b).  The GEMM that PRODUCES the fp32 stream x (epilogue VF_EPI_F32 / VF_EPI_RES_F32) also writes
+ * out16 = the bf16 copy of x [M, ld16] and part_stats [ceil(N/32), M, 2] = (sum, sum of squares) of every 32-column part
+ * of the row (give out16 + part_stats, leave row_stats / colsum NULL); vf_ln_finalize turns the parts into row_stats
+ * [M, 2] = (mean, rstd); the GEMM that CONSUMES LN(x) (epilogue VF_EPI_BF16 / VF_EPI_GEGLU_BF16) takes A = out16,
+ * W = bf16(gamma (.) W), bias = W . beta + b, colsum[n] = sum_k W'[n][k] and row_stats (give those two, leave out16 /
+ * part_stats NULL).  vf_row_stats_cast produces (out16, row_stats) for a stream no GEMM produced.  Replaces the
+ * nn.LayerNorm -> nn.Linear pairs of the layers (seq2gene/modules/layers.py:105-162, seq2reg/modules.py:155-187).
+ * MFMA path only: K % 64 == 0. */
+int vf_gemm_ln_bf16(const void* A, int64_t lda, const void* W, const float* bias, const float* residual, int64_t ldr,
+                    void* out, int64_t ldo, int M, int N, int K, int epilogue, const float* row_stats,
+                    const float* colsum, void* out16, int64_t ld16, float* part_stats, void* stream);
+int vf_ln_finalize(const float* part_stats, int64_t rows, int n_parts, int D, float eps, float* row_stats, void* stream);
+int vf_row_stats_cast(const float* x, int64_t rows, int D, float eps, void* out16, int out_dtype, float* row_stats,
+                      void* stream);
+
 /* Permute rows of a [2F, K] 16-bit (bf16 or fp16) weight (and its fp32 bias, may be NULL) into the VF_EPI_GEGLU_BF16
  * layout (one-time weight repack at checkpoint load). */
 int vf_pack_geglu_rows(const void* W, const float* bias, void* W_out, float* bias_out,

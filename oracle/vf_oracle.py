@@ -92,22 +92,58 @@ def pad_input(packed: torch.Tensor, indices: torch.Tensor, batch: int, seqlen: i
     return out.view(batch, seqlen, *packed.shape[1:])
 
 
-class Rounding:
-    """Rounding policy: where the HIP kernels store bf16, the oracle rounds to bf16."""
+class LnPending:
+    """LayerNorm(x; gamma, beta) not yet applied: the Linear that consumes it evaluates the pair in the folded form of
+    the HIP path (see `linear`)."""
 
-    def __init__(self, mode: str | None):
+    def __init__(self, x, gamma, beta):
+        self.x, self.gamma, self.beta = x, gamma, beta
+
+    @property
+    def shape(self):
+        return self.x.shape
+
+
+class Rounding:
+    """Rounding policy: where the HIP kernels store bf16, the oracle rounds to bf16.  `fold_ln` restates where the bf16
+    HIP path rounds around a LayerNorm -> Linear pair: the GEMM reads bf16(x) and bf16(gamma (.) W)
+    and the fp32 row statistics are applied to its fp32 accumulator, instead of bf16(LayerNorm(x)) . bf16(W).  Same
+    algebra, different rounding points; default = what variantformer_amd does (bf16 operands, VF_LN_FOLD != 0)."""
+
+    def __init__(self, mode: str | None, fold_ln: bool | None = None):
         assert mode in (None, "bf16", "fp16")
         self.mode = mode
+        if fold_ln is None:
+            import os
+            fold_ln = mode == "bf16" and os.environ.get("VF_LN_FOLD", "1") != "0"
+        self.fold_ln = bool(fold_ln)
 
     def r(self, x: torch.Tensor) -> torch.Tensor:
         if self.mode is None:
             return x
         return x.to(torch.bfloat16 if self.mode == "bf16" else torch.float16).to(torch.float32)
 
+    def ln(self, x, w, b, fold: bool = True):
+        """LayerNorm whose only consumers are Linear layers: rounded output, or the pending (folded) form."""
+        if self.fold_ln and fold and x.shape[-1] % 64 == 0:
+            return LnPending(x, w, b)
+        return self.r(layer_norm(x, w, b))
+
 
 def linear(x, w, b, rnd: Rounding):
     """nn.Linear under the kernel contract: bf16 operands (x already rounded by its
-    producer, w rounded once at load), fp32 accumulate, fp32 bias."""
+    producer, w rounded once at load), fp32 accumulate, fp32 bias.
+    With a pending LayerNorm:  LN(x) W^T + b = rstd * (x W'^T - mean * rowsum(W')) + (W beta + b),  W' = gamma (.) W,
+    operands x and W' rounded, statistics and the correction in fp32."""
+    if isinstance(x, LnPending):
+        xs = x.x
+        mean = xs.mean(dim=-1, keepdim=True)
+        rstd = torch.rsqrt(xs.var(dim=-1, unbiased=False, keepdim=True) + 1e-5)
+        wp = rnd.r(w * x.gamma[None, :])
+        bias = w @ x.beta
+        if b is not None:
+            bias = bias + b
+        return (F.linear(rnd.r(xs), wp) - mean * wp.sum(dim=1)[None, :]) * rstd + bias
     return F.linear(rnd.r(x), rnd.r(w), b)
 
 
@@ -199,10 +235,10 @@ def seq2reg_layer(x, cu, sd, pfx, hp: Seq2RegHP, slopes, rnd: Rounding):
     """FlashTransformerLayer.forward (seq2reg/modules.py:149-191) on the packed valid tokens.
     Pad positions never influence valid ones (attention runs on the unpadded stream, :159-171;
     everything else is per-token) and are excluded from the pool, so only valid tokens are kept."""
-    h = rnd.r(layer_norm(x, sd[pfx + "norm1.weight"], sd[pfx + "norm1.bias"]))
+    h = rnd.ln(x, sd[pfx + "norm1.weight"], sd[pfx + "norm1.bias"])
     a = mha_self(h, sd, pfx + "MHA.", hp.num_heads, cu, slopes, rnd)
     x1 = a + x                                                       # :179  x += res_short
-    h = rnd.r(layer_norm(x1, sd[pfx + "norm2.weight"], sd[pfx + "norm2.bias"]))
+    h = rnd.ln(x1, sd[pfx + "norm2.weight"], sd[pfx + "norm2.bias"])
     return geglu_ffn(h, sd, pfx, rnd) + x                            # :188  x += res_long (= layer input)
 
 
@@ -210,11 +246,11 @@ def seq2reg_context_layer(x, ctx, cu, sd, pfx, hp: Seq2RegHP, slopes, rnd: Round
     """seq2reg's ContextFlashAttentionEncoderLayer.forward (seq2reg/modules.py:72-126), make_data_kv false: LN1 ->
     self-MHA -> +src -> LN2 -> cross-MHA(q = x, kv = context rows of the same window, no ALiBi, same key padding as the
     tokens :105-112) -> +res_short -> LN3 -> GeGLU -> + src."""
-    h = rnd.r(layer_norm(x, sd[pfx + "norm1.weight"], sd[pfx + "norm1.bias"]))
+    h = rnd.ln(x, sd[pfx + "norm1.weight"], sd[pfx + "norm1.bias"])
     x1 = mha_self(h, sd, pfx + "mixer.MHA.", hp.num_heads, cu, slopes, rnd) + x
-    h = rnd.r(layer_norm(x1, sd[pfx + "norm2.weight"], sd[pfx + "norm2.bias"]))
+    h = rnd.ln(x1, sd[pfx + "norm2.weight"], sd[pfx + "norm2.bias"])
     x2 = mha_cross(h, ctx, sd, pfx + "crossMHA.MHA.", hp.num_heads, cu, cu, rnd) + x1
-    h = rnd.r(layer_norm(x2, sd[pfx + "norm3.weight"], sd[pfx + "norm3.bias"]))
+    h = rnd.ln(x2, sd[pfx + "norm3.weight"], sd[pfx + "norm3.bias"])
     return geglu_ffn(h, sd, pfx, rnd) + x
 
 
@@ -308,20 +344,20 @@ def modulator_layer(src, ctx, cu_src, cu_ctx, sd, pfx, H, slopes, rnd: Rounding,
     """ContextFlashAttentionEncoderLayer.forward (seq2gene/modules/layers.py:88-165) on packed
     streams: LN1 -> self-MHA(ALiBi) -> +src -> LN2 -> cross-MHA(q = x, kv = ctx RAW, no norm)
     -> +res_short -> LN3 -> GeGLU -> + src (the LAYER INPUT, :99,163)."""
-    h = rnd.r(layer_norm(src, sd[pfx + "norm1.weight"], sd[pfx + "norm1.bias"]))
+    h = rnd.ln(src, sd[pfx + "norm1.weight"], sd[pfx + "norm1.bias"])
     x1 = mha_self(h, sd, pfx + "mixer.MHA.", H, cu_src, slopes, rnd) + src
-    h = rnd.r(layer_norm(x1, sd[pfx + "norm2.weight"], sd[pfx + "norm2.bias"]))
+    h = rnd.ln(x1, sd[pfx + "norm2.weight"], sd[pfx + "norm2.bias"])
     x2 = mha_cross(h, ctx, sd, pfx + "crossMHA.MHA.", H, cu_src, cu_ctx, rnd, cross_slopes) + x1
-    h = rnd.r(layer_norm(x2, sd[pfx + "norm3.weight"], sd[pfx + "norm3.bias"]))
+    h = rnd.ln(x2, sd[pfx + "norm3.weight"], sd[pfx + "norm3.bias"])
     return geglu_ffn(h, sd, pfx, rnd) + src
 
 
 def self_only_layer(src, cu_src, sd, pfx, H, slopes, rnd: Rounding):
     """FlashAttentionEncoderLayer.forward (layers.py:168-228): LN1 -> self-MHA(ALiBi) -> +src -> LN2 -> GeGLU -> + src
     (norm3 is constructed but never applied)."""
-    h = rnd.r(layer_norm(src, sd[pfx + "norm1.weight"], sd[pfx + "norm1.bias"]))
+    h = rnd.ln(src, sd[pfx + "norm1.weight"], sd[pfx + "norm1.bias"])
     x1 = mha_self(h, sd, pfx + "mixer.MHA.", H, cu_src, slopes, rnd) + src
-    h = rnd.r(layer_norm(x1, sd[pfx + "norm2.weight"], sd[pfx + "norm2.bias"]))
+    h = rnd.ln(x1, sd[pfx + "norm2.weight"], sd[pfx + "norm2.bias"])
     return geglu_ffn(h, sd, pfx, rnd) + src
 
 
@@ -335,9 +371,9 @@ def cre_layer(cre, ctx, cu_cre, sd, pfx, hp, slopes, rnd: Rounding):
 def cross_only_layer(src, ctx, cu_src, cu_ctx, sd, pfx, H, rnd: Rounding, cross_slopes=None):
     """ContextFlashCrossAttentionEncoderLayer.forward (layers.py:231-325): LN1 -> cross-MHA(q = x, kv = ctx raw)
     -> +src -> LN2 -> GeGLU -> + src (the layer input)."""
-    h = rnd.r(layer_norm(src, sd[pfx + "norm1.weight"], sd[pfx + "norm1.bias"]))
+    h = rnd.ln(src, sd[pfx + "norm1.weight"], sd[pfx + "norm1.bias"])
     x1 = mha_cross(h, ctx, sd, pfx + "crossMHA.MHA.", H, cu_src, cu_ctx, rnd, cross_slopes) + src
-    h = rnd.r(layer_norm(x1, sd[pfx + "norm2.weight"], sd[pfx + "norm2.bias"]))
+    h = rnd.ln(x1, sd[pfx + "norm2.weight"], sd[pfx + "norm2.bias"])
     return geglu_ffn(h, sd, pfx, rnd) + src
 
 
@@ -410,7 +446,7 @@ def forward(batch: dict, sd: dict, cre_hp: Seq2RegHP, gene_hp: Seq2RegHP, hp: Se
     the tissue-independent CRE stream once per gene -- the exact de-duplication the HIP path
     uses; tests assert both give the same numbers.
     """
-    rnd = Rounding(rounding)
+    rnd = rounding if isinstance(rounding, Rounding) else Rounding(rounding)
     n_genes = len(batch["cre_sequences"])
     D = hp.emb_dim
     # --- seq2reg over CRE windows and gene chunks (transform_with_batching, :722-829).  The
@@ -497,11 +533,11 @@ def _modulator_shared(cre_x, gene_x, labels, T, G, sd, hp: Seq2GeneHP, rnd: Roun
     cu_g = torch.arange(0, T + 1, dtype=torch.int32) * G
 
     def gene_layer(src, kvsrc, p):
-        h = rnd.r(layer_norm(src, sd[p + "norm1.weight"], sd[p + "norm1.bias"]))
+        h = rnd.ln(src, sd[p + "norm1.weight"], sd[p + "norm1.bias"])
         x1 = mha_self(h, sd, p + "mixer.MHA.", H, cu_g, slopes, rnd) + src
-        h = rnd.r(layer_norm(x1, sd[p + "norm2.weight"], sd[p + "norm2.bias"]))
+        h = rnd.ln(x1, sd[p + "norm2.weight"], sd[p + "norm2.bias"])
         x2 = mha_cross(h, kvsrc, sd, p + "crossMHA.MHA.", H, torch.tensor([0, T * G], dtype=torch.int32), cu_c, rnd) + x1
-        h = rnd.r(layer_norm(x2, sd[p + "norm3.weight"], sd[p + "norm3.bias"]))
+        h = rnd.ln(x2, sd[p + "norm3.weight"], sd[p + "norm3.bias"])
         return geglu_ffn(h, sd, p, rnd) + src
 
     cre, gene = cre_x, gene_x

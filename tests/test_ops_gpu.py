@@ -510,3 +510,101 @@ def test_layernorm_cast_pool_fp16_outputs(ops):
     m = ops.segment_mean(x.cuda(), cu.cuda(), torch.float16)
     np.testing.assert_allclose(m[0].float().cpu().numpy(), x[:5].mean(0).numpy(), rtol=2 ** -11, atol=1e-3)
     np.testing.assert_allclose(m[2].float().cpu().numpy(), x[5:].mean(0).numpy(), rtol=2 ** -11, atol=1e-3)
+
+
+# ---------------------------------------------------------------------------------------------
+# LayerNorm folded into the GEMMs (vf_gemm_ln_bf16 / vf_ln_finalize / vf_row_stats_cast): the producer epilogue's bf16
+# copy and row statistics, the consumer epilogue's correction; shapes chosen so that pick_variant takes each tile
+# configuration (64x64: M = 515; 128x128: M = 10854; two-group 256x256: M = 16387, both at N = 1536)
+# ---------------------------------------------------------------------------------------------
+def _row_sample(M, n=96, seed=5):
+    g = torch.Generator().manual_seed(seed)
+    idx = torch.randperm(M, generator=g)[:min(n, M)]
+    return torch.cat([idx, torch.tensor([0, M - 1])]).unique()
+
+
+@pytest.mark.parametrize("M,N,K", [(515, 1536, 1536), (10854, 1536, 1024), (16387, 1536, 1536), (40000, 512, 512),
+                                   (300, 776, 192), (1, 64, 64)])
+@pytest.mark.parametrize("with_res", [True, False])
+def test_gemm_ln_producer(ops, M, N, K, with_res):
+    a = _bf(_rand((M, K), 301))
+    w = _bf(_rand((N, K), 302, 1.0 / math.sqrt(K)))
+    b = _rand((N,), 303, 0.5)
+    res = _rand((M, N), 304, 3.0) + 0.7 if with_res else None      # non-zero row mean
+    s = ops.gemm_ln_producer(a.cuda().bfloat16(), w.cuda().bfloat16(), b.cuda(), None if res is None else res.cuda())
+    plain = ops.gemm(a.cuda().bfloat16(), w.cuda().bfloat16(), b.cuda(), ops.EPI_RES_F32 if with_res else ops.EPI_F32,
+                     residual=None if res is None else res.cuda())
+    torch.cuda.synchronize()
+    assert torch.equal(s.x, plain), "the producer epilogue must not change the fp32 result"
+    assert torch.equal(s.x16, s.x.bfloat16()), "bf16 copy = round-to-nearest-even of the fp32 stream"
+    rows = _row_sample(M)
+    x = s.x[rows.cuda()].double().cpu()
+    ref = a[rows] @ w.t() + b + (res[rows] if with_res else 0)
+    np.testing.assert_allclose(x.float().numpy(), ref.numpy(), rtol=2e-5, atol=2e-5 * math.sqrt(K))
+    mean = x.mean(dim=1)
+    rstd = 1.0 / torch.sqrt(x.var(dim=1, unbiased=False) + 1e-5)
+    st = s.stats[rows.cuda()].double().cpu()
+    np.testing.assert_allclose(st[:, 0].numpy(), mean.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(st[:, 1].numpy(), rstd.numpy(), rtol=2e-5)
+
+
+@pytest.mark.parametrize("rows,D", [(1, 64), (37, 512), (1000, 1536), (5, 4096)])
+def test_ln_stream_stats_and_copy(ops, rows, D):
+    x = _rand((rows, D), 311, 2.0) + _rand((rows, 1), 312, 4.0)
+    s = ops.ln_stream(x.cuda())
+    torch.cuda.synchronize()
+    assert torch.equal(s.x16.cpu(), x.bfloat16())
+    xd = x.double()
+    np.testing.assert_allclose(s.stats[:, 0].double().cpu().numpy(), xd.mean(dim=1).numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(s.stats[:, 1].double().cpu().numpy(),
+                               (1.0 / torch.sqrt(xd.var(dim=1, unbiased=False) + 1e-5)).numpy(), rtol=1e-5)
+
+
+@pytest.mark.parametrize("M,N,K", [(515, 4608, 1536), (10854, 1536, 1536), (16387, 4608, 1536), (40000, 1536, 512),
+                                   (77, 72, 64)])
+@pytest.mark.parametrize("geglu", [False, True])
+def test_gemm_ln_consumer_matches_folded_oracle(ops, M, N, K, geglu):
+    """LayerNorm -> Linear as the HIP path evaluates it against the oracle's statement of the same rounding points
+    (oracle.linear on a pending LayerNorm), and against the unfolded fp32 pair at bf16-level tolerance."""
+    from variantformer_amd.seq2gene.modules.layers import packed_linear_ln
+    if geglu and N % 32:
+        pytest.skip("GEGLU packing needs 2F % 32 == 0")
+    x = _rand((M, K), 321, 2.0) + _rand((M, 1), 322, 1.5) + 0.3 * _rand((1, K), 323, 4.0)
+    lin = torch.nn.Linear(K, N)
+    norm = torch.nn.LayerNorm(K)
+    with torch.no_grad():
+        lin.weight.copy_(_rand((N, K), 324, 1.0 / math.sqrt(K)))
+        lin.bias.copy_(_rand((N,), 325, 0.5))
+        norm.weight.copy_(1.0 + _rand((K,), 326, 0.3))
+        norm.bias.copy_(_rand((K,), 327, 0.2))
+    rows = _row_sample(M)
+    rnd = O.Rounding("bf16", fold_ln=True)
+    ref = O.linear(rnd.ln(x[rows], norm.weight.detach(), norm.bias.detach()), lin.weight.detach(), lin.bias.detach(), rnd)
+    plain = F.linear(F.layer_norm(x[rows], (K,), norm.weight, norm.bias, 1e-5), lin.weight, lin.bias).detach()
+    if geglu:
+        ref = ref[:, :N // 2] * F.gelu(ref[:, N // 2:])
+        plain = plain[:, :N // 2] * F.gelu(plain[:, N // 2:])
+    lin, norm = lin.cuda(), norm.cuda()
+    wp, bp, cs = packed_linear_ln(lin, norm, geglu=geglu)
+    s = ops.ln_stream(x.cuda())
+    out = ops.gemm_ln_consumer(s, wp, bp, cs, ops.EPI_GEGLU_BF16 if geglu else ops.EPI_BF16)
+    torch.cuda.synchronize()
+    got = out[rows.cuda()].float().cpu()
+    # same rounding points: differences = fp32 summation order + one bf16 output rounding
+    np.testing.assert_allclose(got.numpy(), ref.detach().numpy(), rtol=2 ** -7, atol=4e-3)
+    assert _rel_err(got, plain) < 2e-2
+
+
+def test_gelu_epilogue_accuracy_over_the_whole_range(ops):
+    """The kernels' erf GELU (erfc-based, vf_common.h gelu_erf4) against float64 erf on a dense grid of bf16-exact
+    inputs in [-12, 12] pushed through an identity GEMM with the fp32 GELU epilogue: absolute error <= 5e-7 (what
+    0.5 x (1 + erff(x / sqrt 2)) gives in fp32 as well), and no blow-up of the relative error on the negative tail."""
+    K = 64
+    xs = torch.linspace(-12, 12, 64 * 4096).bfloat16().float().view(-1, K)
+    eye = torch.eye(K)
+    out = ops.gemm(xs.cuda().bfloat16(), eye.cuda().bfloat16(), None, ops.EPI_GELU_F32).cpu().double()
+    xd = xs.double()
+    ref = 0.5 * xd * (1.0 + torch.erf(xd / math.sqrt(2.0)))
+    assert float((out - ref).abs().max()) <= 5e-7
+    tail = (xd < -1) & (xd > -5)
+    assert float(((out - ref).abs() / ref.abs())[tail].max()) < 5e-3

@@ -72,6 +72,22 @@ def test_bf16_rounding_mode_is_close_to_fp32(golden):
         np.testing.assert_allclose(out["pred_gene_exp"][i], arrays[f"pred_gene_exp_{i}"], rtol=3e-2, atol=3e-2)
 
 
+def test_folded_layernorm_is_the_same_algebra(golden):
+    """The LayerNorm -> Linear fold the bf16 HIP path uses (oracle.linear on a pending LayerNorm) is exact algebra: with
+    no operand rounding it reproduces the reference outputs like the plain form; with bf16 operands it stays at
+    bf16-level distance."""
+    meta, arrays, sd, batch = golden
+    cre_hp, gene_hp, hp = _hps(meta)
+    for share in (False, True):
+        out = O.predict_step(batch, sd, cre_hp, gene_hp, hp, rounding=O.Rounding(None, fold_ln=True), share_cre_stream=share)
+        for i in range(len(meta["n_cres"])):
+            np.testing.assert_allclose(out["pred_gene_exp"][i], arrays[f"pred_gene_exp_{i}"], rtol=RTOL, atol=ATOL)
+            np.testing.assert_allclose(out["embeddings"][i], arrays[f"embeddings_{i}"], rtol=RTOL, atol=ATOL)
+    a = O.predict_step(batch, sd, cre_hp, gene_hp, hp, rounding=O.Rounding("bf16", fold_ln=True), share_cre_stream=True)
+    for i in range(len(meta["n_cres"])):
+        np.testing.assert_allclose(a["pred_gene_exp"][i], arrays[f"pred_gene_exp_{i}"], rtol=3e-2, atol=3e-2)
+
+
 def test_alibi_pe_precision_known_answers():
     misc = np.load(os.path.join(GOLDEN, "misc.npz"))
     for h in (2, 4, 8, 12, 32):

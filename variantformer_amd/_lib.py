@@ -27,6 +27,9 @@ SIGNATURES = {
     "vf_gemm_bf16_ex": [_p, _l, _p, _p, _p, _l, _p, _l, _i, _i, _i, _i, _i, _p],
     "vf_gemm_f16": [_p, _l, _p, _p, _p, _l, _p, _l, _i, _i, _i, _i, _p],
     "vf_gemm_f16_ex": [_p, _l, _p, _p, _p, _l, _p, _l, _i, _i, _i, _i, _i, _p],
+    "vf_gemm_ln_bf16": [_p, _l, _p, _p, _p, _l, _p, _l, _i, _i, _i, _i, _p, _p, _p, _l, _p, _p],
+    "vf_ln_finalize": [_p, _l, _i, _i, _f, _p, _p],
+    "vf_row_stats_cast": [_p, _l, _i, _f, _p, _i, _p, _p],
     "vf_pack_geglu_rows": [_p, _p, _p, _p, _i, _i, _p],
     "vf_attn_varlen_fwd": [_p, _p, _p, _p, _l, _l, _l, _l, _p, _p, _i, _i, _i, _i, _i, _p, _f, _p],
     "vf_attn_varlen_fwd_qstart": [_p, _p, _p, _p, _l, _l, _l, _l, _p, _p, _i, _i, _i, _i, _i, _p, _f, _p],

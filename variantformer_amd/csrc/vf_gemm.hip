@@ -41,6 +41,52 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// ---- LayerNorm folded into the GEMMs around it ("LayerNorm without a pass") -------------------
+// LN(x) . W^T = rstd * (x . (gamma (.) W)^T - mean * rowsum(gamma (.) W)) + (W . beta + b): the PRODUCER of x (a GEMM with an
+// fp32 epilogue) also writes the 16-bit copy of x and, per row and 32-column part, (sum, sum of squares); a tiny kernel
+// turns the parts into (mean, rstd) per row; the CONSUMER runs on the 16-bit x with gamma folded into its weights and
+// applies the row statistics in its epilogue.  No kernel reads x again just to normalise it.
+struct LnArgs {
+    const float* row_stats;   // consumer: [M][2] = (mean, rstd) of the rows of A's fp32 source
+    const float* colsum;      // consumer: [N]    = sum_k W'[n][k] over the 16-bit folded weights, fp32
+    void* out16;              // producer: [M][ld16] 16-bit copy of the fp32 output
+    float* part_stats;        // producer: [n_parts][M][2] = (sum, sum of squares) of each 32-column part of every row
+                              // (part-major: a wave writes runs of consecutive rows of one part, vf_ln_finalize reads
+                              // consecutive rows per thread)
+    int64_t ld16;
+    int64_t rows;             // M
+};
+enum { VF_LN_NONE = 0, VF_LN_CONSUMER = 1, VF_LN_PRODUCER = 2 };
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
+// producer side of one read-back item: lane holds the final fp32 values f of one row, 4 consecutive columns (a
+// 32-column part of a row = 8 consecutive lanes); valid = row and columns inside the matrix; p16 / ppart = where this
+// lane's 16-bit values and its part's (sum, sum of squares) go
+template <int DT>
+__device__ __forceinline__ void ln_emit(f32x4_t f, bool valid, unsigned short* p16, float* ppart, int lane) {
+    float s1 = valid ? (f[0] + f[1]) + (f[2] + f[3]) : 0.f;
+    float s2 = valid ? (f[0] * f[0] + f[1] * f[1]) + (f[2] * f[2] + f[3] * f[3]) : 0.f;
+    // butterfly over the 8 lanes of the part on the DPP path of the VALU (__shfl_xor would be a ds_bpermute round trip
+    // per step): quad_perm [1,0,3,2], quad_perm [2,3,0,1], then row_half_mirror (lane i <-> 7 - i: the other quad's sum)
+    s1 += dpp_f32<0xB1>(s1);
+    s2 += dpp_f32<0xB1>(s2);
+    s1 += dpp_f32<0x4E>(s1);
+    s2 += dpp_f32<0x4E>(s2);
+    s1 += dpp_f32<0x141>(s1);
+    s2 += dpp_f32<0x141>(s2);
+    if (valid) {
+        u32x2_t pk;
+        pk[0] = Op16<DT>::pack2(f[0], f[1]);
+        pk[1] = Op16<DT>::pack2(f[2], f[3]);
+        *reinterpret_cast<u32x2_t*>(p16) = pk;
+        if ((lane & 7) == 0) *reinterpret_cast<f32x2_t*>(ppart) = (f32x2_t){s1, s2};
+    }
+}
+
 // Epilogue for 4 consecutive n (n_base .. n_base+3) of row m.  For GEGLU `v` is the `a` half and
 // `gate` the gate half; n_out is the output column of v[0].
 template <int EPI, int DT = VF_BF16>
@@ -55,12 +101,10 @@ __device__ __forceinline__ void epilogue_store(f32x4_t v, f32x4_t gate, int64_t 
     }
     if (EPI == VF_EPI_RES_F32) v += res_pre ? *res_pre : *reinterpret_cast<const f32x4_t*>(res + m * ldr + n_out);
     if (EPI == VF_EPI_GEGLU_BF16) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = v[i] * gelu_erf(gate[i]);
+        v = v * gelu_erf4(gate);
     }
     if (EPI == VF_EPI_GELU_F32 || EPI == VF_EPI_GELU_BF16) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = gelu_erf(v[i]);
+        v = gelu_erf4(v);
     }
     if (EPI == VF_EPI_F32 || EPI == VF_EPI_RES_F32 || EPI == VF_EPI_GELU_F32) {
         *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(out) + m * ldo + n_out) = v;
@@ -92,13 +136,13 @@ struct Cfg {
 
 // DBG (diagnostic builds only, never selected automatically): 1 = no global loads (fragment reads + MFMA ceiling),
 // 2 = no fragment reads / MFMA (LDS-DMA fill ceiling).  Results are meaningless in both.
-template <class C, int EPI, int DT = VF_BF16, int DBG = 0>
+template <class C, int EPI, int DT = VF_BF16, int DBG = 0, int LN = VF_LN_NONE>
 __global__ __launch_bounds__(C::THREADS, 2) void gemm_mfma_kernel(const unsigned short* __restrict__ A, int64_t lda,
                                                               const unsigned short* __restrict__ W,
                                                               const float* __restrict__ bias,
                                                               const float* __restrict__ res, int64_t ldr, void* out,
                                                               int64_t ldo, int M, int N, int K, int tiles_n, int n_blocks,
-                                                              int GROUP_M) {
+                                                              int GROUP_M, LnArgs ln) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using frag_t = typename Op16<DT>::frag;
     constexpr int BM = C::BM, BN = C::BN, TM = C::TM, TN = C::TN, STAGES = C::STAGES, LPT = C::LPT;
@@ -360,6 +404,31 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_mfma_kernel(const unsigned
 #pragma unroll
         for (int in = 0; in < TN; ++in) bvec[in] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     }
+    // LayerNorm consumer: acc -> rstd[m] * (acc - mean[m] * colsum[n]); the folded bias is `bias`
+    f32x4_t svec[LN == VF_LN_CONSUMER ? TN : 1];
+    float ln_mu[LN == VF_LN_CONSUMER ? TM : 1], ln_rs[LN == VF_LN_CONSUMER ? TM : 1];
+    if (LN == VF_LN_CONSUMER) {
+#pragma unroll
+        for (int in = 0; in < TN; ++in) {
+            int nb = (EPI == VF_EPI_GEGLU_BF16) ? nw0 + (in >> 1) * 32 + (in & 1) * 16 + 4 * g : nw0 + in * 16 + 4 * g;
+            nb = nb < N ? nb : 0;
+            svec[LN == VF_LN_CONSUMER ? in : 0] = *reinterpret_cast<const f32x4_t*>(ln.colsum + nb);
+        }
+#pragma unroll
+        for (int im = 0; im < TM; ++im) {
+            int64_t m = mw0 + im * 16 + r;
+            m = m < M ? m : M - 1;
+            const f32x2_t st = *reinterpret_cast<const f32x2_t*>(ln.row_stats + 2 * m);
+            ln_mu[LN == VF_LN_CONSUMER ? im : 0] = st[0];
+            ln_rs[LN == VF_LN_CONSUMER ? im : 0] = st[1];
+        }
+    }
+    auto lnv = [&](int in, int im) -> f32x4_t {
+        if (LN == VF_LN_CONSUMER)
+            return (acc[in][im] - ln_mu[LN == VF_LN_CONSUMER ? im : 0] * svec[LN == VF_LN_CONSUMER ? in : 0]) *
+                   ln_rs[LN == VF_LN_CONSUMER ? im : 0];
+        return acc[in][im];
+    };
     char* const region = smem + wave * REGION;
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
@@ -373,19 +442,19 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_mfma_kernel(const unsigned
                 if (EPI == VF_EPI_GEGLU_BF16) {
 #pragma unroll
                     for (int ip = 0; ip < TN / 2; ++ip) {
-                        const f32x4_t v = acc[2 * ip][im] + bvec[2 * ip], gt = acc[2 * ip + 1][im] + bvec[2 * ip + 1];
+                        const f32x4_t v = lnv(2 * ip, im) + bvec[2 * ip], gt = lnv(2 * ip + 1, im) + bvec[2 * ip + 1];
                         u32x2_t pk;
-                        pk[0] = Op16<DT>::pack2(v[0] * gelu_erf(gt[0]), v[1] * gelu_erf(gt[1]));
-                        pk[1] = Op16<DT>::pack2(v[2] * gelu_erf(gt[2]), v[3] * gelu_erf(gt[3]));
+                        const f32x4_t y = v * gelu_erf4(gt);
+                        pk[0] = Op16<DT>::pack2(y[0], y[1]);
+                        pk[1] = Op16<DT>::pack2(y[2], y[3]);
                         *reinterpret_cast<u32x2_t*>(rowp + (ip * 16 + 4 * g) * 2) = pk;
                     }
                 } else {
 #pragma unroll
                     for (int in = 0; in < TN; ++in) {
-                        f32x4_t v = acc[in][im] + bvec[in];
+                        f32x4_t v = lnv(in, im) + bvec[in];
                         if (EPI == VF_EPI_GELU_F32 || EPI == VF_EPI_GELU_BF16) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                            v = gelu_erf4(v);
                         }
                         if (OUT_F32) {
                             *reinterpret_cast<f32x4_t*>(rowp + (in * 16 + 4 * g) * 4) = v;
@@ -419,7 +488,12 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_mfma_kernel(const unsigned
                     f += RES_PRE ? resv[RES_PRE ? ps : 0][RES_PRE ? k0 + k : 0] : rbuf[ps & 1][RES_PIPE ? k0 + k : 0];
                     d = __builtin_bit_cast(u32x4_t, f);
                 }
-                if (ps * RP + row < WT_M && m < M && ep_col < n_out_total)
+                const bool ok = ps * RP + row < WT_M && m < M && ep_col < n_out_total;
+                if (LN == VF_LN_PRODUCER && OUT_F32)
+                    ln_emit<DT>(__builtin_bit_cast(f32x4_t, d), ok,
+                                reinterpret_cast<unsigned short*>(ln.out16) + m * ln.ld16 + ep_col,
+                                ln.part_stats + ((int64_t)(ep_col >> 5) * ln.rows + m) * 2, lane);
+                if (ok)
                     *reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(out) + (m * ldo + ep_col) * ES) = d;
             }
         }
@@ -642,15 +716,16 @@ struct Cfg8 {
     static constexpr int HALF_BYTES = 128 * 128;                // one half-tile: 128 rows x 64 bf16
     static constexpr int TILE_BYTES = 4 * HALF_BYTES;           // WL | AL | WH | AH
     static constexpr int LDS_BYTES = 2 * TILE_BYTES;            // 128 KiB
+    static constexpr int SIDE_BYTES = 4096;                     // behind the ring: bias | colsum | (mean, rstd) of the tile
     enum { WL = 0, AL = 1, WH = 2, AH = 3 };
 };
 
-template <int EPI, int DT = VF_BF16>
+template <int EPI, int DT = VF_BF16, int LN = VF_LN_NONE>
 __global__ __launch_bounds__(512, 2) void gemm8_kernel(const unsigned short* __restrict__ A, int64_t lda,
                                                        const unsigned short* __restrict__ W,
                                                        const float* __restrict__ bias, const float* __restrict__ res,
                                                        int64_t ldr, void* out, int64_t ldo, int M, int N, int K,
-                                                       int tiles_n, int n_blocks, int GROUP_M) {
+                                                       int tiles_n, int n_blocks, int GROUP_M, LnArgs ln) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using frag_t = typename Op16<DT>::frag;
     using C = Cfg8;
@@ -750,6 +825,28 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const unsigned short* __r
                         Op16<DT>::mfma(WF[i][ks], af[j][ks], acc[IN0 + i][IM0 + j]); \
     } while (0)
 
+    // ---- epilogue operands of the tile (bias and, for the LayerNorm consumer, colsum of its 256 columns and (mean,
+    // rstd) of its 256 rows) are requested by LDS-DMA BEFORE the first K-tile into a side area behind the ring: they
+    // are the oldest entries of every wave's vmcnt queue, so the prologue's wait + barrier publishes them, and the
+    // epilogue reads them from LDS instead of paying an exposed L2 round trip per output tile.
+    char* const side = smem + C::LDS_BYTES;          // [0, 1K) bias, [1K, 2K) colsum, [2K, 4K) row statistics
+    if (bias && wave == 0) {
+        int n = n0 + 4 * lane;
+        n = n < N ? n : N - 4;
+        glds16(bias + n, side);
+    }
+    if (LN == VF_LN_CONSUMER) {
+        if (wave == 1) {
+            int n = n0 + 4 * lane;
+            n = n < N ? n : N - 4;
+            glds16(ln.colsum + n, side + 1024);
+        }
+        int64_t m = m0 + 32 * wave + (lane >> 1);    // every wave: 32 rows x (mean, rstd), one dword per lane
+        m = m < M ? m : M - 1;
+        __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) void*)(ln.row_stats + 2 * m + (lane & 1)),
+                                         (__attribute__((address_space(3))) void*)(side + 2048 + wave * 256), 4, 0, 0);
+    }
+
     // ---- prologue: K-tile 0 complete, the first three half-tiles of K-tile 1 in flight
     const int nkt = K / BK;
     issue(0, C::WL); issue(0, C::AL); issue(0, C::WH); issue(0, C::AH);
@@ -813,7 +910,9 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const unsigned short* __r
     constexpr int WT_NO = (EPI == VF_EPI_GEGLU_BF16) ? WT_N / 2 : WT_N;
     constexpr int PITCH = WT_NO * ES + 16;
     constexpr int REGION = C::LDS_BYTES / C::NW;
-    constexpr int RP = (((REGION / PITCH) < WT_M ? (REGION / PITCH) : WT_M) / 16) * 16;
+    constexpr int RP_FIT = (((REGION / PITCH) < WT_M ? (REGION / PITCH) : WT_M) / 16) * 16;
+    // the LayerNorm producer carries extra live values through the read-back: 32-row passes keep it inside 256 VGPRs
+    constexpr int RP = (LN == VF_LN_PRODUCER && EPI == VF_EPI_RES_F32 && RP_FIT > 32) ? 32 : RP_FIT;
     constexpr int IMP = RP / 16, NPASS = (TM + IMP - 1) / IMP;
     constexpr int CR = WT_NO * ES / 16, RI = 64 / CR, NI = RP / RI;
     static_assert(RP >= 16 && CR >= 1 && CR <= 64 && 64 % CR == 0, "epilogue geometry");
@@ -823,33 +922,67 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const unsigned short* __r
     const int nw0 = n0 + wn * WT_N;
     const int no0 = (EPI == VF_EPI_GEGLU_BF16) ? nw0 / 2 : nw0;
     const int ep_row = lane / CR, ep_col = no0 + (lane % CR) * (16 / ES);
+    // Addresses of this lane's read-back items.  Item j = pass * NI + k is row j * RI + ep_row of the wave tile, so every
+    // pointer is "first row + j * (RI rows)": ONE 64-bit multiply per lane, the per-item steps are wave-uniform scalars
+    // (a multiply per item costs quarter-rate v_mul_lo_u32 / v_mad_u64_u32 pairs: 192 of the 766 VALU instructions of
+    // the fp32-residual epilogue before this).  Rows past M read the last row instead (never stored).
+    const int rows_left = (int)(M - mw0) - ep_row;              // item j is a row of the matrix iff j * RI < rows_left
+    const int64_t row0 = mw0 + ep_row;
+    const int colc = ep_col < N ? ep_col : N - 4;
+    const float* const res_p = RES ? res + row0 * ldr + colc : nullptr;
+    const float* const res_last = RES ? res + (int64_t)(M - 1) * ldr + colc : nullptr;
+    const int64_t res_step = (int64_t)RI * ldr;
+    char* const out_p = reinterpret_cast<char*>(out) + (row0 * ldo + ep_col) * ES;
+    const int64_t out_step = (int64_t)RI * ldo * ES;
+    unsigned short* const o16_p = (LN == VF_LN_PRODUCER) ? reinterpret_cast<unsigned short*>(ln.out16) + row0 * ln.ld16 + ep_col : nullptr;
+    const int64_t o16_step = (int64_t)RI * ln.ld16;
+    float* const part_p = (LN == VF_LN_PRODUCER) ? ln.part_stats + ((int64_t)(ep_col >> 5) * ln.rows + row0) * 2 : nullptr;
     f32x4_t rbuf[2][RES ? NI : 1];
     auto load_res_pass = [&](int ps, f32x4_t (&dst)[RES ? NI : 1]) {
         if (RES) {
 #pragma unroll
             for (int k = 0; k < NI; ++k) {
-                int64_t m = mw0 + ps * RP + k * RI + ep_row;
-                m = m < M ? m : M - 1;
-                const int col = ep_col < N ? ep_col : N - 4;
-                dst[RES ? k : 0] = *reinterpret_cast<const f32x4_t*>(res + m * ldr + col);
+                const int j = ps * NI + k;
+                const float* rp = (j * RI < rows_left) ? res_p + j * res_step : res_last;
+                dst[RES ? k : 0] = *reinterpret_cast<const f32x4_t*>(rp);
             }
         }
     };
     load_res_pass(0, rbuf[0]);
-    // bias of the wave's columns: ONE branch and one batch of loads (a per-element `if (bias) v += load` makes hipcc
-    // branch around every load and drain vmcnt(0) behind each: 32 dependent L2 round trips per wave)
+    // bias of the wave's columns, from the side area (requested before the first K-tile)
     f32x4_t bvec[TN];
     if (bias) {
 #pragma unroll
         for (int in = 0; in < TN; ++in) {
-            int nb = (EPI == VF_EPI_GEGLU_BF16) ? nw0 + (in >> 1) * 32 + (in & 1) * 16 + 4 * g : nw0 + in * 16 + 4 * g;
-            nb = nb < N ? nb : 0;
-            bvec[in] = *reinterpret_cast<const f32x4_t*>(bias + nb);
+            const int nl = wn * WT_N + ((EPI == VF_EPI_GEGLU_BF16) ? (in >> 1) * 32 + (in & 1) * 16 + 4 * g : in * 16 + 4 * g);
+            bvec[in] = *reinterpret_cast<const f32x4_t*>(side + nl * 4);
         }
     } else {
 #pragma unroll
         for (int in = 0; in < TN; ++in) bvec[in] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     }
+    // LayerNorm consumer: acc -> rstd[m] * (acc - mean[m] * colsum[n]); the folded bias is `bias`
+    f32x4_t svec[LN == VF_LN_CONSUMER ? TN : 1];
+    float ln_mu[LN == VF_LN_CONSUMER ? TM : 1], ln_rs[LN == VF_LN_CONSUMER ? TM : 1];
+    if (LN == VF_LN_CONSUMER) {
+#pragma unroll
+        for (int in = 0; in < TN; ++in) {
+            const int nl = wn * WT_N + ((EPI == VF_EPI_GEGLU_BF16) ? (in >> 1) * 32 + (in & 1) * 16 + 4 * g : in * 16 + 4 * g);
+            svec[LN == VF_LN_CONSUMER ? in : 0] = *reinterpret_cast<const f32x4_t*>(side + 1024 + nl * 4);
+        }
+#pragma unroll
+        for (int im = 0; im < TM; ++im) {
+            const f32x2_t st = *reinterpret_cast<const f32x2_t*>(side + 2048 + (wm * WT_M + im * 16 + r) * 8);
+            ln_mu[LN == VF_LN_CONSUMER ? im : 0] = st[0];
+            ln_rs[LN == VF_LN_CONSUMER ? im : 0] = st[1];
+        }
+    }
+    auto lnv = [&](int in, int im) -> f32x4_t {
+        if (LN == VF_LN_CONSUMER)
+            return (acc[in][im] - ln_mu[LN == VF_LN_CONSUMER ? im : 0] * svec[LN == VF_LN_CONSUMER ? in : 0]) *
+                   ln_rs[LN == VF_LN_CONSUMER ? im : 0];
+        return acc[in][im];
+    };
     char* const region = smem + wave * REGION;
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
@@ -862,19 +995,19 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const unsigned short* __r
                 if (EPI == VF_EPI_GEGLU_BF16) {
 #pragma unroll
                     for (int ip = 0; ip < TN / 2; ++ip) {
-                        const f32x4_t v = acc[2 * ip][im] + bvec[2 * ip], gt = acc[2 * ip + 1][im] + bvec[2 * ip + 1];
+                        const f32x4_t v = lnv(2 * ip, im) + bvec[2 * ip], gt = lnv(2 * ip + 1, im) + bvec[2 * ip + 1];
                         u32x2_t pk;
-                        pk[0] = Op16<DT>::pack2(v[0] * gelu_erf(gt[0]), v[1] * gelu_erf(gt[1]));
-                        pk[1] = Op16<DT>::pack2(v[2] * gelu_erf(gt[2]), v[3] * gelu_erf(gt[3]));
+                        const f32x4_t y = v * gelu_erf4(gt);
+                        pk[0] = Op16<DT>::pack2(y[0], y[1]);
+                        pk[1] = Op16<DT>::pack2(y[2], y[3]);
                         *reinterpret_cast<u32x2_t*>(rowp + (ip * 16 + 4 * g) * 2) = pk;
                     }
                 } else {
 #pragma unroll
                     for (int in = 0; in < TN; ++in) {
-                        f32x4_t v = acc[in][im] + bvec[in];
+                        f32x4_t v = lnv(in, im) + bvec[in];
                         if (EPI == VF_EPI_GELU_F32 || EPI == VF_EPI_GELU_BF16) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                            v = gelu_erf4(v);
                         }
                         if (OUT_F32) {
                             *reinterpret_cast<f32x4_t*>(rowp + (in * 16 + 4 * g) * 4) = v;
@@ -901,16 +1034,17 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const unsigned short* __r
 #pragma unroll
             for (int k = 0; k < KB; ++k) {
                 if (k0 + k >= NI) continue;
-                const int row = (k0 + k) * RI + ep_row;
-                const int64_t m = mw0 + ps * RP + row;
+                const int j = ps * NI + k0 + k;                  // row j * RI + ep_row of the wave tile
                 u32x4_t d = dd[k];
                 if (RES) {
                     f32x4_t f = __builtin_bit_cast(f32x4_t, d);
                     f += rbuf[ps & 1][RES ? k0 + k : 0];
                     d = __builtin_bit_cast(u32x4_t, f);
                 }
-                if (ps * RP + row < WT_M && m < M && ep_col < n_out_total)
-                    *reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(out) + (m * ldo + ep_col) * ES) = d;
+                const bool ok = j * RI + ep_row < WT_M && j * RI < rows_left && ep_col < n_out_total;
+                if (LN == VF_LN_PRODUCER && OUT_F32)
+                    ln_emit<DT>(__builtin_bit_cast(f32x4_t, d), ok, o16_p + j * o16_step, part_p + j * (RI * 2), lane);
+                if (ok) *reinterpret_cast<u32x4_t*>(out_p + j * out_step) = d;
             }
         }
     }
@@ -1154,8 +1288,9 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const unsigned short* __
                     for (int ip = 0; ip < TN / 2; ++ip) {
                         const f32x4_t v = acc[2 * ip][im] + bvec[2 * ip], gt = acc[2 * ip + 1][im] + bvec[2 * ip + 1];
                         u32x2_t pk;
-                        pk[0] = Op16<DT>::pack2(v[0] * gelu_erf(gt[0]), v[1] * gelu_erf(gt[1]));
-                        pk[1] = Op16<DT>::pack2(v[2] * gelu_erf(gt[2]), v[3] * gelu_erf(gt[3]));
+                        const f32x4_t y = v * gelu_erf4(gt);
+                        pk[0] = Op16<DT>::pack2(y[0], y[1]);
+                        pk[1] = Op16<DT>::pack2(y[2], y[3]);
                         const int byte = (ip * 16 + 4 * g) * 2;                 // 8-byte piece inside the 64-byte row
                         *reinterpret_cast<u32x2_t*>(rowp + ((((byte >> 4) ^ sx) << 4) | (byte & 8))) = pk;
                     }
@@ -1164,8 +1299,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const unsigned short* __
                     for (int in = 0; in < TN; ++in) {
                         f32x4_t v = acc[in][im] + bvec[in];
                         if (EPI == VF_EPI_GELU_F32 || EPI == VF_EPI_GELU_BF16) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                            v = gelu_erf4(v);
                         }
                         if (OUT_F32) {
                             *reinterpret_cast<f32x4_t*>(rowp + (((in * 4 + g) ^ sx) << 4)) = v;
@@ -1278,11 +1412,11 @@ using CfgH = Cfg<256, 128, 2, 2, 3, 32>;   // 72 KiB, 4 waves (wave tile 128x64)
 using CfgI = Cfg<128, 256, 2, 2, 3, 32>;   // 72 KiB, 4 waves (wave tile 64x128), BK=32, 2 blocks/CU
 #endif
 
-template <class C, int EPI, int DT = VF_BF16, int DBG = 0>
+template <class C, int EPI, int DT = VF_BF16, int DBG = 0, int LN = VF_LN_NONE>
 int launch_cfg(const void* A, int64_t lda, const void* W, const float* bias, const float* res, int64_t ldr, void* out,
-               int64_t ldo, int M, int N, int K, hipStream_t st) {
+               int64_t ldo, int M, int N, int K, hipStream_t st, LnArgs ln = LnArgs{}) {
     static bool attr_set[VF_MAX_DEVICES] = {};    // per (config, epilogue) instantiation AND per device
-    auto kern = gemm_mfma_kernel<C, EPI, DT, DBG>;
+    auto kern = gemm_mfma_kernel<C, EPI, DT, DBG, LN>;
     const int dev = vf_current_device();
     if (dev < 0 || !attr_set[dev]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1297,7 +1431,7 @@ int launch_cfg(const void* A, int64_t lda, const void* W, const float* bias, con
     const int n_blocks = tiles_m * tiles_n;
     const int group_m = 8;      // m-panels per L2 group; 2 / 4 / 16 measured equal or slower for both tile sizes
     hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(C::THREADS), C::LDS_BYTES, st, (const unsigned short*)A, lda,
-                       (const unsigned short*)W, bias, res, ldr, out, ldo, M, N, K, tiles_n, n_blocks, group_m);
+                       (const unsigned short*)W, bias, res, ldr, out, ldo, M, N, K, tiles_n, n_blocks, group_m, ln);
     VF_CHECK_LAUNCH("vf_gemm_bf16");
     return VF_OK;
 }
@@ -1329,25 +1463,26 @@ int launch_persist(const void* A, int64_t lda, const void* W, const float* bias,
 
 #endif  // VF_TUNING
 
-template <int EPI, int DT = VF_BF16>
+template <int EPI, int DT = VF_BF16, int LN = VF_LN_NONE>
 int launch_gemm8(const void* A, int64_t lda, const void* W, const float* bias, const float* res, int64_t ldr, void* out,
-                 int64_t ldo, int M, int N, int K, hipStream_t st) {
+                 int64_t ldo, int M, int N, int K, hipStream_t st, LnArgs ln = LnArgs{}) {
     static bool attr_set[VF_MAX_DEVICES] = {};
-    auto kern = gemm8_kernel<EPI, DT>;
+    auto kern = gemm8_kernel<EPI, DT, LN>;
     const int dev = vf_current_device();
     if (dev < 0 || !attr_set[dev]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                Cfg8::LDS_BYTES) != hipSuccess) {
+                                Cfg8::LDS_BYTES + Cfg8::SIDE_BYTES) != hipSuccess) {
             (void)hipGetLastError();
-            vf_set_error("vf_gemm_bf16: cannot reserve %d bytes of LDS", Cfg8::LDS_BYTES);
+            vf_set_error("vf_gemm_bf16: cannot reserve %d bytes of LDS", Cfg8::LDS_BYTES + Cfg8::SIDE_BYTES);
             return VF_ERR_LAUNCH;
         }
         if (dev >= 0) attr_set[dev] = true;
     }
     const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256;
     const int n_blocks = tiles_m * tiles_n;
-    hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(512), Cfg8::LDS_BYTES, st, (const unsigned short*)A, lda,
-                       (const unsigned short*)W, bias, res, ldr, out, ldo, M, N, K, tiles_n, n_blocks, 8);
+    const int group_m = 8;
+    hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(512), Cfg8::LDS_BYTES + Cfg8::SIDE_BYTES, st, (const unsigned short*)A, lda,
+                       (const unsigned short*)W, bias, res, ldr, out, ldo, M, N, K, tiles_n, n_blocks, group_m, ln);
     VF_CHECK_LAUNCH("vf_gemm_bf16");
     return VF_OK;
 }
@@ -1487,6 +1622,55 @@ static int gemm_dispatch(const void* A, int64_t lda, const void* W, const float*
         default: VF_REQUIRE(false, "vf_gemm: unknown epilogue %d", epilogue);
     }
     return VF_OK;
+}
+
+// GEMM with a LayerNorm folded around it (LnArgs above): consumer mode when row_stats / colsum are given (16-bit
+// epilogues), producer mode when out16 / part_stats are given (fp32 epilogues); MFMA path only (K % 64 == 0).
+template <int EPI, int DT, int LN>
+static int launch_gemm_ln(const void* A, int64_t lda, const void* W, const float* bias, const float* residual, int64_t ldr,
+                          void* out, int64_t ldo, int M, int N, int K, const LnArgs& ln, hipStream_t st) {
+    switch (pick_variant(M, N, K, EPI)) {
+        case 1: return launch_cfg<CfgA, EPI, DT, 0, LN>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, st, ln);
+        case 5: return launch_cfg<CfgE, EPI, DT, 0, LN>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, st, ln);
+        default: return launch_gemm8<EPI, DT, LN>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, st, ln);
+    }
+}
+
+extern "C" int vf_gemm_ln_bf16(const void* A, int64_t lda, const void* W, const float* bias, const float* residual,
+                               int64_t ldr, void* out, int64_t ldo, int M, int N, int K, int epilogue,
+                               const float* row_stats, const float* colsum, void* out16, int64_t ld16,
+                               float* part_stats, void* stream) {
+    VF_REQUIRE(A && W && out, "vf_gemm_ln_bf16: null pointer");
+    VF_REQUIRE(M >= 0 && N > 0 && K > 0 && K % 64 == 0 && N % 8 == 0, "vf_gemm_ln_bf16: needs K %% 64 == 0, N %% 8 == 0 (N=%d K=%d)", N, K);
+    VF_REQUIRE(lda % 8 == 0 && lda >= K, "vf_gemm_ln_bf16: lda=%lld must be >= K and a multiple of 8", (long long)lda);
+    VF_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)W % 16 == 0) && ((uintptr_t)out % 16 == 0),
+               "vf_gemm_ln_bf16: pointers must be 16-byte aligned");
+    const bool consumer = row_stats && colsum, producer = out16 && part_stats;
+    VF_REQUIRE(consumer != producer, "vf_gemm_ln_bf16: give (row_stats, colsum) OR (out16, part_stats)");
+    if (M == 0) return VF_OK;
+    LnArgs ln{};
+    hipStream_t st = (hipStream_t)stream;
+    if (consumer) {
+        VF_REQUIRE(((uintptr_t)row_stats % 8 == 0) && ((uintptr_t)colsum % 16 == 0), "vf_gemm_ln_bf16: misaligned statistics");
+        VF_REQUIRE(ldo % 8 == 0, "vf_gemm_ln_bf16: ldo=%lld must be a multiple of 8", (long long)ldo);
+        ln.row_stats = row_stats;
+        ln.colsum = colsum;
+        if (epilogue == VF_EPI_BF16)
+            return launch_gemm_ln<VF_EPI_BF16, VF_BF16, VF_LN_CONSUMER>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, ln, st);
+        VF_REQUIRE(epilogue == VF_EPI_GEGLU_BF16 && N % 32 == 0, "vf_gemm_ln_bf16: consumer epilogues are BF16 and GEGLU_BF16");
+        return launch_gemm_ln<VF_EPI_GEGLU_BF16, VF_BF16, VF_LN_CONSUMER>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, ln, st);
+    }
+    VF_REQUIRE(ld16 % 4 == 0 && ld16 >= N && ((uintptr_t)out16 % 8 == 0) && ((uintptr_t)part_stats % 8 == 0) && ldo % 4 == 0,
+               "vf_gemm_ln_bf16: producer outputs must keep 8-byte alignment (ld16=%lld)", (long long)ld16);
+    ln.out16 = out16;
+    ln.part_stats = part_stats;
+    ln.ld16 = ld16;
+    ln.rows = M;
+    if (epilogue == VF_EPI_F32)
+        return launch_gemm_ln<VF_EPI_F32, VF_BF16, VF_LN_PRODUCER>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, ln, st);
+    VF_REQUIRE(epilogue == VF_EPI_RES_F32 && residual && ldr % 4 == 0 && ((uintptr_t)residual % 16 == 0),
+               "vf_gemm_ln_bf16: producer epilogues are F32 and RES_F32 (with an aligned residual)");
+    return launch_gemm_ln<VF_EPI_RES_F32, VF_BF16, VF_LN_PRODUCER>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, ln, st);
 }
 
 extern "C" int vf_gemm_bf16(const void* A, int64_t lda, const void* W, const float* bias, const float* residual,

@@ -87,6 +87,68 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
+// LayerNorm folded into the neighbouring GEMMs (vf_gemm_ln_bf16): row statistics
+// ---------------------------------------------------------------------------------------------
+// (sum, sum of squares) per 32-column part of a row, written by the producing GEMM's epilogue -> (mean, rstd) per row.
+__global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restrict__ part, float* __restrict__ row_stats,
+                                                         int64_t rows, int n_parts, int D, float eps) {
+    // part is [n_parts][rows][2] (part-major): one thread per row, consecutive threads read consecutive rows; the parts
+    // are added in index order, so the result does not depend on the GEMM tile configuration that wrote them
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) return;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll 8
+    for (int p = 0; p < n_parts; ++p) {
+        const f32x2_t v = *reinterpret_cast<const f32x2_t*>(part + ((int64_t)p * rows + row) * 2);
+        s1 += v[0];
+        s2 += v[1];
+    }
+    const float mean = s1 / (float)D;
+    const float var = fmaxf(s2 / (float)D - mean * mean, 0.f);
+    *reinterpret_cast<f32x2_t*>(row_stats + 2 * row) = (f32x2_t){mean, rsqrtf(var + eps)};
+}
+
+// The same statistics for a stream that no GEMM produced (the first layer's input): one wave per row, two-pass
+// mean / variance like layernorm_kernel, plus the 16-bit copy of the row.
+template <int MAXC>
+__global__ __launch_bounds__(256) void row_stats_cast_kernel(const float* __restrict__ x, void* __restrict__ out16,
+                                                            float* __restrict__ row_stats, int64_t rows, int D, float eps,
+                                                            int out_dt) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int n4 = D >> 2;
+    const f32x4_t* xr = reinterpret_cast<const f32x4_t*>(x + row * D);
+    f32x4_t v[MAXC];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int i = lane + 64 * c;
+        v[c] = i < n4 ? xr[i] : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        s += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int i = lane + 64 * c;
+        if (i < n4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[c][e] - mean;
+                ss += d * d;
+            }
+            u32x2_t p;
+            p[0] = pack2_dt(v[c][0], v[c][1], out_dt);
+            p[1] = pack2_dt(v[c][2], v[c][3], out_dt);
+            reinterpret_cast<u32x2_t*>(reinterpret_cast<unsigned short*>(out16) + row * D)[i] = p;
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(ss) / (float)D + eps);
+    if (lane == 0) *reinterpret_cast<f32x2_t*>(row_stats + 2 * row) = (f32x2_t){mean, rstd};
+}
+
+// ---------------------------------------------------------------------------------------------
 // valid-token counts (one wave per window, coalesced byte reads) + exclusive scan of the counts (single block)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void mask_count_kernel(const uint8_t* __restrict__ pad, int32_t* __restrict__ cu,
@@ -301,6 +363,19 @@ __global__ __launch_bounds__(256) void gather_rows_f32_kernel(const float* __res
     }
 }
 
+// narrow fp32 rows (d not a multiple of 4, e.g. the [rows, 2] LayerNorm statistics): one element per thread
+__global__ __launch_bounds__(256) void gather_rows_f32_scalar_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                                    const int64_t* __restrict__ idx, float* __restrict__ out,
+                                                                    int64_t n, int d) {
+    const int64_t total = n * d;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / d;
+        const int c = (int)(i - row * d);
+        const int64_t j = idx[row];
+        out[i] = j >= 0 ? a[j * d + c] : b[(-j - 1) * d + c];
+    }
+}
+
 __global__ __launch_bounds__(256) void gather_rows_bf16_kernel(const unsigned short* __restrict__ src, int64_t ld_src,
                                                               const int64_t* __restrict__ idx,
                                                               unsigned short* __restrict__ out, int64_t ld_out,
@@ -377,6 +452,31 @@ extern "C" int vf_layernorm(const float* x, const float* gamma, const float* bet
     return VF_OK;
 }
 
+extern "C" int vf_ln_finalize(const float* part_stats, int64_t rows, int n_parts, int D, float eps, float* row_stats,
+                              void* stream) {
+    VF_REQUIRE(part_stats && row_stats && n_parts > 0 && D > 0, "vf_ln_finalize: bad arguments");
+    if (rows <= 0) return VF_OK;
+    hipLaunchKernelGGL(ln_finalize_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, part_stats,
+                       row_stats, rows, n_parts, D, eps);
+    VF_CHECK_LAUNCH("vf_ln_finalize");
+    return VF_OK;
+}
+
+extern "C" int vf_row_stats_cast(const float* x, int64_t rows, int D, float eps, void* out16, int out_dtype,
+                                 float* row_stats, void* stream) {
+    VF_REQUIRE(x && out16 && row_stats, "vf_row_stats_cast: null pointer");
+    VF_REQUIRE(D > 0 && D % 4 == 0 && D <= 8192, "vf_row_stats_cast: D=%d must be a multiple of 4 and <= 8192", D);
+    VF_REQUIRE(out_dtype == VF_BF16 || out_dtype == VF_F16, "vf_row_stats_cast: bad out_dtype %d", out_dtype);
+    if (rows <= 0) return VF_OK;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)((rows + 3) / 4));
+    if (D <= 512) hipLaunchKernelGGL(row_stats_cast_kernel<2>, grid, dim3(256), 0, st, x, out16, row_stats, rows, D, eps, out_dtype);
+    else if (D <= 2048) hipLaunchKernelGGL(row_stats_cast_kernel<8>, grid, dim3(256), 0, st, x, out16, row_stats, rows, D, eps, out_dtype);
+    else hipLaunchKernelGGL(row_stats_cast_kernel<32>, grid, dim3(256), 0, st, x, out16, row_stats, rows, D, eps, out_dtype);
+    VF_CHECK_LAUNCH("vf_row_stats_cast");
+    return VF_OK;
+}
+
 extern "C" int vf_mask_to_cu_seqlens(const uint8_t* pad, int32_t* cu, int W, int L, void* stream) {
     VF_REQUIRE(pad && cu && W >= 0 && L > 0, "vf_mask_to_cu_seqlens: bad arguments");
     if (W > 0) hipLaunchKernelGGL(mask_count_kernel, dim3((W + 3) / 4), dim3(256), 0, (hipStream_t)stream, pad, cu, W, L);
@@ -447,9 +547,16 @@ extern "C" int vf_add_rows_f32(const float* a, const int64_t* idx_a, const float
 
 extern "C" int vf_gather_rows_f32(const float* a, const float* b, const int64_t* idx, void* out, int64_t n, int d,
                                   int out_dtype, void* stream) {
-    VF_REQUIRE(a && idx && out && d > 0 && d % 4 == 0, "vf_gather_rows_f32: bad arguments (d=%d)", d);
+    VF_REQUIRE(a && idx && out && d > 0 && (d % 4 == 0 || out_dtype == VF_F32),
+               "vf_gather_rows_f32: 16-bit outputs need d %% 4 == 0 (d=%d)", d);
     VF_REQUIRE(out_dtype == VF_F32 || out_dtype == VF_BF16 || out_dtype == VF_F16, "vf_gather_rows_f32: bad out_dtype %d", out_dtype);
     if (n <= 0) return VF_OK;
+    if (d % 4 != 0) {
+        hipLaunchKernelGGL(gather_rows_f32_scalar_kernel, dim3(stream_grid(n * d)), dim3(256), 0, (hipStream_t)stream, a,
+                           b ? b : a, idx, (float*)out, n, d);
+        VF_CHECK_LAUNCH("vf_gather_rows_f32");
+        return VF_OK;
+    }
     hipLaunchKernelGGL(gather_rows_f32_kernel, dim3(stream_grid(n * (d / 4))), dim3(256), 0, (hipStream_t)stream, a,
                        b ? b : a, idx, out, n, d, out_dtype);
     VF_CHECK_LAUNCH("vf_gather_rows_f32");

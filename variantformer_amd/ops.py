@@ -178,6 +178,94 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None, epilogue: 
     return out
 
 
+class LnStream:
+    """A residual stream as the LayerNorm-folding GEMMs exchange it: x fp32 [M, D], x16 its bf16 copy, stats fp32 [M, 2]
+    = (mean, rstd) of every row (vf_gemm_ln_bf16 / vf_ln_finalize / vf_row_stats_cast)."""
+    __slots__ = ("x", "x16", "stats")
+
+    def __init__(self, x, x16, stats):
+        self.x, self.x16, self.stats = x, x16, stats
+
+
+def ln_stream(x: torch.Tensor, eps: float = 1e-5) -> LnStream:
+    """(x, bf16 copy, row statistics) for a stream no GEMM produced: one pass over x (vf_row_stats_cast)."""
+    _dev(x)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 2
+    M, D = x.shape
+    x16 = torch.empty((M, D), dtype=torch.bfloat16, device=x.device)
+    stats = torch.empty((M, 2), dtype=torch.float32, device=x.device)
+
+    def launch():
+        check(_lib.load().vf_row_stats_cast(x.data_ptr(), M, D, eps, x16.data_ptr(), VF_BF16, stats.data_ptr(), _stream()),
+              "vf_row_stats_cast")
+    if TIMER is not None:
+        TIMER.time("layernorm", 0.0, float(M) * D * 6, launch, f"stats_cast D={D}", _SCOPE)
+    else:
+        launch()
+    return LnStream(x, x16, stats)
+
+
+def ln_stream_rows(s: LnStream, rows: torch.Tensor) -> LnStream:
+    """The rows `rows` (int64) of a stream, statistics included (bit-identical to the full stream's)."""
+    return LnStream(gather_rows_f32(s.x, None, rows), gather_rows_bf16(s.x16, rows), gather_rows_f32(s.stats, None, rows))
+
+
+def gemm_ln_consumer(s: LnStream, w: torch.Tensor, bias: torch.Tensor, colsum: torch.Tensor, epilogue: int,
+                     family: str = "") -> torch.Tensor:
+    """epilogue(LN(s.x) @ W^T + b) without materialising LN(s.x): w = bf16(gamma (.) W) [N, K], bias = W beta + b,
+    colsum = rowsum(w) (layers.packed_linear_ln).  epilogue EPI_BF16 or EPI_GEGLU_BF16."""
+    a = s.x16
+    _dev(a, w, bias, colsum, s.stats)
+    assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and a.shape[1] == w.shape[1] and a.stride(1) == 1
+    M, K = a.shape
+    N = w.shape[0]
+    n_out = N // 2 if epilogue == EPI_GEGLU_BF16 else N
+    out = torch.empty((M, n_out), dtype=torch.bfloat16, device=a.device)
+    lib = _lib.load()
+
+    def launch():
+        check(lib.vf_gemm_ln_bf16(a.data_ptr(), a.stride(0) if M > 1 else max(a.stride(0), K), w.data_ptr(), bias.data_ptr(),
+                                  0, 0, out.data_ptr(), n_out, M, N, K, epilogue, s.stats.data_ptr(), colsum.data_ptr(),
+                                  0, 0, 0, _stream()), "vf_gemm_ln_bf16")
+    if TIMER is not None:
+        nbytes = 2.0 * (M * K + N * K) + out.numel() * 2 + 8.0 * M
+        TIMER.time("gemm", 2.0 * M * N * K, nbytes, launch, f"M={M} N={N} K={K} epi={epilogue} ln=consumer", family or _SCOPE)
+    else:
+        launch()
+    return out
+
+
+def gemm_ln_producer(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None, residual: torch.Tensor | None,
+                     eps: float = 1e-5, family: str = "") -> LnStream:
+    """x = a @ w^T + bias (+ residual), fp32, returned together with its bf16 copy and row statistics (the next
+    LayerNorm's): EPI_RES_F32 when a residual is given, else EPI_F32."""
+    _dev(a, w, bias, residual)
+    assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and a.shape[1] == w.shape[1] and a.stride(1) == 1
+    M, K = a.shape
+    N = w.shape[0]
+    out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    x16 = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+    n_parts = (N + 31) // 32
+    part = torch.empty((n_parts, M, 2), dtype=torch.float32, device=a.device)
+    stats = torch.empty((M, 2), dtype=torch.float32, device=a.device)
+    epi = EPI_F32 if residual is None else EPI_RES_F32
+    if residual is not None:
+        assert residual.dtype == torch.float32 and residual.shape == (M, N) and residual.stride(1) == 1
+    lib = _lib.load()
+
+    def launch():
+        check(lib.vf_gemm_ln_bf16(a.data_ptr(), a.stride(0) if M > 1 else max(a.stride(0), K), w.data_ptr(), _ptr(bias),
+                                  _ptr(residual), 0 if residual is None else residual.stride(0), out.data_ptr(), N, M, N, K,
+                                  epi, 0, 0, x16.data_ptr(), N, part.data_ptr(), _stream()), "vf_gemm_ln_bf16")
+        check(lib.vf_ln_finalize(part.data_ptr(), M, n_parts, N, eps, stats.data_ptr(), _stream()), "vf_ln_finalize")
+    if TIMER is not None:
+        nbytes = 2.0 * (M * K + N * K) + M * N * (4.0 + 2.0) + (0 if residual is None else 4.0 * M * N) + 8.0 * M * n_parts
+        TIMER.time("gemm", 2.0 * M * N * K, nbytes, launch, f"M={M} N={N} K={K} epi={epi} ln=producer", family or _SCOPE)
+    else:
+        launch()
+    return LnStream(out, x16, stats)
+
+
 def pack_geglu_rows(w: torch.Tensor, bias: torch.Tensor | None):
     """Permute a [2F,K] 16-bit weight (+ fp32 bias) into the GEGLU-epilogue row order."""
     _dev(w, bias)

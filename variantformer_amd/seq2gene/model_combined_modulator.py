@@ -30,7 +30,8 @@ from .. import ops
 from ..utils.constants import REF_CREs
 from ..utils.functions import precision2dtype
 from .modules.layers import (AddContext, ContextFlashAttentionEncoderLayer, ContextFlashCrossAttentionEncoderLayer,
-                             FlashAttentionEncoderLayer, MultiRegistry, StartToken, TissueExpressionHeads, packed_linear, pad_input, unpad_input)
+                             FlashAttentionEncoderLayer, MultiRegistry, StartToken, TissueExpressionHeads, ln_fold_enabled,
+                             packed_linear, pad_input, unpad_input)
 
 logger = logging.getLogger(__name__)
 MAX_WINDOW_SIZE = 30000000
@@ -98,6 +99,11 @@ def _side_stream(device):
     return _SIDE_STREAMS[key]
 
 
+def _t(x):
+    """fp32 tensor of a stream the layers may hand over as ops.LnStream (x, bf16 copy, row statistics)."""
+    return x.x if isinstance(x, ops.LnStream) else x
+
+
 def modulator_forward_packed(ctx_embedding, cre_layers, gene_layers, cre_x, gene_x, labels, cu_cre, max_cre,
                              cu_gene_self, max_gene, cu_gene_cross=None, max_gene_cross=None, cu_cre_for_gene=None,
                              final_rows=None, use_res=False):
@@ -112,6 +118,10 @@ def modulator_forward_packed(ctx_embedding, cre_layers, gene_layers, cre_x, gene
     ck = cu_cre if cu_cre_for_gene is None else cu_cre_for_gene
     cre, gene = cre_x, gene_x
     n = len(gene_layers)
+    if ln_fold_enabled(cre_x.shape[1]):
+        # LayerNorm folded into the GEMMs: the streams travel as (fp32, bf16 copy, row statistics); one pass makes the
+        # triple for the raw CRE embeddings (gene layer 0 projects K/V from the copy, CRE layer 0 consumes all three)
+        cre = ops.ln_stream(cre_x)
     # Optional (VF_SIDE_STREAM=1): the CRE stream never reads the gene stream, so its (small, tail-heavy) launches can
     # go to a second HIP stream and fill the CUs the big gene-stream launches leave idle; gene layer i+1 waits for the
     # event after CRE layer i.  Measured +0.8 % genes/s at 8 genes per step; off by default because concurrent
@@ -125,7 +135,7 @@ def modulator_forward_packed(ctx_embedding, cre_layers, gene_layers, cre_x, gene
         gene = gene_layers[0].forward_packed(gene, cu_gene_self, max_gene, context=cre, cu_ctx=ck, max_ctx=max_cre,
                                              cu_cross_q=cq, max_cross_q=mq)
     if use_res:                                     # gene-stream input added back after every gene layer (:253-254)
-        gene = ops.add_rows(gene, gene_x)
+        gene = ops.add_rows(_t(gene), gene_x)
     for i in range(n - 1):
         if overlap:
             with torch.cuda.stream(side):
@@ -133,7 +143,8 @@ def modulator_forward_packed(ctx_embedding, cre_layers, gene_layers, cre_x, gene
                 cre = cre_layers[i].forward_packed(cre, cu_cre, max_cre, context_kv=kv, cu_ctx=cu_cre, max_ctx=max_cre)
                 done = torch.cuda.Event()
                 done.record(side)
-            cre.record_stream(main)                 # allocated on `side`, read by the gene layer on `main`
+            for t in ((cre.x, cre.x16, cre.stats) if isinstance(cre, ops.LnStream) else (cre,)):
+                t.record_stream(main)               # allocated on `side`, read by the gene layer on `main`
             main.wait_event(done)
         else:
             with ops.scope("cre_stream"):
@@ -149,8 +160,8 @@ def modulator_forward_packed(ctx_embedding, cre_layers, gene_layers, cre_x, gene
                 gene = gene_layers[i + 1].forward_packed(gene, cu_gene_self, max_gene, context=cre, cu_ctx=ck,
                                                          max_ctx=max_cre, cu_cross_q=cq, max_cross_q=mq)
                 if use_res:                             # :284-285
-                    gene = ops.add_rows(gene, gene_x)
-    return gene, cre
+                    gene = ops.add_rows(_t(gene), gene_x)
+    return _t(gene), _t(cre)
 
 
 class CombinedModulator(nn.Module):

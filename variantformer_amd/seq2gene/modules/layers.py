@@ -56,6 +56,50 @@ def packed_linear(lin: nn.Linear, geglu: bool = False):
     return wb, b
 
 
+def packed_linear_ln(lin: nn.Linear, norm: nn.LayerNorm, geglu: bool = False):
+    """Operands of a GEMM that consumes LayerNorm(x) without a normalised copy of x (ops.gemm_ln_consumer):
+         w'     = bf16(gamma (.) W)        [N, K]   (gamma scales the K columns)
+         bias'  = W . beta + b             [N] fp32 (from the fp32 master weights)
+         colsum = sum_k float(w'[n, k])    [N] fp32
+       so that LN(x) W^T + b = rstd * (x w'^T - mean * colsum) + bias'.  `geglu` applies the GEGLU row interleave to all
+       three.  One-time weight preparation (cached per parameter versions), torch elementwise / reduce ops on the fp32
+       masters; nothing of this runs per batch."""
+    w, g, be = lin.weight, norm.weight, norm.bias
+    key = (w.data_ptr(), w._version, g.data_ptr(), g._version, be.data_ptr(), be._version, str(w.device), geglu,
+           None if lin.bias is None else (lin.bias.data_ptr(), lin.bias._version))
+    cache = getattr(lin, "_vf_packed_ln", None)
+    if cache is not None and cache[0] == key:
+        return cache[1], cache[2], cache[3]
+    with torch.no_grad():
+        wf = w.detach().float()
+        wb = ops.cast16((wf * g.detach().float()[None, :]).contiguous(), torch.bfloat16)
+        b = wf @ be.detach().float()
+        if lin.bias is not None:
+            b = b + lin.bias.detach().float()
+        b = b.contiguous()
+        if geglu:
+            wb, b = ops.pack_geglu_rows(wb, b)
+        colsum = wb.float().sum(dim=1).contiguous()
+    lin._vf_packed_ln = (key, wb, b, colsum)
+    return wb, b, colsum
+
+
+def ln_fold_enabled(width: int) -> bool:
+    """LayerNorm folded into the neighbouring GEMMs for bf16 operands and widths the MFMA path
+    takes (K % 64 == 0); VF_LN_FOLD=0 keeps the separate LayerNorm pass (the fp16 mode always does: the raw residual
+    stream may exceed the fp16 range, its LayerNorm never does)."""
+    import os
+    return ops.cdt() == torch.bfloat16 and width % 64 == 0 and os.environ.get("VF_LN_FOLD", "1") != "0"
+
+
+def _as_stream(x):
+    return x if isinstance(x, ops.LnStream) else ops.ln_stream(x)
+
+
+def _as_tensor(x):
+    return x.x if isinstance(x, ops.LnStream) else x
+
+
 def _cu_from_padded(batch: int, seqlen: int, device) -> torch.Tensor:
     return torch.arange(0, batch + 1, dtype=torch.int32, device=device) * seqlen
 
@@ -125,6 +169,24 @@ class MHA(nn.Module):
         qkv = ops.gemm(x_bf16, w, b, ops.EPI_BF16)
         return ops.attn_varlen(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], cu_q, None, max_q, max_q,
                                self.num_heads, self.head_dim, self.alibi_slopes, family=self.family)
+
+    def attend_ln(self, s: "ops.LnStream", norm: nn.LayerNorm, kv_bf16, cu_q, max_q, cu_k, max_k) -> torch.Tensor:
+        """attend(LayerNorm(s.x)) with the LayerNorm folded into the Wqkv / Wq projection."""
+        D = self.embed_dim
+        if self.cross_attn:
+            w, b, c = packed_linear_ln(self.Wq, norm)
+            q = ops.gemm_ln_consumer(s, w, b, c, ops.EPI_BF16)
+            return ops.attn_varlen(q, kv_bf16[:, :D], kv_bf16[:, D:], cu_q, cu_k, max_q, max_k, self.num_heads,
+                                   self.head_dim, self.alibi_slopes, family=self.family)
+        w, b, c = packed_linear_ln(self.Wqkv, norm)
+        qkv = ops.gemm_ln_consumer(s, w, b, c, ops.EPI_BF16)
+        return ops.attn_varlen(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], cu_q, None, max_q, max_q,
+                               self.num_heads, self.head_dim, self.alibi_slopes, family=self.family)
+
+    def out_ln(self, a_bf16, residual_f32) -> "ops.LnStream":
+        """out_proj(a) + residual as an LnStream (fp32 stream, its bf16 copy, row statistics for the next LayerNorm)."""
+        w, b = packed_linear(self.out_proj)
+        return ops.gemm_ln_producer(a_bf16, w, b, residual_f32)
 
     def fused(self, x_bf16, residual_f32, cu_q, max_q, kv_bf16=None, cu_k=None, max_k=None) -> torch.Tensor:
         """fp32 [tokens, D] = out_proj(attention(x)) + residual (one GEMM epilogue)."""
@@ -228,13 +290,29 @@ class ContextFlashAttentionEncoderLayer(nn.Module):
         `context` (fp32 packed stream, projected here) or from a precomputed bf16 `context_kv` [tokens_k, 2D].
         `cu_cross_q` lets several self-attention sequences share one K/V block (tissue copies of a gene)."""
         assert not self.make_data_kv
+        cq = cu_src if cu_cross_q is None else cu_cross_q
+        mq = max_src if max_cross_q is None else max_cross_q
+        if ln_fold_enabled(self.norm1.weight.numel()):
+            # LayerNorm folded into the GEMMs: every fp32-residual GEMM also emits the bf16 copy + row statistics of its
+            # output, every LayerNorm -> Linear pair runs on that copy (no LayerNorm pass, no cast of the context)
+            s = _as_stream(src)
+            a = self.mixer.MHA.attend_ln(s, self.norm1, None, cu_src, max_src, None, None)
+            x1 = self.mixer.MHA.out_ln(a, s.x)
+            if context_kv is None:
+                ctx16 = context.x16 if isinstance(context, ops.LnStream) else ops.cast16(context)
+                context_kv = self.crossMHA.MHA.project_kv(ctx16)
+            a = self.crossMHA.MHA.attend_ln(x1, self.norm2, context_kv, cq, mq, cu_ctx, max_ctx)
+            x2 = self.crossMHA.MHA.out_ln(a, x1.x)
+            w1, b1, c1 = packed_linear_ln(self.linear_geglu_1, self.norm3, geglu=True)
+            hg = ops.gemm_ln_consumer(x2, w1, b1, c1, ops.EPI_GEGLU_BF16)
+            w2, b2 = packed_linear(self.linear_geglu_2)
+            return ops.gemm_ln_producer(hg, w2, b2, s.x)
+        src, context = _as_tensor(src), _as_tensor(context)
         h = ops.layernorm(src, self.norm1.weight, self.norm1.bias)
         x1 = self.mixer.MHA.fused(h, src, cu_src, max_src)
         h = ops.layernorm(x1, self.norm2.weight, self.norm2.bias)
         if context_kv is None:
             context_kv = self.crossMHA.MHA.project_kv(ops.cast16(context))
-        cq = cu_src if cu_cross_q is None else cu_cross_q
-        mq = max_src if max_cross_q is None else max_cross_q
         x2 = self.crossMHA.MHA.fused(h, x1, cq, mq, context_kv, cu_ctx, max_ctx)
         h = ops.layernorm(x2, self.norm3.weight, self.norm3.bias)
         w1, b1 = packed_linear(self.linear_geglu_1, geglu=True)
@@ -251,8 +329,28 @@ class ContextFlashAttentionEncoderLayer(nn.Module):
         whose output is consumed only through the registry token (pool_outputs row 0,
         model_combined_modulator.py:391-392): exact, and ~1/25 of the gene-stream work less."""
         assert not self.make_data_kv
-        D = src.shape[1]
         mha = self.mixer.MHA
+        if ln_fold_enabled(self.norm1.weight.numel()):
+            s = _as_stream(src)
+            D = s.x.shape[1]
+            w, b, c = packed_linear_ln(mha.Wqkv, self.norm1)
+            kv = ops.gemm_ln_consumer(s, w[D:], b[D:], c[D:], ops.EPI_BF16)            # all rows (K/V need them)
+            sr = ops.ln_stream_rows(s, rows)
+            q = ops.gemm_ln_consumer(sr, w[:D], b[:D], c[:D], ops.EPI_BF16)            # [R, D]
+            a = ops.attn_varlen(q, kv[:, :D], kv[:, D:], cu_rows, cu_src, 1, max_src, mha.num_heads, mha.head_dim,
+                                mha.alibi_slopes, q_at_start=True, family=mha.family + "_registry_rows")
+            x1 = mha.out_ln(a, sr.x)
+            ctx16 = context.x16 if isinstance(context, ops.LnStream) else ops.cast16(context)
+            ckv = self.crossMHA.MHA.project_kv(ctx16)
+            a = self.crossMHA.MHA.attend_ln(x1, self.norm2, ckv, cu_cross_rows, max_cross_rows, cu_ctx, max_ctx)
+            x2 = self.crossMHA.MHA.out_ln(a, x1.x)
+            w1, b1, c1 = packed_linear_ln(self.linear_geglu_1, self.norm3, geglu=True)
+            hg = ops.gemm_ln_consumer(x2, w1, b1, c1, ops.EPI_GEGLU_BF16)
+            w2, b2 = packed_linear(self.linear_geglu_2)
+            return ops.gemm(hg, w2, b2, ops.EPI_RES_F32, residual=sr.x)
+        ctx16 = context.x16 if isinstance(context, ops.LnStream) else None
+        src, context = _as_tensor(src), _as_tensor(context)
+        D = src.shape[1]
         h = ops.layernorm(src, self.norm1.weight, self.norm1.bias)                       # all rows (K/V need them)
         w, b = packed_linear(mha.Wqkv)
         kv = ops.gemm(h, w[D:], None if b is None else b[D:], ops.EPI_BF16)             # [tokens, 2D]
@@ -264,7 +362,7 @@ class ContextFlashAttentionEncoderLayer(nn.Module):
         wo, bo = packed_linear(mha.out_proj)
         x1 = ops.gemm(a, wo, bo, ops.EPI_RES_F32, residual=src_rows)
         h = ops.layernorm(x1, self.norm2.weight, self.norm2.bias)
-        ckv = self.crossMHA.MHA.project_kv(ops.cast16(context))
+        ckv = self.crossMHA.MHA.project_kv(ctx16 if ctx16 is not None else ops.cast16(context))
         x2 = self.crossMHA.MHA.fused(h, x1, cu_cross_rows, max_cross_rows, ckv, cu_ctx, max_ctx)
         h = ops.layernorm(x2, self.norm3.weight, self.norm3.bias)
         w1, b1 = packed_linear(self.linear_geglu_1, geglu=True)
@@ -289,8 +387,8 @@ class ContextFlashAttentionEncoderLayer(nn.Module):
         info = gene_unpad_info if gene_unpad_info is not None else unpad_info
         if info is not None:
             cinfo = context_unpad_info if context_unpad_info is not None else info
-            return self.forward_packed(src.float().contiguous(), info["cu_seqlens"], info["max_seqlen"],
-                                       context.float().contiguous(), cinfo["cu_seqlens"], cinfo["max_seqlen"]).to(src.dtype)
+            return _as_tensor(self.forward_packed(src.float().contiguous(), info["cu_seqlens"], info["max_seqlen"],
+                                                  context.float().contiguous(), cinfo["cu_seqlens"], cinfo["max_seqlen"])).to(src.dtype)
         batch, seqlen = src.shape[:2]
         if src_key_padding_mask is None:
             xs, cu, mx, idx = src.reshape(batch * seqlen, -1).float().contiguous(), _cu_from_padded(batch, seqlen, src.device), seqlen, None
@@ -298,7 +396,7 @@ class ContextFlashAttentionEncoderLayer(nn.Module):
         else:
             xs, idx, cu, mx, _ = unpad_input(src, ~src_key_padding_mask)
             cs, _, cuk, mxk, _ = unpad_input(context, ~context_padding_mask)
-        out = self.forward_packed(xs, cu, mx, cs, cuk, mxk)
+        out = _as_tensor(self.forward_packed(xs, cu, mx, cs, cuk, mxk))
         if idx is None:
             return out.view(batch, seqlen, -1).to(src.dtype)
         return pad_input(out, idx, batch, seqlen).to(src.dtype)
@@ -324,6 +422,15 @@ class FlashAttentionEncoderLayer(nn.Module):
             self.register_buffer("m", get_alibi_slopes(self.num_heads))
 
     def forward_packed(self, src, cu_src, max_src, **_):
+        if ln_fold_enabled(self.norm1.weight.numel()):
+            s = _as_stream(src)
+            a = self.mixer.MHA.attend_ln(s, self.norm1, None, cu_src, max_src, None, None)
+            x1 = self.mixer.MHA.out_ln(a, s.x)
+            w1, b1, c1 = packed_linear_ln(self.linear_geglu_1, self.norm2, geglu=True)
+            hg = ops.gemm_ln_consumer(x1, w1, b1, c1, ops.EPI_GEGLU_BF16)
+            w2, b2 = packed_linear(self.linear_geglu_2)
+            return ops.gemm_ln_producer(hg, w2, b2, s.x)
+        src = _as_tensor(src)
         h = ops.layernorm(src, self.norm1.weight, self.norm1.bias)
         x1 = self.mixer.MHA.fused(h, src, cu_src, max_src)
         h = ops.layernorm(x1, self.norm2.weight, self.norm2.bias)
@@ -355,11 +462,23 @@ class ContextFlashCrossAttentionEncoderLayer(nn.Module):
     def forward_packed(self, src, cu_src, max_src, context=None, cu_ctx=None, max_ctx=None, context_kv=None,
                        cu_cross_q=None, max_cross_q=None):
         assert not self.make_data_kv
+        cq = cu_src if cu_cross_q is None else cu_cross_q
+        mq = max_src if max_cross_q is None else max_cross_q
+        if ln_fold_enabled(self.norm1.weight.numel()):
+            s = _as_stream(src)
+            if context_kv is None:
+                ctx16 = context.x16 if isinstance(context, ops.LnStream) else ops.cast16(context)
+                context_kv = self.crossMHA.MHA.project_kv(ctx16)
+            a = self.crossMHA.MHA.attend_ln(s, self.norm1, context_kv, cq, mq, cu_ctx, max_ctx)
+            x1 = self.crossMHA.MHA.out_ln(a, s.x)
+            w1, b1, c1 = packed_linear_ln(self.linear_geglu_1, self.norm2, geglu=True)
+            hg = ops.gemm_ln_consumer(x1, w1, b1, c1, ops.EPI_GEGLU_BF16)
+            w2, b2 = packed_linear(self.linear_geglu_2)
+            return ops.gemm_ln_producer(hg, w2, b2, s.x)
+        src, context = _as_tensor(src), _as_tensor(context)
         h = ops.layernorm(src, self.norm1.weight, self.norm1.bias)
         if context_kv is None:
             context_kv = self.crossMHA.MHA.project_kv(ops.cast16(context))
-        cq = cu_src if cu_cross_q is None else cu_cross_q
-        mq = max_src if max_cross_q is None else max_cross_q
         x1 = self.crossMHA.MHA.fused(h, src, cq, mq, context_kv, cu_ctx, max_ctx)
         h = ops.layernorm(x1, self.norm2.weight, self.norm2.bias)
         w1, b1 = packed_linear(self.linear_geglu_1, geglu=True)

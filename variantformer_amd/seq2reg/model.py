@@ -115,6 +115,8 @@ class Seq2RegPredictor(nn.Module):
             else:
                 for layer in self.transformer_encoder:
                     x = layer.forward_packed(x, cu, Lmax)
+            if isinstance(x, ops.LnStream):                           # layers exchange (x, bf16 copy, row statistics)
+                x = x.x
             if self.seq_pool == "mean":                               # :263-267
                 return ops.segment_mean(x, cu, out_dtype)
             if self.seq_pool == "max":                                # :257-261 (pads carry -inf there = valid tokens only)

@@ -26,7 +26,19 @@ class FlashTransformerLayer(nn.Module):
         self.dropout = nn.Dropout(mlp_dout)
         self.linear_geglu_2 = nn.Linear(hidden_dim // 2, d_model)
 
-    def forward_packed(self, src: torch.Tensor, cu: torch.Tensor, max_seqlen: int) -> torch.Tensor:
+    def forward_packed(self, src, cu: torch.Tensor, max_seqlen: int):
+        """src: fp32 [tokens, d] or an ops.LnStream; returns the same kind (an LnStream when LayerNorm is folded into
+        the GEMMs, see seq2gene.modules.layers.ln_fold_enabled)."""
+        from ..seq2gene.modules.layers import _as_stream, _as_tensor, ln_fold_enabled, packed_linear_ln
+        if ln_fold_enabled(self.norm1.weight.numel()):
+            s = _as_stream(src)
+            a = self.MHA.attend_ln(s, self.norm1, None, cu, max_seqlen, None, None)
+            x1 = self.MHA.out_ln(a, s.x)
+            w1, b1, c1 = packed_linear_ln(self.linear_geglu_1, self.norm2, geglu=True)
+            hg = ops.gemm_ln_consumer(x1, w1, b1, c1, ops.EPI_GEGLU_BF16)
+            w2, b2 = packed_linear(self.linear_geglu_2)
+            return ops.gemm_ln_producer(hg, w2, b2, s.x)
+        src = _as_tensor(src)
         h = ops.layernorm(src, self.norm1.weight, self.norm1.bias)
         x1 = self.MHA.fused(h, src, cu, max_seqlen)
         h = ops.layernorm(x1, self.norm2.weight, self.norm2.bias)
@@ -38,10 +50,10 @@ class FlashTransformerLayer(nn.Module):
     def forward(self, src, src_key_padding_mask=None, precision=torch.float32):
         """Reference signature on padded [b, L, d] input; padded rows of the result are left as the
         reference leaves them only where they matter (valid rows); pad rows are returned as zeros."""
-        from ..seq2gene.modules.layers import pad_input, unpad_input, _cu_from_padded
+        from ..seq2gene.modules.layers import _as_tensor, pad_input, unpad_input, _cu_from_padded
         b, L = src.shape[:2]
         if src_key_padding_mask is None:
-            out = self.forward_packed(src.reshape(b * L, -1).float().contiguous(), _cu_from_padded(b, L, src.device), L)
+            out = _as_tensor(self.forward_packed(src.reshape(b * L, -1).float().contiguous(), _cu_from_padded(b, L, src.device), L))
             return out.view(b, L, -1).to(src.dtype)
         xs, idx, cu, mx, _ = unpad_input(src, ~src_key_padding_mask)
-        return pad_input(self.forward_packed(xs, cu, mx), idx, b, L).to(src.dtype)
+        return pad_input(_as_tensor(self.forward_packed(xs, cu, mx)), idx, b, L).to(src.dtype)
