@@ -2,8 +2,10 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from variantformer_amd import ops
+from variantformer_amd import ops, _lib
 from variantformer_amd.seq2gene.modules.layers import get_alibi_slopes
+if os.environ.get("VF_LIB"):                 # A/B against another build of the library on the same box
+    _lib.load(os.path.join(os.path.dirname(_lib.LIB_PATH), os.environ["VF_LIB"]))
 
 def run(name, H, dh, ql, kl, alibi, self_attn, reps=20):
     D = H * dh

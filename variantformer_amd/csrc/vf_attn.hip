@@ -57,13 +57,18 @@ template <int DT> __device__ __forceinline__ u32x4_t q_pad_chunk(int d0, int dh)
 // max over the lanes {l, l^16, l^32, l^48} (the four key sub-blocks g of one query) without LDS round trips:
 // v_permlane16_swap / v_permlane32_swap exchange 16- / 32-lane rows on the VALU (lane semantics checked by
 // tools/hw_probe.hip), replacing two ds_bpermute on the serial softmax chain.
+// max(a, b, c): hipcc selects ONE v_max3_f32 for this shape (the file is built with -fno-honor-nans, so no
+// canonicalising v_max_f32 x, x is put in front of it).  NOT inline asm: the hazard recognizer does not see inside an
+// asm statement, and an MFMA result needs software wait states before a VALU instruction may read it.
+__device__ __forceinline__ float max3f(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+__device__ __forceinline__ float max2f(float a, float b) { return __builtin_fmaxf(a, b); }
 __device__ __forceinline__ float max_over_g(float x) {
     const unsigned u = __float_as_uint(x);
     auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-    const float y = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    const float y = max2f(__uint_as_float(a[0]), __uint_as_float(a[1]));
     const unsigned v = __float_as_uint(y);
     auto b = __builtin_amdgcn_permlane32_swap(v, v, false, false);
-    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+    return max2f(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
 
 struct AttnParams {
@@ -114,6 +119,10 @@ __device__ __forceinline__ s16x4_t lds_tr_read(const char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
 }
 
+#ifndef VF_ATTN_PV_INTERLEAVE
+#define VF_ATTN_PV_INTERLEAVE 1
+#endif
+
 // One 64-key tile for QG query groups of a wave: S^T = K.Q^T, online softmax, O^T += V^T.P^T.
 // sK / sV point at the tile's first key row in LDS.  All state is per lane (r = query, g = key sub-block).
 // DBGT (diagnostic builds of the long-stream kernel only): 1 = no softmax VALU work (P = S), 2 = additionally no LDS
@@ -159,29 +168,66 @@ __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, int kb
 #pragma unroll
             for (int qg = 0; qg < QG; ++qg)
                 s[qg][kt] = Op16<DT>::mfma(kf[kt][ks], qf[qg][ks], s[qg][kt]);
-    frag_t vf0[NDT], vf1[NDT];
+    frag_t vf0[NDT];
     read_v(0, vf0);
 
-    // ---- online softmax per query group (lane (r,g): query r, keys kb0 + 16kt + 4g + e)
+    // ---- online softmax (lane (r,g): query r, keys kb0 + 16kt + 4g + e), in three steps so that the long part is
+    // ONE basic block in which matrix and vector instructions can be interleaved:
+    //   (1) bias / mask and the running maximum of every query group;
+    //   (2) ONE wave-uniform branch: rescale O and l of all groups when any running maximum moved (alpha is exactly 1
+    //       for the rows whose maximum did not move, so the result is the same as a per-group test);
+    //   (3) per group: p = exp2(...), pack to 16 bit -- followed in program order by the PV / row-sum MFMAs of the
+    //       PREVIOUS group, which have no dependence on this group's exponentials: the wave issues in order, so this
+    //       is what lets the matrix pipe work under the v_exp stream (before: 250 VALU instructions with an idle
+    //       matrix pipe, then 21 MFMAs back to back with an idle VALU).
     frag_t pf[QG][2];
     const bool tail = kb0 + BKV > len_k;           // wave-uniform: only the last (ragged) key tile masks keys
     const int klim = len_k - kb0 - 4 * g;          // key 16kt+e of this lane is valid iff 16kt+e < klim
     const float k_pos0 = (float)(kb0 + 4 * g);
+    constexpr unsigned int one2 = Op16<DT>::ONE * 0x10001u;
+    const u32x4_t ones_bits = {one2, one2, one2, one2};
+    const frag_t ones = __builtin_bit_cast(frag_t, ones_bits);
+    auto pack_p = [&](int qg) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            u32x4_t pk;
+            pk[0] = Op16<DT>::pack2(s[qg][2 * kb][0], s[qg][2 * kb][1]);
+            pk[1] = Op16<DT>::pack2(s[qg][2 * kb][2], s[qg][2 * kb][3]);
+            pk[2] = Op16<DT>::pack2(s[qg][2 * kb + 1][0], s[qg][2 * kb + 1][1]);
+            pk[3] = Op16<DT>::pack2(s[qg][2 * kb + 1][2], s[qg][2 * kb + 1][3]);
+            pf[qg][kb] = *reinterpret_cast<frag_t*>(&pk);
+        }
+    };
+    // O^T += V^T . P^T and the softmax denominators of one query group.  The denominators run on the matrix pipe: a
+    // V^T fragment of ones gives l[q] += sum_k P[q][k] in every accumulator row, i.e. each lane ends up with the
+    // complete row sum of its query (no per-element v_add_f32 -- the softmax is VALU-issue bound -- and no cross-lane
+    // reduction at the end).  The sum runs over the 16-bit P the PV product uses, so O / l is an exact convex
+    // combination of the V rows.
+    frag_t vf1[NDT];
+    auto pv = [&](int qg) {
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) o[qg][dt] = Op16<DT>::mfma(vf0[dt], pf[qg][0], o[qg][dt]);
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) o[qg][dt] = Op16<DT>::mfma(vf1[dt], pf[qg][1], o[qg][dt]);
+        if (DBGT == 0) {
+            l_acc[qg] = Op16<DT>::mfma(ones, pf[qg][0], l_acc[qg]);
+            l_acc[qg] = Op16<DT>::mfma(ones, pf[qg][1], l_acc[qg]);
+        }
+    };
+    if (DBGT >= 1) {                                  // diagnostic: P = S, no softmax arithmetic
+        read_v(1, vf1);
+#pragma unroll
+        for (int qg = 0; qg < QG; ++qg) {
+            pack_p(qg);
+            l_acc[qg] = (f32x4_t){1.f, 1.f, 1.f, 1.f};
+            pv(qg);
+        }
+        return;
+    }
+    float m_new[QG];
+    bool moved = false;
 #pragma unroll
     for (int qg = 0; qg < QG; ++qg) {
-        if (DBGT >= 1) {                              // diagnostic: P = S, no softmax arithmetic
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                u32x4_t pk;
-                pk[0] = Op16<DT>::pack2(s[qg][2 * kb][0], s[qg][2 * kb][1]);
-                pk[1] = Op16<DT>::pack2(s[qg][2 * kb][2], s[qg][2 * kb][3]);
-                pk[2] = Op16<DT>::pack2(s[qg][2 * kb + 1][0], s[qg][2 * kb + 1][1]);
-                pk[3] = Op16<DT>::pack2(s[qg][2 * kb + 1][2], s[qg][2 * kb + 1][3]);
-                pf[qg][kb] = *reinterpret_cast<frag_t*>(&pk);
-            }
-            l_acc[qg] = (f32x4_t){1.f, 1.f, 1.f, 1.f};
-            continue;
-        }
         if (ALIBI) {
             const float dq = q_pos[qg] - k_pos0;
 #pragma unroll
@@ -196,64 +242,47 @@ __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, int kb
 #pragma unroll
                 for (int e = 0; e < 4; ++e) s[qg][kt][e] = (16 * kt + e) < klim ? s[qg][kt][e] : -INFINITY;
         }
-        float mx = fmaxf(fmaxf(s[qg][0][0], s[qg][0][1]), fmaxf(s[qg][0][2], s[qg][0][3]));
+        // 16 scores -> 1 maximum in 8 v_max3_f32 + 1 v_max_f32 (two chains of max(max(a, b), c) for instruction-level
+        // parallelism; a pairwise tree compiled to 24 v_max / v_max3 per query group: the loop is VALU-issue bound)
+        float mxa = max3f(s[qg][0][0], s[qg][0][1], s[qg][0][2]);
+        float mxb = max3f(s[qg][2][0], s[qg][2][1], s[qg][2][2]);
+        mxa = max3f(mxa, s[qg][0][3], s[qg][1][0]);
+        mxb = max3f(mxb, s[qg][2][3], s[qg][3][0]);
+        mxa = max3f(mxa, s[qg][1][1], s[qg][1][2]);
+        mxb = max3f(mxb, s[qg][3][1], s[qg][3][2]);
+        mxa = max3f(mxa, s[qg][1][3], s[qg][3][3]);
+        const float mx = max_over_g(max2f(mxa, mxb));
+        m_new[qg] = max2f(m_run[qg], mx);           // finite: tile 0 always holds a valid key
+        moved = moved || (m_new[qg] > m_run[qg]);
+    }
+    if (__any(moved)) {                              // wave-uniform; rare after the first tiles of a sequence
 #pragma unroll
-        for (int kt = 1; kt < 4; ++kt)
-            mx = fmaxf(fmaxf(fmaxf(mx, s[qg][kt][0]), fmaxf(s[qg][kt][1], s[qg][kt][2])), s[qg][kt][3]);
-        mx = max_over_g(mx);
-        const float m_old = m_run[qg];
-        const float m_new = fmaxf(m_old, mx);        // finite: tile 0 always holds a valid key
-        m_run[qg] = m_new;
-        // p = exp2(c*s - c*m) (no ALiBi: scale folded into one packed FMA) or exp2(s - m) (ALiBi: already scaled)
-        const float mc = ALIBI ? -m_new : -m_new * c;
+        for (int qg = 0; qg < QG; ++qg) {
+            const float alpha = __builtin_amdgcn_exp2f(ALIBI ? (m_run[qg] - m_new[qg]) : (m_run[qg] - m_new[qg]) * c);
+            l_acc[qg] *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) o[qg][dt] *= alpha;
+        }
+    }
+    read_v(1, vf1);
+#pragma unroll
+    for (int qg = 0; qg < QG; ++qg) {
+        m_run[qg] = m_new[qg];
+        // p = exp2(c*s - c*m) (no ALiBi: scale folded into one FMA) or exp2(s - m) (ALiBi: already scaled)
+        const float mc = ALIBI ? -m_new[qg] : -m_new[qg] * c;
         const float cc = ALIBI ? 1.0f : c;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
             for (int e = 0; e < 4; ++e) s[qg][kt][e] = __builtin_amdgcn_exp2f(fmaf(s[qg][kt][e], cc, mc));
-        if (__any(m_new > m_old)) {                  // wave-uniform: rescale only when some running max moved
-            const float alpha = __builtin_amdgcn_exp2f(ALIBI ? (m_old - m_new) : (m_old - m_new) * c);
-            l_acc[qg] *= alpha;
-#pragma unroll
-            for (int dt = 0; dt < NDT; ++dt) o[qg][dt] *= alpha;
-        }
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            u32x4_t pk;
-            pk[0] = Op16<DT>::pack2(s[qg][2 * kb][0], s[qg][2 * kb][1]);
-            pk[1] = Op16<DT>::pack2(s[qg][2 * kb][2], s[qg][2 * kb][3]);
-            pk[2] = Op16<DT>::pack2(s[qg][2 * kb + 1][0], s[qg][2 * kb + 1][1]);
-            pk[3] = Op16<DT>::pack2(s[qg][2 * kb + 1][2], s[qg][2 * kb + 1][3]);
-            pf[qg][kb] = *reinterpret_cast<frag_t*>(&pk);
-        }
+        pack_p(qg);
+        if (VF_ATTN_PV_INTERLEAVE && qg > 0) pv(qg - 1);
     }
-
-    // ---- O^T += V^T . P^T : V^T fragments (transposed LDS reads) shared by the QG groups; block 1 is fetched
-    // under block 0's MFMAs
-    read_v(1, vf1);
+    if (VF_ATTN_PV_INTERLEAVE) {
+        pv(QG - 1);
+    } else {
 #pragma unroll
-    for (int dt = 0; dt < NDT; ++dt)
-#pragma unroll
-        for (int qg = 0; qg < QG; ++qg)
-            o[qg][dt] = Op16<DT>::mfma(vf0[dt], pf[qg][0], o[qg][dt]);
-#pragma unroll
-    for (int dt = 0; dt < NDT; ++dt)
-#pragma unroll
-        for (int qg = 0; qg < QG; ++qg)
-            o[qg][dt] = Op16<DT>::mfma(vf1[dt], pf[qg][1], o[qg][dt]);
-    // ---- softmax denominators on the matrix pipe: a V^T fragment of ones gives l[q] += sum_k P[q][k] in every
-    // accumulator row, i.e. each lane ends up with the complete row sum of its query (no per-element v_add_f32 --
-    // the softmax is VALU-issue bound -- and no cross-lane reduction at the end).  The sum runs over the bf16 P the
-    // PV product uses, so O / l is an exact convex combination of the V rows.
-    if (DBGT == 0) {
-        constexpr unsigned int one2 = Op16<DT>::ONE * 0x10001u;
-        const u32x4_t ones_bits = {one2, one2, one2, one2};
-        const frag_t ones = __builtin_bit_cast(frag_t, ones_bits);
-#pragma unroll
-        for (int qg = 0; qg < QG; ++qg) {
-            l_acc[qg] = Op16<DT>::mfma(ones, pf[qg][0], l_acc[qg]);
-            l_acc[qg] = Op16<DT>::mfma(ones, pf[qg][1], l_acc[qg]);
-        }
+        for (int qg = 0; qg < QG; ++qg) pv(qg);
     }
 }
 
@@ -342,17 +371,28 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P) {
     u32x4_t kvreg[NLD2];
     const unsigned short* kbase = P.k + (int64_t)k_tok0 * P.k_stride + h * DH;
     const unsigned short* vbase = P.v + (int64_t)k_tok0 * P.v_stride + h * DH;
+    // per-item constants of the staging list: source pointer at key 0 of the sequence and the row stride; the per-tile
+    // address is base + min(key, len_k - 1) * stride with a 24-bit multiply (full rate; max_seqlen_k * stride < 2^31 is
+    // checked at launch) -- the 64-bit multiply this replaces cost three quarter-rate VALU instructions per load
+    const unsigned short* kv_src[NLD2];
+    unsigned kv_stride[NLD2];
+    int kv_row[NLD2];
+#pragma unroll
+    for (int i = 0; i < NLD2; ++i) {
+        const int item = tid + 256 * i;
+        const bool is_v = item >= NCHUNK;
+        const int ci = is_v ? item - NCHUNK : item;
+        kv_row[i] = ci / CPR;
+        kv_src[i] = (is_v ? vbase : kbase) + (ci % CPR) * 8;
+        kv_stride[i] = (unsigned)(is_v ? P.v_stride : P.k_stride);
+    }
     auto load_regs = [&](int t) {
 #pragma unroll
         for (int i = 0; i < NLD2; ++i) {
-            const int item = tid + 256 * i;
-            const bool is_v = item >= NCHUNK;
-            const int ci = is_v ? item - NCHUNK : item;
-            const int row = ci / CPR, c = ci % CPR;
-            int key = t * BKV + row;
+            int key = t * BKV + kv_row[i];
             key = key < len_k ? key : len_k - 1;                     // finite data for masked keys
-            const unsigned short* src = is_v ? vbase + (int64_t)key * P.v_stride : kbase + (int64_t)key * P.k_stride;
-            kvreg[i] = *reinterpret_cast<const u32x4_t*>(src + c * 8);
+            const unsigned off = __umul24((unsigned)key, kv_stride[i]);
+            kvreg[i] = *reinterpret_cast<const u32x4_t*>(kv_src[i] + off);
         }
     };
     auto write_lds = [&](int stage, int t) {
@@ -642,6 +682,9 @@ static int attn_dispatch(const void* q, const void* k, const void* v, void* out,
     VF_REQUIRE(((uintptr_t)q % 16 == 0) && ((uintptr_t)k % 16 == 0) && ((uintptr_t)v % 16 == 0) && ((uintptr_t)out % 8 == 0),
                "vf_attn_varlen_fwd: pointers must be 16-byte aligned");
     if (n_seq == 0 || max_seqlen_q <= 0 || max_seqlen_k <= 0) return VF_OK;
+    VF_REQUIRE(max_seqlen_k < (1 << 24) && k_stride < (1 << 24) && v_stride < (1 << 24) &&
+                   (int64_t)max_seqlen_k * (k_stride > v_stride ? k_stride : v_stride) < (1LL << 31),
+               "vf_attn_varlen_fwd: max_seqlen_k * row stride must stay below 2^31 elements");
     AttnParams P;
     P.q = (const unsigned short*)q; P.k = (const unsigned short*)k; P.v = (const unsigned short*)v;
     P.out = (unsigned short*)out;
