@@ -338,7 +338,11 @@ def main():
                     "launches_per_step": g["launches"] // args.steps,
                     "avg_launch_us": round(g["total_ms"] * 1e3 / g["launches"], 2),
                     "flop_per_launch": g["flops"] / g["launches"],
-                    "share_of_step_time": round(g["total_ms"] / args.steps / step_ms, 3)}
+                    "share_of_step_time": round(g["total_ms"] / args.steps / step_ms, 3),
+                    "note": ("bf16 mode: the GEMM launches also carry the LayerNorms of the layers (producer epilogues write "
+                             "the bf16 copy of the fp32 stream + per-row partial statistics, consumer epilogues apply mean / "
+                             "rstd; DESIGN.md section 6) -- their bytes are in algorithmic_bytes_per_launch, their time in "
+                             "avg_launch_us; VF_LN_FOLD=0 restores the separate LayerNorm pass")}
             # Per kernel family (KernelTimer families: the module that launched the kernel).  Every family is priced
             # against ITS roofline = min(dense MFMA peak, arithmetic intensity x HBM peak), SURVEY 8d.
             for key, r in sorted(summ.items()):

@@ -257,12 +257,16 @@ def gemm_ln_producer(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None
         check(lib.vf_gemm_ln_bf16(a.data_ptr(), a.stride(0) if M > 1 else max(a.stride(0), K), w.data_ptr(), _ptr(bias),
                                   _ptr(residual), 0 if residual is None else residual.stride(0), out.data_ptr(), N, M, N, K,
                                   epi, 0, 0, x16.data_ptr(), N, part.data_ptr(), _stream()), "vf_gemm_ln_bf16")
+
+    def finalize():
         check(lib.vf_ln_finalize(part.data_ptr(), M, n_parts, N, eps, stats.data_ptr(), _stream()), "vf_ln_finalize")
     if TIMER is not None:
         nbytes = 2.0 * (M * K + N * K) + M * N * (4.0 + 2.0) + (0 if residual is None else 4.0 * M * N) + 8.0 * M * n_parts
         TIMER.time("gemm", 2.0 * M * N * K, nbytes, launch, f"M={M} N={N} K={K} epi={epi} ln=producer", family or _SCOPE)
+        TIMER.time("layernorm", 0.0, 8.0 * M * (n_parts + 1), finalize, f"finalize D={N}", _SCOPE)
     else:
         launch()
+        finalize()
     return LnStream(out, x16, stats)
 
 
