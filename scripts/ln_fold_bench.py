@@ -4,7 +4,9 @@ import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from variantformer_amd import ops
+from variantformer_amd import ops, _lib
+if os.environ.get("VF_LIB"):                 # A/B against another build of the library on the same box
+    _lib.load(os.path.join(os.path.dirname(_lib.LIB_PATH), os.environ["VF_LIB"]))
 
 PRODUCERS = [("gene8 out_proj", 86832, 1536, 1536), ("gene8 ff", 86832, 1536, 1024), ("s2r8 out_proj", 769460, 512, 512),
              ("s2r8 ff", 769460, 512, 1024), ("cre8 out_proj", 8192, 1536, 1536), ("cre8 ff", 8192, 1536, 1024)]
