@@ -82,7 +82,9 @@ int vf_gemm_f16_ex(const void* A, int64_t lda, const void* W, const float* bias,
  * of the row (give out16 + part_stats, leave row_stats / colsum NULL); vf_ln_finalize turns the parts into row_stats
  * [M, 2] = (mean, rstd); the GEMM that CONSUMES LN(x) (epilogue VF_EPI_BF16 / VF_EPI_GEGLU_BF16) takes A = out16,
  * W = bf16(gamma (.) W), bias = W . beta + b, colsum[n] = sum_k W'[n][k] and row_stats (give those two, leave out16 /
- * part_stats NULL).  vf_row_stats_cast produces (out16, row_stats) for a stream no GEMM produced.  Replaces the
+ * part_stats NULL).  A producer whose fp32 result nobody reads (only out16 and the statistics are consumed: the layers'
+ * intermediate streams) may pass out = NULL: nothing is stored there.
+ * vf_row_stats_cast produces (out16, row_stats) for a stream no GEMM produced.  Replaces the
  * nn.LayerNorm -> nn.Linear pairs of the layers (seq2gene/modules/layers.py:105-162, seq2reg/modules.py:155-187).
  * MFMA path only: K % 64 == 0. */
 int vf_gemm_ln_bf16(const void* A, int64_t lda, const void* W, const float* bias, const float* residual, int64_t ldr,

@@ -537,6 +537,11 @@ def test_gemm_ln_producer(ops, M, N, K, with_res):
     torch.cuda.synchronize()
     assert torch.equal(s.x, plain), "the producer epilogue must not change the fp32 result"
     assert torch.equal(s.x16, s.x.bfloat16()), "bf16 copy = round-to-nearest-even of the fp32 stream"
+    # the same launch without the fp32 store (a stream that is only read through the next LayerNorm -> Linear pair)
+    t = ops.gemm_ln_producer(a.cuda().bfloat16(), w.cuda().bfloat16(), b.cuda(), None if res is None else res.cuda(),
+                             need_x=False)
+    torch.cuda.synchronize()
+    assert t.x is None and torch.equal(t.x16, s.x16) and torch.equal(t.stats, s.stats)
     rows = _row_sample(M)
     x = s.x[rows.cuda()].double().cpu()
     ref = a[rows] @ w.t() + b + (res[rows] if with_res else 0)

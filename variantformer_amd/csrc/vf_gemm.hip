@@ -493,7 +493,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_mfma_kernel(const unsigned
                     ln_emit<DT>(__builtin_bit_cast(f32x4_t, d), ok,
                                 reinterpret_cast<unsigned short*>(ln.out16) + m * ln.ld16 + ep_col,
                                 ln.part_stats + ((int64_t)(ep_col >> 5) * ln.rows + m) * 2, lane);
-                if (ok)
+                if (ok && (LN != VF_LN_PRODUCER || out != nullptr))
                     *reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(out) + (m * ldo + ep_col) * ES) = d;
             }
         }
@@ -1044,7 +1044,9 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const unsigned short* __r
                 const bool ok = j * RI + ep_row < WT_M && j * RI < rows_left && ep_col < n_out_total;
                 if (LN == VF_LN_PRODUCER && OUT_F32)
                     ln_emit<DT>(__builtin_bit_cast(f32x4_t, d), ok, o16_p + j * o16_step, part_p + j * (RI * 2), lane);
-                if (ok) *reinterpret_cast<u32x4_t*>(out_p + j * out_step) = d;
+                // a LayerNorm producer whose fp32 result has no reader (only its 16-bit copy and statistics do) passes
+                // out = NULL: the 16-byte store -- 4 of the 10 bytes the epilogue moves per element -- is dropped
+                if (ok && (LN != VF_LN_PRODUCER || out != nullptr)) *reinterpret_cast<u32x4_t*>(out_p + j * out_step) = d;
             }
         }
     }
@@ -1480,7 +1482,10 @@ int launch_gemm8(const void* A, int64_t lda, const void* W, const float* bias, c
     }
     const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256;
     const int n_blocks = tiles_m * tiles_n;
-    const int group_m = 8;
+    int group_m = 8;
+#ifdef VF_TUNING
+    if (const char* e = getenv("VF_G8_GROUP_M")) group_m = atoi(e);     // tile-walk sweep (scripts/gemm_bench.py)
+#endif
     hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(512), Cfg8::LDS_BYTES + Cfg8::SIDE_BYTES, st, (const unsigned short*)A, lda,
                        (const unsigned short*)W, bias, res, ldr, out, ldo, M, N, K, tiles_n, n_blocks, group_m, ln);
     VF_CHECK_LAUNCH("vf_gemm_bf16");
@@ -1640,7 +1645,7 @@ extern "C" int vf_gemm_ln_bf16(const void* A, int64_t lda, const void* W, const 
                                int64_t ldr, void* out, int64_t ldo, int M, int N, int K, int epilogue,
                                const float* row_stats, const float* colsum, void* out16, int64_t ld16,
                                float* part_stats, void* stream) {
-    VF_REQUIRE(A && W && out, "vf_gemm_ln_bf16: null pointer");
+    VF_REQUIRE(A && W && (out || (out16 && part_stats)), "vf_gemm_ln_bf16: null pointer");
     VF_REQUIRE(M >= 0 && N > 0 && K > 0 && K % 64 == 0 && N % 8 == 0, "vf_gemm_ln_bf16: needs K %% 64 == 0, N %% 8 == 0 (N=%d K=%d)", N, K);
     VF_REQUIRE(lda % 8 == 0 && lda >= K, "vf_gemm_ln_bf16: lda=%lld must be >= K and a multiple of 8", (long long)lda);
     VF_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)W % 16 == 0) && ((uintptr_t)out % 16 == 0),
@@ -1651,6 +1656,7 @@ extern "C" int vf_gemm_ln_bf16(const void* A, int64_t lda, const void* W, const 
     LnArgs ln{};
     hipStream_t st = (hipStream_t)stream;
     if (consumer) {
+        VF_REQUIRE(out, "vf_gemm_ln_bf16: the consumer needs an output");
         VF_REQUIRE(((uintptr_t)row_stats % 8 == 0) && ((uintptr_t)colsum % 16 == 0), "vf_gemm_ln_bf16: misaligned statistics");
         VF_REQUIRE(ldo % 8 == 0, "vf_gemm_ln_bf16: ldo=%lld must be a multiple of 8", (long long)ldo);
         ln.row_stats = row_stats;

@@ -236,14 +236,15 @@ def gemm_ln_consumer(s: LnStream, w: torch.Tensor, bias: torch.Tensor, colsum: t
 
 
 def gemm_ln_producer(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None, residual: torch.Tensor | None,
-                     eps: float = 1e-5, family: str = "") -> LnStream:
+                     eps: float = 1e-5, family: str = "", need_x: bool = True) -> LnStream:
     """x = a @ w^T + bias (+ residual), fp32, returned together with its bf16 copy and row statistics (the next
-    LayerNorm's): EPI_RES_F32 when a residual is given, else EPI_F32."""
+    LayerNorm's): EPI_RES_F32 when a residual is given, else EPI_F32.  need_x=False: the fp32 x itself has no reader
+    (a layer's intermediate stream feeds only the next LayerNorm -> Linear pair) and is not stored; .x is None."""
     _dev(a, w, bias, residual)
     assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and a.shape[1] == w.shape[1] and a.stride(1) == 1
     M, K = a.shape
     N = w.shape[0]
-    out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    out = torch.empty((M, N), dtype=torch.float32, device=a.device) if need_x else None
     x16 = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
     n_parts = (N + 31) // 32
     part = torch.empty((n_parts, M, 2), dtype=torch.float32, device=a.device)
@@ -255,14 +256,16 @@ def gemm_ln_producer(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None
 
     def launch():
         check(lib.vf_gemm_ln_bf16(a.data_ptr(), a.stride(0) if M > 1 else max(a.stride(0), K), w.data_ptr(), _ptr(bias),
-                                  _ptr(residual), 0 if residual is None else residual.stride(0), out.data_ptr(), N, M, N, K,
+                                  _ptr(residual), 0 if residual is None else residual.stride(0), _ptr(out), N, M, N, K,
                                   epi, 0, 0, x16.data_ptr(), N, part.data_ptr(), _stream()), "vf_gemm_ln_bf16")
 
     def finalize():
         check(lib.vf_ln_finalize(part.data_ptr(), M, n_parts, N, eps, stats.data_ptr(), _stream()), "vf_ln_finalize")
     if TIMER is not None:
-        nbytes = 2.0 * (M * K + N * K) + M * N * (4.0 + 2.0) + (0 if residual is None else 4.0 * M * N) + 8.0 * M * n_parts
-        TIMER.time("gemm", 2.0 * M * N * K, nbytes, launch, f"M={M} N={N} K={K} epi={epi} ln=producer", family or _SCOPE)
+        nbytes = (2.0 * (M * K + N * K) + M * N * ((4.0 if need_x else 0.0) + 2.0) + (0 if residual is None else 4.0 * M * N)
+                  + 8.0 * M * n_parts)
+        TIMER.time("gemm", 2.0 * M * N * K, nbytes, launch,
+                   f"M={M} N={N} K={K} epi={epi} ln=producer{'' if need_x else '-nox'}", family or _SCOPE)
         TIMER.time("layernorm", 0.0, 8.0 * M * (n_parts + 1), finalize, f"finalize D={N}", _SCOPE)
     else:
         launch()

@@ -183,10 +183,13 @@ class MHA(nn.Module):
         return ops.attn_varlen(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], cu_q, None, max_q, max_q,
                                self.num_heads, self.head_dim, self.alibi_slopes, family=self.family)
 
-    def out_ln(self, a_bf16, residual_f32) -> "ops.LnStream":
-        """out_proj(a) + residual as an LnStream (fp32 stream, its bf16 copy, row statistics for the next LayerNorm)."""
+    def out_ln(self, a_bf16, residual_f32, need_x: bool = True) -> "ops.LnStream":
+        """out_proj(a) + residual as an LnStream (fp32 stream, its bf16 copy, row statistics for the next LayerNorm).
+        need_x=False when the sum is only ever read through the next LayerNorm -> Linear pair (the layers add their FFN
+        to the layer INPUT, reference layers.py:99,163 / seq2reg/modules.py:188, so the stream after the last attention
+        block has no other reader): the fp32 values are then not written to HBM at all."""
         w, b = packed_linear(self.out_proj)
-        return ops.gemm_ln_producer(a_bf16, w, b, residual_f32)
+        return ops.gemm_ln_producer(a_bf16, w, b, residual_f32, need_x=need_x)
 
     def fused(self, x_bf16, residual_f32, cu_q, max_q, kv_bf16=None, cu_k=None, max_k=None) -> torch.Tensor:
         """fp32 [tokens, D] = out_proj(attention(x)) + residual (one GEMM epilogue)."""
@@ -302,7 +305,7 @@ class ContextFlashAttentionEncoderLayer(nn.Module):
                 ctx16 = context.x16 if isinstance(context, ops.LnStream) else ops.cast16(context)
                 context_kv = self.crossMHA.MHA.project_kv(ctx16)
             a = self.crossMHA.MHA.attend_ln(x1, self.norm2, context_kv, cq, mq, cu_ctx, max_ctx)
-            x2 = self.crossMHA.MHA.out_ln(a, x1.x)
+            x2 = self.crossMHA.MHA.out_ln(a, x1.x, need_x=False)
             w1, b1, c1 = packed_linear_ln(self.linear_geglu_1, self.norm3, geglu=True)
             hg = ops.gemm_ln_consumer(x2, w1, b1, c1, ops.EPI_GEGLU_BF16)
             w2, b2 = packed_linear(self.linear_geglu_2)
@@ -343,7 +346,7 @@ class ContextFlashAttentionEncoderLayer(nn.Module):
             ctx16 = context.x16 if isinstance(context, ops.LnStream) else ops.cast16(context)
             ckv = self.crossMHA.MHA.project_kv(ctx16)
             a = self.crossMHA.MHA.attend_ln(x1, self.norm2, ckv, cu_cross_rows, max_cross_rows, cu_ctx, max_ctx)
-            x2 = self.crossMHA.MHA.out_ln(a, x1.x)
+            x2 = self.crossMHA.MHA.out_ln(a, x1.x, need_x=False)
             w1, b1, c1 = packed_linear_ln(self.linear_geglu_1, self.norm3, geglu=True)
             hg = ops.gemm_ln_consumer(x2, w1, b1, c1, ops.EPI_GEGLU_BF16)
             w2, b2 = packed_linear(self.linear_geglu_2)
@@ -425,7 +428,7 @@ class FlashAttentionEncoderLayer(nn.Module):
         if ln_fold_enabled(self.norm1.weight.numel()):
             s = _as_stream(src)
             a = self.mixer.MHA.attend_ln(s, self.norm1, None, cu_src, max_src, None, None)
-            x1 = self.mixer.MHA.out_ln(a, s.x)
+            x1 = self.mixer.MHA.out_ln(a, s.x, need_x=False)
             w1, b1, c1 = packed_linear_ln(self.linear_geglu_1, self.norm2, geglu=True)
             hg = ops.gemm_ln_consumer(x1, w1, b1, c1, ops.EPI_GEGLU_BF16)
             w2, b2 = packed_linear(self.linear_geglu_2)
@@ -470,7 +473,7 @@ class ContextFlashCrossAttentionEncoderLayer(nn.Module):
                 ctx16 = context.x16 if isinstance(context, ops.LnStream) else ops.cast16(context)
                 context_kv = self.crossMHA.MHA.project_kv(ctx16)
             a = self.crossMHA.MHA.attend_ln(s, self.norm1, context_kv, cq, mq, cu_ctx, max_ctx)
-            x1 = self.crossMHA.MHA.out_ln(a, s.x)
+            x1 = self.crossMHA.MHA.out_ln(a, s.x, need_x=False)
             w1, b1, c1 = packed_linear_ln(self.linear_geglu_1, self.norm2, geglu=True)
             hg = ops.gemm_ln_consumer(x1, w1, b1, c1, ops.EPI_GEGLU_BF16)
             w2, b2 = packed_linear(self.linear_geglu_2)

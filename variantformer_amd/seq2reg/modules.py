@@ -33,7 +33,7 @@ class FlashTransformerLayer(nn.Module):
         if ln_fold_enabled(self.norm1.weight.numel()):
             s = _as_stream(src)
             a = self.MHA.attend_ln(s, self.norm1, None, cu, max_seqlen, None, None)
-            x1 = self.MHA.out_ln(a, s.x)
+            x1 = self.MHA.out_ln(a, s.x, need_x=False)           # x1 is read only through norm2 -> linear_geglu_1
             w1, b1, c1 = packed_linear_ln(self.linear_geglu_1, self.norm2, geglu=True)
             hg = ops.gemm_ln_consumer(x1, w1, b1, c1, ops.EPI_GEGLU_BF16)
             w2, b2 = packed_linear(self.linear_geglu_2)
