@@ -5,6 +5,9 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from variantformer_amd import ops, _lib
+if os.environ.get("VF_TUNING_LIB"):          # epilogue probes (VF_G8_DBG) live in libvf_hip_tuning.so only
+    from variantformer_amd.csrc.build import TUNING_LIB
+    _lib.load(TUNING_LIB)
 if os.environ.get("VF_LIB"):                 # A/B against another build of the library on the same box
     _lib.load(os.path.join(os.path.dirname(_lib.LIB_PATH), os.environ["VF_LIB"]))
 

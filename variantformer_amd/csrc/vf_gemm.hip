@@ -67,7 +67,8 @@ __device__ __forceinline__ float dpp_f32(float v) {
 // 32-column part of a row = 8 consecutive lanes); valid = row and columns inside the matrix; p16 / ppart = where this
 // lane's 16-bit values and its part's (sum, sum of squares) go
 template <int DT>
-__device__ __forceinline__ void ln_emit(f32x4_t f, bool valid, unsigned short* p16, float* ppart, int lane) {
+__device__ __forceinline__ void ln_emit(f32x4_t f, bool valid, unsigned short* p16, float* ppart, int lane,
+                                        bool st16 = true, bool stpart = true) {
     float s1 = valid ? (f[0] + f[1]) + (f[2] + f[3]) : 0.f;
     float s2 = valid ? (f[0] * f[0] + f[1] * f[1]) + (f[2] * f[2] + f[3] * f[3]) : 0.f;
     // butterfly over the 8 lanes of the part on the DPP path of the VALU (__shfl_xor would be a ds_bpermute round trip
@@ -82,8 +83,8 @@ __device__ __forceinline__ void ln_emit(f32x4_t f, bool valid, unsigned short* p
         u32x2_t pk;
         pk[0] = Op16<DT>::pack2(f[0], f[1]);
         pk[1] = Op16<DT>::pack2(f[2], f[3]);
-        *reinterpret_cast<u32x2_t*>(p16) = pk;
-        if ((lane & 7) == 0) *reinterpret_cast<f32x2_t*>(ppart) = (f32x2_t){s1, s2};
+        if (st16) *reinterpret_cast<u32x2_t*>(p16) = pk;
+        if (stpart && (lane & 7) == 0) *reinterpret_cast<f32x2_t*>(ppart) = (f32x2_t){s1, s2};
     }
 }
 
@@ -733,6 +734,12 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const unsigned short* __r
 
     // XCD-aware bijective remap + grouped order (same as gemm_mfma_kernel)
     const int bid = blockIdx.x;
+#ifdef VF_TUNING   // cost-centre probes of the epilogue (VF_G8_DBG bit mask, scripts/gemm_bench.py; results meaningless)
+    const int dbg = GROUP_M >> 8;
+    GROUP_M &= 255;
+#else
+    constexpr int dbg = 0;
+#endif
     const int q8 = n_blocks >> 3, r8 = n_blocks & 7, xcd = bid & 7, loc = bid >> 3;
     const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
     const int tiles_m = n_blocks / tiles_n;
@@ -944,6 +951,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const unsigned short* __r
             for (int k = 0; k < NI; ++k) {
                 const int j = ps * NI + k;
                 const float* rp = (j * RI < rows_left) ? res_p + j * res_step : res_last;
+                if (dbg & 8) { dst[RES ? k : 0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; continue; }
                 dst[RES ? k : 0] = *reinterpret_cast<const f32x4_t*>(rp);
             }
         }
@@ -1043,10 +1051,12 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const unsigned short* __r
                 }
                 const bool ok = j * RI + ep_row < WT_M && j * RI < rows_left && ep_col < n_out_total;
                 if (LN == VF_LN_PRODUCER && OUT_F32)
-                    ln_emit<DT>(__builtin_bit_cast(f32x4_t, d), ok, o16_p + j * o16_step, part_p + j * (RI * 2), lane);
+                    ln_emit<DT>(__builtin_bit_cast(f32x4_t, d), ok, o16_p + j * o16_step, part_p + j * (RI * 2), lane,
+                                !(dbg & 2), !(dbg & 4));
                 // a LayerNorm producer whose fp32 result has no reader (only its 16-bit copy and statistics do) passes
                 // out = NULL: the 16-byte store -- 4 of the 10 bytes the epilogue moves per element -- is dropped
-                if (ok && (LN != VF_LN_PRODUCER || out != nullptr)) *reinterpret_cast<u32x4_t*>(out_p + j * out_step) = d;
+                if (ok && (LN != VF_LN_PRODUCER || out != nullptr) && !(dbg & 1))
+                    *reinterpret_cast<u32x4_t*>(out_p + j * out_step) = d;
             }
         }
     }
@@ -1485,6 +1495,7 @@ int launch_gemm8(const void* A, int64_t lda, const void* W, const float* bias, c
     int group_m = 8;
 #ifdef VF_TUNING
     if (const char* e = getenv("VF_G8_GROUP_M")) group_m = atoi(e);     // tile-walk sweep (scripts/gemm_bench.py)
+    if (const char* e = getenv("VF_G8_DBG")) group_m |= atoi(e) << 8;   // epilogue cost-centre probes
 #endif
     hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(512), Cfg8::LDS_BYTES + Cfg8::SIDE_BYTES, st, (const unsigned short*)A, lda,
                        (const unsigned short*)W, bias, res, ldr, out, ldo, M, N, K, tiles_n, n_blocks, group_m, ln);
