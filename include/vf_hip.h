@@ -86,7 +86,7 @@ int vf_gemm_f16_ex(const void* A, int64_t lda, const void* W, const float* bias,
  * intermediate streams) may pass out = NULL: nothing is stored there.
  * vf_row_stats_cast produces (out16, row_stats) for a stream no GEMM produced.  Replaces the
  * nn.LayerNorm -> nn.Linear pairs of the layers (seq2gene/modules/layers.py:105-162, seq2reg/modules.py:155-187).
- * MFMA path only: K % 64 == 0. */
+ * MFMA path only: K % 64 == 0; a producer needs N % 32 == 0. */
 int vf_gemm_ln_bf16(const void* A, int64_t lda, const void* W, const float* bias, const float* residual, int64_t ldr,
                     void* out, int64_t ldo, int M, int N, int K, int epilogue, const float* row_stats,
                     const float* colsum, void* out16, int64_t ld16, float* part_stats, void* stream);

@@ -69,8 +69,10 @@ __device__ __forceinline__ float dpp_f32(float v) {
 template <int DT>
 __device__ __forceinline__ void ln_emit(f32x4_t f, bool valid, unsigned short* p16, float* ppart, int lane,
                                         bool st16 = true, bool stpart = true) {
-    float s1 = valid ? (f[0] + f[1]) + (f[2] + f[3]) : 0.f;
-    float s2 = valid ? (f[0] * f[0] + f[1] * f[1]) + (f[2] * f[2] + f[3] * f[3]) : 0.f;
+    // no masking of the sums: N % 32 == 0 (checked at launch), so the 8 lanes of a part are all inside the matrix or
+    // all outside, and a row past M only ever feeds its own (never stored) part
+    float s1 = (f[0] + f[1]) + (f[2] + f[3]);
+    float s2 = __builtin_fmaf(f[3], f[3], __builtin_fmaf(f[2], f[2], __builtin_fmaf(f[1], f[1], f[0] * f[0])));
     // butterfly over the 8 lanes of the part on the DPP path of the VALU (__shfl_xor would be a ds_bpermute round trip
     // per step): quad_perm [1,0,3,2], quad_perm [2,3,0,1], then row_half_mirror (lane i <-> 7 - i: the other quad's sum)
     s1 += dpp_f32<0xB1>(s1);
@@ -944,13 +946,20 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const unsigned short* __r
     unsigned short* const o16_p = (LN == VF_LN_PRODUCER) ? reinterpret_cast<unsigned short*>(ln.out16) + row0 * ln.ld16 + ep_col : nullptr;
     const int64_t o16_step = (int64_t)RI * ln.ld16;
     float* const part_p = (LN == VF_LN_PRODUCER) ? ln.part_stats + ((int64_t)(ep_col >> 5) * ln.rows + row0) * 2 : nullptr;
+    // the items are visited in increasing j, so each pointer is a running one: p += step per item (one 64-bit add)
+    // instead of base + j * step (hipcc multiplies per item otherwise: 81 quarter-rate v_mad_u64_u32 in this epilogue)
+    const float* res_run = res_p;
+    char* out_run = out_p;
+    unsigned short* o16_run = o16_p;
+    float* part_run = part_p;
     f32x4_t rbuf[2][RES ? NI : 1];
     auto load_res_pass = [&](int ps, f32x4_t (&dst)[RES ? NI : 1]) {
         if (RES) {
 #pragma unroll
             for (int k = 0; k < NI; ++k) {
                 const int j = ps * NI + k;
-                const float* rp = (j * RI < rows_left) ? res_p + j * res_step : res_last;
+                const float* rp = (j * RI < rows_left) ? res_run : res_last;
+                res_run += res_step;
                 if (dbg & 8) { dst[RES ? k : 0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; continue; }
                 dst[RES ? k : 0] = *reinterpret_cast<const f32x4_t*>(rp);
             }
@@ -1050,13 +1059,15 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const unsigned short* __r
                     d = __builtin_bit_cast(u32x4_t, f);
                 }
                 const bool ok = j * RI + ep_row < WT_M && j * RI < rows_left && ep_col < n_out_total;
-                if (LN == VF_LN_PRODUCER && OUT_F32)
-                    ln_emit<DT>(__builtin_bit_cast(f32x4_t, d), ok, o16_p + j * o16_step, part_p + j * (RI * 2), lane,
-                                !(dbg & 2), !(dbg & 4));
+                if (LN == VF_LN_PRODUCER && OUT_F32) {
+                    ln_emit<DT>(__builtin_bit_cast(f32x4_t, d), ok, o16_run, part_run, lane, !(dbg & 2), !(dbg & 4));
+                    o16_run += o16_step;
+                    part_run += RI * 2;
+                }
                 // a LayerNorm producer whose fp32 result has no reader (only its 16-bit copy and statistics do) passes
                 // out = NULL: the 16-byte store -- 4 of the 10 bytes the epilogue moves per element -- is dropped
-                if (ok && (LN != VF_LN_PRODUCER || out != nullptr) && !(dbg & 1))
-                    *reinterpret_cast<u32x4_t*>(out_p + j * out_step) = d;
+                if (ok && (LN != VF_LN_PRODUCER || out != nullptr) && !(dbg & 1)) *reinterpret_cast<u32x4_t*>(out_run) = d;
+                out_run += out_step;
             }
         }
     }
@@ -1679,6 +1690,7 @@ extern "C" int vf_gemm_ln_bf16(const void* A, int64_t lda, const void* W, const 
     }
     VF_REQUIRE(ld16 % 4 == 0 && ld16 >= N && ((uintptr_t)out16 % 8 == 0) && ((uintptr_t)part_stats % 8 == 0) && ldo % 4 == 0,
                "vf_gemm_ln_bf16: producer outputs must keep 8-byte alignment (ld16=%lld)", (long long)ld16);
+    VF_REQUIRE(N % 32 == 0, "vf_gemm_ln_bf16: a producer needs N %% 32 == 0 (whole 32-column parts; N=%d)", N);
     ln.out16 = out16;
     ln.part_stats = part_stats;
     ln.ld16 = ld16;
