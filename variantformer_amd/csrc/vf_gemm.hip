@@ -75,11 +75,16 @@ __device__ __forceinline__ void ln_emit(f32x4_t f, bool valid, unsigned short* p
     float s2 = __builtin_fmaf(f[3], f[3], __builtin_fmaf(f[2], f[2], __builtin_fmaf(f[1], f[1], f[0] * f[0])));
     // butterfly over the 8 lanes of the part on the DPP path of the VALU (__shfl_xor would be a ds_bpermute round trip
     // per step): quad_perm [1,0,3,2], quad_perm [2,3,0,1], then row_half_mirror (lane i <-> 7 - i: the other quad's sum)
+    // (the empty asm keeps hipcc from SLP-packing the s1 / s2 adds into v_pk_add_f32, which cannot carry a DPP operand:
+    // packed, every step is two v_mov_b32_dpp + one v_pk_add_f32; unpacked, two v_add_f32_dpp)
     s1 += dpp_f32<0xB1>(s1);
+    asm("" : "+v"(s1));
     s2 += dpp_f32<0xB1>(s2);
     s1 += dpp_f32<0x4E>(s1);
+    asm("" : "+v"(s1));
     s2 += dpp_f32<0x4E>(s2);
     s1 += dpp_f32<0x141>(s1);
+    asm("" : "+v"(s1));
     s2 += dpp_f32<0x141>(s2);
     if (valid) {
         u32x2_t pk;
