@@ -420,15 +420,22 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P) {
     // The last tile is peeled so that the loop body has no conditional loads / stores: with them hipcc's wait
     // bookkeeping turns conservative and drains the just-issued prefetch (s_waitcnt vmcnt(0)) before the first MFMA
     // of every tile.
+    // a wave whose 16 * QG query rows all lie past the sequence (the last query block of a seq2reg window: 98 tokens =
+    // one full block + 34 rows, i.e. one idle and one almost idle wave) still stages K/V and meets the barriers, but
+    // computes nothing
+    // (QG = 1 kernels only: in the 2-group ALiBi instantiation the extra branch costs 4 VGPRs, which is the third wave
+    // per SIMD: 172 > 170)
+    const bool active = QG > 1 || qb0 + wave * QG * 16 < len_q;       // wave-uniform
     for (int t = 0; t + 1 < nkv; ++t) {
         if (DBG < 3) load_regs(t + 1);
         const char* sK = smem + (t & 1) * STAGE;
-        attn_tile<DH, QG, ALIBI, DT, (DBG > 2 ? 0 : DBG)>(sK, sK + K_TILE_BYTES, t * BKV, len_k, r, g, c, slope2, qf, q_pos,
-                                                       o, m_run, l_acc);
+        if (active)
+            attn_tile<DH, QG, ALIBI, DT, (DBG > 2 ? 0 : DBG)>(sK, sK + K_TILE_BYTES, t * BKV, len_k, r, g, c, slope2, qf,
+                                                           q_pos, o, m_run, l_acc);
         if (DBG < 3) write_lds((t + 1) & 1, t + 1);
         if (DBG < 4) __syncthreads();
     }
-    {
+    if (active) {
         const int t = nkv - 1;
         const char* sK = smem + (t & 1) * STAGE;
         attn_tile<DH, QG, ALIBI, DT, (DBG > 2 ? 0 : DBG)>(sK, sK + K_TILE_BYTES, t * BKV, len_k, r, g, c, slope2, qf, q_pos,
@@ -652,7 +659,8 @@ int launch_attn(AttnParams P, int n_seq, int max_q, int max_k, hipStream_t st) {
             return launch_short<DH, 4, ALIBI, DT>(P, n_seq, max_k, st);
         }
     }
-    // long query streams: 2 query groups per wave (halves K/V LDS traffic per MFMA);
+    // long query streams: 2 query groups per wave (halves K/V LDS traffic per MFMA; for seq2reg windows, 70-200 queries,
+    // 128-query blocks measured the same as 64-query blocks: 800 / 428 us either way, the kernel runs at 4 TB/s there);
     // short ones (seq2reg windows, gene stream): 64-query blocks to limit tail waste.
     // 2 query groups per wave only when that still leaves >= 4 blocks per CU (measured: CRE stream, 256 blocks, is
     // 15% faster with 64-query blocks; the 10^4-query gene->CRE cross attention is 17% faster with 128-query blocks).
