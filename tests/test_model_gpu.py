@@ -121,6 +121,28 @@ def test_production_dims_vs_oracle(case):
         assert _rel(out["embeddings"][i], orc["embeddings"][i]) < 3 * NORTH_STAR_RTOL
 
 
+def test_separate_layernorm_pass_mode_vs_oracle(monkeypatch):
+    """VF_LN_FOLD=0: LayerNorm as a kernel of its own (vf_layernorm) in front of plain GEMMs -- the rounding points of
+    round 1 -- against the oracle with fold_ln=False; and the default (LayerNorm folded into the GEMM epilogues) differs
+    from it only at bf16 level on the same inputs."""
+    kw = seq2gene_kw(layers=2)
+    model = build_model(SEQ2REG_512, kw, seed=4242)
+    sd = state_dict_cpu(model)
+    model = model.cuda()
+    batch = make_batch(99, [12, 5], [5, 3], [TISSUES_54[:3], [9]], 200)
+    folded = model.predict_step(batch, 0)
+    monkeypatch.setenv("VF_LN_FOLD", "0")
+    plain = model.predict_step(batch, 0)
+    hp = O.Seq2RegHP.from_hparams(SEQ2REG_512)
+    ghp = O.Seq2GeneHP.from_kwargs(kw)
+    orc = O.predict_step(batch, sd, hp, hp, ghp, rounding=O.Rounding("bf16", fold_ln=False), share_cre_stream=True)
+    for i in range(2):
+        assert _rel(plain["pred_gene_exp"][i], orc["pred_gene_exp"][i]) < NORTH_STAR_RTOL
+        assert _rel(plain["embeddings"][i], orc["embeddings"][i]) < 3 * NORTH_STAR_RTOL
+        assert _rel(plain["pred_gene_exp"][i], folded["pred_gene_exp"][i]) < 10 * NORTH_STAR_RTOL
+        assert not np.array_equal(plain["embeddings"][i], folded["embeddings"][i])      # two different rounding contracts
+
+
 def test_tissue_invariance_and_batch_independence():
     """Size-independent properties: a gene's prediction does not depend on which other genes share its batch,
     nor on how many tissues are requested with it (the exact de-duplication must not leak between rows)."""
