@@ -60,7 +60,8 @@ int vf_gemm_bf16(const void* A, int64_t lda, const void* W, const float* bias,
                  int M, int N, int K, int epilogue, void* stream);
 
 /* Same as vf_gemm_bf16 with an explicit tile configuration (tuning and tests): variant 0 = automatic
- * choice (what vf_gemm_bf16 does); 1 = 128x128, 5 = 64x64, 20 = two-group 256x256 tile (see vf_gemm.hip). */
+ * choice (what vf_gemm_bf16 does); 1 = 128x128, 5 = 64x64, 20 = two-group 256x256 tile, 22 = its persistent form (one
+ * block per CU walks the tiles, K >= 128; see vf_gemm.hip).  All configurations give bit-identical results. */
 int vf_gemm_bf16_ex(const void* A, int64_t lda, const void* W, const float* bias,
                     const float* residual, int64_t ldr, void* out, int64_t ldo,
                     int M, int N, int K, int epilogue, int variant, void* stream);

@@ -308,7 +308,7 @@ def test_rowdot_softplus(ops):
 # GEMM tile configurations at ragged edges (the automatic choice depends on the grid size, so every configuration the
 # pipeline can select is also forced here on shapes whose M / N are not multiples of any tile)
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("variant", [1, 5, 20])
+@pytest.mark.parametrize("variant", [1, 5, 20, 22])
 @pytest.mark.parametrize("epi", ["bf16", "res", "f32"])
 def test_gemm_forced_tile_configs_ragged(ops, variant, epi):
     M, N, K = 515, 776, 192
@@ -325,7 +325,7 @@ def test_gemm_forced_tile_configs_ragged(ops, variant, epi):
     np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), **tol)
 
 
-@pytest.mark.parametrize("variant", [1, 20])
+@pytest.mark.parametrize("variant", [1, 20, 22])
 def test_gemm_geglu_forced_tile_configs_ragged(ops, variant):
     M, F2, K = 515, 1056, 192
     a = _bf(_rand((M, K), 41))
@@ -366,7 +366,7 @@ def test_gemm_auto_selection_at_batch_size(ops, epi):
     np.testing.assert_allclose(out[rows.cuda()].float().cpu().numpy(), ref.numpy(), **tol)
 
 
-@pytest.mark.parametrize("variant", [20])
+@pytest.mark.parametrize("variant", [20, 22])
 @pytest.mark.parametrize("K", [64, 128, 192, 1536])
 @pytest.mark.parametrize("epi", ["bf16", "res", "gelu_f32"])
 def test_gemm_8phase_short_and_odd_k_loops(ops, K, epi, variant):
@@ -392,7 +392,7 @@ def test_gemm_8phase_short_and_odd_k_loops(ops, K, epi, variant):
     np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), **tol)
 
 
-@pytest.mark.parametrize("variant", [20])
+@pytest.mark.parametrize("variant", [20, 22])
 def test_gemm_8phase_race_screen(ops, variant):
     """Exact-integer operands (every product and sum exact in fp32) on a grid of several waves of tiles, repeated: any
     LDS hazard in the staggered two-group schedule (a fragment read before its LDS-DMA landed, a half-tile overwritten

@@ -1078,6 +1078,402 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const unsigned short* __r
     }
 }
 
+// ----------------------------------------------------------------------------------------------------------------------
+// Persistent form of gemm8_kernel: one 8-wave block per CU walks the output tiles bid, bid + grid, ... (same XCD-grouped
+// order) and the prefetch stream runs ONE K-tile across every output-tile boundary: K-tile 0 of the next tile is
+// requested under the last two K-tiles of the current one into the ring buffer that is free by then, so that neither
+// the block launch nor the first fill (~2 us of global -> LDS latency with nothing to compute) is paid per tile.  The
+// epilogue stages through the OTHER buffer -- the one that held the last K-tile, 8 KiB per wave instead of 16 -- and one
+// barrier ends it before the next tile's K-tile 1 is requested into that buffer.  Epilogue operands (bias, colsum, row
+// statistics) of the next tile arrive by LDS-DMA with its K-tile 0, double-buffered behind the ring.  Needs K >= 128.
+// ----------------------------------------------------------------------------------------------------------------------
+template <int EPI, int DT = VF_BF16, int LN = VF_LN_NONE>
+__global__ __launch_bounds__(512, 2) void gemm8x_kernel(const unsigned short* __restrict__ A, int64_t lda,
+                                                       const unsigned short* __restrict__ W,
+                                                       const float* __restrict__ bias, const float* __restrict__ res,
+                                                       int64_t ldr, void* out, int64_t ldo, int M, int N, int K,
+                                                       int tiles_n, int n_tiles, int GROUP_M, LnArgs ln) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using frag_t = typename Op16<DT>::frag;
+    using C = Cfg8;
+    constexpr int BM = C::BM, BN = C::BN, TM = C::TM, TN = C::TN, BK = C::BK;
+
+    // XCD-aware bijective remap + grouped order (same as gemm_mfma_kernel)
+    const int bid = blockIdx.x;
+#ifdef VF_TUNING   // cost-centre probes of the epilogue (VF_G8_DBG bit mask, scripts/gemm_bench.py; results meaningless)
+    const int dbg = GROUP_M >> 8;
+    GROUP_M &= 255;
+#else
+    constexpr int dbg = 0;
+#endif
+    const int grid = gridDim.x;
+    const int my_tiles = (n_tiles - bid + grid - 1) / grid;          // output tiles bid, bid + grid, ... (>= 1)
+    auto tile_origin = [&](int t, int& m0, int& n0) {                 // XCD-contiguous runs, grouped order (see gemm_mfma_kernel)
+        const int q8 = n_tiles >> 3, r8 = n_tiles & 7, xcd = t & 7, loc = t >> 3;
+        const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+        const int tiles_m = n_tiles / tiles_n;
+        const int per_group = GROUP_M * tiles_n;
+        const int grp = wg / per_group, in_grp = wg - grp * per_group;
+        const int first_m = grp * GROUP_M;
+        const int gsz = (tiles_m - first_m) < GROUP_M ? (tiles_m - first_m) : GROUP_M;
+        m0 = (first_m + in_grp % gsz) * BM;
+        n0 = (in_grp / gsz) * BN;
+    };
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int r = lane & 15, g = lane >> 4;
+
+    // ---- LDS-DMA sources of ONE output tile: wave w fills rows 16w .. 16w+15 of every half-tile (two 8-row pieces).
+    // Recomputed in place when the prefetch stream crosses into the next output tile (no second pointer set).
+    const unsigned short* src[4][2];
+    auto set_src = [&](int m0, int n0) {
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi) {
+            const int i = 16 * wave + 8 * pi + (lane >> 3);                   // LDS row inside the half-tile
+            const int c = (lane & 7) ^ ((i >> 1) & 7);                        // logical (source) chunk of this lane
+            const int am = m0 + (i >> 6) * 128 + (i & 63);
+            const int wn_row = n0 + (i >> 5) * 64 + (i & 31);
+            int v;
+            v = am;           v = v < M ? v : M - 1;  src[C::AL][pi] = A + (int64_t)v * lda + c * 8;
+            v = am + 64;      v = v < M ? v : M - 1;  src[C::AH][pi] = A + (int64_t)v * lda + c * 8;
+            v = wn_row;       v = v < N ? v : N - 1;  src[C::WL][pi] = W + (int64_t)v * K + c * 8;
+            v = wn_row + 32;  v = v < N ? v : N - 1;  src[C::WH][pi] = W + (int64_t)v * K + c * 8;
+        }
+    };
+    char* const lds_piece = smem + wave * 2048;                               // + buf * TILE + type * HALF + pi * 1024
+    // half-tile `type` of the K-tile with index kt inside the tile `src` points at; gk = its index in the block's
+    // K-tile stream (the ring buffer is the stream index's parity, so the stream runs across output tiles)
+    auto issue = [&](int gk, int kt, int type) {
+        char* dst = lds_piece + (gk & 1) * C::TILE_BYTES + type * C::HALF_BYTES;
+        glds16(src[type][0] + kt * BK, dst);
+        glds16(src[type][1] + kt * BK, dst + 1024);
+    };
+    // epilogue operands of a tile by LDS-DMA (bias | colsum | row statistics), double-buffered by tile parity
+    auto issue_side = [&](int m0, int n0, int seq) {
+        char* const sd = smem + C::LDS_BYTES + (seq & 1) * C::SIDE_BYTES;
+        int lane;                                    // not hoistable out of the tile loop (see the epilogue's lane id)
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+        if (bias && wave == 0) {
+            int n = n0 + 4 * lane;
+            n = n < N ? n : N - 4;
+            glds16(bias + n, sd);
+        }
+        if (LN == VF_LN_CONSUMER) {
+            if (wave == 1) {
+                int n = n0 + 4 * lane;
+                n = n < N ? n : N - 4;
+                glds16(ln.colsum + n, sd + 1024);
+            }
+            int64_t m = m0 + 32 * wave + (lane >> 1);    // every wave: 32 rows x (mean, rstd), one dword per lane
+            m = m < M ? m : M - 1;
+            __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) void*)(ln.row_stats + 2 * m + (lane & 1)),
+                                             (__attribute__((address_space(3))) void*)(sd + 2048 + wave * 256), 4, 0, 0);
+        }
+    };
+
+    f32x4_t acc[TN][TM];
+
+    // ---- fragment addresses (bytes inside a K-tile buffer): row * 128 + ((4 ks + g) ^ swz(r)) * 16
+    const int sw = (r >> 1) & 7;
+    const int ck0 = ((g) ^ sw) << 4, ck1 = ((4 + g) ^ sw) << 4;
+    const int offW = (wn * 32 + r) * 128;            // + {WL, WH} * HALF + in_local * 2048
+    const int offA = (wm * 64 + r) * 128;            // + {AL, AH} * HALF + im_local * 2048
+    frag_t wlo[2][2], whi[2][2], af[4][2];         // [fragment][k-step]
+    auto read_w = [&](const char* buf, int type, frag_t (&f)[2][2]) {
+        const char* b = buf + type * C::HALF_BYTES + offW;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            f[i][0] = *reinterpret_cast<const frag_t*>(b + i * 2048 + ck0);
+            f[i][1] = *reinterpret_cast<const frag_t*>(b + i * 2048 + ck1);
+        }
+    };
+    auto read_a = [&](const char* buf, int type) {
+        const char* b = buf + type * C::HALF_BYTES + offA;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            af[i][0] = *reinterpret_cast<const frag_t*>(b + i * 2048 + ck0);
+            af[i][1] = *reinterpret_cast<const frag_t*>(b + i * 2048 + ck1);
+        }
+    };
+    // first barrier of a phase, then the fragment reads must be back, then the MFMA cluster, then the second barrier.
+    // sched_barrier(0) keeps hipcc from moving MFMAs or LDS reads across the phase structure; the priority flips keep
+    // the cluster together (cdna_hip_programming.md T5).
+#define VF_G8_SYNC_IN()                                          \
+    do {                                                         \
+        asm volatile("" ::: "memory");                           \
+        __builtin_amdgcn_sched_barrier(0);                       \
+        __builtin_amdgcn_s_barrier();                            \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       \
+        __builtin_amdgcn_sched_barrier(0);                       \
+        __builtin_amdgcn_s_setprio(1);                           \
+    } while (0)
+#define VF_G8_SYNC_OUT()                                         \
+    do {                                                         \
+        __builtin_amdgcn_s_setprio(0);                           \
+        __builtin_amdgcn_sched_barrier(0);                       \
+        __builtin_amdgcn_s_barrier();                            \
+        asm volatile("" ::: "memory");                           \
+        __builtin_amdgcn_sched_barrier(0);                       \
+    } while (0)
+#define VF_G8_MMA(WF, IN0, IM0)                                                                                      \
+    do {                                                                                                             \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                             \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                            \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                        \
+                    acc[IN0 + i][IM0 + j] =                                                                          \
+                        Op16<DT>::mfma(WF[i][ks], af[j][ks], acc[IN0 + i][IM0 + j]); \
+    } while (0)
+
+    // ---- first tile: its epilogue operands and K-tile 0
+    const int nkt = K / BK;                                  // >= 2 (launcher)
+    int m0, n0;
+    tile_origin(bid, m0, n0);
+    set_src(m0, n0);
+    issue_side(m0, n0, 0);
+    issue(0, 0, C::WL); issue(0, 0, C::AL); issue(0, 0, C::WH); issue(0, 0, C::AH);
+
+    int g0 = 0;                                              // stream index of the current tile's K-tile 0
+    for (int ti = 0; ti < my_tiles; ++ti) {
+        const bool has_next = ti + 1 < my_tiles;             // block-uniform
+        tile_origin(bid + ti * grid, m0, n0);
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        // K-tile 0 of this tile: requested in the prologue (first tile) or under the previous tile's last two K-tiles
+        // and already retired there (vmcnt(0) before that tile's epilogue).  Its K-tile 1 goes into the buffer the
+        // previous epilogue staged through (the barrier that ended that epilogue makes it free).
+        issue(g0 + 1, 1, C::WL); issue(g0 + 1, 1, C::AL); issue(g0 + 1, 1, C::WH);
+        if (ti == 0) wait_vmcnt<6>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (wm == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind (matched after the loop)
+
+        for (int t = 0; t < nkt; ++t) {
+            const char* buf = smem + ((g0 + t) & 1) * C::TILE_BYTES;
+            // the stream continues into the NEXT output tile for exactly one K-tile: its K-tile 0 is "K-tile nkt"
+            const bool pre1 = t + 1 < nkt || has_next;                       // AH of stream K-tile t+1
+            const bool pre2 = t + 2 < nkt || (t + 2 == nkt && has_next);     // WL / AL / WH of stream K-tile t+2
+            const bool into_next = t + 2 >= nkt;                             // those belong to the next tile (kt = 0)
+            // ---- P1: (m-lo, n-lo)
+            read_w(buf, C::WL, wlo);
+            __builtin_amdgcn_sched_barrier(0);                       // W-lo reads are issued first ...
+            read_a(buf, C::AL);
+            if (pre1) issue(g0 + t + 1, t + 1 < nkt ? t + 1 : 0, C::AH);
+            asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");       // ... and retired before the barrier (WAR on WL)
+            VF_G8_SYNC_IN();
+            VF_G8_MMA(wlo, 0, 0);
+            VF_G8_SYNC_OUT();
+            if (t + 2 == nkt && has_next) {                          // the stream crosses into the next output tile
+                int m1, n1;
+                tile_origin(bid + (ti + 1) * grid, m1, n1);
+                set_src(m1, n1);
+                issue_side(m1, n1, ti + 1);
+            }
+            // ---- P2: (m-lo, n-hi)
+            read_w(buf, C::WH, whi);
+            if (pre2) issue(g0 + t + 2, into_next ? 0 : t + 2, C::WL);
+            VF_G8_SYNC_IN();
+            VF_G8_MMA(whi, 2, 0);
+            VF_G8_SYNC_OUT();
+            // ---- P3: (m-hi, n-hi)
+            read_a(buf, C::AH);
+            if (pre2) issue(g0 + t + 2, into_next ? 0 : t + 2, C::AL);
+            VF_G8_SYNC_IN();
+            VF_G8_MMA(whi, 2, 4);
+            VF_G8_SYNC_OUT();
+            // ---- P4: (m-hi, n-lo); retire stream K-tile t+1 (all but the three youngest half-tiles)
+            if (pre2) {
+                issue(g0 + t + 2, into_next ? 0 : t + 2, C::WH);
+                wait_vmcnt<6>();
+            } else {
+                wait_vmcnt<0>();
+            }
+            VF_G8_SYNC_IN();
+            VF_G8_MMA(wlo, 0, 4);
+            VF_G8_SYNC_OUT();
+        }
+        if (wm == 0) __builtin_amdgcn_s_barrier();   // matches group 1's extra barrier: every wave is past its last MFMA
+        asm volatile("" ::: "memory");
+        char* const side = smem + C::LDS_BYTES + (ti & 1) * C::SIDE_BYTES;
+        char* const stage_buf = smem + ((g0 + nkt - 1) & 1) * C::TILE_BYTES;   // the last K-tile's buffer: free now
+        // (the other buffer holds, or is receiving, the next tile's K-tile 0)
+        // The epilogue's lane-derived addresses are computed from a lane id the compiler cannot hoist out of the tile
+        // loop: hoisted, they stay live across the K loop, the kernel spills, and the reloads' compiler-inserted
+        // vmcnt(0) drains the hand-counted LDS-DMA stream (cdna_hip_programming.md, attention pitfalls).
+        int lane_e;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+        const int lane = lane_e, r = lane & 15, g = lane >> 4;
+
+        // ---- epilogue: each wave stages its 128 x 64 block through its own 8 KiB slice of the free half of the ring and
+        // writes whole rows, 16 bytes per lane; the fp32 residual rows of pass p+1 are requested while pass p goes through
+        // LDS (same scheme as gemm8_kernel).
+        constexpr bool OUT_F32 = (EPI == VF_EPI_F32 || EPI == VF_EPI_RES_F32 || EPI == VF_EPI_GELU_F32);
+        constexpr int ES = OUT_F32 ? 4 : 2;
+        constexpr int WT_M = 128, WT_N = 64;
+        constexpr int WT_NO = (EPI == VF_EPI_GEGLU_BF16) ? WT_N / 2 : WT_N;
+        constexpr int PITCH = WT_NO * ES + 16;
+        constexpr int REGION = C::TILE_BYTES / C::NW;        // 8 KiB per wave: half of the ring
+        constexpr int RP_FIT = (((REGION / PITCH) < WT_M ? (REGION / PITCH) : WT_M) / 16) * 16;
+        // the LayerNorm producer carries extra live values through the read-back: 32-row passes keep it inside 256 VGPRs
+        constexpr int RP = (LN == VF_LN_PRODUCER && EPI == VF_EPI_RES_F32 && RP_FIT > 32) ? 32 : RP_FIT;
+        constexpr int IMP = RP / 16, NPASS = (TM + IMP - 1) / IMP;
+        constexpr int CR = WT_NO * ES / 16, RI = 64 / CR, NI = RP / RI;
+        static_assert(RP >= 16 && CR >= 1 && CR <= 64 && 64 % CR == 0, "epilogue geometry");
+        constexpr bool RES = (EPI == VF_EPI_RES_F32);
+        const int n_out_total = (EPI == VF_EPI_GEGLU_BF16) ? N / 2 : N;
+        const int64_t mw0 = m0 + wm * WT_M;
+        const int nw0 = n0 + wn * WT_N;
+        const int no0 = (EPI == VF_EPI_GEGLU_BF16) ? nw0 / 2 : nw0;
+        const int ep_row = lane / CR, ep_col = no0 + (lane % CR) * (16 / ES);
+        // Addresses of this lane's read-back items.  Item j = pass * NI + k is row j * RI + ep_row of the wave tile, so every
+        // pointer is "first row + j * (RI rows)": ONE 64-bit multiply per lane, the per-item steps are wave-uniform scalars
+        // (a multiply per item costs quarter-rate v_mul_lo_u32 / v_mad_u64_u32 pairs: 192 of the 766 VALU instructions of
+        // the fp32-residual epilogue before this).  Rows past M read the last row instead (never stored).
+        const int rows_left = (int)(M - mw0) - ep_row;              // item j is a row of the matrix iff j * RI < rows_left
+        const int64_t row0 = mw0 + ep_row;
+        const int colc = ep_col < N ? ep_col : N - 4;
+        const float* const res_p = RES ? res + row0 * ldr + colc : nullptr;
+        const float* const res_last = RES ? res + (int64_t)(M - 1) * ldr + colc : nullptr;
+        const int64_t res_step = (int64_t)RI * ldr;
+        char* const out_p = reinterpret_cast<char*>(out) + (row0 * ldo + ep_col) * ES;
+        const int64_t out_step = (int64_t)RI * ldo * ES;
+        unsigned short* const o16_p = (LN == VF_LN_PRODUCER) ? reinterpret_cast<unsigned short*>(ln.out16) + row0 * ln.ld16 + ep_col : nullptr;
+        const int64_t o16_step = (int64_t)RI * ln.ld16;
+        float* const part_p = (LN == VF_LN_PRODUCER) ? ln.part_stats + ((int64_t)(ep_col >> 5) * ln.rows + row0) * 2 : nullptr;
+        // the items are visited in increasing j, so each pointer is a running one: p += step per item (one 64-bit add)
+        // instead of base + j * step (hipcc multiplies per item otherwise: 81 quarter-rate v_mad_u64_u32 in this epilogue)
+        const float* res_run = res_p;
+        char* out_run = out_p;
+        unsigned short* o16_run = o16_p;
+        float* part_run = part_p;
+        f32x4_t rbuf[2][RES ? NI : 1];
+        auto load_res_pass = [&](int ps, f32x4_t (&dst)[RES ? NI : 1]) {
+            if (RES) {
+#pragma unroll
+                for (int k = 0; k < NI; ++k) {
+                    const int j = ps * NI + k;
+                    const float* rp = (j * RI < rows_left) ? res_run : res_last;
+                    res_run += res_step;
+                    if (dbg & 8) { dst[RES ? k : 0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; continue; }
+                    dst[RES ? k : 0] = *reinterpret_cast<const f32x4_t*>(rp);
+                }
+            }
+        };
+        load_res_pass(0, rbuf[0]);
+        // bias of the wave's columns, from the side area (requested before the first K-tile)
+        f32x4_t bvec[TN];
+        if (bias) {
+#pragma unroll
+            for (int in = 0; in < TN; ++in) {
+                const int nl = wn * WT_N + ((EPI == VF_EPI_GEGLU_BF16) ? (in >> 1) * 32 + (in & 1) * 16 + 4 * g : in * 16 + 4 * g);
+                bvec[in] = *reinterpret_cast<const f32x4_t*>(side + nl * 4);
+            }
+        } else {
+#pragma unroll
+            for (int in = 0; in < TN; ++in) bvec[in] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        }
+        // LayerNorm consumer: acc -> rstd[m] * (acc - mean[m] * colsum[n]); the folded bias is `bias`
+        f32x4_t svec[LN == VF_LN_CONSUMER ? TN : 1];
+        if (LN == VF_LN_CONSUMER) {
+#pragma unroll
+            for (int in = 0; in < TN; ++in) {
+                const int nl = wn * WT_N + ((EPI == VF_EPI_GEGLU_BF16) ? (in >> 1) * 32 + (in & 1) * 16 + 4 * g : in * 16 + 4 * g);
+                svec[LN == VF_LN_CONSUMER ? in : 0] = *reinterpret_cast<const f32x4_t*>(side + 1024 + nl * 4);
+            }
+        }
+        // (mean, rstd) of a row group are read from the side area when its accumulators are staged: 2 live registers
+        // instead of 16 (the persistent loop has none to spare)
+        auto lnv = [&](int in, int im, f32x2_t st) -> f32x4_t {
+            if (LN == VF_LN_CONSUMER) return (acc[in][im] - st[0] * svec[LN == VF_LN_CONSUMER ? in : 0]) * st[1];
+            return acc[in][im];
+        };
+        char* const region = stage_buf + wave * REGION;
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            if (ps + 1 < NPASS) load_res_pass(ps + 1, rbuf[(ps + 1) & 1]);
+#pragma unroll
+            for (int iml = 0; iml < IMP; ++iml) {
+                const int im = ps * IMP + iml;
+                if (im < TM) {
+                    char* rowp = region + (iml * 16 + r) * PITCH;
+                    f32x2_t st = {0.f, 1.f};
+                    if (LN == VF_LN_CONSUMER) st = *reinterpret_cast<const f32x2_t*>(side + 2048 + (wm * WT_M + im * 16 + r) * 8);
+                    if (EPI == VF_EPI_GEGLU_BF16) {
+#pragma unroll
+                        for (int ip = 0; ip < TN / 2; ++ip) {
+                            const f32x4_t v = lnv(2 * ip, im, st) + bvec[2 * ip], gt = lnv(2 * ip + 1, im, st) + bvec[2 * ip + 1];
+                            u32x2_t pk;
+                            const f32x4_t y = v * gelu_erf4(gt);
+                            pk[0] = Op16<DT>::pack2(y[0], y[1]);
+                            pk[1] = Op16<DT>::pack2(y[2], y[3]);
+                            *reinterpret_cast<u32x2_t*>(rowp + (ip * 16 + 4 * g) * 2) = pk;
+                        }
+                    } else {
+#pragma unroll
+                        for (int in = 0; in < TN; ++in) {
+                            f32x4_t v = lnv(in, im, st) + bvec[in];
+                            if (EPI == VF_EPI_GELU_F32 || EPI == VF_EPI_GELU_BF16) {
+                                v = gelu_erf4(v);
+                            }
+                            if (OUT_F32) {
+                                *reinterpret_cast<f32x4_t*>(rowp + (in * 16 + 4 * g) * 4) = v;
+                            } else {
+                                u32x2_t pk;
+                                pk[0] = Op16<DT>::pack2(v[0], v[1]);
+                                pk[1] = Op16<DT>::pack2(v[2], v[3]);
+                                *reinterpret_cast<u32x2_t*>(rowp + (in * 16 + 4 * g) * 2) = pk;
+                            }
+                        }
+                    }
+                }
+            }
+            // (2) read the slice back row-wise: all LDS reads first (unconditional: every row lies inside the slice), then
+            // the predicated stores, so that no store waits behind a per-row ds_read round trip
+            constexpr int KB = RES ? 4 : NI;          // read-back batch (the residual epilogue has fewer registers to spare)
+#pragma unroll
+            for (int k0 = 0; k0 < NI; k0 += KB) {
+                u32x4_t dd[KB];
+#pragma unroll
+                for (int k = 0; k < KB; ++k)
+                    if (k0 + k < NI)
+                        dd[k] = *reinterpret_cast<const u32x4_t*>(region + ((k0 + k) * RI + ep_row) * PITCH + (lane % CR) * 16);
+#pragma unroll
+                for (int k = 0; k < KB; ++k) {
+                    if (k0 + k >= NI) continue;
+                    const int j = ps * NI + k0 + k;                  // row j * RI + ep_row of the wave tile
+                    u32x4_t d = dd[k];
+                    if (RES) {
+                        f32x4_t f = __builtin_bit_cast(f32x4_t, d);
+                        f += rbuf[ps & 1][RES ? k0 + k : 0];
+                        d = __builtin_bit_cast(u32x4_t, f);
+                    }
+                    const bool ok = j * RI + ep_row < WT_M && j * RI < rows_left && ep_col < n_out_total;
+                    if (LN == VF_LN_PRODUCER && OUT_F32) {
+                        ln_emit<DT>(__builtin_bit_cast(f32x4_t, d), ok, o16_run, part_run, lane, !(dbg & 2), !(dbg & 4));
+                        o16_run += o16_step;
+                        part_run += RI * 2;
+                    }
+                    // a LayerNorm producer whose fp32 result has no reader (only its 16-bit copy and statistics do) passes
+                    // out = NULL: the 16-byte store -- 4 of the 10 bytes the epilogue moves per element -- is dropped
+                    if (ok && (LN != VF_LN_PRODUCER || out != nullptr) && !(dbg & 1)) *reinterpret_cast<u32x4_t*>(out_run) = d;
+                    out_run += out_step;
+                }
+            }
+        }
+
+        // every wave's staging reads are done before the next tile's K-tile 1 is requested into this buffer
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        g0 += nkt;
+    }
+#undef VF_G8_SYNC_IN
+#undef VF_G8_SYNC_OUT
+#undef VF_G8_MMA
+}
+
 #ifdef VF_TUNING   // measured: +5 % on the seq2reg Wqkv shape, +1..2 % on Wq / 8192^3, -2..4 % on Wqkv / GeGLU / fp32-residual
                    // (gpurun_out/r2g/gemm_bench.log): not selected, kept for scripts/gemm_bench.py only
 // ----------------------------------------------------------------------------------------------------------------------
@@ -1519,6 +1915,45 @@ int launch_gemm8(const void* A, int64_t lda, const void* W, const float* bias, c
     return VF_OK;
 }
 
+template <int EPI, int DT = VF_BF16, int LN = VF_LN_NONE>
+int launch_gemm8x(const void* A, int64_t lda, const void* W, const float* bias, const float* res, int64_t ldr, void* out,
+                  int64_t ldo, int M, int N, int K, hipStream_t st, LnArgs ln = LnArgs{}) {
+    constexpr int LDS = Cfg8::LDS_BYTES + 2 * Cfg8::SIDE_BYTES;
+    static bool attr_set[VF_MAX_DEVICES] = {};
+    static int n_cu[VF_MAX_DEVICES] = {};
+    auto kern = gemm8x_kernel<EPI, DT, LN>;
+    const int dev = vf_current_device();
+    if (dev < 0 || !attr_set[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
+            hipSuccess) {
+            (void)hipGetLastError();
+            vf_set_error("vf_gemm_bf16: cannot reserve %d bytes of LDS", LDS);
+            return VF_ERR_LAUNCH;
+        }
+        if (dev >= 0) attr_set[dev] = true;
+    }
+    int cus = 256;
+    if (dev >= 0) {
+        if (n_cu[dev] == 0) {
+            int v = 0;
+            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+            n_cu[dev] = v;
+        }
+        cus = n_cu[dev];
+    }
+    const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256;
+    const int n_tiles = tiles_m * tiles_n;
+    const int grid = n_tiles < cus ? n_tiles : cus;              // one resident block per CU
+    int group_m = 8;
+#ifdef VF_TUNING
+    if (const char* e = getenv("VF_G8_DBG")) group_m |= atoi(e) << 8;   // epilogue cost-centre probes
+#endif
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, st, (const unsigned short*)A, lda, (const unsigned short*)W, bias,
+                       res, ldr, out, ldo, M, N, K, tiles_n, n_tiles, group_m, ln);
+    VF_CHECK_LAUNCH("vf_gemm_bf16");
+    return VF_OK;
+}
+
 #ifdef VF_TUNING
 template <int EPI, int DT = VF_BF16>
 int launch_gemm8p(const void* A, int64_t lda, const void* W, const float* bias, const float* res, int64_t ldr, void* out,
@@ -1551,7 +1986,7 @@ int launch_gemm8p(const void* A, int64_t lda, const void* W, const float* bias, 
 // ordering): grids with fewer than 256 128x128 tiles use 64x64 tiles so that all 256 CUs get work; otherwise 256x256
 // (one 8-wave block per CU, half the L2 -> LDS bytes per flop) against 128x128 (two 4-wave blocks per CU) by whole
 // waves of tiles.
-// // variant 0 = automatic; 1 / 5 / 20 force a configuration (tests).  Other numbers exist only under VF_TUNING.
+// variant 0 = automatic; 1 / 5 / 20 / 22 force a configuration (tests).  Other numbers exist only under VF_TUNING.
 int pick_variant(int M, int N, int K, int epilogue) {
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
@@ -1565,7 +2000,14 @@ int pick_variant(int M, int N, int K, int epilogue) {
     (void)K;
     const long waves_small = (t128 + 511) / 512, waves_big = (t256 + 255) / 256;
     const double gain = epilogue == VF_EPI_RES_F32 ? 1.14 : 1.2;
-    return (double)waves_big * 2.0 / gain < (double)waves_small ? 20 : 1;
+    if (!((double)waves_big * 2.0 / gain < (double)waves_small)) return 1;
+    // 16-bit epilogues take the persistent form of the 256x256 kernel (first fill and block launch hidden: seq2reg Wqkv
+    // 890 -> 953, GeGLU 893 -> 976, gene Wqkv / Wq / GeGLU +2-3 %, same box).  The fp32 epilogues stay on the one-shot
+    // kernel: staged through half the ring (16-row passes) the seq2reg N = 512 producers lose 8 %, the gene ones gain
+    // nothing.  VF_GEMM_PERSIST=0 switches the persistent form off (A/B runs).
+    static const int persist = getenv("VF_GEMM_PERSIST") ? atoi(getenv("VF_GEMM_PERSIST")) : 1;
+    const bool out16 = epilogue == VF_EPI_BF16 || epilogue == VF_EPI_GEGLU_BF16 || epilogue == VF_EPI_GELU_BF16;
+    return (persist && out16 && K >= 128) ? 22 : 20;
 }
 
 template <int EPI, int DT>
@@ -1583,6 +2025,8 @@ int launch_gemm(const void* A, int64_t lda, const void* W, const float* bias, co
         case 1: return launch_cfg<CfgA, EPI, DT>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
         case 5: return launch_cfg<CfgE, EPI, DT>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
         case 20: return launch_gemm8<EPI, DT>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
+        case 22: if (K >= 128) return launch_gemm8x<EPI, DT>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
+                 return launch_gemm8<EPI, DT>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
 #ifdef VF_TUNING
         case 21:
             if (K < 128) break;
@@ -1664,6 +2108,7 @@ static int launch_gemm_ln(const void* A, int64_t lda, const void* W, const float
     switch (pick_variant(M, N, K, EPI)) {
         case 1: return launch_cfg<CfgA, EPI, DT, 0, LN>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, st, ln);
         case 5: return launch_cfg<CfgE, EPI, DT, 0, LN>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, st, ln);
+        case 22: return launch_gemm8x<EPI, DT, LN>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, st, ln);
         default: return launch_gemm8<EPI, DT, LN>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, st, ln);
     }
 }
