@@ -8,7 +8,7 @@ for f in glob.glob("gpurun_out/%s_fetch/**/*counter_collection.csv" % tag, recur
     seen = set()
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"]
-        key = ("gemm8_kernel" if "gemm8_kernel" in name else "gemm_mfma_kernel" if "gemm_mfma_kernel" in name else
+        key = ("gemm8_kernel" if ("gemm8_kernel" in name or "gemm8x_kernel" in name) else "gemm_mfma_kernel" if "gemm_mfma_kernel" in name else
                ("attn_kernels" if "attn_" in name else ("layernorm_kernel" if "layernorm" in name else None)))
         if key is None:
             continue
