@@ -725,6 +725,7 @@ struct Cfg8 {
     static constexpr int TILE_BYTES = 4 * HALF_BYTES;           // WL | AL | WH | AH
     static constexpr int LDS_BYTES = 2 * TILE_BYTES;            // 128 KiB
     static constexpr int SIDE_BYTES = 4096;                     // behind the ring: bias | colsum | (mean, rstd) of the tile
+    static constexpr int SPARE_BYTES = 24576;                   // persistent kernel: extra epilogue staging behind buffer 1
     enum { WL = 0, AL = 1, WH = 2, AH = 3 };
 };
 
@@ -1083,9 +1084,10 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const unsigned short* __r
 // order) and the prefetch stream runs ONE K-tile across every output-tile boundary: K-tile 0 of the next tile is
 // requested under the last two K-tiles of the current one into the ring buffer that is free by then, so that neither
 // the block launch nor the first fill (~2 us of global -> LDS latency with nothing to compute) is paid per tile.  The
-// epilogue stages through the OTHER buffer -- the one that held the last K-tile, 8 KiB per wave instead of 16 -- and one
-// barrier ends it before the next tile's K-tile 1 is requested into that buffer.  Epilogue operands (bias, colsum, row
-// statistics) of the next tile arrive by LDS-DMA with its K-tile 0, double-buffered behind the ring.  Needs K >= 128.
+// epilogue stages through the OTHER buffer -- the one that held the last K-tile -- and one
+// barrier ends it before the next tile's K-tile 1 is requested into that buffer (with an even number of K-tiles that is
+// always buffer 1, and the 24 KiB of LDS behind the ring extend it to 11 KiB per wave).  Epilogue operands (bias, colsum, row
+// statistics) of the next tile arrive by LDS-DMA with its K-tile 0, double-buffered behind the ring.  Needs K % 128 == 0.
 // ----------------------------------------------------------------------------------------------------------------------
 template <int EPI, int DT = VF_BF16, int LN = VF_LN_NONE>
 __global__ __launch_bounds__(512, 2) void gemm8x_kernel(const unsigned short* __restrict__ A, int64_t lda,
@@ -1152,7 +1154,7 @@ __global__ __launch_bounds__(512, 2) void gemm8x_kernel(const unsigned short* __
     };
     // epilogue operands of a tile by LDS-DMA (bias | colsum | row statistics), double-buffered by tile parity
     auto issue_side = [&](int m0, int n0, int seq) {
-        char* const sd = smem + C::LDS_BYTES + (seq & 1) * C::SIDE_BYTES;
+        char* const sd = smem + C::LDS_BYTES + C::SPARE_BYTES + (seq & 1) * C::SIDE_BYTES;
         int lane;                                    // not hoistable out of the tile loop (see the epilogue's lane id)
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
         if (bias && wave == 0) {
@@ -1297,9 +1299,11 @@ __global__ __launch_bounds__(512, 2) void gemm8x_kernel(const unsigned short* __
         }
         if (wm == 0) __builtin_amdgcn_s_barrier();   // matches group 1's extra barrier: every wave is past its last MFMA
         asm volatile("" ::: "memory");
-        char* const side = smem + C::LDS_BYTES + (ti & 1) * C::SIDE_BYTES;
-        char* const stage_buf = smem + ((g0 + nkt - 1) & 1) * C::TILE_BYTES;   // the last K-tile's buffer: free now
-        // (the other buffer holds, or is receiving, the next tile's K-tile 0)
+        char* const side = smem + C::LDS_BYTES + C::SPARE_BYTES + (ti & 1) * C::SIDE_BYTES;
+        // Staging: the last K-tile's buffer is free now (the other one holds, or is receiving, the next tile's K-tile 0).
+        // K / 64 is even (launcher), so that is always buffer 1, and the 24 KiB of LDS that lie unused behind the ring
+        // follow it directly: 88 KiB = 11 KiB per wave (32-row passes for fp32 outputs, 64 / 128 rows for 16-bit / GeGLU).
+        char* const stage_buf = smem + C::TILE_BYTES;
         // The epilogue's lane-derived addresses are computed from a lane id the compiler cannot hoist out of the tile
         // loop: hoisted, they stay live across the K loop, the kernel spills, and the reloads' compiler-inserted
         // vmcnt(0) drains the hand-counted LDS-DMA stream (cdna_hip_programming.md, attention pitfalls).
@@ -1315,10 +1319,11 @@ __global__ __launch_bounds__(512, 2) void gemm8x_kernel(const unsigned short* __
         constexpr int WT_M = 128, WT_N = 64;
         constexpr int WT_NO = (EPI == VF_EPI_GEGLU_BF16) ? WT_N / 2 : WT_N;
         constexpr int PITCH = WT_NO * ES + 16;
-        constexpr int REGION = C::TILE_BYTES / C::NW;        // 8 KiB per wave: half of the ring
+        constexpr int REGION = (C::TILE_BYTES + C::SPARE_BYTES) / C::NW;      // 11 KiB per wave: half the ring + the spare
         constexpr int RP_FIT = (((REGION / PITCH) < WT_M ? (REGION / PITCH) : WT_M) / 16) * 16;
-        // the LayerNorm producer carries extra live values through the read-back: 32-row passes keep it inside 256 VGPRs
-        constexpr int RP = (LN == VF_LN_PRODUCER && EPI == VF_EPI_RES_F32 && RP_FIT > 32) ? 32 : RP_FIT;
+        // fp32-residual epilogues: 16-row passes (two residual buffers of 16 registers; with 32-row passes the persistent
+        // loop spills)
+        constexpr int RP = (EPI == VF_EPI_RES_F32 && RP_FIT > 16) ? 16 : RP_FIT;
         constexpr int IMP = RP / 16, NPASS = (TM + IMP - 1) / IMP;
         constexpr int CR = WT_NO * ES / 16, RI = 64 / CR, NI = RP / RI;
         static_assert(RP >= 16 && CR >= 1 && CR <= 64 && 64 % CR == 0, "epilogue geometry");
@@ -1918,7 +1923,7 @@ int launch_gemm8(const void* A, int64_t lda, const void* W, const float* bias, c
 template <int EPI, int DT = VF_BF16, int LN = VF_LN_NONE>
 int launch_gemm8x(const void* A, int64_t lda, const void* W, const float* bias, const float* res, int64_t ldr, void* out,
                   int64_t ldo, int M, int N, int K, hipStream_t st, LnArgs ln = LnArgs{}) {
-    constexpr int LDS = Cfg8::LDS_BYTES + 2 * Cfg8::SIDE_BYTES;
+    constexpr int LDS = Cfg8::LDS_BYTES + Cfg8::SPARE_BYTES + 2 * Cfg8::SIDE_BYTES;      // 160 KiB: all of a CU's LDS
     static bool attr_set[VF_MAX_DEVICES] = {};
     static int n_cu[VF_MAX_DEVICES] = {};
     auto kern = gemm8x_kernel<EPI, DT, LN>;
@@ -2007,7 +2012,7 @@ int pick_variant(int M, int N, int K, int epilogue) {
     // nothing.  VF_GEMM_PERSIST=0 switches the persistent form off (A/B runs).
     static const int persist = getenv("VF_GEMM_PERSIST") ? atoi(getenv("VF_GEMM_PERSIST")) : 1;
     const bool out16 = epilogue == VF_EPI_BF16 || epilogue == VF_EPI_GEGLU_BF16 || epilogue == VF_EPI_GELU_BF16;
-    return (persist && out16 && K >= 128) ? 22 : 20;
+    return (persist && (out16 || persist >= 2) && K % 128 == 0) ? 22 : 20;      // K / 64 even: see the kernel's staging
 }
 
 template <int EPI, int DT>
@@ -2025,7 +2030,7 @@ int launch_gemm(const void* A, int64_t lda, const void* W, const float* bias, co
         case 1: return launch_cfg<CfgA, EPI, DT>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
         case 5: return launch_cfg<CfgE, EPI, DT>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
         case 20: return launch_gemm8<EPI, DT>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
-        case 22: if (K >= 128) return launch_gemm8x<EPI, DT>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
+        case 22: if (K % 128 == 0) return launch_gemm8x<EPI, DT>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
                  return launch_gemm8<EPI, DT>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
 #ifdef VF_TUNING
         case 21:
