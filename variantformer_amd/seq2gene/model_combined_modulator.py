@@ -106,7 +106,7 @@ def _t(x):
 
 def modulator_forward_packed(ctx_embedding, cre_layers, gene_layers, cre_x, gene_x, labels, cu_cre, max_cre,
                              cu_gene_self, max_gene, cu_gene_cross=None, max_gene_cross=None, cu_cre_for_gene=None,
-                             final_rows=None, use_res=False):
+                             final_rows=None, use_res=False, gene_unique=None):
     """Interleaved CRE / gene layer stack on packed streams (reference model_combined_modulator.py:244-285; the
     two-module variant seq2gene/model.py:375-412 + layers.py:620-742,797-921 evaluates the same sequence: gene layer
     i reads the CRE stream after CRE layer i-1, gene layer 0 the raw CRE embeddings).
@@ -132,8 +132,15 @@ def modulator_forward_packed(ctx_embedding, cre_layers, gene_layers, cre_x, gene
     if overlap:
         side.wait_stream(main)                      # inputs (cre_x, labels, cu arrays) were produced on `main`
     with ops.scope("gene_stream"):
+        # gene_unique = (chunk rows, registry table, index): the stream entering gene layer 0 consists of copies of these
+        # rows (one copy of a gene's chunk rows per tissue), so its LayerNorm1 -> Wqkv projection is computed once per
+        # distinct row (exact; the other 24 gene layers see rows that differ by tissue)
+        qkv0 = None
+        if gene_unique is not None and hasattr(gene_layers[0], "self_qkv_of_unique_rows"):
+            qkv0 = gene_layers[0].self_qkv_of_unique_rows(*gene_unique)
+        kw0 = {} if qkv0 is None else {"self_qkv": qkv0}
         gene = gene_layers[0].forward_packed(gene, cu_gene_self, max_gene, context=cre, cu_ctx=ck, max_ctx=max_cre,
-                                             cu_cross_q=cq, max_cross_q=mq)
+                                             cu_cross_q=cq, max_cross_q=mq, **kw0)
     if use_res:                                     # gene-stream input added back after every gene layer (:253-254)
         gene = ops.add_rows(_t(gene), gene_x)
     for i in range(n - 1):
@@ -199,10 +206,11 @@ class CombinedModulator(nn.Module):
                     l.crossMHA.MHA.family = "cre_ctx_cross" if stream == "cre" else "gene_cre_cross"
 
     def forward_packed(self, cre_x, gene_x, labels, cu_cre, max_cre, cu_gene_self, max_gene, cu_gene_cross=None,
-                       max_gene_cross=None, cu_cre_for_gene=None, final_rows=None):
+                       max_gene_cross=None, cu_cre_for_gene=None, final_rows=None, gene_unique=None):
         return modulator_forward_packed(self.second_level_context_embedding, self.cre_layers, self.gene_layers, cre_x,
                                         gene_x, labels, cu_cre, max_cre, cu_gene_self, max_gene, cu_gene_cross,
-                                        max_gene_cross, cu_cre_for_gene, final_rows, use_res=self.use_res)
+                                        max_gene_cross, cu_cre_for_gene, final_rows, use_res=self.use_res,
+                                        gene_unique=gene_unique)
 
     def forward(self, cre_x, gene_x, context=None, cre_padding_mask=None, gene_padding_mask=None,
                 context_padding_mask=None, precision=None, cre_token_position=None, gene_token_position=None):
@@ -449,16 +457,17 @@ class Seq2GenePredictorCombinedModulator(nn.Module):
             return self._forward_general(pb, cre_x, gene_x)
         # registry token per (gene, tissue) + that gene's chunk rows (:357-366, layers.py:508-521)
         gene_stream = ops.gather_rows_f32(gene_x, self.start_tkn.registry_tokens.weight, pb.gene_stream_idx)
+        uniq = (gene_x, self.start_tkn.registry_tokens.weight, pb.gene_stream_idx)     # what gene_stream's rows are copies of
         if return_cre:       # VEP needs every gene token of the last layer (token-position gathers)
             gene_out, cre_out = self._modulator_forward_packed(
                 cre_x, gene_stream, pb.labels, pb.cu_cre, pb.max_cre, pb.cu_gene_self, pb.max_gene,
-                cu_gene_cross=pb.cu_gene_cross, max_gene_cross=pb.max_gene_cross)
+                cu_gene_cross=pb.cu_gene_cross, max_gene_cross=pb.max_gene_cross, gene_unique=uniq)
             emb = ops.gather_rows_f32(gene_out, None, pb.registry_rows)                         # pool_outputs (:391-392)
         else:                # only row 0 (registry token) of the last gene layer is consumed: compute just those rows
             emb, cre_out = self._modulator_forward_packed(
                 cre_x, gene_stream, pb.labels, pb.cu_cre, pb.max_cre, pb.cu_gene_self, pb.max_gene,
                 cu_gene_cross=pb.cu_gene_cross, max_gene_cross=pb.max_gene_cross,
-                final_rows=(pb.registry_rows, pb.cu_registry, pb.cu_registry_cross, pb.max_tissues))
+                final_rows=(pb.registry_rows, pb.cu_registry, pb.cu_registry_cross, pb.max_tissues), gene_unique=uniq)
             gene_out = None
         pred = self.tissue_heads(emb, [t for ts in pb.tissues for t in ts])
         if return_cre:

@@ -180,6 +180,11 @@ class MHA(nn.Module):
                                    self.head_dim, self.alibi_slopes, family=self.family)
         w, b, c = packed_linear_ln(self.Wqkv, norm)
         qkv = ops.gemm_ln_consumer(s, w, b, c, ops.EPI_BF16)
+        return self.attend_qkv(qkv, cu_q, max_q)
+
+    def attend_qkv(self, qkv, cu_q, max_q) -> torch.Tensor:
+        """self attention on a packed [tokens, 3D] 16-bit projection (rows ordered (three, head, dh))."""
+        D = self.embed_dim
         return ops.attn_varlen(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], cu_q, None, max_q, max_q,
                                self.num_heads, self.head_dim, self.alibi_slopes, family=self.family)
 
@@ -287,19 +292,38 @@ class ContextFlashAttentionEncoderLayer(nn.Module):
         if use_alibi:
             self.register_buffer("m", get_alibi_slopes(self.num_heads))
 
+    def self_qkv_of_unique_rows(self, rows_a, rows_b, idx):
+        """LayerNorm1 + Wqkv of a stream whose rows are copies of the rows of two small tables (the gene stream entering
+        the FIRST gene layer: every tissue's copy of a gene holds the same chunk rows, only the registry row differs):
+        projected once per distinct row, then expanded.  idx int64 [tokens]: >= 0 row of rows_a, < 0 row -idx-1 of rows_b.
+        Exact: LayerNorm and the projection are row-wise.  None when the LayerNorm fold is off (fp16 mode)."""
+        if not ln_fold_enabled(self.norm1.weight.numel()):
+            return None
+        w, b, c = packed_linear_ln(self.mixer.MHA.Wqkv, self.norm1)
+        qa = ops.gemm_ln_consumer(ops.ln_stream(rows_a.float().contiguous()), w, b, c, ops.EPI_BF16)
+        qb = ops.gemm_ln_consumer(ops.ln_stream(rows_b.float().contiguous()), w, b, c, ops.EPI_BF16)
+        both = torch.cat([qa, qb], dim=0)                        # (a few thousand rows: index plumbing, not data movement)
+        idx2 = torch.where(idx >= 0, idx, rows_a.shape[0] - idx - 1)
+        return ops.gather_rows_bf16(both, idx2)
+
     def forward_packed(self, src, cu_src, max_src, context=None, cu_ctx=None, max_ctx=None, context_kv=None,
-                       cu_cross_q=None, max_cross_q=None):
+                       cu_cross_q=None, max_cross_q=None, self_qkv=None):
         """src fp32 [tokens, D] packed residual stream.  Cross-attention keys/values come either from
         `context` (fp32 packed stream, projected here) or from a precomputed bf16 `context_kv` [tokens_k, 2D].
-        `cu_cross_q` lets several self-attention sequences share one K/V block (tissue copies of a gene)."""
+        `cu_cross_q` lets several self-attention sequences share one K/V block (tissue copies of a gene).
+        `self_qkv`: precomputed LayerNorm1 -> Wqkv projection of src (self_qkv_of_unique_rows)."""
         assert not self.make_data_kv
         cq = cu_src if cu_cross_q is None else cu_cross_q
         mq = max_src if max_cross_q is None else max_cross_q
         if ln_fold_enabled(self.norm1.weight.numel()):
             # LayerNorm folded into the GEMMs: every fp32-residual GEMM also emits the bf16 copy + row statistics of its
             # output, every LayerNorm -> Linear pair runs on that copy (no LayerNorm pass, no cast of the context)
-            s = _as_stream(src)
-            a = self.mixer.MHA.attend_ln(s, self.norm1, None, cu_src, max_src, None, None)
+            if self_qkv is not None:
+                s = ops.LnStream(_as_tensor(src), None, None)    # only the fp32 rows are read below (residuals)
+                a = self.mixer.MHA.attend_qkv(self_qkv, cu_src, max_src)
+            else:
+                s = _as_stream(src)
+                a = self.mixer.MHA.attend_ln(s, self.norm1, None, cu_src, max_src, None, None)
             x1 = self.mixer.MHA.out_ln(a, s.x)
             if context_kv is None:
                 ctx16 = context.x16 if isinstance(context, ops.LnStream) else ops.cast16(context)
