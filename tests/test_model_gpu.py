@@ -143,6 +143,21 @@ def test_separate_layernorm_pass_mode_vs_oracle(monkeypatch):
         assert not np.array_equal(plain["embeddings"][i], folded["embeddings"][i])      # two different rounding contracts
 
 
+def test_first_gene_layer_projection_dedup_is_exact(monkeypatch):
+    """Gene layer 0 projects LayerNorm1 -> Wqkv once per distinct row of the gene stream (chunk rows are the same for
+    every tissue there) and expands the result: bit-identical to projecting every row of the expanded stream."""
+    from variantformer_amd.seq2gene.modules.layers import ContextFlashAttentionEncoderLayer
+    kw = seq2gene_kw(layers=3)
+    model = build_model(SEQ2REG_512, kw, seed=77).cuda()
+    batch = make_batch(5, [30, 11], [4, 6], [TISSUES_54[:7], [9, 33, 2]], 200)
+    a = model.predict_step(batch, 0)
+    monkeypatch.setattr(ContextFlashAttentionEncoderLayer, "self_qkv_of_unique_rows", lambda self, *args: None)
+    b = model.predict_step(batch, 0)
+    for i in range(2):
+        np.testing.assert_array_equal(a["pred_gene_exp"][i], b["pred_gene_exp"][i])
+        np.testing.assert_array_equal(a["embeddings"][i], b["embeddings"][i])
+
+
 def test_tissue_invariance_and_batch_independence():
     """Size-independent properties: a gene's prediction does not depend on which other genes share its batch,
     nor on how many tissues are requested with it (the exact de-duplication must not leak between rows)."""
