@@ -113,8 +113,9 @@ class Seq2RegPredictor(nn.Module):
                 for layer in self.transformer_encoder:
                     x = layer.forward_packed(x, cu, Lmax, context=ctx, cu_ctx=cu, max_ctx=Lmax)
             else:
-                for layer in self.transformer_encoder:
-                    x = layer.forward_packed(x, cu, Lmax)
+                n_layers = len(self.transformer_encoder)
+                for li, layer in enumerate(self.transformer_encoder):
+                    x = layer.forward_packed(x, cu, Lmax, last=li + 1 == n_layers)
             if isinstance(x, ops.LnStream):                           # layers exchange (x, bf16 copy, row statistics)
                 x = x.x
             if self.seq_pool == "mean":                               # :263-267

@@ -26,9 +26,9 @@ class FlashTransformerLayer(nn.Module):
         self.dropout = nn.Dropout(mlp_dout)
         self.linear_geglu_2 = nn.Linear(hidden_dim // 2, d_model)
 
-    def forward_packed(self, src, cu: torch.Tensor, max_seqlen: int):
+    def forward_packed(self, src, cu: torch.Tensor, max_seqlen: int, last: bool = False):
         """src: fp32 [tokens, d] or an ops.LnStream; returns the same kind (an LnStream when LayerNorm is folded into
-        the GEMMs, see seq2gene.modules.layers.ln_fold_enabled)."""
+        the GEMMs, see seq2gene.modules.layers.ln_fold_enabled; a plain tensor from the `last` layer)."""
         from ..seq2gene.modules.layers import _as_stream, _as_tensor, ln_fold_enabled, packed_linear_ln
         if ln_fold_enabled(self.norm1.weight.numel()):
             s = _as_stream(src)
@@ -37,6 +37,8 @@ class FlashTransformerLayer(nn.Module):
             w1, b1, c1 = packed_linear_ln(self.linear_geglu_1, self.norm2, geglu=True)
             hg = ops.gemm_ln_consumer(x1, w1, b1, c1, ops.EPI_GEGLU_BF16)
             w2, b2 = packed_linear(self.linear_geglu_2)
+            if last:        # the encoder's last layer feeds the pooling, not a LayerNorm: plain fp32 result, no copy / statistics
+                return ops.gemm(hg, w2, b2, ops.EPI_RES_F32, residual=s.x)
             return ops.gemm_ln_producer(hg, w2, b2, s.x)
         src = _as_tensor(src)
         h = ops.layernorm(src, self.norm1.weight, self.norm1.bias)
