@@ -159,8 +159,90 @@ def cpu_baseline(model, hp, kw, executed_full: float, threads: int, budget_s: fl
                       f"executes per full-size gene"}
 
 
-def run_cfg3(args, model, hp, kw, dev, rank, world, use_dist):
-    """BASELINE configs[2]: 256 ragged genes, LPT-sharded, batches of <= genes_per_step, one gather per pass."""
+def _free_port() -> int:
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(args, argv) -> int:
+    """`python bench.py --gpus N` without a launcher around it: THIS process has made no GPU call (importing torch does
+    not initialise HIP), so it starts `python -m torch.distributed.run --nproc-per-node N bench.py <same flags>` as a CHILD
+    process (never an exec: a process that has touched the GPU must not be replaced, and a parent that has not must not
+    need to be), relays the child's stdout -- rank 0's one JSON line -- and returns the child's exit code."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_threads() // max(1, args.gpus))))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
+    json_lines = [ln for ln in lines if ln.lstrip().startswith("{")]
+    for ln in lines:
+        if ln not in json_lines:
+            print(ln, file=sys.stderr)
+    if json_lines:
+        print(json_lines[-1])
+    sys.stdout.flush()
+    return proc.returncode
+
+
+def timed_steps(step, steps: int, warmup: int, use_dist: bool, sync, dev):
+    """The contract's timed region: `warmup` untimed steps, then EXACTLY `steps` steps bracketed by a barrier + device
+    synchronisation on both sides; returns (seconds = MAX over ranks, the last step's result)."""
+    import torch.distributed as dist
+    out = None
+    for _ in range(warmup):
+        out = step()
+    sync()
+    if use_dist:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    sync()
+    if use_dist:
+        dist.barrier()
+    sync()
+    dt = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, out
+
+
+def run_stub(args, rank, world, use_dist):
+    """--stub (tests/test_bench_launcher_cpu.py only; the line says data = "stub" and is NOT a measurement): the
+    launcher, the process group (gloo, CPU), the timed-region skeleton, the per-step gather and the JSON relay with a
+    trivial step standing in for the model -- rank r's "expression" of gene g, tissue t is g * 100 + t."""
+    from variantformer_amd.dist import all_gather_expression
+    G, T = args.genes_per_step, args.tissues
+    dev = torch.device("cpu")
+    if os.environ.get("VF_BENCH_STUB_FAIL_RANK") == str(rank):      # the launcher test's failing rank
+        raise RuntimeError(f"stub: rank {rank} fails on request")
+    owned = [list(range(r * G, (r + 1) * G)) for r in range(world)]
+    local = torch.tensor([[g * 100.0 + t for t in range(T)] for g in owned[rank]], dtype=torch.float32)
+
+    def step():
+        return all_gather_expression(local, owned, world * G) if use_dist else all_gather_expression(local, [owned[0]], G)
+    dt, expr = timed_steps(step, args.steps, args.warmup, use_dist, lambda: None, dev)
+    want = torch.tensor([[g * 100.0 + t for t in range(T)] for g in range(world * G)], dtype=torch.float32)
+    assert torch.equal(expr, want), "gathered matrix is not in query order"
+    if rank == 0:
+        print(json.dumps({"metric": "genes/sec/node (54-tissue expr) at 1 Mb cis-window", "value": round(world * G * args.steps / dt, 4),
+                          "unit": "genes/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "none", "data": "stub",
+                          "config": {"workload": "STUB STEP (launcher / process-group test, not a measurement)",
+                                     "parallelism": f"gene-shard x{world}"}}))
+
+
+def cfg3_pass(args, model, hp, kw, dev, rank, world, use_dist, steps: int, warmup: int) -> dict:
+    """One strong-scaling measurement on BASELINE configs[2] (256 ragged genes, LPT shards, one gather per pass)."""
     import torch.distributed as dist
     from variantformer_amd.dist import all_gather_expression, gene_cost, shard_genes_lpt
     from variantformer_amd.utils.flops import batch_flops
@@ -180,61 +262,100 @@ def run_cfg3(args, model, hp, kw, dev, rank, world, use_dist):
             batch = collate([make_gene(20251205 * 1000003 + g, int(n[g]), int(c[g]), tissues, 200) for g in ids])
             flops_all += batch_flops(batch, hp["embedding_dim"], hp["num_layers"], kw["emb_dim"], kw["num_layers"])
             pbs.append(model.prepare_batch(batch))
+        busy_acc = [0.0]
 
         def one_pass():
             t0 = time.perf_counter()
             parts = [model.forward_prepared(pb)[0].view(pb.n_genes, T) for pb in pbs]
             local = torch.cat(parts) if parts else torch.empty((0, T), device=dev)
             torch.cuda.synchronize()
-            busy = time.perf_counter() - t0
+            busy_acc[0] += time.perf_counter() - t0
             expr = all_gather_expression(local, owned, n_genes) if use_dist else all_gather_expression(local, [mine], n_genes)
-            return expr.cpu(), busy
+            return expr.cpu()
 
-        for _ in range(args.warmup):
+        for _ in range(warmup):
             one_pass()
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        busy = 0.0
-        for _ in range(args.steps):
-            expr, b = one_pass()
-            busy += b
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        busy_acc[0] = 0.0
+        dt, expr = timed_steps(one_pass, steps, 0, use_dist, torch.cuda.synchronize, dev)
+        busy = busy_acc[0]
         busies = [busy]
         if use_dist:
-            t = torch.tensor([dt, busy, flops_all], device=dev, dtype=torch.float64)
+            t = torch.tensor([busy, flops_all], device=dev, dtype=torch.float64)
             allt = [torch.empty_like(t) for _ in range(world)]
             dist.all_gather(allt, t)
-            dt = float(max(float(x[0]) for x in allt))
-            busies = [float(x[1]) for x in allt]
-            flops_all = float(sum(float(x[2]) for x in allt))
+            busies = [float(x[0]) for x in allt]
+            flops_all = float(sum(float(x[1]) for x in allt))
         assert torch.isfinite(expr).all() and tuple(expr.shape) == (n_genes, T)
+    loads = [sum(costs[i] for i in o) for o in owned]
+    return {"value": round(n_genes * steps / dt, 4), "unit": "genes/sec", "scaling": "strong", "steps": steps, "warmup": warmup,
+            "ms_per_pass": round(dt / steps * 1e3, 3), "genes": n_genes, "batch_genes_per_launch": bs, "tissues": T,
+            "algorithmic_tflop_per_pass": round(flops_all / 1e12, 2),
+            "achieved_algorithmic_tflops_whole_step": round(flops_all * steps / dt / 1e12, 1),
+            "rank_busy_seconds_per_pass": [round(b / steps, 4) for b in busies],
+            "busy_imbalance_max_over_mean": round(max(busies) / (sum(busies) / len(busies)), 4),
+            "lpt_cost_imbalance_max_over_mean": round(max(loads) / (sum(loads) / len(loads)), 4),
+            "genes_per_rank": [len(o) for o in owned]}
+
+
+def run_cfg3(args, model, hp, kw, dev, rank, world, use_dist):
+    """--workload cfg3: the line's `value` is the strong-scaling pass over BASELINE configs[2]."""
+    import torch.distributed as dist
+    r = cfg3_pass(args, model, hp, kw, dev, rank, world, use_dist, args.steps, args.warmup)
     if rank == 0:
-        loads = [sum(costs[i] for i in o) for o in owned]
+        T = args.tissues
         print(json.dumps({
-            "metric": "genes/sec/node (54-tissue expr) at 1 Mb cis-window", "value": round(n_genes * args.steps / dt, 4),
+            "metric": "genes/sec/node (54-tissue expr) at 1 Mb cis-window", "value": r["value"],
             "unit": "genes/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "ms_per_step": r["ms_per_pass"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]: 256 ragged genes of one donor (N ~ lognormal(600, 0.6) in [40, 2048] "
                                    "cCRE windows, C ~ U{20..200} gene chunks, %d tissues), full 1.2B-architecture network, "
                                    "random-init weights; one step = one pass over all 256 genes, LPT gene shards, one "
                                    "all-gather of the [256, %d] expression matrix" % (T, T),
-                       "genes": n_genes, "batch_genes_per_launch": bs, "tissues": T, "parallelism": f"gene-shard (LPT) x{world}"},
-            "algorithmic_tflop_per_pass": round(flops_all / 1e12, 2),
-            "achieved_algorithmic_tflops_whole_step": round(flops_all * args.steps / dt / 1e12, 1),
-            "rank_busy_seconds_per_pass": [round(b / args.steps, 4) for b in busies],
-            "busy_imbalance_max_over_mean": round(max(busies) / (sum(busies) / len(busies)), 4),
-            "lpt_cost_imbalance_max_over_mean": round(max(loads) / (sum(loads) / len(loads)), 4),
-            "genes_per_rank": [len(o) for o in owned], "source_sha": source_sha()}))
+                       "genes": 256, "batch_genes_per_launch": args.genes_per_step, "tissues": T,
+                       "parallelism": f"gene-shard (LPT) x{world}"},
+            **{k: r[k] for k in ("algorithmic_tflop_per_pass", "achieved_algorithmic_tflops_whole_step",
+                                 "rank_busy_seconds_per_pass", "busy_imbalance_max_over_mean",
+                                 "lpt_cost_imbalance_max_over_mean", "genes_per_rank")},
+            "source_sha": source_sha()}))
     if use_dist:
         dist.destroy_process_group()
+
+
+def pipelined_product_flow(model, batch, n_batches: int, dev) -> dict:
+    """The product flow on the same genes, host work included: processors.trainer.Trainer.predict over a DataLoader whose
+    items are headline-size collate_fn_batching dicts on the HOST -- prepare_batch (concatenation, structure arrays), the
+    H2D copies, the forward and the D2H of expression AND embeddings (predict_step's dict), software-pipelined by one
+    batch (reference loop: processors/vcfprocessor.py:261-265).  Not `value`: `value` starts with inputs in HBM."""
+    from torch.utils.data import DataLoader, Dataset
+    from variantformer_amd.processors.trainer import Trainer
+
+    class Repeat(Dataset):              # the same host-resident batch n times (what a loader worker would hand over)
+        def __len__(self):
+            return n_batches
+
+        def __getitem__(self, i):
+            return batch
+    loader = DataLoader(Repeat(), batch_size=None, shuffle=False, num_workers=0)
+    trainer = Trainer(precision="bf16-mixed" if model.operand_dtype() == torch.bfloat16 else "16-mixed")
+    keep = model.precision
+    trainer.predict(model, DataLoader(Repeat(), batch_size=None, num_workers=0))        # warm (allocator, caches)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    outs = trainer.predict(model, loader)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    model.precision, model.trainer = keep, None
+    genes = sum(len(o["pred_gene_exp"]) for o in outs)
+    t1 = time.perf_counter()
+    for _ in range(3):
+        model.prepare_batch(batch)
+    torch.cuda.synchronize()
+    prep_ms = (time.perf_counter() - t1) / 3 * 1e3
+    return {"vcf2exp_pipelined_genes_per_s": round(genes / dt, 3), "batches": n_batches, "genes": genes,
+            "prepare_batch_ms_per_batch_incl_h2d": round(prep_ms, 2),
+            "note": "Trainer.predict over host-resident collate_fn_batching dicts: prepare_batch + H2D + forward + D2H of "
+                    "expression and embeddings, one batch of software pipelining; includes one batch of pipeline fill"}
 
 
 def main():
@@ -254,17 +375,32 @@ def main():
     ap.add_argument("--dtype", choices=["bf16", "fp16"], default="bf16", help="16-bit operand type (fp32 accumulation)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-cfg3", action="store_true", help="N > 1: skip the extra strong-scaling pass over BASELINE configs[2]")
+    ap.add_argument("--no-pipelined", action="store_true", help="skip the host-inclusive product-flow measurement")
+    ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)      # launcher test: no model, gloo on CPU
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:        # no launcher around us: start the ranks as a child process
+        sys.exit(self_launch(args, sys.argv[1:]))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or (world == 1 and args.gpus == 1), f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    import torch.distributed as dist
+    use_dist = "RANK" in os.environ          # launched by torch.distributed.run (also with one rank: exercises RCCL)
+    if args.stub:
+        if use_dist:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        run_stub(args, rank, world, use_dist)
+        if use_dist:
+            dist.destroy_process_group()
+        return
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback on the product path)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    import torch.distributed as dist
-    use_dist = "RANK" in os.environ          # launched by torch.distributed.run (also with one rank: exercises RCCL)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -290,41 +426,28 @@ def main():
     with torch.no_grad():
         pb = model.prepare_batch(batch)                      # inputs resident in HBM before the timed region
 
-        def step():
+        def step_local():
             pred, emb = model.forward_prepared(pb)
-            expr = pred.view(G, len(tissues))
+            return pred.view(G, len(tissues)), emb
+
+        def step():
+            expr, emb = step_local()
             if use_dist:
                 expr = all_gather_expression(expr, owned, world * G)
             return expr.cpu(), emb                            # D2H of the expression matrix (sync point of a step)
 
-        for _ in range(args.warmup):
-            step()
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            expr, _ = step()
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        if use_dist:
-            t = torch.tensor([dt], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        assert torch.isfinite(expr).all()
+        dt, (expr, _) = timed_steps(step, args.steps, args.warmup, use_dist, torch.cuda.synchronize, dev)
+        assert torch.isfinite(expr).all() and tuple(expr.shape) == (world * G, len(tissues))
 
         roof = None
         kernels = {}
         if rank == 0 and not args.no_kernel_timing:
             # Per-kernel durations: the same K steps replayed with HIP events bracketing each launch on the launch
-            # stream (kept out of the timed region above so that event overhead does not enter `value`).
+            # stream (kept out of the timed region above so that event overhead does not enter `value`).  The replay is
+            # LOCAL (no gather): the other ranks are not replaying, and a collective here would wait for them forever.
             ops.TIMER = ops.KernelTimer()
             for _ in range(args.steps):
-                step()
+                step_local()[0].cpu()
             summ = ops.TIMER.summary()
             ops.TIMER = None
             g = summ["gemm"]
@@ -340,8 +463,8 @@ def main():
                     "avg_launch_us": round(g["total_ms"] * 1e3 / g["launches"], 2),
                     "flop_per_launch": g["flops"] / g["launches"],
                     "share_of_step_time": round(g["total_ms"] / args.steps / step_ms, 3),
-                    "note": ("bf16 mode: the GEMM launches also carry the LayerNorms of the layers (producer epilogues write "
-                             "the bf16 copy of the fp32 stream + per-row partial statistics, consumer epilogues apply mean / "
+                    "note": ("the GEMM launches also carry the LayerNorms of the layers (producer epilogues write "
+                             "the 16-bit copy of the fp32 stream + per-row partial statistics, consumer epilogues apply mean / "
                              "rstd; DESIGN.md section 6) -- their bytes are in algorithmic_bytes_per_launch, their time in "
                              "avg_launch_us; VF_LN_FOLD=0 restores the separate LayerNorm pass")}
             # Per kernel family (KernelTimer families: the module that launched the kernel).  Every family is priced
@@ -365,6 +488,14 @@ def main():
                     ent.update({"bound": "hbm", "frac_of_roofline": round(r["bytes"] / sec / 1e9 / HBM_PEAK_GBS, 4)})
                 kernels[f"{kind}/{fam}"] = ent
 
+        strong = None
+        if world > 1 and not args.no_cfg3:
+            # the informative multi-GPU number: total work fixed (BASELINE configs[2]), LPT shards, busy time per rank
+            strong = cfg3_pass(args, model, hp, kw, dev, rank, world, use_dist, steps=2, warmup=1)
+        flow = None
+        if rank == 0 and world == 1 and not args.no_pipelined:
+            flow = pipelined_product_flow(model, batch, max(4, min(args.steps, 10)), dev)
+
     if rank == 0:
         value = world * G * args.steps / dt
         out = {
@@ -382,6 +513,10 @@ def main():
             "achieved_algorithmic_tflops_whole_step": round(world * flops_step * args.steps / dt / 1e12, 1),
             "roofline": roof, "kernel_families": kernels, "source_sha": source_sha(),
         }
+        if strong is not None:
+            out["cfg3_strong_scaling"] = strong
+        if flow is not None:
+            out.update({"vcf2exp_pipelined_genes_per_s": flow["vcf2exp_pipelined_genes_per_s"], "vcf2exp_pipelined": flow})
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(model, hp, kw, executed_step / G, host_threads())
         print(json.dumps(out))

@@ -79,8 +79,8 @@ int vf_gemm_f16_ex(const void* A, int64_t lda, const void* W, const float* bias,
 
 /* LayerNorm without a pass of its own: LN(x) . W^T = rstd * (x . (gamma (.) W)^T - mean * rowsum(gamma (.) W))
  * + (W . beta + b).  The GEMM that PRODUCES the fp32 stream x (epilogue VF_EPI_F32 / VF_EPI_RES_F32) also writes
- * out16 = the bf16 copy of x [M, ld16] and part_stats [ceil(N/32), M, 2] = (sum, sum of squares) of every 32-column part
- * of the row (give out16 + part_stats, leave row_stats / colsum NULL); vf_ln_finalize turns the parts into row_stats
+ * out16 = the bf16 copy of x [M, ld16] and part_stats [ceil(N/32), M, 2] = (sum, second moment about the part's own mean) of every
+ * 32-column part of the row (give out16 + part_stats, leave row_stats / colsum NULL); vf_ln_finalize turns the parts into row_stats
  * [M, 2] = (mean, rstd); the GEMM that CONSUMES LN(x) (epilogue VF_EPI_BF16 / VF_EPI_GEGLU_BF16) takes A = out16,
  * W = bf16(gamma (.) W), bias = W . beta + b, colsum[n] = sum_k W'[n][k] and row_stats (give those two, leave out16 /
  * part_stats NULL).  A producer whose fp32 result nobody reads (only out16 and the statistics are consumed: the layers'

@@ -85,3 +85,30 @@ def test_live_cross_check_against_huggingface_tokenizers(enc):
         cases.append("".join(rng.choice(list("AC"), n, p=[.9, .1])))              # long runs of one base
     for s in cases:
         assert enc.encode_forward(s).tolist() == ref.encode(s).ids, (len(s), s[:40])
+
+
+def test_create_refuses_merge_lists_the_bucket_order_cannot_serve():
+    """vf_bpe_create accepts only merge lists in which every rule ranks above EVERY rule that creates one of its operands
+    (true of any BPE-trained vocabulary).  A token id produced by two rules, with a rule about that id ranked between the
+    two, would put a pair created by the later rule into a rank bucket that was already processed (round-2 advice): such
+    a list must be refused, not mis-tokenised."""
+    import ctypes as C
+    import numpy as np
+    from variantformer_amd import _lib
+    lib = _lib.load()
+    lib.vf_bpe_create.restype = C.c_void_p
+    lib.vf_bpe_create.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    lib.vf_bpe_destroy.argtypes = [C.c_void_p]
+    char_ids = np.full(256, -1, np.int32)
+    for k, ch in enumerate("ACGT"):
+        char_ids[ord(ch)] = k                                   # ids 0..3 = A C G T; 4, 5, 6 = merged tokens
+    ok = np.array([[0, 1, 4], [4, 2, 5], [2, 3, 6]], np.int32)               # AC -> 4, (4, G) -> 5, GT -> 6: monotone
+    h = lib.vf_bpe_create(char_ids.ctypes.data, 7, ok.ctypes.data, len(ok))
+    assert h
+    lib.vf_bpe_destroy(h)
+    # id 4 is created at rank 0 (AC) and again at rank 2 (GT); the rule (4, A) at rank 1 lies between the two
+    bad = np.array([[0, 1, 4], [4, 0, 5], [2, 3, 4]], np.int32)
+    assert not lib.vf_bpe_create(char_ids.ctypes.data, 7, bad.ctypes.data, len(bad))
+    # an operand that is created only later
+    bad2 = np.array([[4, 0, 5], [0, 1, 4]], np.int32)
+    assert not lib.vf_bpe_create(char_ids.ctypes.data, 7, bad2.ctypes.data, len(bad2))

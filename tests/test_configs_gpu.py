@@ -16,7 +16,7 @@ import torch
 
 from oracle import vf_oracle as O
 from tests.conftest import load_vep_model_fixture
-from tests.helpers import SEQ2REG_512, build_model, seq2gene_kw, state_dict_cpu
+from tests.helpers import SEQ2REG_512, build_model, check_signal, erel, prel, seq2gene_kw, state_dict_cpu
 from variantformer_amd.dist import gene_cost, shard_batch, shard_genes_lpt
 from variantformer_amd.utils.synthetic import TISSUES_54, cfg3_gene_sizes, make_batch, make_vep_batch
 
@@ -27,12 +27,6 @@ EMB_RTOL = 1e-2            # 1536-wide embedding rows after 49 bf16-operand laye
 SEAM_RTOL = 1e-2           # one attention module: bf16 attention output (half an ulp = 2^-9) mixed by out_proj; the kernel
                            # rounds P against the running max, the oracle against the final max (same bound as
                            # tests/test_ops_gpu.py::test_attention_matches_oracle: rtol 2^-7)
-
-
-def erel(a, b):
-    """max over elements of |a-b| / (|b| + rms(b))."""
-    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
-    return float((np.abs(a - b) / (np.abs(b) + np.sqrt((b * b).mean()) + 1e-30)).max())
 
 
 @pytest.fixture(scope="module")
@@ -58,12 +52,19 @@ def test_cfg1_single_gene_128kb_one_tissue(full_model):
     out = model.predict_step(batch, 0)
     assert out["pred_gene_exp"][0].shape == (1, 1) and out["embeddings"][0].shape == (1, 1536)
     orc = _oracle(batch, sd, hp, kw)
-    assert erel(out["pred_gene_exp"][0], orc["pred_gene_exp"][0]) < NORTH_STAR_RTOL
+    assert prel(out["pred_gene_exp"][0], orc["pred_gene_exp"][0]) < NORTH_STAR_RTOL
     assert erel(out["embeddings"][0], orc["embeddings"][0]) < EMB_RTOL
     f32 = _oracle(batch, sd, hp, kw, rounding=None)
-    e_pred, e_emb = erel(out["pred_gene_exp"][0], f32["pred_gene_exp"][0]), erel(out["embeddings"][0], f32["embeddings"][0])
+    e_pred, e_emb = prel(out["pred_gene_exp"][0], f32["pred_gene_exp"][0]), erel(out["embeddings"][0], f32["embeddings"][0])
     print(f"[cfg1] HIP(bf16 operands) vs fp32 oracle, full depth: expression {e_pred:.2e}, embedding {e_emb:.2e} (element-wise)")
-    assert e_pred < 1e-2 and e_emb < 5e-2            # bf16-operand deviation from fp32 arithmetic, stated not hidden
+    # bf16 operands against pure fp32 arithmetic: the expression meets the north-star bar (1e-3 relative) directly; the
+    # 1536-wide embedding row carries the bf16 noise of 49 layers (measured 7e-3 ... 1.1e-2)
+    assert e_pred < NORTH_STAR_RTOL and e_emb < 2e-2
+    # signal scale for a one-value output: the same gene over all 54 tissues (HIP), error of the one tissue against it
+    spread = float(np.std(model.predict_step(dict(batch, tissue_context=[torch.tensor(TISSUES_54)]), 0)["pred_gene_exp"][0]))
+    err = float(np.abs(out["pred_gene_exp"][0] - f32["pred_gene_exp"][0]).max())
+    print(f"[signal] cfg1 vs pure fp32: |err| {err:.2e} = {err / spread:.2e} of the 54-tissue spread {spread:.3e}")
+    assert err / spread < 5e-2
 
 
 def test_cfg3_256_ragged_genes_lpt_shards(full_model):
@@ -100,7 +101,8 @@ def test_cfg3_256_ragged_genes_lpt_shards(full_model):
     cheapest = sorted(range(n_genes), key=lambda i: costs[i])[:3]
     orc = _oracle(gene_batch(cheapest), sd, hp, kw)
     for j, g in enumerate(cheapest):
-        assert erel(a[g], orc["pred_gene_exp"][j][:, 0]) < NORTH_STAR_RTOL, (g, int(n[g]), int(c[g]))
+        assert prel(a[g], orc["pred_gene_exp"][j][:, 0]) < NORTH_STAR_RTOL, (g, int(n[g]), int(c[g]))
+    check_signal("cfg3, three genes x 54 tissues", [a[g] for g in cheapest], [orc["pred_gene_exp"][j][:, 0] for j in range(3)])
     loads = [sum(costs[i] for i in o) for o in owned]
     print(f"[cfg3] LPT imbalance max/mean = {max(loads) / (sum(loads) / 8):.4f}; genes per rank {[len(o) for o in owned]}")
 
@@ -109,6 +111,53 @@ def make_batch_by_gene(ids, n, c):
     """collate of the cfg-3 genes `ids`: gene g is always built from seed (20251205, g), whatever batch it lands in."""
     from variantformer_amd.utils.synthetic import collate, make_gene
     return collate([make_gene(20251205 * 1000003 + int(g), int(n[g]), int(c[g]), TISSUES_54, 200) for g in ids])
+
+
+def test_cfg5_whole_genome_scan_fp16_ragged_genes(full_model):
+    """BASELINE configs[4] workload ("whole-genome scan ... fp16 with fp32 accumulate"; SURVEY 8d cfg 5: 40 000 genes from
+    the cfg-3 distribution): 32 genes of that draw (indices 256 ... 287, i.e. not the 256 of cfg 3), full depth,
+    precision "16-mixed" -> fp16 operands.  (1) the three cheapest genes against oracle(rounding="fp16") and against pure
+    fp32; (2) every gene is independent of its shard and batch: LPT shards of 8 ranks in batches of 8 vs round-robin
+    shards in batches of 5; (3) finite, positive, query order."""
+    model, hp, kw, sd = full_model
+    T, first, count = 54, 256, 32
+    n_all, c_all = cfg3_gene_sizes(40000)
+    ids_all = list(range(first, first + count))
+    n, c = {g: int(n_all[g]) for g in ids_all}, {g: int(c_all[g]) for g in ids_all}
+    costs = [gene_cost(n[g], c[g], T) for g in ids_all]
+    owned = [[ids_all[i] for i in o] for o in shard_genes_lpt(costs, 8)]
+
+    def run(partition, bs):
+        expr = {}
+        for shard in partition:
+            for s0 in range(0, len(shard), bs):
+                ids = shard[s0:s0 + bs]
+                out = model.predict_step(make_batch_by_gene(ids, n_all, c_all), 0)
+                for j, g in enumerate(ids):
+                    expr[g] = out["pred_gene_exp"][j][:, 0]
+        return np.stack([expr[g] for g in ids_all])
+
+    keep = model.precision
+    model.precision = "16-mixed"
+    try:
+        assert model.operand_dtype() == torch.float16
+        a = run(owned, 8)
+        assert a.shape == (count, T) and np.isfinite(a).all() and (a > 0).all()
+        b = run([ids_all[r::8] for r in range(8)], 5)
+        np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-6)
+        cheapest = [ids_all[i] for i in sorted(range(count), key=lambda i: costs[i])[:3]]
+        batch = make_batch_by_gene(cheapest, n_all, c_all)
+        orc = _oracle(batch, sd, hp, kw, rounding="fp16")
+        f32 = _oracle(batch, sd, hp, kw, rounding=None)
+        for j, g in enumerate(cheapest):
+            got = a[ids_all.index(g)]
+            e16, e32 = prel(got, orc["pred_gene_exp"][j][:, 0]), prel(got, f32["pred_gene_exp"][j][:, 0])
+            print(f"[cfg5] gene {g} (N={n[g]}, C={c[g]}): fp16-operand HIP vs oracle(fp16) {e16:.2e}, vs pure fp32 {e32:.2e}")
+            assert e16 < NORTH_STAR_RTOL and e32 < NORTH_STAR_RTOL
+        check_signal("cfg5 fp16, three genes x 54 tissues vs oracle(fp16)", [a[ids_all.index(g)] for g in cheapest],
+                     [orc["pred_gene_exp"][j][:, 0] for j in range(3)])
+    finally:
+        model.precision = keep
 
 
 def test_cfg4_paired_ref_alt_full_size(full_model):
@@ -277,8 +326,8 @@ def test_variant_prediction_vs_reference_golden():
     orc = O.variant_prediction(vb, sd, hp, hp, ghp, rounding="bf16", share_cre_stream=True)
     assert out["variant_type"] == meta["variant_type"]
     for i in range(3):
-        assert erel(out["pred_gene_exp"][i], arrays[f"pos.pred_gene_exp_{i}"]) < NORTH_STAR_RTOL
-        assert erel(out["pred_gene_exp"][i], orc["pred_gene_exp"][i]) < NORTH_STAR_RTOL
+        assert prel(out["pred_gene_exp"][i], arrays[f"pos.pred_gene_exp_{i}"]) < NORTH_STAR_RTOL
+        assert prel(out["pred_gene_exp"][i], orc["pred_gene_exp"][i]) < NORTH_STAR_RTOL
         for k, ref_tol in (("embd", 1e-2), ("gene_token_embedding", 1e-2), ("cre_token_embedding", 1e-2)):
             got = out[k][i]
             assert got.shape == arrays[f"pos.{k}_{i}"].shape
@@ -307,6 +356,6 @@ def test_variant_prediction_production_width_vs_oracle():
     hp = O.Seq2RegHP.from_hparams(SEQ2REG_512)
     orc = O.variant_prediction(vb, sd, hp, hp, O.Seq2GeneHP.from_kwargs(kw), rounding="bf16", share_cre_stream=True)
     for i in range(3):
-        assert erel(out["pred_gene_exp"][i], orc["pred_gene_exp"][i]) < NORTH_STAR_RTOL
+        assert prel(out["pred_gene_exp"][i], orc["pred_gene_exp"][i]) < NORTH_STAR_RTOL
         for k in ("embd", "gene_token_embedding", "cre_token_embedding"):
             assert erel(out[k][i], orc[k][i]) < 5e-3, (k, i)

@@ -216,15 +216,72 @@ def test_bcftools_iupac_rule_known_answers(tmp_path):
     #       A  K  G  KM  C  GTT  T  A    G  TAAA  A  C        A  T  G  T  AC
     want = "A" "K" "G" "KM" "C" "GTT" "T" "A" "G" "TAAA" "A" "C" "A" "T" "G" "T" "AC"
     assert got == want and n == 7
-    # SNP mode keeps a record as soon as ONE alt is a snp (bcftools TYPE!="snp" is false then): the mixed record at 12
-    # takes part (and applies its insertion allele, which is what the genotype names), the pure indels / MNPs do not --
-    # so the SNP at 15, no longer inside an applied deletion, is applied
-    got_snp, _ = h.consensus("chr1", 0, ref, True)
-    assert got_snp == "A" "K" "G" "TA" "C" "G" "T" "AC" "G" "TAAA" "A" "CAT" "A" "T" "G" "T" "AC"
+    # SNP mode = -e 'ALT~"<.*>" || TYPE!="snp"': bcftools compares TYPE as a bit set, `=` / `!=` against the union of the
+    # alleles' types, so a site is kept only when EVERY ALT is a snp (bcftools(1) EXPRESSIONS; filter.c
+    # filters_cmp_bit_and).  The mixed snp + insertion record at 12 is dropped like the pure indels / MNPs, and the snp at
+    # 15, no longer inside an applied deletion, is applied.
+    got_snp, n_snp = h.consensus("chr1", 0, ref, True)
+    assert got_snp == "AKGTACGTACGTACATATGTAC" and n_snp == 3
     # lower-case reference bases keep their case under same-length replacements
     vcf2 = str(tmp_path / "c.vcf")
     write_vcf(vcf2, {"chr1": [(2, "CG", ["TA"], "0/1")]})
     assert dp.VCFHandle(vcf2).consensus("chr1", 0, "AcGT", False)[0] == "AyRT"
+
+
+def test_snp_filter_is_all_alleles_and_uses_trimmed_types(tmp_path):
+    """TYPE!="snp" under the SNP filter (reference utils/data_process.py:38-59, SNP mode): the site's type set must be
+    exactly {snp}.  Types are per ALT allele after trimming the common prefix / suffix against REF (htslib
+    bcf_set_variant_type), so REF=AT ALT=AC is a snp although REF has two bases; '*' is its own type (overlap)."""
+    #      12345678901234567890
+    ref = "ACGTACGTACGTACGTACGT"
+    recs = [(1, "A", ["G", "AT"], "1/2"),       # snp + insertion: mixed -> dropped (even though the genotype names the snp)
+            (3, "GT", ["GC"], "0/1"),           # snp written with a flanking base: type snp -> applied position-wise: G, {T,C}=Y
+            (6, "C", ["T", "*"], "0/1"),        # snp + '*': type set {snp, overlap} -> dropped
+            (8, "T", ["A", "G"], "1/2"),        # two snps -> kept: {A,G}=R
+            (10, "CG", ["TA"], "1/1"),          # MNP -> dropped
+            (13, "A", ["A"], "0/1"),            # ALT identical to REF adds no type bit; no snp either -> type set {} != {snp}: dropped
+            (15, "GTA", ["GCA"], "1/1"),        # snp in the middle of a 3-base REF -> snp: applied, G C A
+            (18, "C", ["."], "0/1")]            # '.' is written as an ALT string here: not a base, not a snp -> dropped
+    vcf = str(tmp_path / "t.vcf")
+    write_vcf(vcf, {"chr1": recs})
+    h = dp.VCFHandle(vcf)
+    got, n = h.consensus("chr1", 0, ref, True, indel_policy="error")       # nothing here needs an indel rule in SNP mode
+    #       1 2 3 4 5 6 7 8 9 0 1 2 3 4 5 6 7 8 9 0
+    want = "A" "C" "G" "Y" "A" "C" "G" "R" "A" "C" "G" "T" "A" "C" "G" "C" "A" "C" "G" "T"
+    assert got == want and n == 3
+
+
+def test_overlapping_deletions_and_window_edges(tmp_path, capfd):
+    """All-variants mode (vcf2exp path, -e 'ALT~"<.*>"' only), cases round 2's advisor listed as thin: a deletion that
+    overlaps an applied deletion is skipped (bcftools: "overlaps with another variant, skipping"), a deletion that
+    starts inside the window but runs past its end is skipped, one that starts before the window is not seen at all
+    (records are located by POS, as `bcftools consensus` over a `samtools faidx` region does), and a deletion that ends
+    exactly at the window end is applied.  The first non-SNP record applied under the default policy prints the
+    parity-unpinned notice once."""
+    #      1234567890123456
+    ref = "ACGTACGTACGTACGT"
+    recs = [(2, "CGT", ["C"], "1/1"),           # deletes 3-4
+            (3, "GTA", ["G"], "1/1"),           # starts inside the span of the applied deletion -> skipped
+            (4, "T", ["C"], "1/1"),             # snp inside the applied deletion -> skipped
+            (6, "CG", ["C"], "0/1"),            # het deletion: unequal lengths -> first non-REF allele = the deletion
+            (7, "G", ["T"], "1/1"),             # overlaps the record at 6 (REF span 6-7) -> skipped
+            (9, "ACGT", ["A"], "1/1"),          # deletes 10-12
+            (12, "T", ["TGG"], "1/1"),          # insertion anchored on a deleted base -> skipped
+            (14, "CGT", ["C"], "1/1")]          # ends exactly at the window end (16) -> applied
+    vcf = str(tmp_path / "o.vcf")
+    write_vcf(vcf, {"chr1": recs})
+    h = dp.VCFHandle(vcf)
+    got, n = h.consensus("chr1", 0, ref, False)
+    assert got == "AC" "A" "C" "TA" "A" "C" and n == 4          # A C [GT gone] A C [G gone] T A [CGT gone] A C [GT gone]
+    err = capfd.readouterr().err
+    assert err.count("parity with bcftools 1.21 is UNPINNED") <= 1             # once per process (maybe earlier in the run)
+    # the same records seen through narrower windows
+    assert h.consensus("chr1", 0, ref[:15], False)[0] == "AC" "A" "C" "TA" "A" "CG"     # 14:CGT>C would cross the end: skipped
+    # window starting at position 3: the record at POS 2 lies outside, so the one at 3 (GTA>G, deletes 4-5) is now the
+    # first to apply: G | C (6:CG>C) | T | A (9:ACGT>A) | A | C (14:CGT>C)
+    assert h.consensus("chr1", 2, ref[2:], False)[0] == "GCTAAC"
+    with pytest.raises(dp.ConsensusError):
+        h.consensus("chr1", 0, ref, False, indel_policy="error")                # strict mode refuses the first indel
 
 
 def test_sample_selection_and_plain_text(world, tmp_path):

@@ -142,3 +142,43 @@ def test_predict_sharded_single_process_and_empty_shard():
     assert res["embeddings"][3][2].tolist() == [3.5, 32.0, -1.0]
     out = all_gather_ragged([np.ones((2, 4), np.float32)], [[0]], 1, "cpu")
     assert out[0].shape == (2, 4)
+
+
+def _toy_predict_failing(batch, batch_idx):
+    if 4 in batch["gene"]:
+        raise ValueError("gene 4 cannot be built")
+    return _toy_predict(batch, batch_idx)
+
+
+def _failing_worker(rank, world, port, n, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from variantformer_amd.dist import predict_sharded
+        try:
+            predict_sharded(_toy_predict_failing, _ToyGenes(n), _toy_collate, costs=[1.0] * n, batch_size=2, device="cpu")
+            q.put((rank, "no error"))
+        except Exception as e:                                   # noqa: BLE001
+            q.put((rank, f"{type(e).__name__}: {e}"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_predict_sharded_failure_on_one_rank_raises_on_every_rank():
+    """A rank whose predict_batch raises must not leave the others blocked in the gathers (round-2 advice): one small
+    all-reduce of a failure flag precedes them, and EVERY rank raises -- the failing one its own error, the others a
+    RuntimeError naming the situation.  Both processes must finish within seconds, not at a collective timeout."""
+    world, n = 2, 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    msgs = sorted(res.values())
+    assert any(m.startswith("ValueError: gene 4") for m in msgs), msgs
+    assert any(m.startswith("RuntimeError: predict_sharded: another rank failed") for m in msgs), msgs

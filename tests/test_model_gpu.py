@@ -12,7 +12,7 @@ import torch
 
 from oracle import vf_oracle as O
 from tests.conftest import load_fixture
-from tests.helpers import SEQ2REG_512, build_model, seq2gene_kw, state_dict_cpu
+from tests.helpers import SEQ2REG_512, build_model, check_signal, prel, seq2gene_kw, state_dict_cpu
 from variantformer_amd.utils.synthetic import TISSUES_54, make_batch
 
 pytestmark = pytest.mark.gpu
@@ -49,10 +49,13 @@ def test_predict_step_vs_reference_golden(golden):
         assert p.dtype == np.float32 and p.shape == (len(meta["tissues"][i]), 1)
         assert e.shape == (len(meta["tissues"][i]), meta["seq2gene"]["emb_dim"])
         # expression output vs the REFERENCE's fp32 value: inside the north-star tolerance directly
-        assert _rel(p, arrays[f"pred_gene_exp_{i}"]) < NORTH_STAR_RTOL
+        assert prel(p, arrays[f"pred_gene_exp_{i}"]) < NORTH_STAR_RTOL
         assert _rel(e, arrays[f"embeddings_{i}"]) < 5e-3               # bf16-operand noise on a D-wide vector (max norm)
-        assert _rel(p, orc["pred_gene_exp"][i]) < NORTH_STAR_RTOL
+        assert prel(p, orc["pred_gene_exp"][i]) < NORTH_STAR_RTOL
         assert _rel(e, orc["embeddings"][i]) < 3 * NORTH_STAR_RTOL     # 1536-wide vector: max over many elements
+    n = len(meta["n_cres"])
+    check_signal("golden fixture vs reference fp32", out["pred_gene_exp"], [arrays[f"pred_gene_exp_{i}"] for i in range(n)])
+    check_signal("golden fixture vs same-rounding oracle", out["pred_gene_exp"], orc["pred_gene_exp"])
 
 
 def test_seq2reg_embeddings_vs_reference_golden(golden):
@@ -117,8 +120,9 @@ def test_production_dims_vs_oracle(case):
     ghp = O.Seq2GeneHP.from_kwargs(kw)
     orc = O.predict_step(batch, sd, hp, hp, ghp, rounding="bf16", share_cre_stream=True)
     for i in range(len(n_cres)):
-        assert _rel(out["pred_gene_exp"][i], orc["pred_gene_exp"][i]) < NORTH_STAR_RTOL
+        assert prel(out["pred_gene_exp"][i], orc["pred_gene_exp"][i]) < NORTH_STAR_RTOL
         assert _rel(out["embeddings"][i], orc["embeddings"][i]) < 3 * NORTH_STAR_RTOL
+    check_signal(case, out["pred_gene_exp"], orc["pred_gene_exp"])
 
 
 def test_separate_layernorm_pass_mode_vs_oracle(monkeypatch):
@@ -137,10 +141,11 @@ def test_separate_layernorm_pass_mode_vs_oracle(monkeypatch):
     ghp = O.Seq2GeneHP.from_kwargs(kw)
     orc = O.predict_step(batch, sd, hp, hp, ghp, rounding=O.Rounding("bf16", fold_ln=False), share_cre_stream=True)
     for i in range(2):
-        assert _rel(plain["pred_gene_exp"][i], orc["pred_gene_exp"][i]) < NORTH_STAR_RTOL
+        assert prel(plain["pred_gene_exp"][i], orc["pred_gene_exp"][i]) < NORTH_STAR_RTOL
         assert _rel(plain["embeddings"][i], orc["embeddings"][i]) < 3 * NORTH_STAR_RTOL
-        assert _rel(plain["pred_gene_exp"][i], folded["pred_gene_exp"][i]) < 10 * NORTH_STAR_RTOL
+        assert prel(plain["pred_gene_exp"][i], folded["pred_gene_exp"][i]) < 10 * NORTH_STAR_RTOL
         assert not np.array_equal(plain["embeddings"][i], folded["embeddings"][i])      # two different rounding contracts
+    check_signal("VF_LN_FOLD=0 vs oracle(fold_ln=False)", plain["pred_gene_exp"], orc["pred_gene_exp"])
 
 
 def test_first_gene_layer_projection_dedup_is_exact(monkeypatch):
@@ -211,14 +216,18 @@ def test_full_depth_production_model_vs_oracle():
     f32 = O.predict_step(batch, sd, shp, shp, O.Seq2GeneHP.from_kwargs(kw), rounding=None, share_cre_stream=True)
     for i in range(2):
         assert np.isfinite(out["pred_gene_exp"][i]).all()
-        assert _rel(out["pred_gene_exp"][i], orc["pred_gene_exp"][i]) < NORTH_STAR_RTOL
+        assert prel(out["pred_gene_exp"][i], orc["pred_gene_exp"][i]) < NORTH_STAR_RTOL
         assert _rel(out["embeddings"][i], orc["embeddings"][i]) < 5e-3
         # the real bf16-operand deviation from fp32 arithmetic at full depth, element-wise (|a-b| / (|b| + rms(b)))
-        ep, ee = _erel(out["pred_gene_exp"][i], f32["pred_gene_exp"][i]), _erel(out["embeddings"][i], f32["embeddings"][i])
+        ep, ee = prel(out["pred_gene_exp"][i], f32["pred_gene_exp"][i]), _erel(out["embeddings"][i], f32["embeddings"][i])
         print(f"[full depth] gene {i}: HIP vs fp32 oracle element-wise: expression {ep:.2e}, embedding {ee:.2e}; "
               f"vs same-rounding oracle: expression {_erel(out['pred_gene_exp'][i], orc['pred_gene_exp'][i]):.2e}, "
               f"embedding {_erel(out['embeddings'][i], orc['embeddings'][i]):.2e}")
-        assert ep < 1e-2 and ee < 5e-2
+        # bf16 OPERANDS against pure fp32 ARITHMETIC at full depth: the expression still meets the north-star bar; the
+        # 1536-wide embedding rows carry the bf16 noise of 49 layers (measured 7e-3 ... 1.1e-2 element-wise)
+        assert ep < NORTH_STAR_RTOL and ee < 2e-2
+    check_signal("full depth vs same-rounding oracle", out["pred_gene_exp"], orc["pred_gene_exp"])
+    check_signal("full depth, bf16 operands vs pure fp32 oracle", out["pred_gene_exp"], f32["pred_gene_exp"])
 
 
 def test_vep_window_dedupe_is_exact():
@@ -256,8 +265,10 @@ def test_two_module_variant_vs_reference_golden():
     b["cre_attention_mask"] = b.pop("cre_attention_masks")           # the key this class reads in the reference
     out = m.predict_step(b, 0)
     for i in range(len(meta["n_cres"])):
-        assert _rel(out["pred_gene_exp"][i], arrays[f"pred_gene_exp_{i}"]) < NORTH_STAR_RTOL
+        assert prel(out["pred_gene_exp"][i], arrays[f"pred_gene_exp_{i}"]) < NORTH_STAR_RTOL
         assert _rel(out["embeddings"][i], arrays[f"embeddings_{i}"]) < 5e-3
+    check_signal("two-module class vs reference fp32", out["pred_gene_exp"],
+                 [arrays[f"pred_gene_exp_{i}"] for i in range(len(meta["n_cres"]))])
 
 
 def test_edge_geometries_vs_oracle():
@@ -274,8 +285,9 @@ def test_edge_geometries_vs_oracle():
     orc = O.predict_step(batch, sd, hp, hp, O.Seq2GeneHP.from_kwargs(kw), rounding="bf16", share_cre_stream=True)
     for i in range(3):
         assert out["pred_gene_exp"][i].shape == orc["pred_gene_exp"][i].shape
-        assert _rel(out["pred_gene_exp"][i], orc["pred_gene_exp"][i]) < NORTH_STAR_RTOL
+        assert prel(out["pred_gene_exp"][i], orc["pred_gene_exp"][i]) < NORTH_STAR_RTOL
         assert _rel(out["embeddings"][i], orc["embeddings"][i]) < 5e-3
+    check_signal("edge geometries", out["pred_gene_exp"], orc["pred_gene_exp"])
 
 
 def test_last_layer_registry_only_path_is_exact():
@@ -316,8 +328,9 @@ def test_headline_size_gene_vs_oracle_and_properties():
     shp = O.Seq2RegHP.from_hparams(hp)
     torch.set_num_threads(min(16, bench.host_threads()))
     orc = O.predict_step(first, sd, shp, shp, O.Seq2GeneHP.from_kwargs(kw), rounding="bf16", share_cre_stream=True)
-    assert _rel(alone["pred_gene_exp"][0], orc["pred_gene_exp"][0]) < NORTH_STAR_RTOL
+    assert prel(alone["pred_gene_exp"][0], orc["pred_gene_exp"][0]) < NORTH_STAR_RTOL
     assert _rel(alone["embeddings"][0], orc["embeddings"][0]) < 5e-3
+    check_signal("headline gene, 54 tissues", alone["pred_gene_exp"][0], orc["pred_gene_exp"][0])
 
 
 @pytest.mark.parametrize("name", ["small_opts_a", "small_opts_b", "small_opts_c", "small_opts_d"])
@@ -337,10 +350,12 @@ def test_non_shipped_options_vs_reference_golden(name):
         p, e = out["pred_gene_exp"][i], out["embeddings"][i]
         assert p.shape == (len(meta["tissues"][i]), 1) and e.shape == (len(meta["tissues"][i]), meta["seq2gene"]["emb_dim"])
         emb_tol = 1e-2 if meta["seq2gene"]["gene_pooling"] == "max" else 5e-3   # max pooling keeps per-column extremes
-        assert _rel(p, arrays[f"pred_gene_exp_{i}"]) < NORTH_STAR_RTOL                # of bf16-noisy rows
+        assert prel(p, arrays[f"pred_gene_exp_{i}"]) < NORTH_STAR_RTOL                # of bf16-noisy rows
         assert _rel(e, arrays[f"embeddings_{i}"]) < emb_tol
-        assert _rel(p, orc["pred_gene_exp"][i]) < NORTH_STAR_RTOL
+        assert prel(p, orc["pred_gene_exp"][i]) < NORTH_STAR_RTOL
         assert _rel(e, orc["embeddings"][i]) < emb_tol
+    check_signal(name + " vs reference fp32", out["pred_gene_exp"],
+                 [arrays[f"pred_gene_exp_{i}"] for i in range(len(meta["n_cres"]))])
     if not general:
         return
     model.vep = True
@@ -382,11 +397,12 @@ def test_fp16_operand_mode_vs_oracle_and_reference_golden(golden):
     orc = O.predict_step(batch, sd, cre_hp, gene_hp, hp, rounding="fp16", share_cre_stream=True)
     e16 = ebf = 0.0
     for i in range(len(meta["n_cres"])):
-        assert _erel(out["pred_gene_exp"][i], orc["pred_gene_exp"][i]) < NORTH_STAR_RTOL
+        assert prel(out["pred_gene_exp"][i], orc["pred_gene_exp"][i]) < NORTH_STAR_RTOL
         assert _erel(out["embeddings"][i], orc["embeddings"][i]) < 3 * NORTH_STAR_RTOL
-        assert _erel(out["pred_gene_exp"][i], arrays[f"pred_gene_exp_{i}"]) < NORTH_STAR_RTOL
+        assert prel(out["pred_gene_exp"][i], arrays[f"pred_gene_exp_{i}"]) < NORTH_STAR_RTOL
         e16 = max(e16, _erel(out["embeddings"][i], arrays[f"embeddings_{i}"]))
         ebf = max(ebf, _erel(bf["embeddings"][i], arrays[f"embeddings_{i}"]))
+    check_signal("fp16 operands vs oracle(fp16)", out["pred_gene_exp"], orc["pred_gene_exp"])
     print(f"[fp16 mode] embedding error vs the reference fp32 fixture: fp16 operands {e16:.2e}, bf16 operands {ebf:.2e}")
     assert e16 < ebf
     model.trainer = types.SimpleNamespace(precision="bf16-mixed")
@@ -406,9 +422,11 @@ def test_fp16_operand_mode_production_width_vs_oracle():
     orc = O.predict_step(batch, sd, hp, hp, O.Seq2GeneHP.from_kwargs(kw), rounding="fp16", share_cre_stream=True)
     f32 = O.predict_step(batch, sd, hp, hp, O.Seq2GeneHP.from_kwargs(kw), rounding=None, share_cre_stream=True)
     for i in range(3):
-        assert _erel(out["pred_gene_exp"][i], orc["pred_gene_exp"][i]) < NORTH_STAR_RTOL
+        assert prel(out["pred_gene_exp"][i], orc["pred_gene_exp"][i]) < NORTH_STAR_RTOL
         assert _erel(out["embeddings"][i], orc["embeddings"][i]) < 3 * NORTH_STAR_RTOL
-        assert _erel(out["pred_gene_exp"][i], f32["pred_gene_exp"][i]) < NORTH_STAR_RTOL      # fp16 operands vs pure fp32
+        assert prel(out["pred_gene_exp"][i], f32["pred_gene_exp"][i]) < NORTH_STAR_RTOL      # fp16 operands vs pure fp32
+    check_signal("fp16 operands, production width vs oracle(fp16)", out["pred_gene_exp"], orc["pred_gene_exp"])
+    check_signal("fp16 operands, production width vs pure fp32", out["pred_gene_exp"], f32["pred_gene_exp"])
 
 
 def test_seq2reg_options_vs_reference_golden():

@@ -136,15 +136,22 @@ extern "C" void* vf_bpe_create(const int32_t* char_ids, int n_ids, const int32_t
     for (size_t k = 0; k < B->rank.size(); ++k) B->rank16[k] = (int16_t)B->rank[k];
     B->new_id_of_rank.assign((size_t)(n_merges > 0 ? n_merges : 1), -1);
     // rank at which every token is created (characters: -1); the bucket algorithm needs rank(rule) > creation rank of
-    // both of its operands, which holds for any vocabulary learned by BPE training
+    // both of its operands, which holds for any vocabulary learned by BPE training.  A token id may be the product of
+    // SEVERAL active rules (HF training can emit one id from two rules): a merge at the later of them creates pairs
+    // (x, c) too, so the rule for such a pair must rank above the LAST rule that creates c -- born[] is the maximum
+    // creation rank, computed before any rule is checked (round-2 advice: with the first rank, a pair created at the
+    // later rule could fall into a bucket already processed and be dropped silently).
     std::vector<int32_t> born((size_t)n_ids, -1);
     for (int r = 0; r < n_merges; ++r) {
         const int32_t a = merges[3 * r], b = merges[3 * r + 1], c = merges[3 * r + 2];
-        const size_t k = (size_t)a * n_ids + b;
-        if (B->rank[k] != r) continue;                       // a later duplicate of an earlier rule never fires
+        if (B->rank[(size_t)a * n_ids + b] != r) continue;   // a later duplicate of an earlier rule never fires
         B->new_id_of_rank[(size_t)r] = c;
+        if (born[(size_t)c] < r) born[(size_t)c] = r;
+    }
+    for (int r = 0; r < n_merges; ++r) {
+        const int32_t a = merges[3 * r], b = merges[3 * r + 1];
+        if (B->rank[(size_t)a * n_ids + b] != r) continue;
         if (born[(size_t)a] >= r || born[(size_t)b] >= r) B->monotone = false;
-        if (born[(size_t)c] < 0) born[(size_t)c] = r;
     }
     if (!B->monotone) { delete B; return nullptr; }          // not a BPE-trained merge list: refuse rather than mis-tokenise
     return B;

@@ -43,14 +43,14 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 // ---- LayerNorm folded into the GEMMs around it ("LayerNorm without a pass") -------------------
 // LN(x) . W^T = rstd * (x . (gamma (.) W)^T - mean * rowsum(gamma (.) W)) + (W . beta + b): the PRODUCER of x (a GEMM with an
-// fp32 epilogue) also writes the 16-bit copy of x and, per row and 32-column part, (sum, sum of squares); a tiny kernel
+// fp32 epilogue) also writes the 16-bit copy of x and, per row and 32-column part, (sum, M2 about the part mean); a tiny kernel
 // turns the parts into (mean, rstd) per row; the CONSUMER runs on the 16-bit x with gamma folded into its weights and
 // applies the row statistics in its epilogue.  No kernel reads x again just to normalise it.
 struct LnArgs {
     const float* row_stats;   // consumer: [M][2] = (mean, rstd) of the rows of A's fp32 source
     const float* colsum;      // consumer: [N]    = sum_k W'[n][k] over the 16-bit folded weights, fp32
     void* out16;              // producer: [M][ld16] 16-bit copy of the fp32 output
-    float* part_stats;        // producer: [n_parts][M][2] = (sum, sum of squares) of each 32-column part of every row
+    float* part_stats;        // producer: [n_parts][M][2] = (sum, second moment about the part mean) of each 32-column part of every row
                               // (part-major: a wave writes runs of consecutive rows of one part, vf_ln_finalize reads
                               // consecutive rows per thread)
     int64_t ld16;
@@ -65,26 +65,26 @@ __device__ __forceinline__ float dpp_f32(float v) {
 
 // producer side of one read-back item: lane holds the final fp32 values f of one row, 4 consecutive columns (a
 // 32-column part of a row = 8 consecutive lanes); valid = row and columns inside the matrix; p16 / ppart = where this
-// lane's 16-bit values and its part's (sum, sum of squares) go
+// lane's 16-bit values and its part's (sum, M2 about the part mean) go
 template <int DT>
 __device__ __forceinline__ void ln_emit(f32x4_t f, bool valid, unsigned short* p16, float* ppart, int lane,
                                         bool st16 = true, bool stpart = true) {
     // no masking of the sums: N % 32 == 0 (checked at launch), so the 8 lanes of a part are all inside the matrix or
     // all outside, and a row past M only ever feeds its own (never stored) part
     float s1 = (f[0] + f[1]) + (f[2] + f[3]);
-    float s2 = __builtin_fmaf(f[3], f[3], __builtin_fmaf(f[2], f[2], __builtin_fmaf(f[1], f[1], f[0] * f[0])));
     // butterfly over the 8 lanes of the part on the DPP path of the VALU (__shfl_xor would be a ds_bpermute round trip
-    // per step): quad_perm [1,0,3,2], quad_perm [2,3,0,1], then row_half_mirror (lane i <-> 7 - i: the other quad's sum)
-    // (the empty asm keeps hipcc from SLP-packing the s1 / s2 adds into v_pk_add_f32, which cannot carry a DPP operand:
-    // packed, every step is two v_mov_b32_dpp + one v_pk_add_f32; unpacked, two v_add_f32_dpp)
+    // per step): quad_perm [1,0,3,2], quad_perm [2,3,0,1], then row_half_mirror (lane i <-> 7 - i: the other quad's sum);
+    // every lane of the part ends with the part's sum
     s1 += dpp_f32<0xB1>(s1);
-    asm("" : "+v"(s1));
-    s2 += dpp_f32<0xB1>(s2);
     s1 += dpp_f32<0x4E>(s1);
-    asm("" : "+v"(s1));
-    s2 += dpp_f32<0x4E>(s2);
     s1 += dpp_f32<0x141>(s1);
-    asm("" : "+v"(s1));
+    // second moment ABOUT THE PART'S MEAN (not sum of squares): vf_ln_finalize merges the parts with the parallel-variance
+    // formula, so the row variance never is a difference of two large numbers, whatever the row mean (round-2 advice)
+    const float mp = s1 * (1.0f / 32.0f);
+    const float d0 = f[0] - mp, d1 = f[1] - mp, d2 = f[2] - mp, d3 = f[3] - mp;
+    float s2 = __builtin_fmaf(d3, d3, __builtin_fmaf(d2, d2, __builtin_fmaf(d1, d1, d0 * d0)));
+    s2 += dpp_f32<0xB1>(s2);
+    s2 += dpp_f32<0x4E>(s2);
     s2 += dpp_f32<0x141>(s2);
     if (valid) {
         u32x2_t pk;

@@ -89,23 +89,28 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // ---------------------------------------------------------------------------------------------
 // LayerNorm folded into the neighbouring GEMMs (vf_gemm_ln_bf16): row statistics
 // ---------------------------------------------------------------------------------------------
-// (sum, sum of squares) per 32-column part of a row, written by the producing GEMM's epilogue -> (mean, rstd) per row.
+// (sum, second moment about the part mean) per 32-column part of a row, written by the producing GEMM's epilogue ->
+// (mean, rstd) per row.  Parts are merged with the parallel-variance formula (Chan et al.): M2 = sum_p M2_p +
+// 32 * sum_p (mean_p - mean)^2 -- every term is non-negative, so rows whose mean is large against their spread lose no
+// digits (E[x^2] - mean^2 would).
 __global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restrict__ part, float* __restrict__ row_stats,
                                                          int64_t rows, int n_parts, int D, float eps) {
     // part is [n_parts][rows][2] (part-major): one thread per row, consecutive threads read consecutive rows; the parts
     // are added in index order, so the result does not depend on the GEMM tile configuration that wrote them
     const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (row >= rows) return;
-    float s1 = 0.f, s2 = 0.f;
+    float s1 = 0.f;
 #pragma unroll 8
-    for (int p = 0; p < n_parts; ++p) {
-        const f32x2_t v = *reinterpret_cast<const f32x2_t*>(part + ((int64_t)p * rows + row) * 2);
-        s1 += v[0];
-        s2 += v[1];
-    }
+    for (int p = 0; p < n_parts; ++p) s1 += part[((int64_t)p * rows + row) * 2];
     const float mean = s1 / (float)D;
-    const float var = fmaxf(s2 / (float)D - mean * mean, 0.f);
-    *reinterpret_cast<f32x2_t*>(row_stats + 2 * row) = (f32x2_t){mean, rsqrtf(var + eps)};
+    float m2 = 0.f;
+#pragma unroll 8
+    for (int p = 0; p < n_parts; ++p) {                  // second sweep: the same lines, L2-resident
+        const f32x2_t v = *reinterpret_cast<const f32x2_t*>(part + ((int64_t)p * rows + row) * 2);
+        const float d = v[0] * (1.0f / 32.0f) - mean;
+        m2 += v[1] + 32.0f * d * d;
+    }
+    *reinterpret_cast<f32x2_t*>(row_stats + 2 * row) = (f32x2_t){mean, rsqrtf(m2 / (float)D + eps)};
 }
 
 // The same statistics for a stream that no GEMM produced (the first layer's input): one wave per row, two-pass

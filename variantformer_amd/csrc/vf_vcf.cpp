@@ -8,7 +8,13 @@
 // this image, so nothing here could be checked against it.  The semantics below restate bcftools-consensus' documented
 // behaviour for `-H I` ("IUPAC code for all genotypes") on single-base substitutions, which is what the reference's
 // "SNP" mode selects (`-e 'ALT~"<.*>" || TYPE!="snp"'`):
-//   * a record takes part when no ALT allele is symbolic (`<...>`) and -- SNP mode -- REF and every ALT are one base;
+//   * a record takes part when no ALT allele is symbolic (`<...>`) and -- SNP mode -- EVERY ALT allele is a snp.
+//     bcftools' filter compares TYPE as a bit set: `TYPE="snp"` holds when the union of the alleles' types (htslib
+//     bcf_get_variant_types: each ALT classified against REF after trimming the common prefix / suffix) is exactly
+//     {snp}, `TYPE~"snp"` when it contains snp (bcftools(1), EXPRESSIONS: "the equal sign to require that all alleles
+//     are of the given type", filter.c filters_cmp_bit_and: `a == b` for TOK_EQ / TOK_NE, `a & b` for the regex
+//     forms).  `-e 'TYPE!="snp"'` therefore drops a multi-allelic site that mixes a snp with an indel, an MNP or '*'
+//     (round 2 kept such sites: the "any ALT is a snp" reading belongs to `!~`, not to `!=`);
 //   * the genotype is the first sample's (or the named sample's) FORMAT/GT; a missing first allele skips the record,
 //     a missing second allele counts as the first; haploid calls use their only allele;
 //   * both alleles equal: that allele's base (nothing to do for 0/0); different: the IUPAC code of the two bases
@@ -36,6 +42,7 @@
 // bcftools does for overlaps ("The site ... overlaps with another variant, skipping").  Still PARITY UNPINNED: no
 // bcftools binary exists offline to generate vectors from.
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <zlib.h>
@@ -54,9 +61,26 @@ struct Rec {
     uint8_t n_alt;
     int8_t a0, a1;      // genotype allele indices; -1 missing
     uint8_t symbolic;   // some ALT is <...> or a breakend
-    uint8_t all_snp;    // REF and every ALT are a single base
-    uint8_t any_snp;    // some ALT differs from REF by exactly one base at equal length (bcftools TYPE has the snp bit)
+    uint8_t types;      // union of the ALT alleles' types (T_* bits below), htslib bcf_set_variant_type per allele
 };
+enum : uint8_t { T_SNP = 1, T_MNP = 2, T_INDEL = 4, T_OTHER = 8, T_OVERLAP = 16 };   // ref-identical alleles add no bit
+
+// Type of one ALT allele against REF (htslib vcf.c bcf_set_variant_type, restated): '*' = overlap, symbolic / breakend =
+// other, else trim the common prefix and the common suffix; nothing left = ref, one base against one base = snp, equal
+// lengths = mnp, else indel.
+uint8_t allele_type(const char* ref, size_t ref_len, const char* alt, size_t alt_len) {
+    auto U = [](char c) { return (c >= 'a' && c <= 'z') ? (char)(c - 32) : c; };
+    if (alt_len == 1 && alt[0] == '*') return T_OVERLAP;
+    if (alt[0] == '<' || memchr(alt, '[', alt_len) || memchr(alt, ']', alt_len)) return T_OTHER;
+    size_t lo = 0;
+    while (lo < ref_len && lo < alt_len && U(ref[lo]) == U(alt[lo])) ++lo;
+    if (lo == ref_len && lo == alt_len) return 0;
+    size_t re = ref_len, ae = alt_len;
+    while (re > lo && ae > lo && U(ref[re - 1]) == U(alt[ae - 1])) { --re; --ae; }
+    if (re - lo == ae - lo) return (re - lo == 1) ? T_SNP : T_MNP;
+    return T_INDEL;
+}
+
 struct Chrom {
     std::vector<Rec> recs;
     bool sorted = true;
@@ -130,7 +154,7 @@ bool parse_line(Vcf& V, char* line, int sample_col) {
     r.ref_len = (uint16_t)ref_len;
     r.ref_off = (uint32_t)V.pool.size();
     V.pool.insert(V.pool.end(), ref, ref + ref_len + 1);
-    r.all_snp = ref_len == 1;
+    r.types = 0;
     r.n_alt = 0;
     if (!(alt[0] == '.' && alt[1] == 0)) {
         char* a = alt;
@@ -139,20 +163,13 @@ bool parse_line(Vcf& V, char* line, int sample_col) {
             if (comma) *comma = 0;
             const size_t al = strlen(a);
             if (a[0] == '<' || strchr(a, '[') || strchr(a, ']')) r.symbolic = 1;     // the filter is ALT~"<.*>": '*' alone passes it
-            if (al != 1) r.all_snp = 0;
-            if (al == ref_len && a[0] != '<' && a[0] != '*') {
-                int diff = 0;
-                for (size_t k = 0; k < al; ++k) diff += up(a[k]) != up(ref[k]);
-                if (diff == 1) r.any_snp = 1;
-            }
+            r.types |= allele_type(ref, ref_len, a, al);
             V.pool.insert(V.pool.end(), a, a + al + 1);
             if (r.n_alt < 255) ++r.n_alt;
             if (!comma) break;
             a = comma + 1;
         }
-    } else {
-        r.all_snp = 0;                      // no ALT: TYPE is "ref"
-    }
+    }                                       // no ALT: TYPE is "ref" (types stays 0)
     // genotype
     r.a0 = r.a1 = 0;
     if (n >= 10 && sample_col >= 9) {
@@ -205,6 +222,21 @@ bool parse_line(Vcf& V, char* line, int sample_col) {
     return true;
 }
 
+}  // namespace
+
+namespace {
+// the indel / MNP / multi-allelic rules are restated, not pinned against bcftools: say so once per process
+// when the default policy actually applies such a record (VF_VCF_QUIET=1 silences it).
+void warn_non_snp_once() {
+    static bool warned = false;
+    if (warned) return;
+    warned = true;
+    const char* q = getenv("VF_VCF_QUIET");
+    if (q && q[0] == '1') return;
+    fprintf(stderr, "vf_vcf: applying a non-SNP record (indel / MNP / multi-allelic) with the restated `bcftools consensus "
+                    "-H I` rules; parity with bcftools 1.21 is UNPINNED for such records (INTEGRATION.md, section on "
+                    "consensus). indel_policy=\"error\" refuses them instead.\n");
+}
 }  // namespace
 
 extern "C" void* vf_vcf_open(const char* path, const char* sample) {
@@ -291,7 +323,7 @@ extern "C" int64_t vf_vcf_consensus(const void* h, const char* chrom, int64_t st
     const char* pool = V->pool.data();
     for (auto r = first; r != R.end() && r->pos <= hi1; ++r) {
         if (r->symbolic) continue;                                   // -e 'ALT~"<.*>"'
-        if (snp_only && !r->any_snp) continue;                       // ... || TYPE!="snp" (true when NO alt is a snp)
+        if (snp_only && r->types != T_SNP) continue;                 // ... || TYPE!="snp": not every ALT is a snp
         if (r->a0 < 0) continue;                                     // missing genotype
         if (r->a0 > r->n_alt || r->a1 > r->n_alt) return VF_CONS_BAD_GT;
         if (r->a0 == 0 && r->a1 == 0) continue;                      // hom-ref
@@ -312,7 +344,9 @@ extern "C" int64_t vf_vcf_consensus(const void* h, const char* chrom, int64_t st
         std::string repl;
         if (single && iupac_mask(al0[0]) >= 0 && iupac_mask(al1[0]) >= 0) {
             repl.assign(1, mask_iupac(iupac_mask(al0[0]) | iupac_mask(al1[0])));
-        } else if (indel_policy == 2) {                              // bcftools consensus -H I
+        } else if (indel_policy == 2 || (snp_only && r->types == T_SNP)) {   // bcftools consensus -H I; a snp written with
+            // flanking bases (REF=AT ALT=AC) passed the TYPE filter and is an equal-length replacement in every policy
+            if (indel_policy == 2 && r->types != T_SNP) warn_non_snp_once();
             const int gt[2] = {r->a0, r->a1};
             const int fallback = gt[0] > 0 ? gt[0] : gt[1];          // first non-REF genotype allele (REF if none)
             auto iupac_ok = [](const char* a) {

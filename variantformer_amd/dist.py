@@ -79,6 +79,7 @@ def all_gather_ragged(rows: list, owned: list[list[int]], n_items: int, device, 
     assert len(rows) == len(owned[rank])
     rows = [torch.as_tensor(r, dtype=torch.float32) for r in rows]
     trail = tuple(rows[0].shape[1:]) if rows else ()
+    assert len(trail) <= 4, "all_gather_ragged: at most 4 trailing dims (the metadata exchanged between ranks is fixed-size)"
     if dist.is_initialized():                       # agree on trailing dims / longest item even if a shard is empty
         meta = torch.tensor([max([r.shape[0] for r in rows], default=0)] + list(trail) + [-1] * (4 - len(trail)),
                             dtype=torch.int64, device=device)
@@ -128,14 +129,30 @@ def predict_sharded(predict_batch, dataset, collate_fn, costs=None, batch_size: 
     mine = owned[rank]
     preds, embs = [], []
     t0 = time.perf_counter()
-    if mine:
-        loader = DataLoader(Subset(dataset, mine), batch_size=batch_size, shuffle=False, collate_fn=collate_fn,
-                            **(loader_kwargs or {}))
-        for i, batch in enumerate(loader):
-            out = predict_batch(batch, i)
-            preds.extend(out["pred_gene_exp"])
-            embs.extend(out["embeddings"])
+    failure = None
+    try:
+        if mine:
+            loader = DataLoader(Subset(dataset, mine), batch_size=batch_size, shuffle=False, collate_fn=collate_fn,
+                                **(loader_kwargs or {}))
+            for i, batch in enumerate(loader):
+                out = predict_batch(batch, i)
+                preds.extend(out["pred_gene_exp"])
+                embs.extend(out["embeddings"])
+        if len(preds) != len(mine):
+            raise RuntimeError(f"rank {rank}: {len(preds)} predictions for {len(mine)} genes")
+    except Exception as e:                  # noqa: BLE001 -- reported to every rank below, then re-raised
+        failure = e
     busy = time.perf_counter() - t0
-    assert len(preds) == len(mine)
+    # A rank that failed must not leave the others blocked in the gathers until the collective times out: every rank
+    # learns about it through ONE tiny all-reduce (MAX of a 0/1 flag) and raises.
+    if dist.is_initialized():
+        flag = torch.tensor([1 if failure is not None else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+        if int(flag.item()):
+            if failure is not None:
+                raise failure
+            raise RuntimeError(f"predict_sharded: another rank failed (this is rank {rank}); no results were gathered")
+    elif failure is not None:
+        raise failure
     return {"pred_gene_exp": all_gather_ragged(preds, owned, n, device, group),
             "embeddings": all_gather_ragged(embs, owned, n, device, group)}, busy

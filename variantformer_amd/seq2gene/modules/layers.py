@@ -53,6 +53,7 @@ def packed_linear(lin: nn.Linear, geglu: bool = False):
         if geglu:
             wb, b = ops.pack_geglu_rows(wb, b)
     lin._vf_packed = (key, wb, b)
+    lin._vf_packed_ln = None          # one operand copy per Linear: a module runs folded or unfolded, not both at once
     return wb, b
 
 
@@ -81,15 +82,18 @@ def packed_linear_ln(lin: nn.Linear, norm: nn.LayerNorm, geglu: bool = False):
             wb, b = ops.pack_geglu_rows(wb, b)
         colsum = wb.float().sum(dim=1).contiguous()
     lin._vf_packed_ln = (key, wb, b, colsum)
+    lin._vf_packed = None             # drop the plain 16-bit copy a previous unfolded / fp16 run may have left
     return wb, b, colsum
 
 
-def ln_fold_enabled(width: int) -> bool:
-    """LayerNorm folded into the neighbouring GEMMs for bf16 operands and widths the MFMA path
-    takes (K % 64 == 0); VF_LN_FOLD=0 keeps the separate LayerNorm pass (the fp16 mode always does: the raw residual
-    stream may exceed the fp16 range, its LayerNorm never does)."""
+def ln_fold_enabled(*widths: int) -> bool:
+    """LayerNorm folded into the neighbouring GEMMs for bf16 operands when EVERY contraction width of
+    the layer's folded GEMMs (d_model, and hidden_dim / 2 for the down-projection producer) is one the MFMA path takes
+    (K % 64 == 0); otherwise -- and with VF_LN_FOLD=0 -- the separate LayerNorm pass (the fp16 mode always does: the raw
+    residual stream may exceed the fp16 range, its LayerNorm never does)."""
     import os
-    return ops.cdt() == torch.bfloat16 and width % 64 == 0 and os.environ.get("VF_LN_FOLD", "1") != "0"
+    return (ops.cdt() == torch.bfloat16 and all(int(w) % 64 == 0 for w in widths)
+            and os.environ.get("VF_LN_FOLD", "1") != "0")
 
 
 def _as_stream(x):
@@ -297,7 +301,7 @@ class ContextFlashAttentionEncoderLayer(nn.Module):
         the FIRST gene layer: every tissue's copy of a gene holds the same chunk rows, only the registry row differs):
         projected once per distinct row, then expanded.  idx int64 [tokens]: >= 0 row of rows_a, < 0 row -idx-1 of rows_b.
         Exact: LayerNorm and the projection are row-wise.  None when the LayerNorm fold is off (fp16 mode)."""
-        if not ln_fold_enabled(self.norm1.weight.numel()):
+        if not ln_fold_enabled(self.norm1.weight.numel(), self.linear_geglu_2.in_features):
             return None
         w, b, c = packed_linear_ln(self.mixer.MHA.Wqkv, self.norm1)
         qa = ops.gemm_ln_consumer(ops.ln_stream(rows_a.float().contiguous()), w, b, c, ops.EPI_BF16)
@@ -315,7 +319,7 @@ class ContextFlashAttentionEncoderLayer(nn.Module):
         assert not self.make_data_kv
         cq = cu_src if cu_cross_q is None else cu_cross_q
         mq = max_src if max_cross_q is None else max_cross_q
-        if ln_fold_enabled(self.norm1.weight.numel()):
+        if ln_fold_enabled(self.norm1.weight.numel(), self.linear_geglu_2.in_features):
             # LayerNorm folded into the GEMMs: every fp32-residual GEMM also emits the bf16 copy + row statistics of its
             # output, every LayerNorm -> Linear pair runs on that copy (no LayerNorm pass, no cast of the context)
             if self_qkv is not None:
@@ -357,7 +361,7 @@ class ContextFlashAttentionEncoderLayer(nn.Module):
         model_combined_modulator.py:391-392): exact, and ~1/25 of the gene-stream work less."""
         assert not self.make_data_kv
         mha = self.mixer.MHA
-        if ln_fold_enabled(self.norm1.weight.numel()):
+        if ln_fold_enabled(self.norm1.weight.numel(), self.linear_geglu_2.in_features):
             s = _as_stream(src)
             D = s.x.shape[1]
             w, b, c = packed_linear_ln(mha.Wqkv, self.norm1)
@@ -449,7 +453,7 @@ class FlashAttentionEncoderLayer(nn.Module):
             self.register_buffer("m", get_alibi_slopes(self.num_heads))
 
     def forward_packed(self, src, cu_src, max_src, **_):
-        if ln_fold_enabled(self.norm1.weight.numel()):
+        if ln_fold_enabled(self.norm1.weight.numel(), self.linear_geglu_2.in_features):
             s = _as_stream(src)
             a = self.mixer.MHA.attend_ln(s, self.norm1, None, cu_src, max_src, None, None)
             x1 = self.mixer.MHA.out_ln(a, s.x, need_x=False)
@@ -491,7 +495,7 @@ class ContextFlashCrossAttentionEncoderLayer(nn.Module):
         assert not self.make_data_kv
         cq = cu_src if cu_cross_q is None else cu_cross_q
         mq = max_src if max_cross_q is None else max_cross_q
-        if ln_fold_enabled(self.norm1.weight.numel()):
+        if ln_fold_enabled(self.norm1.weight.numel(), self.linear_geglu_2.in_features):
             s = _as_stream(src)
             if context_kv is None:
                 ctx16 = context.x16 if isinstance(context, ops.LnStream) else ops.cast16(context)

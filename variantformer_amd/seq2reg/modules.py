@@ -30,7 +30,7 @@ class FlashTransformerLayer(nn.Module):
         """src: fp32 [tokens, d] or an ops.LnStream; returns the same kind (an LnStream when LayerNorm is folded into
         the GEMMs, see seq2gene.modules.layers.ln_fold_enabled; a plain tensor from the `last` layer)."""
         from ..seq2gene.modules.layers import _as_stream, _as_tensor, ln_fold_enabled, packed_linear_ln
-        if ln_fold_enabled(self.norm1.weight.numel()):
+        if ln_fold_enabled(self.norm1.weight.numel(), self.linear_geglu_2.in_features):
             s = _as_stream(src)
             a = self.MHA.attend_ln(s, self.norm1, None, cu, max_seqlen, None, None)
             x1 = self.MHA.out_ln(a, s.x, need_x=False)           # x1 is read only through norm2 -> linear_geglu_1
