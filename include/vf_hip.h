@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define VF_ABI_VERSION 2
+#define VF_ABI_VERSION 3
 
 enum vf_status {
     VF_OK = 0,
@@ -91,7 +91,26 @@ int vf_gemm_f16_ex(const void* A, int64_t lda, const void* W, const float* bias,
 int vf_gemm_ln_bf16(const void* A, int64_t lda, const void* W, const float* bias, const float* residual, int64_t ldr,
                     void* out, int64_t ldo, int M, int N, int K, int epilogue, const float* row_stats,
                     const float* colsum, void* out16, int64_t ld16, float* part_stats, void* stream);
+/* General form (ABI 3): operand_dtype VF_BF16 or VF_F16 (reference precision "16-mixed": the LayerNorm fold for fp16
+ * operands).  An fp16 stream is stored SCALED, out16 = fp16(x * x16_scale) with a power-of-two x16_scale, so that the raw
+ * residual stream cannot leave the fp16 range (LayerNorm is scale-invariant; vf_ln_finalize2 writes the pair the consumer
+ * needs for the scaled operand: (mean * c, rstd / c)); bf16 streams use x16_scale = 1.  residual_dtype VF_F32: fp32
+ * residual rows as above; residual_dtype == operand_dtype: the residual is read from the 16-BIT COPY of a stream
+ * (value = float(res16) * res16_scale) -- the stream after a layer's self-attention block is otherwise only read through
+ * LayerNorm -> Linear, so its fp32 rows need not exist (the reference's own autocast keeps that stream in 16 bits,
+ * seq2gene/modules/layers.py:128-140).  vf_gemm_ln_bf16 = this with VF_BF16, VF_F32 residual, scales 1. */
+int vf_gemm_ln(const void* A, int64_t lda, const void* W, const float* bias, const void* residual, int64_t ldr,
+               int residual_dtype, void* out, int64_t ldo, int M, int N, int K, int epilogue, int operand_dtype,
+               const float* row_stats, const float* colsum, void* out16, int64_t ld16, float* part_stats,
+               float x16_scale, float res16_scale, void* stream);
 int vf_ln_finalize(const float* part_stats, int64_t rows, int n_parts, int D, float eps, float* row_stats, void* stream);
+/* ..2 forms: x16_scale as above; alert (optional, device int): set to 1 when some row has |mean| > ratio_limit standard
+ * deviations -- the regime where rounding the UNCENTRED row to 16 bits costs the folded form accuracy; callers read it back
+ * with their outputs and warn (variantformer_amd.ops.ln_fold_alert). */
+int vf_ln_finalize2(const float* part_stats, int64_t rows, int n_parts, int D, float eps, float x16_scale, float ratio_limit,
+                    int* alert, float* row_stats, void* stream);
+int vf_row_stats_cast2(const float* x, int64_t rows, int D, float eps, void* out16, int out_dtype, float x16_scale,
+                       float ratio_limit, int* alert, float* row_stats, void* stream);
 int vf_row_stats_cast(const float* x, int64_t rows, int D, float eps, void* out16, int out_dtype, float* row_stats,
                       void* stream);
 

@@ -108,15 +108,25 @@ class Rounding:
     """Rounding policy: where the HIP kernels store bf16, the oracle rounds to bf16.  `fold_ln` restates where the bf16
     HIP path rounds around a LayerNorm -> Linear pair: the GEMM reads bf16(x) and bf16(gamma (.) W)
     and the fp32 row statistics are applied to its fp32 accumulator, instead of bf16(LayerNorm(x)) . bf16(W).  Same
-    algebra, different rounding points; default = what variantformer_amd does (bf16 operands, VF_LN_FOLD != 0)."""
+    algebra, different rounding points; default = what variantformer_amd does (16-bit operands, VF_LN_FOLD != 0; an fp16
+    stream's copy is stored scaled by a power of two, which rounds identically inside the fp16 normal range).
+    `res16`: with the fold on, the stream after a layer's self-attention block enters the cross-attention out-projection's
+    residual add through its 16-bit copy (its fp32 rows are never stored: layers.res16_enabled, VF_RES16 != 0)."""
 
-    def __init__(self, mode: str | None, fold_ln: bool | None = None):
+    def __init__(self, mode: str | None, fold_ln: bool | None = None, res16: bool | None = None):
         assert mode in (None, "bf16", "fp16")
         self.mode = mode
+        import os
         if fold_ln is None:
-            import os
-            fold_ln = mode == "bf16" and os.environ.get("VF_LN_FOLD", "1") != "0"
+            fold_ln = mode is not None and os.environ.get("VF_LN_FOLD", "1") != "0"
         self.fold_ln = bool(fold_ln)
+        if res16 is None:
+            res16 = os.environ.get("VF_RES16", "1") != "0"
+        self.res16 = bool(res16) and self.fold_ln
+
+    def res(self, x1: torch.Tensor) -> torch.Tensor:
+        """x1 as the residual of the cross-attention out-projection (see `res16`)."""
+        return self.r(x1) if (self.res16 and x1.shape[-1] % 64 == 0) else x1
 
     def r(self, x: torch.Tensor) -> torch.Tensor:
         if self.mode is None:
@@ -249,7 +259,7 @@ def seq2reg_context_layer(x, ctx, cu, sd, pfx, hp: Seq2RegHP, slopes, rnd: Round
     h = rnd.ln(x, sd[pfx + "norm1.weight"], sd[pfx + "norm1.bias"])
     x1 = mha_self(h, sd, pfx + "mixer.MHA.", hp.num_heads, cu, slopes, rnd) + x
     h = rnd.ln(x1, sd[pfx + "norm2.weight"], sd[pfx + "norm2.bias"])
-    x2 = mha_cross(h, ctx, sd, pfx + "crossMHA.MHA.", hp.num_heads, cu, cu, rnd) + x1
+    x2 = mha_cross(h, ctx, sd, pfx + "crossMHA.MHA.", hp.num_heads, cu, cu, rnd) + rnd.res(x1)
     h = rnd.ln(x2, sd[pfx + "norm3.weight"], sd[pfx + "norm3.bias"])
     return geglu_ffn(h, sd, pfx, rnd) + x
 
@@ -347,7 +357,7 @@ def modulator_layer(src, ctx, cu_src, cu_ctx, sd, pfx, H, slopes, rnd: Rounding,
     h = rnd.ln(src, sd[pfx + "norm1.weight"], sd[pfx + "norm1.bias"])
     x1 = mha_self(h, sd, pfx + "mixer.MHA.", H, cu_src, slopes, rnd) + src
     h = rnd.ln(x1, sd[pfx + "norm2.weight"], sd[pfx + "norm2.bias"])
-    x2 = mha_cross(h, ctx, sd, pfx + "crossMHA.MHA.", H, cu_src, cu_ctx, rnd, cross_slopes) + x1
+    x2 = mha_cross(h, ctx, sd, pfx + "crossMHA.MHA.", H, cu_src, cu_ctx, rnd, cross_slopes) + rnd.res(x1)
     h = rnd.ln(x2, sd[pfx + "norm3.weight"], sd[pfx + "norm3.bias"])
     return geglu_ffn(h, sd, pfx, rnd) + src
 

@@ -23,15 +23,17 @@ def signal_rel(got, want):
     divided by the standard deviation of `want` across all genes x tissues.  Random-weight expressions sit in a narrow
     band around softplus(0) ~ 0.69, so an error that is small against the VALUE (the north-star's relative tolerance) can
     still be a visible fraction of the differences between tissues; this metric says how much.  nan when `want` holds
-    fewer than 3 values (no spread to compare with)."""
+    fewer than 3 values or its spread is below 1 % of its mean (nothing to compare with: e.g. fixture small_opts_a, whose
+    start-token pooling gives every tissue of a gene the same expression)."""
     g = np.concatenate([np.asarray(x, np.float64).ravel() for x in (got if isinstance(got, (list, tuple)) else [got])])
     w = np.concatenate([np.asarray(x, np.float64).ravel() for x in (want if isinstance(want, (list, tuple)) else [want])])
-    if w.size < 3 or w.std() == 0:
-        return float("nan")
+    if w.size < 3 or w.std() < 1e-2 * np.abs(w).mean():
+        return float("nan")          # no spread to speak of (one value, or all tissues within 1 % of each other)
     return float(np.abs(g - w).max() / w.std())
 
 
-SIGNAL_RTOL = 5e-2      # expression error allowed as a fraction of the across-gene / across-tissue spread (signal_rel)
+SIGNAL_RTOL = 3e-2      # expression error allowed as a fraction of the across-gene / across-tissue spread (signal_rel);
+                        # measured on MI355X: 5e-4 ... 1.5e-2 (gpurun_out/r3a/pytest.log)
 
 
 def check_signal(tag, got, want, tol=SIGNAL_RTOL):

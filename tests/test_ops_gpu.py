@@ -553,6 +553,74 @@ def test_gemm_ln_producer(ops, M, N, K, with_res):
     np.testing.assert_allclose(st[:, 1].numpy(), rstd.numpy(), rtol=2e-5)
 
 
+@pytest.mark.parametrize("M,N,K", [(515, 1536, 1536), (10854, 1536, 1536), (16387, 1536, 1536), (40000, 512, 512)])
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_gemm_ln_producer_with_16bit_residual(ops, M, N, K, dtype):
+    """vf_gemm_ln with residual_dtype = operand type (every tile configuration): the residual is the 16-bit copy of a
+    stream (unscaled on read), x = a @ w^T + b + float(res16) / scale.  Bit-identical to the plain fp32-residual GEMM fed
+    with that value; the copy and statistics follow from x as in the fp32-residual form; need_x=False drops only the store."""
+    td = torch.bfloat16 if dtype == "bf16" else torch.float16
+    with ops.compute_dtype(td):
+        a = _rand((M, K), 341).to(td)
+        w = (_rand((N, K), 342, 1.0 / math.sqrt(K))).to(td)
+        b = _rand((N,), 343, 0.5)
+        res = _rand((M, N), 344, 3.0) + 0.7
+        s0 = ops.ln_stream(res.cuda())                                   # the stream whose 16-bit copy is the residual
+        scale = ops.x16_scale_for(td)
+        assert s0.scale == scale and (scale == 1.0) == (dtype == "bf16")
+        assert torch.equal(s0.x16, (res.cuda() * scale).to(td))
+        res_val = s0.x16.float() / scale                                  # what the kernel must add
+        s = ops.gemm_ln_producer(a.cuda(), w.cuda(), b.cuda(), s0)
+        plain = ops.gemm(a.cuda(), w.cuda(), b.cuda(), ops.EPI_RES_F32, residual=res_val.contiguous())
+        torch.cuda.synchronize()
+        assert torch.equal(s.x, plain)
+        assert torch.equal(s.x16, (s.x * scale).to(td))
+        t = ops.gemm_ln_producer(a.cuda(), w.cuda(), b.cuda(), s0, need_x=False)
+        torch.cuda.synchronize()
+        assert t.x is None and torch.equal(t.x16, s.x16) and torch.equal(t.stats, s.stats)
+        xd = s.x.double()
+        mean = xd.mean(dim=1)
+        rstd = 1.0 / torch.sqrt(xd.var(dim=1, unbiased=False) + 1e-5)
+        np.testing.assert_allclose(s.stats[:, 0].double().cpu().numpy(), (mean * scale).cpu().numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(s.stats[:, 1].double().cpu().numpy(), (rstd / scale).cpu().numpy(), rtol=2e-5)
+
+
+@pytest.mark.parametrize("M,N,K", [(515, 4608, 1536), (16387, 1536, 512), (10854, 2048, 1536)])
+def test_gemm_ln_fp16_consumer_matches_folded_oracle_and_unfolded_pair(ops, M, N, K):
+    """The LayerNorm fold for fp16 operands (BASELINE configs[4]): the stream copy is fp16(x * 2^-4) and the statistics are
+    (mean * c, rstd / c); the consumer must reproduce the oracle's folded statement (rounding="fp16": the power-of-two
+    scale rounds identically inside the fp16 normal range) on every row, and stay at fp16 level from the unfolded pair.
+    Rows carry a large common offset so that an unscaled fp16 copy would not be at risk here but the scale path is
+    exercised with values over three decades."""
+    from variantformer_amd.seq2gene.modules.layers import packed_linear_ln
+    geglu = N == 2048
+    x = (_rand((M, K), 351, 2.0) + _rand((M, 1), 352, 1.5)) * (10.0 ** _rand((M, 1), 353, 1.5))      # row scales 0.03 .. 30
+    lin, norm = torch.nn.Linear(K, N), torch.nn.LayerNorm(K)
+    with torch.no_grad():
+        lin.weight.copy_(_rand((N, K), 354, 1.0 / math.sqrt(K)))
+        lin.bias.copy_(_rand((N,), 355, 0.5))
+        norm.weight.copy_(1.0 + _rand((K,), 356, 0.3))
+        norm.bias.copy_(_rand((K,), 357, 0.2))
+    rnd = O.Rounding("fp16", fold_ln=True)
+    ref = O.linear(rnd.ln(x, norm.weight.detach(), norm.bias.detach()), lin.weight.detach(), lin.bias.detach(), rnd)
+    plain = F.linear(F.layer_norm(x, (K,), norm.weight, norm.bias, 1e-5), lin.weight, lin.bias).detach()
+    if geglu:
+        ref = ref[:, :N // 2] * F.gelu(ref[:, N // 2:])
+        plain = plain[:, :N // 2] * F.gelu(plain[:, N // 2:])
+    lin, norm = lin.cuda(), norm.cuda()
+    with ops.compute_dtype(torch.float16):
+        wp, bp, cs = packed_linear_ln(lin, norm, geglu=geglu)
+        assert wp.dtype == torch.float16
+        s = ops.ln_stream(x.cuda())
+        assert s.x16.dtype == torch.float16 and s.scale == 2.0 ** -4
+        out = ops.gemm_ln_consumer(s, wp, bp, cs, ops.EPI_GEGLU_BF16 if geglu else ops.EPI_BF16)
+    torch.cuda.synchronize()
+    assert out.dtype == torch.float16
+    got = out.float().cpu()
+    np.testing.assert_allclose(got.numpy(), ref.detach().numpy(), rtol=2 ** -10, atol=1e-3)       # all rows
+    assert _rel_err(got, plain) < 4e-3
+
+
 @pytest.mark.parametrize("rows,D", [(1, 64), (37, 512), (1000, 1536), (5, 4096)])
 def test_ln_stream_stats_and_copy(ops, rows, D):
     x = _rand((rows, D), 311, 2.0) + _rand((rows, 1), 312, 4.0)

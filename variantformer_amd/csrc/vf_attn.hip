@@ -20,6 +20,7 @@
 // dh = 48 (the modulator's 1536/32) is padded to 64 only along the QK^T contraction (zero chunks in
 // the K tile and zero Q fragments); PV uses exactly dh/16 output tiles.
 #include <stdlib.h>
+#include <type_traits>
 #include "vf_common.h"
 
 namespace {
@@ -460,6 +461,242 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Long query streams without positional bias at dh = 48 (the gene -> CRE cross attention: the T x G ~ 10^4 query rows of a
+// gene against its ~10^3 CRE keys) on v_mfma_f32_32x32x16.  Why a second formulation: with 16x16x32 tiles this shape is
+// bound by instruction ISSUE, not by the matrix pipe (per 64-key tile and wave 64 MFMAs x 8 issue cycles + 64 v_exp x 8 +
+// ~300 other VALU x 4 = 2000 cycles against 1024 cycles of matrix work), and dh = 48 wastes a quarter of the QK^T MFMAs on
+// padding the contraction to 64.  Here
+//   S^T[key 32][query 32] = K . Q^T   A = 32 key rows x 16 d (ds_read_b128, three 16-deep steps = 48 exactly),
+//                                     B = Q^T from registers; lane (q = lane & 31, h = lane >> 5) ends up with 16 keys of
+//                                     ITS query per 32-key block: the row maximum is in-lane plus ONE half swap;
+//   O^T[d 32][query 32] += V^T . P^T  A = V^T gathered by ds_read_b64_tr_b16 from the row-major V tile, B = P^T straight
+//                                     from the score registers (regs 8s .. 8s+7 of a 32-key block are the 16-deep step s;
+//                                     the k order inside a step is permuted identically on both operands);
+//   the head dimension is padded to 64 on the OUTPUT side only, and the first padding column of V holds 1.0: row 48 of
+//   O^T is then sum_k P = the softmax denominator -- the padding MFMAs do the row sums (no ones-fragment MFMAs).
+// Per tile and wave (64 queries x 64 keys): 28 MFMAs of 32 cycles (12 QK^T + 16 PV) instead of 64 of 16, one permlane
+// step per 32 queries instead of two per 16.
+// LDS: K rows 112 B (96 + 16: the ds_read_b128 lane groups {0-3, 12-15, 20-27} then hit 16 distinct 16-byte slots),
+// V rows 192 B (the 4 rows x 64 B a 32-lane half reads transposed fall on four distinct quarters of the 256-B bank row).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int DT, int QB>
+__global__ __launch_bounds__(256) void attn_x32_kernel(AttnParams P) {
+    using frag_t = typename Op16<DT>::frag;
+    constexpr int DH = 48, KSTEPS = 3, KROW = 112, VROW = 192;
+    constexpr int K_TILE = BKV * KROW, V_TILE = BKV * VROW, STAGE = K_TILE + V_TILE;
+    constexpr int CPR = DH / 8, NCHUNK = BKV * CPR, NLD2 = 2 * NCHUNK / 256;
+    constexpr int BQ = 4 * QB * 32;
+    static_assert(2 * NCHUNK % 256 == 0, "staging items must divide over the threads");
+    extern __shared__ __attribute__((aligned(16))) char smem[];       // 2 * STAGE bytes
+
+    int seq, hd, qblk;
+    if (!block_coords(P, seq, hd, qblk)) return;
+    const int q_tok0 = P.cu_q[seq], len_q = P.cu_q[seq + 1] - q_tok0;
+    const int k_tok0 = P.cu_k[seq], len_k = P.cu_k[seq + 1] - k_tok0;
+    const int qb0 = qblk * BQ;
+    if (qb0 >= len_q) return;                         // block-uniform
+    if (len_k <= 0) {
+        zero_rows<DH>(P, q_tok0 + qb0, (len_q - qb0) < BQ ? (len_q - qb0) : BQ, hd);
+        return;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ql = lane & 31, h = lane >> 5;
+
+    // padding columns 48 .. 63 of every V row, both stages, once: column 48 = 1.0 (the denominator column), the rest 0
+    if (tid < 2 * BKV) {
+        char* vp = smem + (tid >> 6) * STAGE + K_TILE + (tid & 63) * VROW + DH * 2;
+        *reinterpret_cast<u32x4_t*>(vp) = (u32x4_t){Op16<DT>::ONE, 0u, 0u, 0u};
+        *reinterpret_cast<u32x4_t*>(vp + 16) = (u32x4_t){0u, 0u, 0u, 0u};
+    }
+
+    // ---- Q fragments (B operand): lane (q, h) holds Q[q][16 ks + 8 h .. + 7]
+    frag_t qf[QB][KSTEPS];
+    int q_abs[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        q_abs[qb] = qb0 + (wave * QB + qb) * 32 + ql;
+        const int row = q_abs[qb] < len_q ? q_abs[qb] : len_q - 1;
+        const unsigned short* qp = P.q + (int64_t)(q_tok0 + row) * P.q_stride + hd * DH + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const u32x4_t raw = *reinterpret_cast<const u32x4_t*>(qp + 16 * ks);
+            qf[qb][ks] = __builtin_bit_cast(frag_t, raw);
+        }
+    }
+    const float c = P.scale_log2;
+    f32x16_t o[QB][2];
+    float m_run[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        m_run[qb] = -INFINITY;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[qb][dt][i] = 0.f;
+    }
+
+    // ---- K/V tile staging: global -> registers -> LDS, one list of 2 * NCHUNK 16-byte items, NLD2 per thread (see
+    // attn_fwd_kernel: no divergent branch around the prefetch)
+    u32x4_t kvreg[NLD2];
+    const unsigned short* kbase = P.k + (int64_t)k_tok0 * P.k_stride + hd * DH;
+    const unsigned short* vbase = P.v + (int64_t)k_tok0 * P.v_stride + hd * DH;
+    const unsigned short* kv_src[NLD2];
+    unsigned kv_stride[NLD2];
+    int kv_row[NLD2], kv_off[NLD2];
+#pragma unroll
+    for (int i = 0; i < NLD2; ++i) {
+        const int item = tid + 256 * i;
+        const bool is_v = item >= NCHUNK;
+        const int ci = is_v ? item - NCHUNK : item;
+        kv_row[i] = ci / CPR;
+        kv_src[i] = (is_v ? vbase : kbase) + (ci % CPR) * 8;
+        kv_stride[i] = (unsigned)(is_v ? P.v_stride : P.k_stride);
+        kv_off[i] = is_v ? K_TILE + kv_row[i] * VROW + (ci % CPR) * 16 : kv_row[i] * KROW + (ci % CPR) * 16;
+    }
+    auto load_regs = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < NLD2; ++i) {
+            int key = t * BKV + kv_row[i];
+            key = key < len_k ? key : len_k - 1;                     // finite data for masked keys
+            kvreg[i] = *reinterpret_cast<const u32x4_t*>(kv_src[i] + __umul24((unsigned)key, kv_stride[i]));
+        }
+    };
+    auto write_lds = [&](int stage) {
+#pragma unroll
+        for (int i = 0; i < NLD2; ++i) *reinterpret_cast<u32x4_t*>(smem + stage * STAGE + kv_off[i]) = kvreg[i];
+    };
+
+    // fragment addresses inside a stage
+    const int k_off = ql * KROW + h * 16;                                           // + kb * 32 * KROW + ks * 32
+    const int v_off = K_TILE + (4 * h + ((lane & 15) >> 2)) * VROW + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+    //                                                                              // + (32 kb + 16 s [+ 8]) * VROW + dt * 64
+
+    // TAIL: the key tile may reach past len_k (only the last tile of a sequence; a compile-time flag, so that the
+    // steady-state loop body carries no masking code at all)
+    auto tile = [&](const char* st, int kb0, auto tail_c) {
+        constexpr bool TAIL = decltype(tail_c)::value;
+        // ---- S^T = K . Q^T
+        frag_t kf[2][KSTEPS];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks)
+                kf[kb][ks] = *reinterpret_cast<const frag_t*>(st + k_off + kb * 32 * KROW + ks * 32);
+        f32x16_t s[QB][2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s[qb][kb][i] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < KSTEPS; ++ks) s[qb][kb] = Op16<DT>::mfma32(kf[kb][ks], qf[qb][ks], s[qb][kb]);
+            }
+        // V^T fragments of the whole tile: [kb][s][dt]
+        frag_t vf[2][2][2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const char* vp = st + v_off + (32 * kb + 16 * sx) * VROW + dt * 64;
+                    const s16x4_t lo = lds_tr_read(vp);
+                    const s16x4_t hi = lds_tr_read(vp + 8 * VROW);
+                    vf[kb][sx][dt] = __builtin_bit_cast(frag_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+        // ---- online softmax: lane (q, h) holds keys kb0 + 32 kb + (i & 3) + 8 (i >> 2) + 4 h of query q
+        float m_new[QB];
+        bool moved = false;
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            if (TAIL) {
+                const int klim = len_k - kb0 - 4 * h;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        s[qb][kb][i] = (32 * kb + (i & 3) + 8 * (i >> 2)) < klim ? s[qb][kb][i] : -INFINITY;
+            }
+            float ma = max3f(s[qb][0][0], s[qb][0][1], s[qb][0][2]);
+            float mb = max3f(s[qb][1][0], s[qb][1][1], s[qb][1][2]);
+#pragma unroll
+            for (int i = 3; i + 1 < 16; i += 2) {
+                ma = max3f(ma, s[qb][0][i], s[qb][0][i + 1]);
+                mb = max3f(mb, s[qb][1][i], s[qb][1][i + 1]);
+            }
+            const float mx = max3f(ma, mb, max2f(s[qb][0][15], s[qb][1][15]));
+            const unsigned u = __float_as_uint(mx);
+            auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+            m_new[qb] = max3f(m_run[qb], __uint_as_float(sw[0]), __uint_as_float(sw[1]));   // finite: tile 0 holds a valid key
+            moved = moved || (m_new[qb] > m_run[qb]);
+        }
+        if (__any(moved)) {                              // wave-uniform; rare after the first tiles of a sequence
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new[qb]) * c);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) o[qb][dt] *= alpha;     // row 48 (the denominator) included
+            }
+        }
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            m_run[qb] = m_new[qb];
+            const float mc = -m_new[qb] * c;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s[qb][kb][i] = __builtin_amdgcn_exp2f(fmaf(s[qb][kb][i], c, mc));
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int sx = 0; sx < 2; ++sx) {
+                    u32x4_t pk;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) pk[j] = Op16<DT>::pack2(s[qb][kb][8 * sx + 2 * j], s[qb][kb][8 * sx + 2 * j + 1]);
+                    const frag_t pf = __builtin_bit_cast(frag_t, pk);
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) o[qb][dt] = Op16<DT>::mfma32(vf[kb][sx][dt], pf, o[qb][dt]);
+                }
+        }
+    };
+
+    const int nkv = (len_k + BKV - 1) / BKV;
+    load_regs(0);
+    write_lds(0);
+    __syncthreads();
+    const bool active = qb0 + wave * QB * 32 < len_q;                 // wave-uniform
+    for (int t = 0; t + 1 < nkv; ++t) {
+        load_regs(t + 1);
+        if (active) tile(smem + (t & 1) * STAGE, t * BKV, std::false_type{});
+        write_lds((t + 1) & 1);
+        __syncthreads();
+    }
+    if (active) tile(smem + ((nkv - 1) & 1) * STAGE, (nkv - 1) * BKV, std::true_type{});
+
+    // ---- normalise and store: lane (q, h) holds O[q][d = 32 dt + (i & 3) + 8 (i >> 2) + 4 h]; the denominator is row
+    // d = 48 = element 8 of the dt = 1 tile in the h = 0 lane
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const unsigned lu = __float_as_uint(o[qb][1][8]);
+        auto sw = __builtin_amdgcn_permlane32_swap(lu, lu, false, false);
+        const float inv = 1.0f / __uint_as_float(sw[0]);              // the lower half's value in both halves
+        if (q_abs[qb] < len_q) {
+            unsigned short* op = P.out + (int64_t)(q_tok0 + q_abs[qb]) * P.o_stride + hd * DH + 4 * h;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int gq = 0; gq < (dt == 0 ? 4 : 2); ++gq) {
+                    u32x2_t pk;
+                    pk[0] = Op16<DT>::pack2(o[qb][dt][4 * gq] * inv, o[qb][dt][4 * gq + 1] * inv);
+                    pk[1] = Op16<DT>::pack2(o[qb][dt][4 * gq + 2] * inv, o[qb][dt][4 * gq + 3] * inv);
+                    *reinterpret_cast<u32x2_t*>(op + 32 * dt + 8 * gq) = pk;
+                }
+        }
+    }
+}
+
 // Short sequences (<= 256 queries and keys: seq2reg windows, the gene stream): one block per (sequence, head).
 // The whole K/V of the sequence is staged into LDS once (all loads issued before the first store: one load latency,
 // no per-tile barriers) and is fetched once per (sequence, head) instead of once per 64-query block.
@@ -647,6 +884,14 @@ int launch_short(AttnParams P, int n_seq, int max_k, hipStream_t st) {
     return VF_OK;
 }
 
+template <int DT, int QB>
+int launch_x32(const AttnParams& P, dim3 grid, hipStream_t st) {
+    constexpr int lds = 2 * BKV * (112 + 192);
+    hipLaunchKernelGGL((attn_x32_kernel<DT, QB>), grid, dim3(256), lds, st, P);
+    VF_CHECK_LAUNCH("vf_attn_varlen_fwd");
+    return VF_OK;
+}
+
 template <int DH, bool ALIBI, int DT>
 int launch_attn(AttnParams P, int n_seq, int max_q, int max_k, hipStream_t st) {
     // Measured on MI355X (scripts/attn_bench.py, 8 genes): the one-block-per-(sequence, head) kernel wins for the gene
@@ -680,8 +925,11 @@ int launch_attn(AttnParams P, int n_seq, int max_q, int max_k, hipStream_t st) {
             // 4 query groups per wave (256-query blocks) once that still leaves >= 8 blocks per CU: every K/V fragment
             // read feeds 4 MFMAs (gene->CRE cross attention at 8 genes: 948 vs 993 us; no gain at one gene, 1376 blocks)
             if constexpr (DH == 48 && !ALIBI) {
-                if ((long)n_seq * P.H * ((max_q + 255) / 256) >= 2048)
+                static const int x32 = getenv("VF_ATTN_X32") ? atoi(getenv("VF_ATTN_X32")) : 1;      // A/B switch
+                if ((long)n_seq * P.H * ((max_q + 255) / 256) >= 2048) {
+                    if (x32) return launch_x32<DT, 2>(P, dim3(set_grid(P, n_seq, (max_q + 255) / 256)), st);
                     return launch_fwd<48, 4, false, DT>(P, dim3(set_grid(P, n_seq, (max_q + 255) / 256)), st);
+                }
             }
             return launch_fwd<DH, 2, ALIBI, DT>(P, grid, st);
         }

@@ -8,6 +8,7 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 
@@ -79,6 +80,9 @@ template <> struct Op16<VF_BF16> {
     static __device__ __forceinline__ f32x4_t mfma(frag a, frag b, f32x4_t c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
     }
+    static __device__ __forceinline__ f32x16_t mfma32(frag a, frag b, f32x16_t c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
     static __device__ __forceinline__ unsigned int pack2(float lo, float hi) { return pack2bf(lo, hi); }
     static __device__ __forceinline__ float to_f32(unsigned short b) { return bf2f(b); }
     static constexpr unsigned int ONE = 0x3F80u, NEG_BIG = 0xC700u;
@@ -87,6 +91,9 @@ template <> struct Op16<VF_F16> {
     using frag = f16x8_t;
     static __device__ __forceinline__ f32x4_t mfma(frag a, frag b, f32x4_t c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x16_t mfma32(frag a, frag b, f32x16_t c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
     }
     static __device__ __forceinline__ unsigned int pack2(float lo, float hi) { return pack2h(lo, hi); }
     static __device__ __forceinline__ float to_f32(unsigned short b) { return h2f(b); }

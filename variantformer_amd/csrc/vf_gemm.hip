@@ -15,6 +15,7 @@
 // (16-byte chunk c of row r lives at chunk c ^ ((r>>1)&7)) is applied to the per-lane SOURCE
 // address and again on the fragment read (cdna_hip_programming.md rule 21).  With it the
 // ds_read_b128 fragment reads are conflict-free (checked against the 4x16-lane group rule).
+#include <type_traits>
 #include "vf_common.h"
 
 namespace {
@@ -55,8 +56,26 @@ struct LnArgs {
                               // consecutive rows per thread)
     int64_t ld16;
     int64_t rows;             // M
+    float x16_scale;          // producer: out16 = 16-bit(x * x16_scale) (a power of two; 1 for bf16, whose exponent range is
+                              // fp32's; fp16 streams are stored scaled so that the raw residual cannot leave the fp16 range:
+                              // LayerNorm is scale-invariant and vf_ln_finalize writes (mean * c, rstd / c) for the consumer)
+    float res16_scale;        // VF_LN_PRODUCER_R16: residual = float(res16) * res16_scale (= 1 / x16_scale of that stream)
+    const unsigned short* res16;   // VF_LN_PRODUCER_R16: the residual as the 16-bit copy of a stream [M][ldr16] instead of
+    int64_t ldr16;                 // its fp32 rows (a stream that is otherwise only read through LayerNorm -> Linear)
 };
-enum { VF_LN_NONE = 0, VF_LN_CONSUMER = 1, VF_LN_PRODUCER = 2 };
+// VF_LN_PRODUCER_R16 = producer whose residual is read from a 16-bit stream copy (EPI is VF_EPI_RES_F32; `res` unused)
+enum { VF_LN_NONE = 0, VF_LN_CONSUMER = 1, VF_LN_PRODUCER = 2, VF_LN_PRODUCER_R16 = 3 };
+constexpr bool ln_is_producer(int ln) { return ln == VF_LN_PRODUCER || ln == VF_LN_PRODUCER_R16; }
+
+// 4 consecutive 16-bit values (8 bytes) -> fp32
+template <int DT>
+__device__ __forceinline__ f32x4_t cvt4_16(u32x2_t v) {
+    if (DT == VF_BF16)
+        return (f32x4_t){__uint_as_float(v[0] << 16), __uint_as_float(v[0] & 0xFFFF0000u), __uint_as_float(v[1] << 16),
+                         __uint_as_float(v[1] & 0xFFFF0000u)};
+    return (f32x4_t){Op16<DT>::to_f32((unsigned short)(v[0] & 0xFFFFu)), Op16<DT>::to_f32((unsigned short)(v[0] >> 16)),
+                     Op16<DT>::to_f32((unsigned short)(v[1] & 0xFFFFu)), Op16<DT>::to_f32((unsigned short)(v[1] >> 16))};
+}
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_f32(float v) {
@@ -68,7 +87,7 @@ __device__ __forceinline__ float dpp_f32(float v) {
 // lane's 16-bit values and its part's (sum, M2 about the part mean) go
 template <int DT>
 __device__ __forceinline__ void ln_emit(f32x4_t f, bool valid, unsigned short* p16, float* ppart, int lane,
-                                        bool st16 = true, bool stpart = true) {
+                                        float x16_scale = 1.0f, bool st16 = true, bool stpart = true) {
     // no masking of the sums: N % 32 == 0 (checked at launch), so the 8 lanes of a part are all inside the matrix or
     // all outside, and a row past M only ever feeds its own (never stored) part
     float s1 = (f[0] + f[1]) + (f[2] + f[3]);
@@ -88,6 +107,7 @@ __device__ __forceinline__ void ln_emit(f32x4_t f, bool valid, unsigned short* p
     s2 += dpp_f32<0x141>(s2);
     if (valid) {
         u32x2_t pk;
+        if (DT == VF_F16) f *= x16_scale;                 // statistics above are those of the UNSCALED row
         pk[0] = Op16<DT>::pack2(f[0], f[1]);
         pk[1] = Op16<DT>::pack2(f[2], f[3]);
         if (st16) *reinterpret_cast<u32x2_t*>(p16) = pk;
@@ -308,7 +328,19 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_mfma_kernel(const unsigned
     const int no0 = (EPI == VF_EPI_GEGLU_BF16) ? (n0 + wn * WT_N) / 2 : (n0 + wn * WT_N);
     const int ep_row = lane / CR, ep_col = no0 + (lane % CR) * (16 / ES);
     constexpr bool RES_PRE = (EPI == VF_EPI_RES_F32) && (TN * TM <= 16);
-    f32x4_t resv[RES_PRE ? NPASS : 1][RES_PRE ? NI : 1];
+    // the residual: fp32 rows, or (VF_LN_PRODUCER_R16) the 16-bit copy of a stream -- 8 instead of 16 bytes per item,
+    // converted (and unscaled) where it is added
+    constexpr bool R16 = LN == VF_LN_PRODUCER_R16;
+    using res_t = typename std::conditional<R16, u32x2_t, f32x4_t>::type;
+    auto res_load = [&](int64_t m, int col) -> res_t {
+        if constexpr (R16) return *reinterpret_cast<const u32x2_t*>(ln.res16 + m * ln.ldr16 + col);
+        else return *reinterpret_cast<const f32x4_t*>(res + m * ldr + col);
+    };
+    auto res_value = [&](res_t v) -> f32x4_t {
+        if constexpr (R16) return cvt4_16<DT>(v) * ln.res16_scale;
+        else return v;
+    };
+    res_t resv[RES_PRE ? NPASS : 1][RES_PRE ? NI : 1];
     auto prefetch_residual = [&]() {
         if (RES_PRE) {
 #pragma unroll
@@ -318,22 +350,22 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_mfma_kernel(const unsigned
                     int64_t m = mw0 + ps * RP + k * RI + ep_row;
                     m = m < M ? m : M - 1;
                     const int col = ep_col < N ? ep_col : N - 4;
-                    resv[RES_PRE ? ps : 0][RES_PRE ? k : 0] = *reinterpret_cast<const f32x4_t*>(res + m * ldr + col);
+                    resv[RES_PRE ? ps : 0][RES_PRE ? k : 0] = res_load(m, col);
                 }
         }
     };
     // Wave tiles too large to hold their whole residual in registers (256x256 tiles): the residual rows of epilogue
     // pass ps+1 are requested while pass ps goes through LDS, so only the first pass pays a load latency.
     constexpr bool RES_PIPE = (EPI == VF_EPI_RES_F32) && !RES_PRE;
-    f32x4_t rbuf[2][RES_PIPE ? NI : 1];
-    auto load_res_pass = [&](int ps, f32x4_t (&dst)[RES_PIPE ? NI : 1]) {
+    res_t rbuf[2][RES_PIPE ? NI : 1];
+    auto load_res_pass = [&](int ps, res_t (&dst)[RES_PIPE ? NI : 1]) {
         if (RES_PIPE) {
 #pragma unroll
             for (int k = 0; k < NI; ++k) {
                 int64_t m = mw0 + ps * RP + k * RI + ep_row;
                 m = m < M ? m : M - 1;
                 const int col = ep_col < N ? ep_col : N - 4;
-                dst[RES_PIPE ? k : 0] = *reinterpret_cast<const f32x4_t*>(res + m * ldr + col);
+                dst[RES_PIPE ? k : 0] = res_load(m, col);
             }
         }
     };
@@ -493,15 +525,15 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_mfma_kernel(const unsigned
                 u32x4_t d = dd[k];
                 if (EPI == VF_EPI_RES_F32) {
                     f32x4_t f = __builtin_bit_cast(f32x4_t, d);
-                    f += RES_PRE ? resv[RES_PRE ? ps : 0][RES_PRE ? k0 + k : 0] : rbuf[ps & 1][RES_PIPE ? k0 + k : 0];
+                    f += res_value(RES_PRE ? resv[RES_PRE ? ps : 0][RES_PRE ? k0 + k : 0] : rbuf[ps & 1][RES_PIPE ? k0 + k : 0]);
                     d = __builtin_bit_cast(u32x4_t, f);
                 }
                 const bool ok = ps * RP + row < WT_M && m < M && ep_col < n_out_total;
-                if (LN == VF_LN_PRODUCER && OUT_F32)
+                if (ln_is_producer(LN) && OUT_F32)
                     ln_emit<DT>(__builtin_bit_cast(f32x4_t, d), ok,
                                 reinterpret_cast<unsigned short*>(ln.out16) + m * ln.ld16 + ep_col,
-                                ln.part_stats + ((int64_t)(ep_col >> 5) * ln.rows + m) * 2, lane);
-                if (ok && (LN != VF_LN_PRODUCER || out != nullptr))
+                                ln.part_stats + ((int64_t)(ep_col >> 5) * ln.rows + m) * 2, lane, ln.x16_scale);
+                if (ok && (!ln_is_producer(LN) || out != nullptr))
                     *reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(out) + (m * ldo + ep_col) * ES) = d;
             }
         }
@@ -927,7 +959,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const unsigned short* __r
     constexpr int REGION = C::LDS_BYTES / C::NW;
     constexpr int RP_FIT = (((REGION / PITCH) < WT_M ? (REGION / PITCH) : WT_M) / 16) * 16;
     // the LayerNorm producer carries extra live values through the read-back: 32-row passes keep it inside 256 VGPRs
-    constexpr int RP = (LN == VF_LN_PRODUCER && EPI == VF_EPI_RES_F32 && RP_FIT > 32) ? 32 : RP_FIT;
+    constexpr int RP = (ln_is_producer(LN) && EPI == VF_EPI_RES_F32 && RP_FIT > 32) ? 32 : RP_FIT;
     constexpr int IMP = RP / 16, NPASS = (TM + IMP - 1) / IMP;
     constexpr int CR = WT_NO * ES / 16, RI = 64 / CR, NI = RP / RI;
     static_assert(RP >= 16 && CR >= 1 && CR <= 64 && 64 % CR == 0, "epilogue geometry");
@@ -944,32 +976,43 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const unsigned short* __r
     const int rows_left = (int)(M - mw0) - ep_row;              // item j is a row of the matrix iff j * RI < rows_left
     const int64_t row0 = mw0 + ep_row;
     const int colc = ep_col < N ? ep_col : N - 4;
-    const float* const res_p = RES ? res + row0 * ldr + colc : nullptr;
-    const float* const res_last = RES ? res + (int64_t)(M - 1) * ldr + colc : nullptr;
-    const int64_t res_step = (int64_t)RI * ldr;
+    // the residual: fp32 rows, or (VF_LN_PRODUCER_R16) the 16-bit copy of a stream: 8 instead of 16 bytes per item,
+    // converted (and unscaled) where it is added.  Byte pointers so that both forms share the running-pointer scheme.
+    constexpr bool R16 = LN == VF_LN_PRODUCER_R16;
+    using res_t = typename std::conditional<R16, u32x2_t, f32x4_t>::type;
+    const char* const res_base = R16 ? reinterpret_cast<const char*>(ln.res16) : reinterpret_cast<const char*>(res);
+    const int64_t res_ld = R16 ? ln.ldr16 : ldr;                // elements per residual row
+    constexpr int RES_ES = R16 ? 2 : 4;
+    const char* const res_p = RES ? res_base + (row0 * res_ld + colc) * RES_ES : nullptr;
+    const char* const res_last = RES ? res_base + ((int64_t)(M - 1) * res_ld + colc) * RES_ES : nullptr;
+    const int64_t res_step = (int64_t)RI * res_ld * RES_ES;
     char* const out_p = reinterpret_cast<char*>(out) + (row0 * ldo + ep_col) * ES;
     const int64_t out_step = (int64_t)RI * ldo * ES;
-    unsigned short* const o16_p = (LN == VF_LN_PRODUCER) ? reinterpret_cast<unsigned short*>(ln.out16) + row0 * ln.ld16 + ep_col : nullptr;
+    unsigned short* const o16_p = ln_is_producer(LN) ? reinterpret_cast<unsigned short*>(ln.out16) + row0 * ln.ld16 + ep_col : nullptr;
     const int64_t o16_step = (int64_t)RI * ln.ld16;
-    float* const part_p = (LN == VF_LN_PRODUCER) ? ln.part_stats + ((int64_t)(ep_col >> 5) * ln.rows + row0) * 2 : nullptr;
+    float* const part_p = ln_is_producer(LN) ? ln.part_stats + ((int64_t)(ep_col >> 5) * ln.rows + row0) * 2 : nullptr;
     // the items are visited in increasing j, so each pointer is a running one: p += step per item (one 64-bit add)
     // instead of base + j * step (hipcc multiplies per item otherwise: 81 quarter-rate v_mad_u64_u32 in this epilogue)
-    const float* res_run = res_p;
+    const char* res_run = res_p;
     char* out_run = out_p;
     unsigned short* o16_run = o16_p;
     float* part_run = part_p;
-    f32x4_t rbuf[2][RES ? NI : 1];
-    auto load_res_pass = [&](int ps, f32x4_t (&dst)[RES ? NI : 1]) {
+    res_t rbuf[2][RES ? NI : 1];
+    auto load_res_pass = [&](int ps, res_t (&dst)[RES ? NI : 1]) {
         if (RES) {
 #pragma unroll
             for (int k = 0; k < NI; ++k) {
                 const int j = ps * NI + k;
-                const float* rp = (j * RI < rows_left) ? res_run : res_last;
+                const char* rp = (j * RI < rows_left) ? res_run : res_last;
                 res_run += res_step;
-                if (dbg & 8) { dst[RES ? k : 0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; continue; }
-                dst[RES ? k : 0] = *reinterpret_cast<const f32x4_t*>(rp);
+                if (dbg & 8) { dst[RES ? k : 0] = res_t{}; continue; }
+                dst[RES ? k : 0] = *reinterpret_cast<const res_t*>(rp);
             }
         }
+    };
+    auto res_value = [&](res_t v) -> f32x4_t {
+        if constexpr (R16) return cvt4_16<DT>(v) * ln.res16_scale;
+        else return v;
     };
     load_res_pass(0, rbuf[0]);
     // bias of the wave's columns, from the side area (requested before the first K-tile)
@@ -1061,18 +1104,18 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const unsigned short* __r
                 u32x4_t d = dd[k];
                 if (RES) {
                     f32x4_t f = __builtin_bit_cast(f32x4_t, d);
-                    f += rbuf[ps & 1][RES ? k0 + k : 0];
+                    f += res_value(rbuf[ps & 1][RES ? k0 + k : 0]);
                     d = __builtin_bit_cast(u32x4_t, f);
                 }
                 const bool ok = j * RI + ep_row < WT_M && j * RI < rows_left && ep_col < n_out_total;
-                if (LN == VF_LN_PRODUCER && OUT_F32) {
-                    ln_emit<DT>(__builtin_bit_cast(f32x4_t, d), ok, o16_run, part_run, lane, !(dbg & 2), !(dbg & 4));
+                if (ln_is_producer(LN) && OUT_F32) {
+                    ln_emit<DT>(__builtin_bit_cast(f32x4_t, d), ok, o16_run, part_run, lane, ln.x16_scale, !(dbg & 2), !(dbg & 4));
                     o16_run += o16_step;
                     part_run += RI * 2;
                 }
                 // a LayerNorm producer whose fp32 result has no reader (only its 16-bit copy and statistics do) passes
                 // out = NULL: the 16-byte store -- 4 of the 10 bytes the epilogue moves per element -- is dropped
-                if (ok && (LN != VF_LN_PRODUCER || out != nullptr) && !(dbg & 1)) *reinterpret_cast<u32x4_t*>(out_run) = d;
+                if (ok && (!ln_is_producer(LN) || out != nullptr) && !(dbg & 1)) *reinterpret_cast<u32x4_t*>(out_run) = d;
                 out_run += out_step;
             }
         }
@@ -1345,9 +1388,9 @@ __global__ __launch_bounds__(512, 2) void gemm8x_kernel(const unsigned short* __
         const int64_t res_step = (int64_t)RI * ldr;
         char* const out_p = reinterpret_cast<char*>(out) + (row0 * ldo + ep_col) * ES;
         const int64_t out_step = (int64_t)RI * ldo * ES;
-        unsigned short* const o16_p = (LN == VF_LN_PRODUCER) ? reinterpret_cast<unsigned short*>(ln.out16) + row0 * ln.ld16 + ep_col : nullptr;
+        unsigned short* const o16_p = ln_is_producer(LN) ? reinterpret_cast<unsigned short*>(ln.out16) + row0 * ln.ld16 + ep_col : nullptr;
         const int64_t o16_step = (int64_t)RI * ln.ld16;
-        float* const part_p = (LN == VF_LN_PRODUCER) ? ln.part_stats + ((int64_t)(ep_col >> 5) * ln.rows + row0) * 2 : nullptr;
+        float* const part_p = ln_is_producer(LN) ? ln.part_stats + ((int64_t)(ep_col >> 5) * ln.rows + row0) * 2 : nullptr;
         // the items are visited in increasing j, so each pointer is a running one: p += step per item (one 64-bit add)
         // instead of base + j * step (hipcc multiplies per item otherwise: 81 quarter-rate v_mad_u64_u32 in this epilogue)
         const float* res_run = res_p;
@@ -1456,14 +1499,14 @@ __global__ __launch_bounds__(512, 2) void gemm8x_kernel(const unsigned short* __
                         d = __builtin_bit_cast(u32x4_t, f);
                     }
                     const bool ok = j * RI + ep_row < WT_M && j * RI < rows_left && ep_col < n_out_total;
-                    if (LN == VF_LN_PRODUCER && OUT_F32) {
-                        ln_emit<DT>(__builtin_bit_cast(f32x4_t, d), ok, o16_run, part_run, lane, !(dbg & 2), !(dbg & 4));
+                    if (ln_is_producer(LN) && OUT_F32) {
+                        ln_emit<DT>(__builtin_bit_cast(f32x4_t, d), ok, o16_run, part_run, lane, ln.x16_scale, !(dbg & 2), !(dbg & 4));
                         o16_run += o16_step;
                         part_run += RI * 2;
                     }
                     // a LayerNorm producer whose fp32 result has no reader (only its 16-bit copy and statistics do) passes
                     // out = NULL: the 16-byte store -- 4 of the 10 bytes the epilogue moves per element -- is dropped
-                    if (ok && (LN != VF_LN_PRODUCER || out != nullptr) && !(dbg & 1)) *reinterpret_cast<u32x4_t*>(out_run) = d;
+                    if (ok && (!ln_is_producer(LN) || out != nullptr) && !(dbg & 1)) *reinterpret_cast<u32x4_t*>(out_run) = d;
                     out_run += out_step;
                 }
             }
@@ -2113,48 +2156,84 @@ static int launch_gemm_ln(const void* A, int64_t lda, const void* W, const float
     switch (pick_variant(M, N, K, EPI)) {
         case 1: return launch_cfg<CfgA, EPI, DT, 0, LN>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, st, ln);
         case 5: return launch_cfg<CfgE, EPI, DT, 0, LN>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, st, ln);
-        case 22: return launch_gemm8x<EPI, DT, LN>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, st, ln);
+        case 22:
+            if constexpr (LN != VF_LN_PRODUCER_R16)      // (fp32 epilogues never take the persistent form by default)
+                return launch_gemm8x<EPI, DT, LN>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, st, ln);
         default: return launch_gemm8<EPI, DT, LN>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, st, ln);
     }
+}
+
+template <int DT>
+static int gemm_ln_dispatch(const void* A, int64_t lda, const void* W, const float* bias, const void* residual, int64_t ldr,
+                            int residual_dtype, void* out, int64_t ldo, int M, int N, int K, int epilogue,
+                            const float* row_stats, const float* colsum, void* out16, int64_t ld16, float* part_stats,
+                            float x16_scale, float res16_scale, void* stream) {
+    VF_REQUIRE(A && W && (out || (out16 && part_stats)), "vf_gemm_ln: null pointer");
+    VF_REQUIRE(M >= 0 && N > 0 && K > 0 && K % 64 == 0 && N % 8 == 0, "vf_gemm_ln: needs K %% 64 == 0, N %% 8 == 0 (N=%d K=%d)", N, K);
+    VF_REQUIRE(lda % 8 == 0 && lda >= K, "vf_gemm_ln: lda=%lld must be >= K and a multiple of 8", (long long)lda);
+    VF_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)W % 16 == 0) && ((uintptr_t)out % 16 == 0),
+               "vf_gemm_ln: pointers must be 16-byte aligned");
+    const bool consumer = row_stats && colsum, producer = out16 && part_stats;
+    VF_REQUIRE(consumer != producer, "vf_gemm_ln: give (row_stats, colsum) OR (out16, part_stats)");
+    if (M == 0) return VF_OK;
+    LnArgs ln{};
+    ln.x16_scale = 1.0f;
+    ln.res16_scale = 1.0f;
+    hipStream_t st = (hipStream_t)stream;
+    if (consumer) {
+        VF_REQUIRE(out, "vf_gemm_ln: the consumer needs an output");
+        VF_REQUIRE(((uintptr_t)row_stats % 8 == 0) && ((uintptr_t)colsum % 16 == 0), "vf_gemm_ln: misaligned statistics");
+        VF_REQUIRE(ldo % 8 == 0, "vf_gemm_ln: ldo=%lld must be a multiple of 8", (long long)ldo);
+        ln.row_stats = row_stats;
+        ln.colsum = colsum;
+        if (epilogue == VF_EPI_BF16)
+            return launch_gemm_ln<VF_EPI_BF16, DT, VF_LN_CONSUMER>(A, lda, W, bias, nullptr, 0, out, ldo, M, N, K, ln, st);
+        VF_REQUIRE(epilogue == VF_EPI_GEGLU_BF16 && N % 32 == 0, "vf_gemm_ln: consumer epilogues are BF16 and GEGLU_BF16 (16-bit out)");
+        return launch_gemm_ln<VF_EPI_GEGLU_BF16, DT, VF_LN_CONSUMER>(A, lda, W, bias, nullptr, 0, out, ldo, M, N, K, ln, st);
+    }
+    VF_REQUIRE(ld16 % 4 == 0 && ld16 >= N && ((uintptr_t)out16 % 8 == 0) && ((uintptr_t)part_stats % 8 == 0) && ldo % 4 == 0,
+               "vf_gemm_ln: producer outputs must keep 8-byte alignment (ld16=%lld)", (long long)ld16);
+    VF_REQUIRE(N % 32 == 0, "vf_gemm_ln: a producer needs N %% 32 == 0 (whole 32-column parts; N=%d)", N);
+    VF_REQUIRE(x16_scale > 0.f && (DT == VF_F16 || x16_scale == 1.0f), "vf_gemm_ln: x16_scale must be > 0 (and 1 for bf16 streams)");
+    ln.out16 = out16;
+    ln.part_stats = part_stats;
+    ln.ld16 = ld16;
+    ln.rows = M;
+    ln.x16_scale = x16_scale;
+    if (epilogue == VF_EPI_F32)
+        return launch_gemm_ln<VF_EPI_F32, DT, VF_LN_PRODUCER>(A, lda, W, bias, nullptr, 0, out, ldo, M, N, K, ln, st);
+    VF_REQUIRE(epilogue == VF_EPI_RES_F32 && residual, "vf_gemm_ln: producer epilogues are F32 and RES_F32 (with a residual)");
+    if (residual_dtype == VF_F32) {
+        VF_REQUIRE(ldr % 4 == 0 && ((uintptr_t)residual % 16 == 0), "vf_gemm_ln: misaligned fp32 residual");
+        return launch_gemm_ln<VF_EPI_RES_F32, DT, VF_LN_PRODUCER>(A, lda, W, bias, (const float*)residual, ldr, out, ldo, M, N, K, ln, st);
+    }
+    VF_REQUIRE(residual_dtype == DT, "vf_gemm_ln: a 16-bit residual must have the operand type");
+    VF_REQUIRE(ldr % 4 == 0 && ((uintptr_t)residual % 8 == 0) && res16_scale > 0.f, "vf_gemm_ln: misaligned 16-bit residual");
+    ln.res16 = (const unsigned short*)residual;
+    ln.ldr16 = ldr;
+    ln.res16_scale = res16_scale;
+    // `res` must be non-null for the RES_F32 epilogue's own checks downstream; it is never dereferenced in R16 kernels
+    return launch_gemm_ln<VF_EPI_RES_F32, DT, VF_LN_PRODUCER_R16>(A, lda, W, bias, (const float*)residual, ldr, out, ldo, M, N, K, ln, st);
+}
+
+extern "C" int vf_gemm_ln(const void* A, int64_t lda, const void* W, const float* bias, const void* residual, int64_t ldr,
+                          int residual_dtype, void* out, int64_t ldo, int M, int N, int K, int epilogue, int operand_dtype,
+                          const float* row_stats, const float* colsum, void* out16, int64_t ld16, float* part_stats,
+                          float x16_scale, float res16_scale, void* stream) {
+    if (operand_dtype == VF_BF16)
+        return gemm_ln_dispatch<VF_BF16>(A, lda, W, bias, residual, ldr, residual_dtype, out, ldo, M, N, K, epilogue, row_stats,
+                                         colsum, out16, ld16, part_stats, x16_scale, res16_scale, stream);
+    VF_REQUIRE(operand_dtype == VF_F16, "vf_gemm_ln: operand_dtype must be VF_BF16 or VF_F16");
+    return gemm_ln_dispatch<VF_F16>(A, lda, W, bias, residual, ldr, residual_dtype, out, ldo, M, N, K, epilogue, row_stats,
+                                    colsum, out16, ld16, part_stats, x16_scale, res16_scale, stream);
 }
 
 extern "C" int vf_gemm_ln_bf16(const void* A, int64_t lda, const void* W, const float* bias, const float* residual,
                                int64_t ldr, void* out, int64_t ldo, int M, int N, int K, int epilogue,
                                const float* row_stats, const float* colsum, void* out16, int64_t ld16,
                                float* part_stats, void* stream) {
-    VF_REQUIRE(A && W && (out || (out16 && part_stats)), "vf_gemm_ln_bf16: null pointer");
-    VF_REQUIRE(M >= 0 && N > 0 && K > 0 && K % 64 == 0 && N % 8 == 0, "vf_gemm_ln_bf16: needs K %% 64 == 0, N %% 8 == 0 (N=%d K=%d)", N, K);
-    VF_REQUIRE(lda % 8 == 0 && lda >= K, "vf_gemm_ln_bf16: lda=%lld must be >= K and a multiple of 8", (long long)lda);
-    VF_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)W % 16 == 0) && ((uintptr_t)out % 16 == 0),
-               "vf_gemm_ln_bf16: pointers must be 16-byte aligned");
-    const bool consumer = row_stats && colsum, producer = out16 && part_stats;
-    VF_REQUIRE(consumer != producer, "vf_gemm_ln_bf16: give (row_stats, colsum) OR (out16, part_stats)");
-    if (M == 0) return VF_OK;
-    LnArgs ln{};
-    hipStream_t st = (hipStream_t)stream;
-    if (consumer) {
-        VF_REQUIRE(out, "vf_gemm_ln_bf16: the consumer needs an output");
-        VF_REQUIRE(((uintptr_t)row_stats % 8 == 0) && ((uintptr_t)colsum % 16 == 0), "vf_gemm_ln_bf16: misaligned statistics");
-        VF_REQUIRE(ldo % 8 == 0, "vf_gemm_ln_bf16: ldo=%lld must be a multiple of 8", (long long)ldo);
-        ln.row_stats = row_stats;
-        ln.colsum = colsum;
-        if (epilogue == VF_EPI_BF16)
-            return launch_gemm_ln<VF_EPI_BF16, VF_BF16, VF_LN_CONSUMER>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, ln, st);
-        VF_REQUIRE(epilogue == VF_EPI_GEGLU_BF16 && N % 32 == 0, "vf_gemm_ln_bf16: consumer epilogues are BF16 and GEGLU_BF16");
-        return launch_gemm_ln<VF_EPI_GEGLU_BF16, VF_BF16, VF_LN_CONSUMER>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, ln, st);
-    }
-    VF_REQUIRE(ld16 % 4 == 0 && ld16 >= N && ((uintptr_t)out16 % 8 == 0) && ((uintptr_t)part_stats % 8 == 0) && ldo % 4 == 0,
-               "vf_gemm_ln_bf16: producer outputs must keep 8-byte alignment (ld16=%lld)", (long long)ld16);
-    VF_REQUIRE(N % 32 == 0, "vf_gemm_ln_bf16: a producer needs N %% 32 == 0 (whole 32-column parts; N=%d)", N);
-    ln.out16 = out16;
-    ln.part_stats = part_stats;
-    ln.ld16 = ld16;
-    ln.rows = M;
-    if (epilogue == VF_EPI_F32)
-        return launch_gemm_ln<VF_EPI_F32, VF_BF16, VF_LN_PRODUCER>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, ln, st);
-    VF_REQUIRE(epilogue == VF_EPI_RES_F32 && residual && ldr % 4 == 0 && ((uintptr_t)residual % 16 == 0),
-               "vf_gemm_ln_bf16: producer epilogues are F32 and RES_F32 (with an aligned residual)");
-    return launch_gemm_ln<VF_EPI_RES_F32, VF_BF16, VF_LN_PRODUCER>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, ln, st);
+    return gemm_ln_dispatch<VF_BF16>(A, lda, W, bias, residual, ldr, VF_F32, out, ldo, M, N, K, epilogue, row_stats, colsum,
+                                     out16, ld16, part_stats, 1.0f, 1.0f, stream);
 }
 
 extern "C" int vf_gemm_bf16(const void* A, int64_t lda, const void* W, const float* bias, const float* residual,

@@ -93,8 +93,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // (mean, rstd) per row.  Parts are merged with the parallel-variance formula (Chan et al.): M2 = sum_p M2_p +
 // 32 * sum_p (mean_p - mean)^2 -- every term is non-negative, so rows whose mean is large against their spread lose no
 // digits (E[x^2] - mean^2 would).
+// x16_scale: the 16-bit copy of the stream holds x * c (fp16 streams; 1 otherwise) -- the consumer GEMM's accumulator is
+// then c * (x . w'), so the pair it needs is (mean * c, rstd / c).  alert (optional): set to 1 when a row's |mean| exceeds
+// ratio_limit standard deviations, the regime in which the folded form's 16-bit rounding of the UNCENTRED row costs
+// accuracy (tests/test_ops_gpu.py::test_ln_fold_rows_with_large_mean); the model reads the flag back with its outputs.
 __global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restrict__ part, float* __restrict__ row_stats,
-                                                         int64_t rows, int n_parts, int D, float eps) {
+                                                         int64_t rows, int n_parts, int D, float eps, float x16_scale,
+                                                         float ratio_limit, int* __restrict__ alert) {
     // part is [n_parts][rows][2] (part-major): one thread per row, consecutive threads read consecutive rows; the parts
     // are added in index order, so the result does not depend on the GEMM tile configuration that wrote them
     const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -110,7 +115,9 @@ __global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restric
         const float d = v[0] * (1.0f / 32.0f) - mean;
         m2 += v[1] + 32.0f * d * d;
     }
-    *reinterpret_cast<f32x2_t*>(row_stats + 2 * row) = (f32x2_t){mean, rsqrtf(m2 / (float)D + eps)};
+    const float rstd = rsqrtf(m2 / (float)D + eps);
+    *reinterpret_cast<f32x2_t*>(row_stats + 2 * row) = (f32x2_t){mean * x16_scale, rstd / x16_scale};
+    if (alert && fabsf(mean) * rstd > ratio_limit) *alert = 1;      // benign race: every writer stores the same value
 }
 
 // The same statistics for a stream that no GEMM produced (the first layer's input): one wave per row, two-pass
@@ -118,7 +125,8 @@ __global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restric
 template <int MAXC>
 __global__ __launch_bounds__(256) void row_stats_cast_kernel(const float* __restrict__ x, void* __restrict__ out16,
                                                             float* __restrict__ row_stats, int64_t rows, int D, float eps,
-                                                            int out_dt) {
+                                                            int out_dt, float x16_scale, float ratio_limit,
+                                                            int* __restrict__ alert) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -144,13 +152,16 @@ __global__ __launch_bounds__(256) void row_stats_cast_kernel(const float* __rest
                 ss += d * d;
             }
             u32x2_t p;
-            p[0] = pack2_dt(v[c][0], v[c][1], out_dt);
-            p[1] = pack2_dt(v[c][2], v[c][3], out_dt);
+            p[0] = pack2_dt(v[c][0] * x16_scale, v[c][1] * x16_scale, out_dt);
+            p[1] = pack2_dt(v[c][2] * x16_scale, v[c][3] * x16_scale, out_dt);
             reinterpret_cast<u32x2_t*>(reinterpret_cast<unsigned short*>(out16) + row * D)[i] = p;
         }
     }
     const float rstd = rsqrtf(wave_sum(ss) / (float)D + eps);
-    if (lane == 0) *reinterpret_cast<f32x2_t*>(row_stats + 2 * row) = (f32x2_t){mean, rstd};
+    if (lane == 0) {
+        *reinterpret_cast<f32x2_t*>(row_stats + 2 * row) = (f32x2_t){mean * x16_scale, rstd / x16_scale};
+        if (alert && fabsf(mean) * rstd > ratio_limit) *alert = 1;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -457,29 +468,40 @@ extern "C" int vf_layernorm(const float* x, const float* gamma, const float* bet
     return VF_OK;
 }
 
-extern "C" int vf_ln_finalize(const float* part_stats, int64_t rows, int n_parts, int D, float eps, float* row_stats,
-                              void* stream) {
-    VF_REQUIRE(part_stats && row_stats && n_parts > 0 && D > 0, "vf_ln_finalize: bad arguments");
+extern "C" int vf_ln_finalize2(const float* part_stats, int64_t rows, int n_parts, int D, float eps, float x16_scale,
+                               float ratio_limit, int* alert, float* row_stats, void* stream) {
+    VF_REQUIRE(part_stats && row_stats && n_parts > 0 && D > 0 && x16_scale > 0.f, "vf_ln_finalize: bad arguments");
     if (rows <= 0) return VF_OK;
     hipLaunchKernelGGL(ln_finalize_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, part_stats,
-                       row_stats, rows, n_parts, D, eps);
+                       row_stats, rows, n_parts, D, eps, x16_scale, ratio_limit, alert);
     VF_CHECK_LAUNCH("vf_ln_finalize");
+    return VF_OK;
+}
+
+extern "C" int vf_ln_finalize(const float* part_stats, int64_t rows, int n_parts, int D, float eps, float* row_stats,
+                              void* stream) {
+    return vf_ln_finalize2(part_stats, rows, n_parts, D, eps, 1.0f, 0.f, nullptr, row_stats, stream);
+}
+
+extern "C" int vf_row_stats_cast2(const float* x, int64_t rows, int D, float eps, void* out16, int out_dtype, float x16_scale,
+                                  float ratio_limit, int* alert, float* row_stats, void* stream) {
+    VF_REQUIRE(x && out16 && row_stats, "vf_row_stats_cast: null pointer");
+    VF_REQUIRE(D > 0 && D % 4 == 0 && D <= 8192, "vf_row_stats_cast: D=%d must be a multiple of 4 and <= 8192", D);
+    VF_REQUIRE(out_dtype == VF_BF16 || out_dtype == VF_F16, "vf_row_stats_cast: bad out_dtype %d", out_dtype);
+    VF_REQUIRE(x16_scale > 0.f, "vf_row_stats_cast: x16_scale must be positive");
+    if (rows <= 0) return VF_OK;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)((rows + 3) / 4));
+    if (D <= 512) hipLaunchKernelGGL(row_stats_cast_kernel<2>, grid, dim3(256), 0, st, x, out16, row_stats, rows, D, eps, out_dtype, x16_scale, ratio_limit, alert);
+    else if (D <= 2048) hipLaunchKernelGGL(row_stats_cast_kernel<8>, grid, dim3(256), 0, st, x, out16, row_stats, rows, D, eps, out_dtype, x16_scale, ratio_limit, alert);
+    else hipLaunchKernelGGL(row_stats_cast_kernel<32>, grid, dim3(256), 0, st, x, out16, row_stats, rows, D, eps, out_dtype, x16_scale, ratio_limit, alert);
+    VF_CHECK_LAUNCH("vf_row_stats_cast");
     return VF_OK;
 }
 
 extern "C" int vf_row_stats_cast(const float* x, int64_t rows, int D, float eps, void* out16, int out_dtype,
                                  float* row_stats, void* stream) {
-    VF_REQUIRE(x && out16 && row_stats, "vf_row_stats_cast: null pointer");
-    VF_REQUIRE(D > 0 && D % 4 == 0 && D <= 8192, "vf_row_stats_cast: D=%d must be a multiple of 4 and <= 8192", D);
-    VF_REQUIRE(out_dtype == VF_BF16 || out_dtype == VF_F16, "vf_row_stats_cast: bad out_dtype %d", out_dtype);
-    if (rows <= 0) return VF_OK;
-    hipStream_t st = (hipStream_t)stream;
-    dim3 grid((unsigned)((rows + 3) / 4));
-    if (D <= 512) hipLaunchKernelGGL(row_stats_cast_kernel<2>, grid, dim3(256), 0, st, x, out16, row_stats, rows, D, eps, out_dtype);
-    else if (D <= 2048) hipLaunchKernelGGL(row_stats_cast_kernel<8>, grid, dim3(256), 0, st, x, out16, row_stats, rows, D, eps, out_dtype);
-    else hipLaunchKernelGGL(row_stats_cast_kernel<32>, grid, dim3(256), 0, st, x, out16, row_stats, rows, D, eps, out_dtype);
-    VF_CHECK_LAUNCH("vf_row_stats_cast");
-    return VF_OK;
+    return vf_row_stats_cast2(x, rows, D, eps, out16, out_dtype, 1.0f, 0.f, nullptr, row_stats, stream);
 }
 
 extern "C" int vf_mask_to_cu_seqlens(const uint8_t* pad, int32_t* cu, int W, int L, void* stream) {

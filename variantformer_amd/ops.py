@@ -179,54 +179,100 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None, epilogue: 
 
 
 class LnStream:
-    """A residual stream as the LayerNorm-folding GEMMs exchange it: x fp32 [M, D], x16 its bf16 copy, stats fp32 [M, 2]
-    = (mean, rstd) of every row (vf_gemm_ln_bf16 / vf_ln_finalize / vf_row_stats_cast)."""
-    __slots__ = ("x", "x16", "stats")
+    """A residual stream as the LayerNorm-folding GEMMs exchange it: x fp32 [M, D] (None when the fp32 rows have no
+    reader), x16 its 16-bit copy -- for fp16 streams stored SCALED, x16 = fp16(x * scale) --, stats fp32 [M, 2] =
+    (mean * scale, rstd / scale) of every row: exactly the pair the consumer GEMM applies to its accumulator of the
+    scaled operand (vf_gemm_ln / vf_ln_finalize2 / vf_row_stats_cast2).  scale = 1 for bf16 streams."""
+    __slots__ = ("x", "x16", "stats", "scale")
 
-    def __init__(self, x, x16, stats):
-        self.x, self.x16, self.stats = x, x16, stats
+    def __init__(self, x, x16, stats, scale: float = 1.0):
+        self.x, self.x16, self.stats, self.scale = x, x16, stats, float(scale)
+
+    def operand16(self):
+        """The stream as a plain 16-bit GEMM operand (un-normalised use: the K/V projection of a cross attention):
+        the copy itself when it is unscaled, else a cast of the fp32 rows."""
+        return self.x16 if self.scale == 1.0 else cast16(self.x, self.x16.dtype)
+
+
+def x16_scale_for(dtype) -> float:
+    """Power-of-two scale of the 16-bit copy of a residual stream: 1 for bf16 (fp32's exponent range); 2^-4 for fp16, which
+    keeps |x| < 1e6 representable (the reference's own fp16 autocast overflows at 65504) at no cost in precision --
+    10 mantissa bits at every magnitude above 1e-3 -- and LayerNorm is scale-invariant.  VF_X16_SCALE_LOG2 overrides."""
+    import os
+    if dtype != torch.float16:
+        return 1.0
+    return 2.0 ** int(os.environ.get("VF_X16_SCALE_LOG2", "-4"))
+
+
+# Rows whose |mean| exceeds this many standard deviations make the folded LayerNorm -> Linear lose accuracy (it rounds
+# the UNCENTRED row to 16 bits; tests/test_ops_gpu.py::test_ln_fold_rows_with_large_mean: error ~ 2^-9 x |mean| / std).
+# The statistics kernels raise a device flag; ln_fold_alert() reads it (one int, with the outputs of a batch).
+LN_FOLD_RATIO_LIMIT = 8.0
+_ALERT: dict = {}
+
+
+def _alert_flag(device) -> torch.Tensor:
+    key = (device.type, device.index)
+    if key not in _ALERT:
+        _ALERT[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return _ALERT[key]
+
+
+def ln_fold_alert(device, reset: bool = True) -> bool:
+    """True when, since the last reset, some row of a LayerNorm-folded stream had |mean| > LN_FOLD_RATIO_LIMIT standard
+    deviations (synchronises: call it where the outputs are copied back).  VF_LN_FOLD=0 avoids the regime."""
+    key = (device.type, device.index)
+    if key not in _ALERT:
+        return False
+    hit = bool(int(_ALERT[key].item()))
+    if hit and reset:
+        _ALERT[key].zero_()
+    return hit
 
 
 def ln_stream(x: torch.Tensor, eps: float = 1e-5) -> LnStream:
-    """(x, bf16 copy, row statistics) for a stream no GEMM produced: one pass over x (vf_row_stats_cast)."""
+    """(x, 16-bit copy, row statistics) for a stream no GEMM produced: one pass over x (vf_row_stats_cast2)."""
     _dev(x)
     assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 2
     M, D = x.shape
-    x16 = torch.empty((M, D), dtype=torch.bfloat16, device=x.device)
+    x16 = torch.empty((M, D), dtype=_CDT, device=x.device)
     stats = torch.empty((M, 2), dtype=torch.float32, device=x.device)
+    scale = x16_scale_for(_CDT)
+    alert = _alert_flag(x.device)
 
     def launch():
-        check(_lib.load().vf_row_stats_cast(x.data_ptr(), M, D, eps, x16.data_ptr(), VF_BF16, stats.data_ptr(), _stream()),
-              "vf_row_stats_cast")
+        check(_lib.load().vf_row_stats_cast2(x.data_ptr(), M, D, eps, x16.data_ptr(), _dt(_CDT), scale, LN_FOLD_RATIO_LIMIT,
+                                             alert.data_ptr(), stats.data_ptr(), _stream()), "vf_row_stats_cast")
     if TIMER is not None:
         TIMER.time("layernorm", 0.0, float(M) * D * 6, launch, f"stats_cast D={D}", _SCOPE)
     else:
         launch()
-    return LnStream(x, x16, stats)
+    return LnStream(x, x16, stats, scale)
 
 
 def ln_stream_rows(s: LnStream, rows: torch.Tensor) -> LnStream:
     """The rows `rows` (int64) of a stream, statistics included (bit-identical to the full stream's)."""
-    return LnStream(gather_rows_f32(s.x, None, rows), gather_rows_bf16(s.x16, rows), gather_rows_f32(s.stats, None, rows))
+    return LnStream(None if s.x is None else gather_rows_f32(s.x, None, rows), gather_rows_bf16(s.x16, rows),
+                    gather_rows_f32(s.stats, None, rows), s.scale)
 
 
 def gemm_ln_consumer(s: LnStream, w: torch.Tensor, bias: torch.Tensor, colsum: torch.Tensor, epilogue: int,
                      family: str = "") -> torch.Tensor:
-    """epilogue(LN(s.x) @ W^T + b) without materialising LN(s.x): w = bf16(gamma (.) W) [N, K], bias = W beta + b,
-    colsum = rowsum(w) (layers.packed_linear_ln).  epilogue EPI_BF16 or EPI_GEGLU_BF16."""
+    """epilogue(LN(s.x) @ W^T + b) without materialising LN(s.x): w = 16-bit(gamma (.) W) [N, K], bias = W beta + b,
+    colsum = rowsum(w) (layers.packed_linear_ln).  epilogue EPI_BF16 or EPI_GEGLU_BF16 (16-bit output, operand type)."""
     a = s.x16
     _dev(a, w, bias, colsum, s.stats)
-    assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and a.shape[1] == w.shape[1] and a.stride(1) == 1
+    assert _is16(a.dtype) and w.dtype == a.dtype and a.shape[1] == w.shape[1] and a.stride(1) == 1
     M, K = a.shape
     N = w.shape[0]
     n_out = N // 2 if epilogue == EPI_GEGLU_BF16 else N
-    out = torch.empty((M, n_out), dtype=torch.bfloat16, device=a.device)
+    out = torch.empty((M, n_out), dtype=a.dtype, device=a.device)
     lib = _lib.load()
 
     def launch():
-        check(lib.vf_gemm_ln_bf16(a.data_ptr(), a.stride(0) if M > 1 else max(a.stride(0), K), w.data_ptr(), bias.data_ptr(),
-                                  0, 0, out.data_ptr(), n_out, M, N, K, epilogue, s.stats.data_ptr(), colsum.data_ptr(),
-                                  0, 0, 0, _stream()), "vf_gemm_ln_bf16")
+        check(lib.vf_gemm_ln(a.data_ptr(), a.stride(0) if M > 1 else max(a.stride(0), K), w.data_ptr(), bias.data_ptr(),
+                             0, 0, VF_F32, out.data_ptr(), n_out, M, N, K, epilogue, _dt(a.dtype), s.stats.data_ptr(),
+                             colsum.data_ptr(), 0, 0, 0, 1.0, 1.0, _stream()), "vf_gemm_ln")
     if TIMER is not None:
         nbytes = 2.0 * (M * K + N * K) + out.numel() * 2 + 8.0 * M
         TIMER.time("gemm", 2.0 * M * N * K, nbytes, launch, f"M={M} N={N} K={K} epi={epilogue} ln=consumer", family or _SCOPE)
@@ -235,42 +281,55 @@ def gemm_ln_consumer(s: LnStream, w: torch.Tensor, bias: torch.Tensor, colsum: t
     return out
 
 
-def gemm_ln_producer(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None, residual: torch.Tensor | None,
+def gemm_ln_producer(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None, residual,
                      eps: float = 1e-5, family: str = "", need_x: bool = True) -> LnStream:
-    """x = a @ w^T + bias (+ residual), fp32, returned together with its bf16 copy and row statistics (the next
-    LayerNorm's): EPI_RES_F32 when a residual is given, else EPI_F32.  need_x=False: the fp32 x itself has no reader
-    (a layer's intermediate stream feeds only the next LayerNorm -> Linear pair) and is not stored; .x is None."""
-    _dev(a, w, bias, residual)
-    assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and a.shape[1] == w.shape[1] and a.stride(1) == 1
+    """x = a @ w^T + bias (+ residual), fp32, returned together with its 16-bit copy and row statistics (the next
+    LayerNorm's): EPI_RES_F32 when a residual is given, else EPI_F32.  `residual`: an fp32 tensor [M, N], or an LnStream
+    whose 16-BIT COPY is the residual (its fp32 rows need not exist).  need_x=False: the fp32 x itself has no reader (a
+    layer's intermediate stream feeds only the next LayerNorm -> Linear pair) and is not stored; .x is None."""
+    res16 = residual if isinstance(residual, LnStream) else None
+    res32 = None if res16 is not None else residual
+    _dev(a, w, bias, res32, None if res16 is None else res16.x16)
+    assert _is16(a.dtype) and w.dtype == a.dtype and a.shape[1] == w.shape[1] and a.stride(1) == 1
     M, K = a.shape
     N = w.shape[0]
     out = torch.empty((M, N), dtype=torch.float32, device=a.device) if need_x else None
-    x16 = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+    x16 = torch.empty((M, N), dtype=a.dtype, device=a.device)
     n_parts = (N + 31) // 32
     part = torch.empty((n_parts, M, 2), dtype=torch.float32, device=a.device)
     stats = torch.empty((M, 2), dtype=torch.float32, device=a.device)
     epi = EPI_F32 if residual is None else EPI_RES_F32
-    if residual is not None:
-        assert residual.dtype == torch.float32 and residual.shape == (M, N) and residual.stride(1) == 1
+    if res32 is not None:
+        assert res32.dtype == torch.float32 and res32.shape == (M, N) and res32.stride(1) == 1
+        r_ptr, r_ld, r_dt, r_scale = res32.data_ptr(), res32.stride(0), VF_F32, 1.0
+    elif res16 is not None:
+        r = res16.x16
+        assert r.dtype == a.dtype and r.shape == (M, N) and r.stride(1) == 1
+        r_ptr, r_ld, r_dt, r_scale = r.data_ptr(), r.stride(0), _dt(r.dtype), 1.0 / res16.scale
+    else:
+        r_ptr, r_ld, r_dt, r_scale = 0, 0, VF_F32, 1.0
+    scale = x16_scale_for(a.dtype)
+    alert = _alert_flag(a.device)
     lib = _lib.load()
 
     def launch():
-        check(lib.vf_gemm_ln_bf16(a.data_ptr(), a.stride(0) if M > 1 else max(a.stride(0), K), w.data_ptr(), _ptr(bias),
-                                  _ptr(residual), 0 if residual is None else residual.stride(0), _ptr(out), N, M, N, K,
-                                  epi, 0, 0, x16.data_ptr(), N, part.data_ptr(), _stream()), "vf_gemm_ln_bf16")
+        check(lib.vf_gemm_ln(a.data_ptr(), a.stride(0) if M > 1 else max(a.stride(0), K), w.data_ptr(), _ptr(bias),
+                             r_ptr, r_ld, r_dt, _ptr(out), N, M, N, K, epi, _dt(a.dtype), 0, 0, x16.data_ptr(), N,
+                             part.data_ptr(), scale, r_scale, _stream()), "vf_gemm_ln")
 
     def finalize():
-        check(lib.vf_ln_finalize(part.data_ptr(), M, n_parts, N, eps, stats.data_ptr(), _stream()), "vf_ln_finalize")
+        check(lib.vf_ln_finalize2(part.data_ptr(), M, n_parts, N, eps, scale, LN_FOLD_RATIO_LIMIT, alert.data_ptr(),
+                                  stats.data_ptr(), _stream()), "vf_ln_finalize")
     if TIMER is not None:
-        nbytes = (2.0 * (M * K + N * K) + M * N * ((4.0 if need_x else 0.0) + 2.0) + (0 if residual is None else 4.0 * M * N)
-                  + 8.0 * M * n_parts)
-        TIMER.time("gemm", 2.0 * M * N * K, nbytes, launch,
-                   f"M={M} N={N} K={K} epi={epi} ln=producer{'' if need_x else '-nox'}", family or _SCOPE)
+        res_bytes = 0.0 if residual is None else (4.0 if res32 is not None else 2.0) * M * N
+        nbytes = 2.0 * (M * K + N * K) + M * N * ((4.0 if need_x else 0.0) + 2.0) + res_bytes + 8.0 * M * n_parts
+        tag = "producer" + ("" if need_x else "-nox") + ("-r16" if res16 is not None else "")
+        TIMER.time("gemm", 2.0 * M * N * K, nbytes, launch, f"M={M} N={N} K={K} epi={epi} ln={tag}", family or _SCOPE)
         TIMER.time("layernorm", 0.0, 8.0 * M * (n_parts + 1), finalize, f"finalize D={N}", _SCOPE)
     else:
         launch()
         finalize()
-    return LnStream(out, x16, stats)
+    return LnStream(out, x16, stats, scale)
 
 
 def pack_geglu_rows(w: torch.Tensor, bias: torch.Tensor | None):

@@ -66,14 +66,14 @@ def packed_linear_ln(lin: nn.Linear, norm: nn.LayerNorm, geglu: bool = False):
        three.  One-time weight preparation (cached per parameter versions), torch elementwise / reduce ops on the fp32
        masters; nothing of this runs per batch."""
     w, g, be = lin.weight, norm.weight, norm.bias
-    key = (w.data_ptr(), w._version, g.data_ptr(), g._version, be.data_ptr(), be._version, str(w.device), geglu,
+    key = (w.data_ptr(), w._version, g.data_ptr(), g._version, be.data_ptr(), be._version, str(w.device), geglu, ops.cdt(),
            None if lin.bias is None else (lin.bias.data_ptr(), lin.bias._version))
     cache = getattr(lin, "_vf_packed_ln", None)
     if cache is not None and cache[0] == key:
         return cache[1], cache[2], cache[3]
     with torch.no_grad():
         wf = w.detach().float()
-        wb = ops.cast16((wf * g.detach().float()[None, :]).contiguous(), torch.bfloat16)
+        wb = ops.cast16((wf * g.detach().float()[None, :]).contiguous())            # current operand type (bf16 / fp16)
         b = wf @ be.detach().float()
         if lin.bias is not None:
             b = b + lin.bias.detach().float()
@@ -87,13 +87,22 @@ def packed_linear_ln(lin: nn.Linear, norm: nn.LayerNorm, geglu: bool = False):
 
 
 def ln_fold_enabled(*widths: int) -> bool:
-    """LayerNorm folded into the neighbouring GEMMs for bf16 operands when EVERY contraction width of
-    the layer's folded GEMMs (d_model, and hidden_dim / 2 for the down-projection producer) is one the MFMA path takes
-    (K % 64 == 0); otherwise -- and with VF_LN_FOLD=0 -- the separate LayerNorm pass (the fp16 mode always does: the raw
-    residual stream may exceed the fp16 range, its LayerNorm never does)."""
+    """LayerNorm folded into the neighbouring GEMMs when EVERY contraction width of the layer's
+    folded GEMMs (d_model, and hidden_dim / 2 for the down-projection producer) is one the MFMA path takes (K % 64 == 0);
+    otherwise -- and with VF_LN_FOLD=0 -- the separate LayerNorm pass.  Both operand types: an fp16 stream's 16-bit copy
+    is stored scaled by a power of two (ops.x16_scale_for), so the raw residual cannot leave the fp16 range."""
     import os
-    return (ops.cdt() == torch.bfloat16 and all(int(w) % 64 == 0 for w in widths)
-            and os.environ.get("VF_LN_FOLD", "1") != "0")
+    return all(int(w) % 64 == 0 for w in widths) and os.environ.get("VF_LN_FOLD", "1") != "0"
+
+
+def res16_enabled() -> bool:
+    """The stream after a layer's self-attention block (x1 = out_proj(attn) + src) is read by LayerNorm2 -> Wq and as the
+    residual of the cross-attention out-projection, nothing else.  With this on (default; VF_RES16=0 restores fp32) the
+    residual is taken from x1's 16-bit copy and its fp32 rows are never written: 6 bytes per element less traffic in the
+    two producer epilogues.  The reference's own autocast keeps that stream in 16 bits; oracle.Rounding(res16=True)
+    restates the rounding point."""
+    import os
+    return os.environ.get("VF_RES16", "1") != "0"
 
 
 def _as_stream(x):
@@ -193,7 +202,8 @@ class MHA(nn.Module):
                                self.num_heads, self.head_dim, self.alibi_slopes, family=self.family)
 
     def out_ln(self, a_bf16, residual_f32, need_x: bool = True) -> "ops.LnStream":
-        """out_proj(a) + residual as an LnStream (fp32 stream, its bf16 copy, row statistics for the next LayerNorm).
+        """out_proj(a) + residual as an LnStream (fp32 stream, its 16-bit copy, row statistics for the next LayerNorm).
+        `residual_f32`: the fp32 rows, or an LnStream whose 16-bit copy is the residual (layers.res16_enabled).
         need_x=False when the sum is only ever read through the next LayerNorm -> Linear pair (the layers add their FFN
         to the layer INPUT, reference layers.py:99,163 / seq2reg/modules.py:188, so the stream after the last attention
         block has no other reader): the fp32 values are then not written to HBM at all."""
@@ -328,12 +338,13 @@ class ContextFlashAttentionEncoderLayer(nn.Module):
             else:
                 s = _as_stream(src)
                 a = self.mixer.MHA.attend_ln(s, self.norm1, None, cu_src, max_src, None, None)
-            x1 = self.mixer.MHA.out_ln(a, s.x)
+            r16 = res16_enabled()
+            x1 = self.mixer.MHA.out_ln(a, s.x, need_x=not r16)
             if context_kv is None:
-                ctx16 = context.x16 if isinstance(context, ops.LnStream) else ops.cast16(context)
+                ctx16 = context.operand16() if isinstance(context, ops.LnStream) else ops.cast16(context)
                 context_kv = self.crossMHA.MHA.project_kv(ctx16)
             a = self.crossMHA.MHA.attend_ln(x1, self.norm2, context_kv, cq, mq, cu_ctx, max_ctx)
-            x2 = self.crossMHA.MHA.out_ln(a, x1.x, need_x=False)
+            x2 = self.crossMHA.MHA.out_ln(a, x1 if r16 else x1.x, need_x=False)
             w1, b1, c1 = packed_linear_ln(self.linear_geglu_1, self.norm3, geglu=True)
             hg = ops.gemm_ln_consumer(x2, w1, b1, c1, ops.EPI_GEGLU_BF16)
             w2, b2 = packed_linear(self.linear_geglu_2)
@@ -370,16 +381,17 @@ class ContextFlashAttentionEncoderLayer(nn.Module):
             q = ops.gemm_ln_consumer(sr, w[:D], b[:D], c[:D], ops.EPI_BF16)            # [R, D]
             a = ops.attn_varlen(q, kv[:, :D], kv[:, D:], cu_rows, cu_src, 1, max_src, mha.num_heads, mha.head_dim,
                                 mha.alibi_slopes, q_at_start=True, family=mha.family + "_registry_rows")
-            x1 = mha.out_ln(a, sr.x)
-            ctx16 = context.x16 if isinstance(context, ops.LnStream) else ops.cast16(context)
+            r16 = res16_enabled()
+            x1 = mha.out_ln(a, sr.x, need_x=not r16)
+            ctx16 = context.operand16() if isinstance(context, ops.LnStream) else ops.cast16(context)
             ckv = self.crossMHA.MHA.project_kv(ctx16)
             a = self.crossMHA.MHA.attend_ln(x1, self.norm2, ckv, cu_cross_rows, max_cross_rows, cu_ctx, max_ctx)
-            x2 = self.crossMHA.MHA.out_ln(a, x1.x, need_x=False)
+            x2 = self.crossMHA.MHA.out_ln(a, x1 if r16 else x1.x, need_x=False)
             w1, b1, c1 = packed_linear_ln(self.linear_geglu_1, self.norm3, geglu=True)
             hg = ops.gemm_ln_consumer(x2, w1, b1, c1, ops.EPI_GEGLU_BF16)
             w2, b2 = packed_linear(self.linear_geglu_2)
             return ops.gemm(hg, w2, b2, ops.EPI_RES_F32, residual=sr.x)
-        ctx16 = context.x16 if isinstance(context, ops.LnStream) else None
+        ctx16 = context.operand16() if isinstance(context, ops.LnStream) else None
         src, context = _as_tensor(src), _as_tensor(context)
         D = src.shape[1]
         h = ops.layernorm(src, self.norm1.weight, self.norm1.bias)                       # all rows (K/V need them)
@@ -498,7 +510,7 @@ class ContextFlashCrossAttentionEncoderLayer(nn.Module):
         if ln_fold_enabled(self.norm1.weight.numel(), self.linear_geglu_2.in_features):
             s = _as_stream(src)
             if context_kv is None:
-                ctx16 = context.x16 if isinstance(context, ops.LnStream) else ops.cast16(context)
+                ctx16 = context.operand16() if isinstance(context, ops.LnStream) else ops.cast16(context)
                 context_kv = self.crossMHA.MHA.project_kv(ctx16)
             a = self.crossMHA.MHA.attend_ln(s, self.norm1, context_kv, cq, mq, cu_ctx, max_ctx)
             x1 = self.crossMHA.MHA.out_ln(a, s.x, need_x=False)
