@@ -160,23 +160,34 @@ def test_cfg5_whole_genome_scan_fp16_ragged_genes(full_model):
         model.precision = keep
 
 
-def test_cfg4_paired_ref_alt_full_size(full_model):
-    """BASELINE configs[3] (snp_indel_predictions geometry): two full-size 1 Mb genes (N = 1024, C = 200, T = 54) that
-    differ in 5 cCRE windows and 5 gene chunks.  The variant-effect delta = alt - ref of the HIP path must follow the
-    oracle's delta; the ref half must not notice the alt half (pair vs alone), and the VEP window de-duplication must
-    reproduce the plain evaluation bit for bit at this size."""
-    model, hp, kw, sd = full_model
-    ref = make_batch(40404, [1024], [200], [TISSUES_54], 200)
+def _variant_pair(seed, n_cre, n_chunk, tissues, n_var=5, whole_window=True):
+    """ref gene + alt gene = the same gene with `n_var` cCRE windows and `n_var` gene chunks changed (BASELINE configs[3] /
+    SURVEY 8d cfg 4: <= 5 + <= 5).  whole_window: every valid token of the window is re-drawn (an indel re-tokenises the
+    window from the variant on); else 3 token ids per window (a substitution)."""
+    ref = make_batch(seed, [n_cre], [n_chunk], [tissues], 200)
     pair = {k: (v + [t.clone() for t in v] if isinstance(v, list) else v.repeat(2, 1)) for k, v in ref.items()}
     rng = np.random.default_rng(7)
-    for w in rng.choice(1024, 5, replace=False):
-        valid = int((~pair["cre_attention_masks"][1][w, 0]).sum())
-        pos = rng.choice(valid, 3, replace=False)
-        pair["cre_sequences"][1][w, 0, pos] = torch.from_numpy(rng.integers(4, 18, 3))
-    for w in rng.choice(200, 5, replace=False):
-        valid = int((~pair["gene_attention_masks"][1][w, 0]).sum())
-        pos = rng.choice(valid, 3, replace=False)
-        pair["gene_embeddings"][1][w, 0, pos] = torch.from_numpy(rng.integers(4, 18, 3))
+    for key, mkey, n in (("cre_sequences", "cre_attention_masks", n_cre), ("gene_embeddings", "gene_attention_masks", n_chunk)):
+        for w in rng.choice(n, n_var, replace=False):
+            valid = int((~pair[mkey][1][w, 0]).sum())
+            if whole_window:
+                pair[key][1][w, 0, :valid] = torch.from_numpy(rng.integers(4, 500, valid))
+            else:
+                pos = rng.choice(valid, 3, replace=False)
+                pair[key][1][w, 0, pos] = torch.from_numpy(rng.integers(4, 18, 3))
+    return ref, pair
+
+
+def test_cfg4_paired_ref_alt_full_size(full_model):
+    """BASELINE configs[3] (snp_indel_predictions geometry) at FULL SIZE: two 1 Mb genes (N = 1024, C = 200, T = 54) that
+    differ in 5 cCRE windows and 5 gene chunks.  Structure: the ref half must not notice the alt half (pair vs alone), a
+    tissue subset reproduces the full run, the VEP window de-duplication reproduces the plain evaluation bit for bit, and
+    each half meets the north-star tolerance against the oracle.  The DELTA of this pair is reported, not asserted: with
+    plain random weights the expression hardly depends on the sequence (utils.synthetic.calibrate_sequence_sensitivity has
+    the measurement), |delta| ~ 1e-5 sits far below the bf16 rounding noise of ANY bf16 implementation -- resolving a
+    variant effect is tested on a sequence-sensitive model in test_cfg4_variant_effect_is_resolved."""
+    model, hp, kw, sd = full_model
+    ref, pair = _variant_pair(40404, 1024, 200, TISSUES_54, whole_window=False)
     both = model.predict_step(pair, 0)
     alone = model.predict_step(ref, 0)
     np.testing.assert_allclose(both["pred_gene_exp"][0], alone["pred_gene_exp"][0], rtol=1e-5, atol=1e-6)
@@ -186,8 +197,6 @@ def test_cfg4_paired_ref_alt_full_size(full_model):
         assert dd.cre_ids.shape[0] == 1024 + 5 and dd.gene_ids.shape[0] == 200 + 5
         dedup = model.forward_prepared(dd)
     assert torch.equal(plain[0], dedup[0]) and torch.equal(plain[1], dedup[1])
-    delta = both["pred_gene_exp"][1] - both["pred_gene_exp"][0]
-    assert np.abs(delta).max() > 0
     # Oracle on both halves for a 6-tissue subset (a tissue's result does not depend on the other tissues requested --
     # asserted at this size by test_headline_size_gene_vs_oracle_and_properties -- and the oracle's cost is dominated by
     # the per-tissue gene stream): 2 x ~7.5 TFLOP on the host cores instead of 2 x 18.
@@ -198,17 +207,67 @@ def test_cfg4_paired_ref_alt_full_size(full_model):
         np.testing.assert_allclose(hip6["pred_gene_exp"][i], both["pred_gene_exp"][i][sub], rtol=1e-5, atol=1e-6)
     orc = _oracle(pair6, sd, hp, kw)
     for i in range(2):
-        assert erel(hip6["pred_gene_exp"][i], orc["pred_gene_exp"][i]) < NORTH_STAR_RTOL
+        assert prel(hip6["pred_gene_exp"][i], orc["pred_gene_exp"][i]) < NORTH_STAR_RTOL
+    check_signal("cfg4 full size, ref + alt x 6 tissues", hip6["pred_gene_exp"], orc["pred_gene_exp"])
     d_hip = hip6["pred_gene_exp"][1] - hip6["pred_gene_exp"][0]
     d_orc = orc["pred_gene_exp"][1] - orc["pred_gene_exp"][0]
-    # the delta is a difference of two numbers each good to 1e-3 relative: compare on the scale of the expression
-    scale = np.abs(orc["pred_gene_exp"][0]).max()
-    err = np.abs(d_hip - d_orc).max() / scale
-    print(f"[cfg4] max |delta| {np.abs(d_orc).max():.3e} on expression scale {scale:.3f}; |delta_hip - delta_oracle| / scale = {err:.2e}")
-    assert err < NORTH_STAR_RTOL
+    noise = np.abs(d_hip - d_orc).max()
+    print(f"[cfg4 full size, plain random weights] |delta_oracle| {np.abs(d_orc).max():.2e}, |delta_hip - delta_oracle| {noise:.2e}: "
+          f"SNR {np.abs(d_orc).max() / noise:.2f} (reported only: the model is sequence-insensitive, see the docstring)")
     log2fc_h = np.log2(hip6["pred_gene_exp"][1] / hip6["pred_gene_exp"][0])
     log2fc_o = np.log2(orc["pred_gene_exp"][1] / orc["pred_gene_exp"][0])
     assert np.abs(log2fc_h - log2fc_o).max() < 1e-3          # the reference's own VEP tolerance (tests/test_vep.py atol 1e-3)
+
+
+def test_cfg4_variant_effect_is_resolved(full_model):
+    """The variant-effect delta must be RESOLVED, not merely bounded: on a sequence-sensitive model (the full 1.2 B
+    architecture with cre_map / gene_map re-centred and rescaled, utils.synthetic.calibrate_sequence_sensitivity) and a
+    locus in which 5 cCRE windows + 5 gene chunks are a visible share (N = 48, C = 20, T = 6), ref / alt differ by
+    |log2FC| ~ 1e-2.  SNR = |delta_oracle| / |delta_hip - delta_oracle| against the same-rounding oracle AND against the
+    pure-fp32 oracle must be >= 5 with bf16 operands and >= 20 with fp16 operands (measured 8 ... 10 and ~ 60: the bf16
+    figure is the resolution of 8 mantissa bits, not of this implementation -- more gain in the calibration raises signal
+    and rounding noise alike, scripts-free probe in DESIGN.md section 7); the log2FC must agree with fp32 to the
+    reference's own 1e-3 (reference tests/test_vep.py:215-258) and have the right sign wherever |log2FC| > 2e-3."""
+    import bench
+    from variantformer_amd.utils.synthetic import calibrate_sequence_sensitivity, restore_maps
+    model, hp, kw, _ = full_model
+    saved = calibrate_sequence_sensitivity(model)
+    keep = model.precision
+    try:
+        sd = state_dict_cpu(model)
+        tissues = [TISSUES_54[i] for i in (3, 11, 20, 31, 42, 53)]
+        _, pair = _variant_pair(50505, 48, 20, tissues)
+        shp = O.Seq2RegHP.from_hparams(hp)
+        ghp = O.Seq2GeneHP.from_kwargs(kw)
+        torch.set_num_threads(min(16, bench.host_threads()))
+        f32 = O.predict_step(pair, sd, shp, shp, ghp, rounding=None, share_cre_stream=True)["pred_gene_exp"]
+        d32 = f32[1] - f32[0]
+        l32 = np.log2(f32[1] / f32[0])
+        print(f"[cfg4 sensitive model] fp32 oracle: max |delta| {np.abs(d32).max():.3e}, max |log2FC| {np.abs(l32).max():.3e}, "
+              f"expression {f32[0].ravel()}")
+        assert np.abs(l32).max() > 5e-3, "the calibrated model must show a variant effect worth resolving"
+        for mode, prec in (("bf16", "bf16-mixed"), ("fp16", "16-mixed")):
+            model.precision = prec
+            hip = model.predict_step(pair, 0)["pred_gene_exp"]
+            orc = O.predict_step(pair, sd, shp, shp, ghp, rounding=mode, share_cre_stream=True)["pred_gene_exp"]
+            d_hip, d_orc = hip[1] - hip[0], orc[1] - orc[0]
+            snr_same = np.abs(d_orc).max() / np.abs(d_hip - d_orc).max()
+            snr_f32 = np.abs(d32).max() / np.abs(d_hip - d32).max()
+            l_hip = np.log2(hip[1] / hip[0])
+            print(f"[cfg4 sensitive model, {mode} operands] SNR vs same-rounding oracle {snr_same:.1f}, vs pure fp32 {snr_f32:.1f}; "
+                  f"|log2FC_hip - log2FC_fp32| {np.abs(l_hip - l32).max():.2e}; halves vs same-rounding oracle "
+                  f"{max(prel(hip[i], orc[i]) for i in range(2)):.2e}")
+            # measured on MI355X (gpurun_out/r3d): bf16 7.9 vs the same-rounding oracle / 10.3 vs pure fp32 -- what 8
+            # mantissa bits resolve of a |log2FC| ~ 9e-3 effect through 55 layers, for ANY bf16-operand implementation;
+            # fp16 operands (3 more bits) must clear 20
+            floor = 5.0 if mode == "bf16" else 20.0
+            assert snr_same >= floor and snr_f32 >= floor, \
+                f"{mode}: variant effect not resolved (SNR {snr_same:.1f} vs same-rounding oracle, {snr_f32:.1f} vs fp32)"
+            assert np.abs(l_hip - l32).max() < 1e-3
+            assert np.sign(l_hip[np.abs(l32) > 2e-3]).tolist() == np.sign(l32[np.abs(l32) > 2e-3]).tolist()   # direction of effect
+    finally:
+        model.precision = keep
+        restore_maps(model, saved)
 
 
 # ------------------------------------------------------------------------------------------------------------------

@@ -196,6 +196,47 @@ def test_attention_online_softmax_rescale_branch(ops):
     np.testing.assert_allclose(out.float().cpu().numpy(), _bf(ref).numpy(), rtol=2 ** -7, atol=6e-3)
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_attention_long_stream_32x32_kernel(ops, dtype):
+    """The long-stream dh = 48 kernel on 32x32x16 MFMAs (attn_x32_kernel; taken when n_seq * H * ceil(max_q / 256) >= 2048:
+    the batched gene -> CRE cross attention).  Ragged query blocks (not multiples of 32 / 64 / 256), key streams of 1, 31,
+    63, 64, 65 and 1024 keys (tail masking inside the first 32-key block, at a block edge, one past it), a sequence
+    without keys (zero rows), a sequence of one query; every output element against the oracle.  A spike key in a LATE
+    tile forces the online-softmax rescale branch with non-trivial accumulators (guide rule 26)."""
+    td = torch.bfloat16 if dtype == "bf16" else torch.float16
+    rnd = O.Rounding(dtype)
+    dh, H = 48, 32
+    D = H * dh
+    ql = [5000, 33, 2049, 777, 1, 3000, 1024, 900, 256, 257, 4000, 31]
+    kl = [1024, 1, 63, 64, 200, 65, 0, 31, 129, 1000, 300, 2]
+    assert len(ql) * H * ((max(ql) + 255) // 256) >= 2048
+    tq, tk = sum(ql), sum(kl)
+    cu_q = torch.tensor([0] + list(np.cumsum(ql)), dtype=torch.int32)
+    cu_k = torch.tensor([0] + list(np.cumsum(kl)), dtype=torch.int32)
+    q = rnd.r(_rand((tq, D), 24, 2.0))
+    kv = rnd.r(_rand((tk, 2 * D), 25, 2.0))
+    k, v = kv[:, :D].clone(), kv[:, D:].clone()
+    # spike: key 900 of sequence 0 is aligned with its query 4321 in every head -> the running maximum of that query
+    # (and of many others) jumps in key tile 14 of 16
+    k[900] = rnd.r(q[4321] * 1.5)
+    ref = torch.zeros(tq, D)
+    for b in range(len(ql)):
+        a, e, ka, ke = int(cu_q[b]), int(cu_q[b + 1]), int(cu_k[b]), int(cu_k[b + 1])
+        if ke > ka:
+            ref[a:e] = O.attention(q[a:e].view(-1, H, dh), k[ka:ke].view(-1, H, dh), v[ka:ke].view(-1, H, dh), None,
+                                   rnd).reshape(e - a, D)
+    dkv = torch.cat([k, v], dim=1).cuda().to(td)
+    out = torch.full((tq, D), float("nan"), device="cuda").to(td)
+    ops.attn_varlen(q.cuda().to(td), dkv[:, :D], dkv[:, D:], cu_q.cuda(), cu_k.cuda(), max(ql), max(kl), H, dh, out=out)
+    torch.cuda.synchronize()
+    got = out.float().cpu()
+    assert torch.isfinite(got).all()
+    z0, z1 = int(cu_q[6]), int(cu_q[7])
+    assert float(got[z0:z1].abs().max()) == 0.0                       # the sequence without keys
+    tol = dict(rtol=2 ** -7, atol=6e-3) if dtype == "bf16" else dict(rtol=2 ** -9, atol=2e-3)
+    np.testing.assert_allclose(got.numpy(), rnd.r(ref).numpy(), **tol)
+
+
 def test_attention_uniform_values_property(ops):
     """Size-independent property at full size: with V constant along keys the output equals that
     constant row exactly up to bf16 rounding of P (softmax weights sum to one)."""

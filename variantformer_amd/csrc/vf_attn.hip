@@ -898,6 +898,18 @@ int launch_attn(AttnParams P, int n_seq, int max_q, int max_k, hipStream_t st) {
     // stream (201-token sequences, dh 48: 396 vs 485 us); for seq2reg windows / chunks (dh 64, <= 200 tokens) the tiled
     // kernel with 64-query blocks is faster (460 vs 613 us on 200-token chunks: more blocks in flight, fewer registers;
     // the K/V re-reads of its query blocks hit the XCD's L2 thanks to block_coords).
+    // dh = 48 without positional bias (every cross attention of the modulator): ONE kernel for every geometry, so that a
+    // gene's result cannot depend on the batch it is evaluated in (the query-block size only changes which wave owns a
+    // query, never the arithmetic of a query: tests test_cfg3 / test_headline batch independence at 1e-5).  64 queries
+    // per wave once that leaves >= 8 blocks per CU (the batched gene -> CRE cross attention), else 32 (3 waves / SIMD).
+    if constexpr (DH == 48 && !ALIBI) {
+        static const int x32 = getenv("VF_ATTN_X32") ? atoi(getenv("VF_ATTN_X32")) : 1;      // 0: the 16x16x32 kernels (A/B)
+        if (x32) {
+            if (x32 != 2 && (long)n_seq * P.H * ((max_q + 255) / 256) >= 2048)
+                return launch_x32<DT, 2>(P, dim3(set_grid(P, n_seq, (max_q + 255) / 256)), st);
+            return launch_x32<DT, 1>(P, dim3(set_grid(P, n_seq, (max_q + 127) / 128)), st);
+        }
+    }
     if constexpr (DH <= 48) {
         if (max_q > 128 && max_q <= 256 && max_k <= 256) {
             if (max_q <= 192) return launch_short<DH, 3, ALIBI, DT>(P, n_seq, max_k, st);
@@ -925,11 +937,8 @@ int launch_attn(AttnParams P, int n_seq, int max_q, int max_k, hipStream_t st) {
             // 4 query groups per wave (256-query blocks) once that still leaves >= 8 blocks per CU: every K/V fragment
             // read feeds 4 MFMAs (gene->CRE cross attention at 8 genes: 948 vs 993 us; no gain at one gene, 1376 blocks)
             if constexpr (DH == 48 && !ALIBI) {
-                static const int x32 = getenv("VF_ATTN_X32") ? atoi(getenv("VF_ATTN_X32")) : 1;      // A/B switch
-                if ((long)n_seq * P.H * ((max_q + 255) / 256) >= 2048) {
-                    if (x32) return launch_x32<DT, 2>(P, dim3(set_grid(P, n_seq, (max_q + 255) / 256)), st);
+                if ((long)n_seq * P.H * ((max_q + 255) / 256) >= 2048)
                     return launch_fwd<48, 4, false, DT>(P, dim3(set_grid(P, n_seq, (max_q + 255) / 256)), st);
-                }
             }
             return launch_fwd<DH, 2, ALIBI, DT>(P, grid, st);
         }

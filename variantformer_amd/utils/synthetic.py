@@ -207,3 +207,43 @@ def cfg3_gene_sizes(n_genes: int, seed: int = 20251205):
     n = np.clip(np.round(600.0 * np.exp(0.6 * z)), 40, 2048).astype(np.int64)
     c = randint(n_genes, 20, 201, seed, 13)
     return n, c
+
+
+def calibrate_sequence_sensitivity(model, cre_std: float = 8.0, gene_std: float = 1.0, seed: int = 999):
+    """Make a random-weight model SEQUENCE-SENSITIVE (tests only; BASELINE configs[3], the variant-effect delta).
+
+    With plain random weights every cCRE window / gene chunk embedding is 99 % one common vector (the mean over ~100
+    tokens of positional encoding + token embedding; measured: |common| 12.5, window-specific part 1.5), attention is
+    uniform, and the expression hardly depends on the DNA at all: replacing EVERY window of a gene moves it by 3e-4 --
+    the size of the bf16 rounding noise -- so no implementation, the reference's bf16-mixed path included, could resolve a
+    5-window variant.  A trained tokenizer does not behave like that.  This stands in for the training: `cre_map` /
+    `gene_map` (plain Linear layers, so still an ordinary state dict) are re-centred on the population mean of the pooled
+    embeddings and rescaled so that the rows entering the modulator have element standard deviation `cre_std` /
+    `gene_std`:  W' = S W,  b' = b - S W mu.  Large un-normalised CRE rows are what make the gene -> CRE cross attention
+    selective (its K / V projections read the raw rows).  Returns the original (weight, bias) tensors so that a caller can
+    restore them.  The statistics are taken on the model's own device from a seeded calibration batch."""
+    dev = model.gene_map.weight.device
+    cal = make_batch(seed, [256], [64], [TISSUES_54[:1]], 200)
+    saved = {}
+    with torch.no_grad():
+        for name, tok, ids, mask, tgt in (("cre_map", model.cre_tokenizer, cal["cre_sequences"][0], cal["cre_attention_masks"][0], cre_std),
+                                          ("gene_map", model.gene_tokenizer if model.gene_tokenizer is not None else model.cre_tokenizer,
+                                           cal["gene_embeddings"][0], cal["gene_attention_masks"][0], gene_std)):
+            lin = getattr(model, name, None)
+            if lin is None:
+                continue
+            x = tok(ids, mask, None, only_embed=True)[:, 0].float().to(dev)
+            W, b = lin.weight.detach().clone(), lin.bias.detach().clone()
+            saved[name] = (W.clone(), b.clone())
+            mu = x.mean(0)
+            S = tgt / float(((x - mu) @ W.t()).std())
+            lin.weight.copy_(W * S)
+            lin.bias.copy_(b - S * (W @ mu))
+    return saved
+
+
+def restore_maps(model, saved: dict) -> None:
+    with torch.no_grad():
+        for name, (W, b) in saved.items():
+            getattr(model, name).weight.copy_(W)
+            getattr(model, name).bias.copy_(b)
