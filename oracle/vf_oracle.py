@@ -110,8 +110,9 @@ class Rounding:
     and the fp32 row statistics are applied to its fp32 accumulator, instead of bf16(LayerNorm(x)) . bf16(W).  Same
     algebra, different rounding points; default = what variantformer_amd does (16-bit operands, VF_LN_FOLD != 0; an fp16
     stream's copy is stored scaled by a power of two, which rounds identically inside the fp16 normal range).
-    `res16`: with the fold on, the stream after a layer's self-attention block enters the cross-attention out-projection's
-    residual add through its 16-bit copy (its fp32 rows are never stored: layers.res16_enabled, VF_RES16 != 0)."""
+    `res16`: with the fold on, in a layer that has BOTH attention blocks the two attention out-projections take their
+    residuals from 16-bit stream copies -- x1 = self(..) + r(src), x2 = cross(..) + r(x1) -- and x1's fp32 rows are never
+    stored; the layer output keeps the fp32 layer input as its residual (layers.res16_enabled, VF_RES16 != 0)."""
 
     def __init__(self, mode: str | None, fold_ln: bool | None = None, res16: bool | None = None):
         assert mode in (None, "bf16", "fp16")
@@ -257,7 +258,7 @@ def seq2reg_context_layer(x, ctx, cu, sd, pfx, hp: Seq2RegHP, slopes, rnd: Round
     self-MHA -> +src -> LN2 -> cross-MHA(q = x, kv = context rows of the same window, no ALiBi, same key padding as the
     tokens :105-112) -> +res_short -> LN3 -> GeGLU -> + src."""
     h = rnd.ln(x, sd[pfx + "norm1.weight"], sd[pfx + "norm1.bias"])
-    x1 = mha_self(h, sd, pfx + "mixer.MHA.", hp.num_heads, cu, slopes, rnd) + x
+    x1 = mha_self(h, sd, pfx + "mixer.MHA.", hp.num_heads, cu, slopes, rnd) + rnd.res(x)
     h = rnd.ln(x1, sd[pfx + "norm2.weight"], sd[pfx + "norm2.bias"])
     x2 = mha_cross(h, ctx, sd, pfx + "crossMHA.MHA.", hp.num_heads, cu, cu, rnd) + rnd.res(x1)
     h = rnd.ln(x2, sd[pfx + "norm3.weight"], sd[pfx + "norm3.bias"])
@@ -355,7 +356,7 @@ def modulator_layer(src, ctx, cu_src, cu_ctx, sd, pfx, H, slopes, rnd: Rounding,
     streams: LN1 -> self-MHA(ALiBi) -> +src -> LN2 -> cross-MHA(q = x, kv = ctx RAW, no norm)
     -> +res_short -> LN3 -> GeGLU -> + src (the LAYER INPUT, :99,163)."""
     h = rnd.ln(src, sd[pfx + "norm1.weight"], sd[pfx + "norm1.bias"])
-    x1 = mha_self(h, sd, pfx + "mixer.MHA.", H, cu_src, slopes, rnd) + src
+    x1 = mha_self(h, sd, pfx + "mixer.MHA.", H, cu_src, slopes, rnd) + rnd.res(src)
     h = rnd.ln(x1, sd[pfx + "norm2.weight"], sd[pfx + "norm2.bias"])
     x2 = mha_cross(h, ctx, sd, pfx + "crossMHA.MHA.", H, cu_src, cu_ctx, rnd, cross_slopes) + rnd.res(x1)
     h = rnd.ln(x2, sd[pfx + "norm3.weight"], sd[pfx + "norm3.bias"])

@@ -97,10 +97,12 @@ def ln_fold_enabled(*widths: int) -> bool:
 
 def res16_enabled() -> bool:
     """The stream after a layer's self-attention block (x1 = out_proj(attn) + src) is read by LayerNorm2 -> Wq and as the
-    residual of the cross-attention out-projection, nothing else.  With this on (default; VF_RES16=0 restores fp32) the
-    residual is taken from x1's 16-bit copy and its fp32 rows are never written: 6 bytes per element less traffic in the
-    two producer epilogues.  The reference's own autocast keeps that stream in 16 bits; oracle.Rounding(res16=True)
-    restates the rounding point."""
+    residual of the cross-attention out-projection, nothing else; both read it in 16 bits.  With this on (default;
+    VF_RES16=0 restores fp32) the 16-bit copies serve as the residuals of the two attention out-projections -- x1 = ... +
+    float(src16), x2 = ... + float(x1_16) -- and x1's fp32 rows are never written: 8 bytes per element less traffic in
+    the two producer epilogues.  The trunk stays fp32: a layer's output is still W2.h + src with the fp32 layer input, so
+    the 16-bit roundings only ever enter branch inputs.  The reference's own autocast keeps these streams in 16 bits;
+    oracle.Rounding(res16=True) restates the rounding points."""
     import os
     return os.environ.get("VF_RES16", "1") != "0"
 
@@ -332,14 +334,16 @@ class ContextFlashAttentionEncoderLayer(nn.Module):
         if ln_fold_enabled(self.norm1.weight.numel(), self.linear_geglu_2.in_features):
             # LayerNorm folded into the GEMMs: every fp32-residual GEMM also emits the bf16 copy + row statistics of its
             # output, every LayerNorm -> Linear pair runs on that copy (no LayerNorm pass, no cast of the context)
+            r16 = res16_enabled()
             if self_qkv is not None:
-                s = ops.LnStream(_as_tensor(src), None, None)    # only the fp32 rows are read below (residuals)
+                # the projection was computed on the distinct rows; below only the residuals read the stream: its fp32
+                # rows (layer output) and, with res16, its 16-bit copy (self-attention block)
+                s = _as_stream(src) if r16 else ops.LnStream(_as_tensor(src), None, None)
                 a = self.mixer.MHA.attend_qkv(self_qkv, cu_src, max_src)
             else:
                 s = _as_stream(src)
                 a = self.mixer.MHA.attend_ln(s, self.norm1, None, cu_src, max_src, None, None)
-            r16 = res16_enabled()
-            x1 = self.mixer.MHA.out_ln(a, s.x, need_x=not r16)
+            x1 = self.mixer.MHA.out_ln(a, s if r16 else s.x, need_x=not r16)
             if context_kv is None:
                 ctx16 = context.operand16() if isinstance(context, ops.LnStream) else ops.cast16(context)
                 context_kv = self.crossMHA.MHA.project_kv(ctx16)
@@ -382,7 +386,7 @@ class ContextFlashAttentionEncoderLayer(nn.Module):
             a = ops.attn_varlen(q, kv[:, :D], kv[:, D:], cu_rows, cu_src, 1, max_src, mha.num_heads, mha.head_dim,
                                 mha.alibi_slopes, q_at_start=True, family=mha.family + "_registry_rows")
             r16 = res16_enabled()
-            x1 = mha.out_ln(a, sr.x, need_x=not r16)
+            x1 = mha.out_ln(a, sr if r16 else sr.x, need_x=not r16)
             ctx16 = context.operand16() if isinstance(context, ops.LnStream) else ops.cast16(context)
             ckv = self.crossMHA.MHA.project_kv(ctx16)
             a = self.crossMHA.MHA.attend_ln(x1, self.norm2, ckv, cu_cross_rows, max_cross_rows, cu_ctx, max_ctx)
