@@ -110,9 +110,9 @@ class Rounding:
     and the fp32 row statistics are applied to its fp32 accumulator, instead of bf16(LayerNorm(x)) . bf16(W).  Same
     algebra, different rounding points; default = what variantformer_amd does (16-bit operands, VF_LN_FOLD != 0; an fp16
     stream's copy is stored scaled by a power of two, which rounds identically inside the fp16 normal range).
-    `res16`: with the fold on, in a layer that has BOTH attention blocks the two attention out-projections take their
-    residuals from 16-bit stream copies -- x1 = self(..) + r(src), x2 = cross(..) + r(x1) -- and x1's fp32 rows are never
-    stored; the layer output keeps the fp32 layer input as its residual (layers.res16_enabled, VF_RES16 != 0)."""
+    `res16`: with the fold on, every attention out-projection takes its residual from a 16-bit stream copy -- x1 = attn(..)
+    + r(src), x2 = cross(..) + r(x1) -- and those sums' fp32 rows are never stored; a layer's OUTPUT keeps the fp32 layer
+    input as its residual, so the trunk stays fp32 (layers.res16_enabled, VF_RES16 != 0)."""
 
     def __init__(self, mode: str | None, fold_ln: bool | None = None, res16: bool | None = None):
         assert mode in (None, "bf16", "fp16")
@@ -248,7 +248,7 @@ def seq2reg_layer(x, cu, sd, pfx, hp: Seq2RegHP, slopes, rnd: Rounding):
     everything else is per-token) and are excluded from the pool, so only valid tokens are kept."""
     h = rnd.ln(x, sd[pfx + "norm1.weight"], sd[pfx + "norm1.bias"])
     a = mha_self(h, sd, pfx + "MHA.", hp.num_heads, cu, slopes, rnd)
-    x1 = a + x                                                       # :179  x += res_short
+    x1 = a + rnd.res(x)                                              # :179  x += res_short (16-bit copy: Rounding.res16)
     h = rnd.ln(x1, sd[pfx + "norm2.weight"], sd[pfx + "norm2.bias"])
     return geglu_ffn(h, sd, pfx, rnd) + x                            # :188  x += res_long (= layer input)
 
@@ -367,7 +367,7 @@ def self_only_layer(src, cu_src, sd, pfx, H, slopes, rnd: Rounding):
     """FlashAttentionEncoderLayer.forward (layers.py:168-228): LN1 -> self-MHA(ALiBi) -> +src -> LN2 -> GeGLU -> + src
     (norm3 is constructed but never applied)."""
     h = rnd.ln(src, sd[pfx + "norm1.weight"], sd[pfx + "norm1.bias"])
-    x1 = mha_self(h, sd, pfx + "mixer.MHA.", H, cu_src, slopes, rnd) + src
+    x1 = mha_self(h, sd, pfx + "mixer.MHA.", H, cu_src, slopes, rnd) + rnd.res(src)
     h = rnd.ln(x1, sd[pfx + "norm2.weight"], sd[pfx + "norm2.bias"])
     return geglu_ffn(h, sd, pfx, rnd) + src
 
@@ -383,7 +383,7 @@ def cross_only_layer(src, ctx, cu_src, cu_ctx, sd, pfx, H, rnd: Rounding, cross_
     """ContextFlashCrossAttentionEncoderLayer.forward (layers.py:231-325): LN1 -> cross-MHA(q = x, kv = ctx raw)
     -> +src -> LN2 -> GeGLU -> + src (the layer input)."""
     h = rnd.ln(src, sd[pfx + "norm1.weight"], sd[pfx + "norm1.bias"])
-    x1 = mha_cross(h, ctx, sd, pfx + "crossMHA.MHA.", H, cu_src, cu_ctx, rnd, cross_slopes) + src
+    x1 = mha_cross(h, ctx, sd, pfx + "crossMHA.MHA.", H, cu_src, cu_ctx, rnd, cross_slopes) + rnd.res(src)
     h = rnd.ln(x1, sd[pfx + "norm2.weight"], sd[pfx + "norm2.bias"])
     return geglu_ffn(h, sd, pfx, rnd) + src
 

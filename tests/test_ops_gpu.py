@@ -811,6 +811,7 @@ def test_ln_fold_rows_with_large_mean(ops, ratio, monkeypatch):
     stream with a large row mean is known before a real checkpoint runs."""
     from variantformer_amd.seq2gene.modules.layers import packed_linear, packed_linear_ln
     M, K, N = 4099, 1536, 1536
+    ops.ln_fold_alert(torch.device("cuda", torch.cuda.current_device()))         # clear whatever earlier tests left
     std = 0.5
     x_c = _rand((M, K), 401, std * math.sqrt(3.0))                       # uniform with standard deviation `std`
     x_c = x_c - x_c.mean(dim=1, keepdim=True)
@@ -838,10 +839,12 @@ def test_ln_fold_rows_with_large_mean(ops, ratio, monkeypatch):
     folded = ops.gemm_ln_consumer(s, wp, bp, cs, ops.EPI_BF16).double().cpu()
     wq, bq = packed_linear(lin)
     plain = ops.gemm(ops.layernorm(res.cuda(), norm.weight, norm.bias, torch.bfloat16), wq, bq, ops.EPI_BF16).double().cpu()
-    e_fold, e_plain = float((folded - exact).abs().max()), float((plain - exact).abs().max())
+    e_fold, e_plain = float((folded - exact.detach()).abs().max()), float((plain - exact.detach()).abs().max())
     print(f"[ln fold, |mean| = {ratio:g} x std] max abs error on an O(1) output: folded {e_fold:.3e}, separate LayerNorm {e_plain:.3e}")
     assert e_plain < 2 ** -6
-    assert e_fold < 2 ** -8 * (1.5 + ratio) * 4
+    assert e_fold < 2 ** -8 * (3.0 + 1.5 * ratio)          # measured 1.3e-2 / 5.6e-2 / 4.6e-1 at ratio 1 / 10 / 100
+    # the statistics kernels flag rows beyond LN_FOLD_RATIO_LIMIT (8) standard deviations
+    assert ops.ln_fold_alert(torch.device("cuda", torch.cuda.current_device())) == (ratio > ops.LN_FOLD_RATIO_LIMIT)
 
 
 def test_gelu_epilogue_accuracy_over_the_whole_range(ops):

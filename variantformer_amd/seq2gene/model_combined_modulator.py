@@ -99,6 +99,17 @@ def _side_stream(device):
     return _SIDE_STREAMS[key]
 
 
+def _warn_if_ln_fold_alert(device):
+    """After the outputs of a batch were copied back: one device int says whether some row of a LayerNorm-folded stream had
+    |mean| > ops.LN_FOLD_RATIO_LIMIT standard deviations, where rounding the uncentred row to 16 bits costs accuracy
+    (DESIGN.md section 5).  Never seen with synthetic weights; a real checkpoint that trips it should run VF_LN_FOLD=0."""
+    if device.type == "cuda" and ops.ln_fold_alert(device):
+        import warnings
+        warnings.warn("variantformer_amd: a residual-stream row has |mean| > %g standard deviations; the folded LayerNorm "
+                      "loses accuracy there (set VF_LN_FOLD=0 for the separate LayerNorm pass)" % ops.LN_FOLD_RATIO_LIMIT,
+                      RuntimeWarning, stacklevel=3)
+
+
 def _t(x):
     """fp32 tensor of a stream the layers may hand over as ops.LnStream (x, bf16 copy, row statistics)."""
     return x.x if isinstance(x, ops.LnStream) else x
@@ -595,8 +606,10 @@ class Seq2GenePredictorCombinedModulator(nn.Module):
     @staticmethod
     def predict_finish(handle, batch_idx, dataloader_idx=None):
         tissues, pred, emb = handle
+        dev = pred.device
         pred = pred.detach().cpu().float().numpy()          # D2H: the sync point of the step
         emb = emb.detach().cpu().float().numpy()
+        _warn_if_ln_fold_alert(dev)
         preds, embs, s = [], [], 0
         for t in tissues:
             preds.append(pred[s:s + len(t)])
@@ -624,8 +637,10 @@ class Seq2GenePredictorCombinedModulator(nn.Module):
                 x, batch["cre_attention_masks"], batch["tissue_context"], batch["ref_labels"], batch["strand"],
                 batch["gene_embeddings"], batch["gene_attention_masks"], return_embedding=True,
                 cre_token_position=cre_pos, gene_token_position=gene_pos, dedupe_windows=True)
+        dev = pred.device
         pred, embd = pred.cpu().float().numpy(), embd.cpu().float().numpy()
         gtok, ctok = gtok.cpu().float().numpy(), ctok.cpu().float().numpy()
+        _warn_if_ln_fold_alert(dev)
         out = {"pred_gene_exp": [], "embd": [], "variant_type": batch["variant_type"],
                "gene_token_embedding": [], "cre_token_embedding": []}
         s = 0

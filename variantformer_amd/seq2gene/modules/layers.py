@@ -96,8 +96,8 @@ def ln_fold_enabled(*widths: int) -> bool:
 
 
 def res16_enabled() -> bool:
-    """The stream after a layer's self-attention block (x1 = out_proj(attn) + src) is read by LayerNorm2 -> Wq and as the
-    residual of the cross-attention out-projection, nothing else; both read it in 16 bits.  With this on (default;
+    """Every attention block's output sum (x1 = out_proj(attn) + src, x2 = out_proj(cross) + x1) is read only through the
+    next LayerNorm -> Linear pair and as the next attention block's residual; both read it in 16 bits.  With this on (default;
     VF_RES16=0 restores fp32) the 16-bit copies serve as the residuals of the two attention out-projections -- x1 = ... +
     float(src16), x2 = ... + float(x1_16) -- and x1's fp32 rows are never written: 8 bytes per element less traffic in
     the two producer epilogues.  The trunk stays fp32: a layer's output is still W2.h + src with the fp32 layer input, so
@@ -472,7 +472,7 @@ class FlashAttentionEncoderLayer(nn.Module):
         if ln_fold_enabled(self.norm1.weight.numel(), self.linear_geglu_2.in_features):
             s = _as_stream(src)
             a = self.mixer.MHA.attend_ln(s, self.norm1, None, cu_src, max_src, None, None)
-            x1 = self.mixer.MHA.out_ln(a, s.x, need_x=False)
+            x1 = self.mixer.MHA.out_ln(a, s if res16_enabled() else s.x, need_x=False)
             w1, b1, c1 = packed_linear_ln(self.linear_geglu_1, self.norm2, geglu=True)
             hg = ops.gemm_ln_consumer(x1, w1, b1, c1, ops.EPI_GEGLU_BF16)
             w2, b2 = packed_linear(self.linear_geglu_2)
@@ -517,7 +517,7 @@ class ContextFlashCrossAttentionEncoderLayer(nn.Module):
                 ctx16 = context.operand16() if isinstance(context, ops.LnStream) else ops.cast16(context)
                 context_kv = self.crossMHA.MHA.project_kv(ctx16)
             a = self.crossMHA.MHA.attend_ln(s, self.norm1, context_kv, cq, mq, cu_ctx, max_ctx)
-            x1 = self.crossMHA.MHA.out_ln(a, s.x, need_x=False)
+            x1 = self.crossMHA.MHA.out_ln(a, s if res16_enabled() else s.x, need_x=False)
             w1, b1, c1 = packed_linear_ln(self.linear_geglu_1, self.norm2, geglu=True)
             hg = ops.gemm_ln_consumer(x1, w1, b1, c1, ops.EPI_GEGLU_BF16)
             w2, b2 = packed_linear(self.linear_geglu_2)

@@ -29,11 +29,12 @@ class FlashTransformerLayer(nn.Module):
     def forward_packed(self, src, cu: torch.Tensor, max_seqlen: int, last: bool = False):
         """src: fp32 [tokens, d] or an ops.LnStream; returns the same kind (an LnStream when LayerNorm is folded into
         the GEMMs, see seq2gene.modules.layers.ln_fold_enabled; a plain tensor from the `last` layer)."""
-        from ..seq2gene.modules.layers import _as_stream, _as_tensor, ln_fold_enabled, packed_linear_ln
+        from ..seq2gene.modules.layers import _as_stream, _as_tensor, ln_fold_enabled, packed_linear_ln, res16_enabled
         if ln_fold_enabled(self.norm1.weight.numel(), self.linear_geglu_2.in_features):
             s = _as_stream(src)
             a = self.MHA.attend_ln(s, self.norm1, None, cu, max_seqlen, None, None)
-            x1 = self.MHA.out_ln(a, s.x, need_x=False)           # x1 is read only through norm2 -> linear_geglu_1
+            # x1 is read only through norm2 -> linear_geglu_1: no fp32 store, and (res16) its residual is the 16-bit copy
+            x1 = self.MHA.out_ln(a, s if res16_enabled() else s.x, need_x=False)
             w1, b1, c1 = packed_linear_ln(self.linear_geglu_1, self.norm2, geglu=True)
             hg = ops.gemm_ln_consumer(x1, w1, b1, c1, ops.EPI_GEGLU_BF16)
             w2, b2 = packed_linear(self.linear_geglu_2)
