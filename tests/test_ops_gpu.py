@@ -847,6 +847,28 @@ def test_ln_fold_rows_with_large_mean(ops, ratio, monkeypatch):
     assert ops.ln_fold_alert(torch.device("cuda", torch.cuda.current_device())) == (ratio > ops.LN_FOLD_RATIO_LIMIT)
 
 
+@pytest.mark.parametrize("M,N,epi", [(70001, 1536, "bf16"), (1000, 2048, "geglu"), (255, 128, "bf16"), (256 * 9 + 1, 1024, "geglu")])
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_x_stationary_gemm_k512_is_bit_identical_to_the_tile_kernels(ops, M, N, epi, dtype):
+    """The X-stationary K = 512 kernel (variant 30: a block owns 256 rows for the whole width, its rows live in registers,
+    W streams through LDS; an experiment of round 3, selectable with VF_GEMM_XS) must reproduce the 256x256 tile kernel bit
+    for bit -- same K order, same epilogue arithmetic -- on ragged M (last block partial, 1 row over), one and many passes
+    of 128 columns, both 16-bit epilogues and both operand types."""
+    td = torch.bfloat16 if dtype == "bf16" else torch.float16
+    K = 512
+    a = _rand((M, K), 361).cuda().to(td)
+    w = (_rand((N, K), 362, 1.0 / math.sqrt(K))).cuda().to(td)
+    b = _rand((N,), 363, 0.5).cuda()
+    code = ops.EPI_GEGLU_BF16 if epi == "geglu" else ops.EPI_BF16
+    if epi == "geglu":
+        w, b = ops.pack_geglu_rows(w, b)
+    ref = ops.gemm(a, w, b, code, variant=20)
+    for _ in range(3):
+        got = ops.gemm(a, w, b, code, variant=30)
+        torch.cuda.synchronize()
+        assert torch.equal(got, ref), f"{int((got != ref).sum())} elements differ"
+
+
 def test_gelu_epilogue_accuracy_over_the_whole_range(ops):
     """The kernels' erf GELU (erfc-based, vf_common.h gelu_erf4) against float64 erf on a dense grid of bf16-exact
     inputs in [-12, 12] pushed through an identity GEMM with the fp32 GELU epilogue: absolute error <= 5e-7 (what

@@ -1870,6 +1870,267 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(const unsigned short*
     }
 }
 
+// ======================================================================================================================
+// X-STATIONARY GEMM for K = 512 (the seq2reg consumers: Wqkv 512 -> 1536, GeGLU 512 -> 2048).
+// At K = 512 a 256x256 output tile lives for 8 K-tiles (11 us) and pays 4-7 us of ramp + epilogue around them, and the
+// A row panel is re-read from L2 by every one of the N / 256 column tiles.  Here a block of 8 waves owns 256 ROWS for the
+// whole width N: each wave keeps its 32 rows x 512 as B-operand fragments in registers (32 k-steps x 4 VGPRs = 128),
+// W streams through an LDS ring in chunks of 128 columns x 64 k (16 KiB, LDS-DMA, full 128-byte lines, XOR-swizzled on the
+// source side like the other kernels), and the output is produced in passes of 128 columns: 8 chunks x 16 MFMAs
+// (v_mfma_f32_32x32x16, A = W fragment by ds_read_b128, B = the resident X fragment) into 64 accumulator registers, then
+// that pass's epilogue.  No per-tile prologue, no A re-reads, X is read from HBM exactly once.
+// C layout of a 32x32 tile: lane (t = lane & 31 -> ROW, h = lane >> 5), reg i -> column (i & 3) + 8 (i >> 2) + 4 h: a lane
+// holds 4 consecutive columns of its own row per register quad (8-byte 16-bit pieces), and for the GeGLU epilogue the
+// 16-row interleave of the packed weights puts `a` into regs 0-7 and its `gate` into regs 8-15 of the same lane.
+// ======================================================================================================================
+struct CfgXS {
+    static constexpr int K = 512, BM = 256, NB = 128, CK = 64;          // rows per block, columns per pass, k per chunk
+    static constexpr int CHUNK_BYTES = NB * CK * 2;                     // 16 KiB
+    static constexpr int SLOTS = 4, RING_BYTES = SLOTS * CHUNK_BYTES;   // 64 KiB
+    static constexpr int STAGE_BYTES = 8 * 32 * (NB * 2 + 16);          // per-wave output staging: 32 rows x (256 + 16) B
+    static constexpr int MAX_N = 2048;                                  // bias | colsum of all N columns live in LDS
+    static constexpr int LDS_BYTES = RING_BYTES + STAGE_BYTES + MAX_N * 2 * 4;      // 64 + 68 + 16 KiB
+};
+
+template <int EPI, int DT, int LN>
+__global__ __launch_bounds__(512, 2) void xs_gemm_kernel(const unsigned short* __restrict__ A, int64_t lda,
+                                                         const unsigned short* __restrict__ W,
+                                                         const float* __restrict__ bias, void* out, int64_t ldo, int M, int N,
+                                                         LnArgs ln) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using frag_t = typename Op16<DT>::frag;
+    using C = CfgXS;
+    constexpr bool GEGLU = EPI == VF_EPI_GEGLU_BF16;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int t = lane & 31, h = lane >> 5;
+    const int64_t m0 = (int64_t)blockIdx.x * C::BM;
+    const int64_t row = m0 + 32 * wave + t;                              // this lane's output row
+    const int64_t row_c = row < M ? row : M - 1;
+
+    char* const ring = smem;
+    char* const stage = smem + C::RING_BYTES + wave * (32 * (C::NB * 2 + 16));
+    float* const side = reinterpret_cast<float*>(smem + C::RING_BYTES + C::STAGE_BYTES);      // bias[N] | colsum[N]
+
+    // ---- W chunk q = (pass, c): columns [128 pass, +128) x k [64 c, +64).  One LDS-DMA wave-instruction fills 8 column
+    // rows x 128 B; wave w fills rows 16 w .. 16 w + 15 of the chunk (two instructions).  Lane l of an instruction: row
+    // l >> 3, PHYSICAL 16-byte piece l & 7 = logical piece (l & 7) ^ ((row >> 1) & 7).
+    const int n_pass = N / C::NB;
+    const int total = n_pass * 8;
+    const unsigned short* wsrc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = 16 * wave + 8 * i + (lane >> 3);
+        const int p = (lane & 7) ^ ((r >> 1) & 7);
+        wsrc[i] = W + (int64_t)r * C::K + p * 8;                          // + pass * 128 * K + c * 64
+    }
+    auto issue = [&](int q) {
+        const int pass = q >> 3, c = q & 7;
+        char* dst = ring + (q & (C::SLOTS - 1)) * C::CHUNK_BYTES + wave * 2048;
+        const int64_t off = (int64_t)pass * C::NB * C::K + c * C::CK;
+        glds16(wsrc[0] + off, dst);
+        glds16(wsrc[1] + off, dst + 1024);
+    };
+    // first three chunks in flight while the X fragments load
+    issue(0);
+    if (total > 1) issue(1);
+    if (total > 2) issue(2);
+
+    // ---- epilogue constants: bias (and colsum) of all N columns into LDS, (mean, rstd) of this lane's row
+    for (int i = tid; i < N / 4; i += 512) {
+        reinterpret_cast<f32x4_t*>(side)[i] = bias ? reinterpret_cast<const f32x4_t*>(bias)[i] : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        if (LN == VF_LN_CONSUMER) reinterpret_cast<f32x4_t*>(side + N)[i] = reinterpret_cast<const f32x4_t*>(ln.colsum)[i];
+    }
+    float mu = 0.f, rs = 1.f;
+    if (LN == VF_LN_CONSUMER) {
+        const f32x2_t st = *reinterpret_cast<const f32x2_t*>(ln.row_stats + 2 * row_c);
+        mu = st[0];
+        rs = st[1];
+    }
+
+    // ---- the wave's 32 rows as B-operand fragments: lane (t, h), k-step ks holds X[row][16 ks + 8 h .. + 7]
+    frag_t xf[32];
+    {
+        const unsigned short* xp = A + row_c * lda + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < 32; ++ks) xf[ks] = __builtin_bit_cast(frag_t, *reinterpret_cast<const u32x4_t*>(xp + 16 * ks));
+    }
+
+    // fragment read address inside a chunk: column row (32 ct + t) * 128 B + ((2 ksl + h) ^ swz(row)) * 16
+    int foff[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) foff[ct] = (32 * ct + t) * 128;
+    const int sw = ((t >> 1) & 7);                                      // (32 ct + t) >> 1 & 7 == (t >> 1) & 7
+
+    f32x16_t acc[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[ct][i] = 0.f;
+
+    // Two wave groups (waves 0-3 / 4-7 sit pairwise on the 4 SIMDs) run one barrier apart, as in gemm8_kernel: a phase is
+    //     [8 fragment reads (two 16-deep k-steps) + the chunk bookkeeping]  s_barrier  [8 MFMAs]  s_barrier
+    // so that on every SIMD one wave issues MFMAs while its partner reads fragments.  Two phases per chunk.
+    //   RAW  chunk q+1 is waited for (own pieces, counted vmcnt) before the first barrier of the SECOND phase of chunk q and
+    //        first read in the first phase of chunk q+1: every wave's wait lies at least one barrier before any read.
+    //   WAR  chunk q+3 goes into the slot of chunk q-1, requested in the read section of the second phase of chunk q: the
+    //        lagging group retired its last reads of chunk q-1 two barriers earlier.
+    const int grp = wave >> 2;
+#define VF_XS_IN()                                               \
+    do {                                                         \
+        asm volatile("" ::: "memory");                           \
+        __builtin_amdgcn_sched_barrier(0);                       \
+        __builtin_amdgcn_s_barrier();                            \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       \
+        __builtin_amdgcn_sched_barrier(0);                       \
+        __builtin_amdgcn_s_setprio(1);                           \
+    } while (0)
+#define VF_XS_OUT()                                              \
+    do {                                                         \
+        __builtin_amdgcn_s_setprio(0);                           \
+        __builtin_amdgcn_sched_barrier(0);                       \
+        __builtin_amdgcn_s_barrier();                            \
+        asm volatile("" ::: "memory");                           \
+        __builtin_amdgcn_sched_barrier(0);                       \
+    } while (0)
+    // prologue: chunk 0 landed for everybody
+    if (total > 2) wait_vmcnt<4>();
+    else if (total > 1) wait_vmcnt<2>();
+    else wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // the side-area writes above
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (grp == 1) __builtin_amdgcn_s_barrier();                          // group 1 runs one barrier behind
+
+    for (int pass = 0; pass < n_pass; ++pass) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {                                    // compile-time c: xf[] stays in registers
+            const int q = pass * 8 + c;
+            const char* ck = ring + (q & (C::SLOTS - 1)) * C::CHUNK_BYTES;
+            frag_t wf[2][4];
+            // ---- phase A: k-steps 0, 1 of the chunk
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+                    wf[kk][ct] = *reinterpret_cast<const frag_t*>(ck + foff[ct] + (((2 * kk + h) ^ sw) << 4));
+            VF_XS_IN();
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) acc[ct] = Op16<DT>::mfma32(wf[kk][ct], xf[4 * c + kk], acc[ct]);
+            VF_XS_OUT();
+            // ---- phase B: k-steps 2, 3; request chunk q+3, retire chunk q+1
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+                    wf[kk][ct] = *reinterpret_cast<const frag_t*>(ck + foff[ct] + (((2 * (kk + 2) + h) ^ sw) << 4));
+            if (q + 3 < total) {
+                issue(q + 3);
+                // queue, oldest first: chunk q+1, chunk q+2, [the NST row stores of the epilogue that just ran], chunk q+3
+                if (c == 0 && pass > 0) wait_vmcnt<4 + (GEGLU ? 4 : 8)>();
+                else wait_vmcnt<4>();
+            } else if (q + 2 < total) {
+                wait_vmcnt<2>();
+            } else {
+                wait_vmcnt<0>();
+            }
+            VF_XS_IN();
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) acc[ct] = Op16<DT>::mfma32(wf[kk][ct], xf[4 * c + 2 + kk], acc[ct]);
+            VF_XS_OUT();
+        }
+        // ---- epilogue of this pass: columns [128 pass, +128) of the wave's 32 rows
+        const int n0 = pass * C::NB;
+        constexpr int PITCH = C::NB * 2 + 16;                            // staged 16-bit row (GeGLU: half of it is used)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {                             // register quad gq: columns 32 ct + 8 gq + 4 h .. + 3
+                const int col = n0 + 32 * ct + 8 * gq + 4 * h;
+                f32x4_t v = {acc[ct][4 * gq], acc[ct][4 * gq + 1], acc[ct][4 * gq + 2], acc[ct][4 * gq + 3]};
+                const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(side + col);
+                if (LN == VF_LN_CONSUMER) {
+                    const f32x4_t c4 = *reinterpret_cast<const f32x4_t*>(side + N + col);
+                    v = (v - mu * c4) * rs + b4;
+                } else {
+                    v += b4;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[ct][4 * gq + e] = v[e];
+            }
+            if (GEGLU) {
+                // quads 0, 1 = `a` columns 0-15 of this 32-row block of the packed weights, quads 2, 3 = their gates
+#pragma unroll
+                for (int gq = 0; gq < 2; ++gq) {
+                    const f32x4_t a4 = {acc[ct][4 * gq], acc[ct][4 * gq + 1], acc[ct][4 * gq + 2], acc[ct][4 * gq + 3]};
+                    const f32x4_t g4 = {acc[ct][8 + 4 * gq], acc[ct][9 + 4 * gq], acc[ct][10 + 4 * gq], acc[ct][11 + 4 * gq]};
+                    const f32x4_t y = a4 * gelu_erf4(g4);
+                    u32x2_t pk;
+                    pk[0] = Op16<DT>::pack2(y[0], y[1]);
+                    pk[1] = Op16<DT>::pack2(y[2], y[3]);
+                    *reinterpret_cast<u32x2_t*>(stage + t * PITCH + (16 * ct + 8 * gq + 4 * h) * 2) = pk;
+                }
+            } else {
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    u32x2_t pk;
+                    pk[0] = Op16<DT>::pack2(acc[ct][4 * gq], acc[ct][4 * gq + 1]);
+                    pk[1] = Op16<DT>::pack2(acc[ct][4 * gq + 2], acc[ct][4 * gq + 3]);
+                    *reinterpret_cast<u32x2_t*>(stage + t * PITCH + (32 * ct + 8 * gq + 4 * h) * 2) = pk;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[ct][i] = 0.f;
+        }
+        // read the wave's staged rows back 16 bytes per lane (same wave: LDS operations are in order) and store whole rows
+        constexpr int OUT_COLS = GEGLU ? C::NB / 2 : C::NB;              // 16-bit columns per staged row
+        constexpr int CR = OUT_COLS * 2 / 16;                            // 16-byte pieces per row: 16 or 8
+        constexpr int RPI = 64 / CR;                                     // rows per wave-instruction: 4 or 8
+        const int no0 = GEGLU ? n0 / 2 : n0;
+        const int ldo_cols = GEGLU ? N / 2 : N;
+#pragma unroll
+        for (int it = 0; it < 32 / RPI; ++it) {
+            const int r = it * RPI + lane / CR, pc = lane % CR;
+            const u32x4_t d = *reinterpret_cast<const u32x4_t*>(stage + r * PITCH + pc * 16);
+            const int64_t m = m0 + 32 * wave + r;
+            if (m < M && no0 + pc * 8 < ldo_cols)
+                *reinterpret_cast<u32x4_t*>(reinterpret_cast<unsigned short*>(out) + m * ldo + no0 + pc * 8) = d;
+        }
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();                          // matches group 1's extra barrier
+#undef VF_XS_IN
+#undef VF_XS_OUT
+}
+
+template <int EPI, int DT, int LN>
+int launch_xs(const void* A, int64_t lda, const void* W, const float* bias, void* out, int64_t ldo, int M, int N,
+              hipStream_t st, LnArgs ln = LnArgs{}) {
+    static bool attr_set[VF_MAX_DEVICES] = {};
+    auto kern = xs_gemm_kernel<EPI, DT, LN>;
+    const int dev = vf_current_device();
+    if (dev < 0 || !attr_set[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                CfgXS::LDS_BYTES) != hipSuccess) {
+            (void)hipGetLastError();
+            vf_set_error("vf_gemm: cannot reserve %d bytes of LDS", CfgXS::LDS_BYTES);
+            return VF_ERR_LAUNCH;
+        }
+        if (dev >= 0) attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((M + CfgXS::BM - 1) / CfgXS::BM), dim3(512), CfgXS::LDS_BYTES, st, (const unsigned short*)A,
+                       lda, (const unsigned short*)W, bias, out, ldo, M, N, ln);
+    VF_CHECK_LAUNCH("vf_gemm");
+    return VF_OK;
+}
+// the shapes the X-stationary kernel takes: K = 512, whole passes of 128 columns, 16-bit epilogues
+inline bool xs_ok(int N, int K, int epilogue) {
+    return K == 512 && N % 128 == 0 && N <= CfgXS::MAX_N && (epilogue == VF_EPI_BF16 || epilogue == VF_EPI_GEGLU_BF16);
+}
+
 // The product library instantiates only the configurations pick_variant() can select.
 using CfgA = Cfg<128, 128, 2, 2, 2>;       // 64 KiB, 4 waves, 2 blocks/CU
 using CfgE = Cfg<64, 64, 2, 2, 4>;         // 64 KiB, small-M shapes, 2 blocks/CU
@@ -2075,6 +2336,11 @@ int launch_gemm(const void* A, int64_t lda, const void* W, const float* bias, co
         case 20: return launch_gemm8<EPI, DT>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
         case 22: if (K % 128 == 0) return launch_gemm8x<EPI, DT>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
                  return launch_gemm8<EPI, DT>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
+        case 30:
+            if constexpr (EPI == VF_EPI_BF16 || EPI == VF_EPI_GEGLU_BF16) {
+                if (xs_ok(N, K, EPI)) return launch_xs<EPI, DT, VF_LN_NONE>(A, lda, W, bias, out, ldo, M, N, st);
+            }
+            break;
 #ifdef VF_TUNING
         case 21:
             if (K < 128) break;
@@ -2153,6 +2419,13 @@ static int gemm_dispatch(const void* A, int64_t lda, const void* W, const float*
 template <int EPI, int DT, int LN>
 static int launch_gemm_ln(const void* A, int64_t lda, const void* W, const float* bias, const float* residual, int64_t ldr,
                           void* out, int64_t ldo, int M, int N, int K, const LnArgs& ln, hipStream_t st) {
+    if constexpr (LN == VF_LN_CONSUMER) {
+        // A/B switch (off by default: measured 906-942 against 955-1009 TFLOP/s for the persistent tile kernel on the
+        // seq2reg shapes, profiles/r03_e_xs_gemm.log): 1 = grids of >= 256 blocks, 2 = every K = 512 consumer (tests)
+        static const int xs = getenv("VF_GEMM_XS") ? atoi(getenv("VF_GEMM_XS")) : 0;
+        if (xs && xs_ok(N, K, EPI) && (xs >= 2 || M >= 256 * 256))
+            return launch_xs<EPI, DT, LN>(A, lda, W, bias, out, ldo, M, N, st, ln);
+    }
     switch (pick_variant(M, N, K, EPI)) {
         case 1: return launch_cfg<CfgA, EPI, DT, 0, LN>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, st, ln);
         case 5: return launch_cfg<CfgE, EPI, DT, 0, LN>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, st, ln);
