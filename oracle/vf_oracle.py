@@ -112,22 +112,37 @@ class Rounding:
     stream's copy is stored scaled by a power of two, which rounds identically inside the fp16 normal range).
     `res16`: with the fold on, every attention out-projection takes its residual from a 16-bit stream copy -- x1 = attn(..)
     + r(src), x2 = cross(..) + r(x1) -- and those sums' fp32 rows are never stored; a layer's OUTPUT keeps the fp32 layer
-    input as its residual, so the trunk stays fp32 (layers.res16_enabled, VF_RES16 != 0)."""
+    input as its residual (layers.res16_enabled, VF_RES16 != 0).
+    `trunk16` (needs res16): a layer's output reaches the NEXT LAYER of its stack rounded to the operand type -- where the
+    reference's autocast rounds it too (`x = linear_geglu_2(x)` is a 16-bit tensor there and `x += res_long` adds in
+    place, layers.py:161-165, seq2reg/modules.py:186-190); the last layer of a stack keeps fp32
+    (layers.trunk16_enabled; off unless VF_TRUNK16=1)."""
 
-    def __init__(self, mode: str | None, fold_ln: bool | None = None, res16: bool | None = None):
+    def __init__(self, mode: str | None, fold_ln: bool | None = None, res16: bool | None = None,
+                 trunk16: bool | None = None):
         assert mode in (None, "bf16", "fp16")
         self.mode = mode
         import os
+        self._trunk16_arg = trunk16
         if fold_ln is None:
             fold_ln = mode is not None and os.environ.get("VF_LN_FOLD", "1") != "0"
         self.fold_ln = bool(fold_ln)
         if res16 is None:
             res16 = os.environ.get("VF_RES16", "1") != "0"
         self.res16 = bool(res16) and self.fold_ln
+        trunk16 = self._trunk16_arg
+        if trunk16 is None:
+            trunk16 = os.environ.get("VF_TRUNK16", "0") != "0"
+        self.trunk16 = bool(trunk16) and self.res16
 
     def res(self, x1: torch.Tensor) -> torch.Tensor:
         """x1 as the residual of the cross-attention out-projection (see `res16`)."""
         return self.r(x1) if (self.res16 and x1.shape[-1] % 64 == 0) else x1
+
+    def out(self, x: torch.Tensor, last: bool = False) -> torch.Tensor:
+        """A layer's output (the trunk) on its way to the next layer of the stack: fp32, or rounded to the operand type
+        (`trunk16`).  The `last` layer of a stack keeps its fp32 result (it is pooled / returned, not fed to a layer)."""
+        return self.r(x) if (self.trunk16 and not last and x.shape[-1] % 64 == 0) else x
 
     def r(self, x: torch.Tensor) -> torch.Tensor:
         if self.mode is None:
@@ -242,7 +257,7 @@ class Seq2RegHP:
                    hp.get("use_context", False), hp.get("expand_context", False))
 
 
-def seq2reg_layer(x, cu, sd, pfx, hp: Seq2RegHP, slopes, rnd: Rounding):
+def seq2reg_layer(x, cu, sd, pfx, hp: Seq2RegHP, slopes, rnd: Rounding, last=False):
     """FlashTransformerLayer.forward (seq2reg/modules.py:149-191) on the packed valid tokens.
     Pad positions never influence valid ones (attention runs on the unpadded stream, :159-171;
     everything else is per-token) and are excluded from the pool, so only valid tokens are kept."""
@@ -250,10 +265,10 @@ def seq2reg_layer(x, cu, sd, pfx, hp: Seq2RegHP, slopes, rnd: Rounding):
     a = mha_self(h, sd, pfx + "MHA.", hp.num_heads, cu, slopes, rnd)
     x1 = a + rnd.res(x)                                              # :179  x += res_short (16-bit copy: Rounding.res16)
     h = rnd.ln(x1, sd[pfx + "norm2.weight"], sd[pfx + "norm2.bias"])
-    return geglu_ffn(h, sd, pfx, rnd) + x                            # :188  x += res_long (= layer input)
+    return rnd.out(geglu_ffn(h, sd, pfx, rnd) + x, last)                            # :188  x += res_long (= layer input)
 
 
-def seq2reg_context_layer(x, ctx, cu, sd, pfx, hp: Seq2RegHP, slopes, rnd: Rounding):
+def seq2reg_context_layer(x, ctx, cu, sd, pfx, hp: Seq2RegHP, slopes, rnd: Rounding, last=False):
     """seq2reg's ContextFlashAttentionEncoderLayer.forward (seq2reg/modules.py:72-126), make_data_kv false: LN1 ->
     self-MHA -> +src -> LN2 -> cross-MHA(q = x, kv = context rows of the same window, no ALiBi, same key padding as the
     tokens :105-112) -> +res_short -> LN3 -> GeGLU -> + src."""
@@ -262,7 +277,7 @@ def seq2reg_context_layer(x, ctx, cu, sd, pfx, hp: Seq2RegHP, slopes, rnd: Round
     h = rnd.ln(x1, sd[pfx + "norm2.weight"], sd[pfx + "norm2.bias"])
     x2 = mha_cross(h, ctx, sd, pfx + "crossMHA.MHA.", hp.num_heads, cu, cu, rnd) + rnd.res(x1)
     h = rnd.ln(x2, sd[pfx + "norm3.weight"], sd[pfx + "norm3.bias"])
-    return geglu_ffn(h, sd, pfx, rnd) + x
+    return rnd.out(geglu_ffn(h, sd, pfx, rnd) + x, last)
 
 
 def seq2reg_embed(ids, pad_mask, sd, pfx, hp: Seq2RegHP, rnd: Rounding, context=None):
@@ -288,10 +303,11 @@ def seq2reg_embed(ids, pad_mask, sd, pfx, hp: Seq2RegHP, rnd: Rounding, context=
             cfull = c[:, None, :].expand(b * ns, L, d)
         ctx = cfull.reshape(b * ns * L, d)[idx]                       # context rows of the valid tokens
         for l in range(hp.num_layers):
-            xp = seq2reg_context_layer(xp, ctx, cu, sd, f"{pfx}transformer_encoder.{l}.", hp, slopes, rnd)
+            xp = seq2reg_context_layer(xp, ctx, cu, sd, f"{pfx}transformer_encoder.{l}.", hp, slopes, rnd,
+                                       last=l + 1 == hp.num_layers)
     else:
         for l in range(hp.num_layers):
-            xp = seq2reg_layer(xp, cu, sd, f"{pfx}transformer_encoder.{l}.", hp, slopes, rnd)
+            xp = seq2reg_layer(xp, cu, sd, f"{pfx}transformer_encoder.{l}.", hp, slopes, rnd, last=l + 1 == hp.num_layers)
     if hp.seq_pool == "mean":                                         # :263-267
         out = torch.zeros(b * ns, d)
         for w in range(b * ns):
@@ -351,7 +367,7 @@ class Seq2GeneHP:
                    use_bigger_head=kw.get("use_bigger_head", False), head_type=kw.get("head_type", "mlp"))
 
 
-def modulator_layer(src, ctx, cu_src, cu_ctx, sd, pfx, H, slopes, rnd: Rounding, cross_slopes=None):
+def modulator_layer(src, ctx, cu_src, cu_ctx, sd, pfx, H, slopes, rnd: Rounding, cross_slopes=None, last=False):
     """ContextFlashAttentionEncoderLayer.forward (seq2gene/modules/layers.py:88-165) on packed
     streams: LN1 -> self-MHA(ALiBi) -> +src -> LN2 -> cross-MHA(q = x, kv = ctx RAW, no norm)
     -> +res_short -> LN3 -> GeGLU -> + src (the LAYER INPUT, :99,163)."""
@@ -360,32 +376,32 @@ def modulator_layer(src, ctx, cu_src, cu_ctx, sd, pfx, H, slopes, rnd: Rounding,
     h = rnd.ln(x1, sd[pfx + "norm2.weight"], sd[pfx + "norm2.bias"])
     x2 = mha_cross(h, ctx, sd, pfx + "crossMHA.MHA.", H, cu_src, cu_ctx, rnd, cross_slopes) + rnd.res(x1)
     h = rnd.ln(x2, sd[pfx + "norm3.weight"], sd[pfx + "norm3.bias"])
-    return geglu_ffn(h, sd, pfx, rnd) + src
+    return rnd.out(geglu_ffn(h, sd, pfx, rnd) + src, last)
 
 
-def self_only_layer(src, cu_src, sd, pfx, H, slopes, rnd: Rounding):
+def self_only_layer(src, cu_src, sd, pfx, H, slopes, rnd: Rounding, last=False):
     """FlashAttentionEncoderLayer.forward (layers.py:168-228): LN1 -> self-MHA(ALiBi) -> +src -> LN2 -> GeGLU -> + src
     (norm3 is constructed but never applied)."""
     h = rnd.ln(src, sd[pfx + "norm1.weight"], sd[pfx + "norm1.bias"])
     x1 = mha_self(h, sd, pfx + "mixer.MHA.", H, cu_src, slopes, rnd) + rnd.res(src)
     h = rnd.ln(x1, sd[pfx + "norm2.weight"], sd[pfx + "norm2.bias"])
-    return geglu_ffn(h, sd, pfx, rnd) + src
+    return rnd.out(geglu_ffn(h, sd, pfx, rnd) + src, last)
 
 
-def cre_layer(cre, ctx, cu_cre, sd, pfx, hp, slopes, rnd: Rounding):
+def cre_layer(cre, ctx, cu_cre, sd, pfx, hp, slopes, rnd: Rounding, last=False):
     """One CRE layer: with the second-level context (:262-270) or context-free (:271-274).  Never cross_alibi (:78-88)."""
     if hp.use_context:
-        return modulator_layer(cre, ctx, cu_cre, cu_cre, sd, pfx, hp.num_heads, slopes, rnd)
-    return self_only_layer(cre, cu_cre, sd, pfx, hp.num_heads, slopes, rnd)
+        return modulator_layer(cre, ctx, cu_cre, cu_cre, sd, pfx, hp.num_heads, slopes, rnd, last=last)
+    return self_only_layer(cre, cu_cre, sd, pfx, hp.num_heads, slopes, rnd, last=last)
 
 
-def cross_only_layer(src, ctx, cu_src, cu_ctx, sd, pfx, H, rnd: Rounding, cross_slopes=None):
+def cross_only_layer(src, ctx, cu_src, cu_ctx, sd, pfx, H, rnd: Rounding, cross_slopes=None, last=False):
     """ContextFlashCrossAttentionEncoderLayer.forward (layers.py:231-325): LN1 -> cross-MHA(q = x, kv = ctx raw)
     -> +src -> LN2 -> GeGLU -> + src (the layer input)."""
     h = rnd.ln(src, sd[pfx + "norm1.weight"], sd[pfx + "norm1.bias"])
     x1 = mha_cross(h, ctx, sd, pfx + "crossMHA.MHA.", H, cu_src, cu_ctx, rnd, cross_slopes) + rnd.res(src)
     h = rnd.ln(x1, sd[pfx + "norm2.weight"], sd[pfx + "norm2.bias"])
-    return geglu_ffn(h, sd, pfx, rnd) + src
+    return rnd.out(geglu_ffn(h, sd, pfx, rnd) + src, last)
 
 
 def combined_modulator(cre_x, gene_x, ctx_labels, cu_cre, cu_gene, sd, pfx, hp: Seq2GeneHP, rnd: Rounding,
@@ -396,24 +412,27 @@ def combined_modulator(cre_x, gene_x, ctx_labels, cu_cre, cu_gene, sd, pfx, hp: 
     xs = slopes if hp.cross_alibi else None
     ctx = sd[pfx + "second_level_context_embedding.weight"][ctx_labels] if hp.use_context else None   # :166-168
 
-    def gene_layer(g, c, p):
+    nl = hp.num_layers
+
+    def gene_layer(g, c, p, li):
+        last = li == nl - 1 or hp.use_res        # a stream `use_res` adds to keeps its fp32 rows (Rounding.out)
         if hp.only_cross_attention:                                               # :106-119
-            return cross_only_layer(g, c, cu_gene, cu_cre, sd, p, hp.num_heads, rnd, xs)
-        return modulator_layer(g, c, cu_gene, cu_cre, sd, p, hp.num_heads, slopes, rnd, xs)
+            return cross_only_layer(g, c, cu_gene, cu_cre, sd, p, hp.num_heads, rnd, xs, last=last)
+        return modulator_layer(g, c, cu_gene, cu_cre, sd, p, hp.num_heads, slopes, rnd, xs, last=last)
 
     cre, gene = cre_x, gene_x
     gene_res = gene_x if hp.use_res else None                                    # :236
-    gene = gene_layer(gene, cre, pfx + "gene_layers.0.")                         # :244-250
+    gene = gene_layer(gene, cre, pfx + "gene_layers.0.", 0)                      # :244-250
     if collect is not None:
         collect["first_gene_layer_out"] = gene.clone()                          # the layer's own output
     if gene_res is not None:
         gene = gene + gene_res                                                   # :253-254
     for i in range(hp.num_layers - 1):                                           # :258-285
         # the CRE layers are built without cross_alibi (:78-88): their context cross attention never has a bias
-        cre = cre_layer(cre, ctx, cu_cre, sd, f"{pfx}cre_layers.{i}.", hp, slopes, rnd)
+        cre = cre_layer(cre, ctx, cu_cre, sd, f"{pfx}cre_layers.{i}.", hp, slopes, rnd, last=i == nl - 2)
         if collect is not None and i == 0:
             collect["first_cre_layer_out"] = cre.clone()
-        gene = gene_layer(gene, cre, f"{pfx}gene_layers.{i + 1}.")
+        gene = gene_layer(gene, cre, f"{pfx}gene_layers.{i + 1}.", i + 1)
         if gene_res is not None:
             gene = gene + gene_res
     return gene, cre
@@ -543,23 +562,25 @@ def _modulator_shared(cre_x, gene_x, labels, T, G, sd, hp: Seq2GeneHP, rnd: Roun
     cu_c = torch.tensor([0, N], dtype=torch.int32)
     cu_g = torch.arange(0, T + 1, dtype=torch.int32) * G
 
-    def gene_layer(src, kvsrc, p):
+    def gene_layer(src, kvsrc, p, last):
         h = rnd.ln(src, sd[p + "norm1.weight"], sd[p + "norm1.bias"])
-        x1 = mha_self(h, sd, p + "mixer.MHA.", H, cu_g, slopes, rnd) + src
+        x1 = mha_self(h, sd, p + "mixer.MHA.", H, cu_g, slopes, rnd) + rnd.res(src)
         h = rnd.ln(x1, sd[p + "norm2.weight"], sd[p + "norm2.bias"])
-        x2 = mha_cross(h, kvsrc, sd, p + "crossMHA.MHA.", H, torch.tensor([0, T * G], dtype=torch.int32), cu_c, rnd) + x1
+        x2 = mha_cross(h, kvsrc, sd, p + "crossMHA.MHA.", H, torch.tensor([0, T * G], dtype=torch.int32), cu_c, rnd) \
+            + rnd.res(x1)
         h = rnd.ln(x2, sd[p + "norm3.weight"], sd[p + "norm3.bias"])
-        return geglu_ffn(h, sd, p, rnd) + src
+        return rnd.out(geglu_ffn(h, sd, p, rnd) + src, last)
 
+    nl = hp.num_layers
     cre, gene = cre_x, gene_x
-    gene = gene_layer(gene, cre, pfx + "gene_layers.0.")
+    gene = gene_layer(gene, cre, pfx + "gene_layers.0.", nl == 1)
     if collect is not None:
         collect["first_gene_layer_out"] = gene.clone()
     for i in range(hp.num_layers - 1):
-        cre = cre_layer(cre, ctx, cu_c, sd, f"{pfx}cre_layers.{i}.", hp, slopes, rnd)
+        cre = cre_layer(cre, ctx, cu_c, sd, f"{pfx}cre_layers.{i}.", hp, slopes, rnd, last=i == nl - 2)
         if collect is not None and i == 0:
             collect["first_cre_layer_out"] = cre.repeat(T, 1)
-        gene = gene_layer(gene, cre, f"{pfx}gene_layers.{i + 1}.")
+        gene = gene_layer(gene, cre, f"{pfx}gene_layers.{i + 1}.", i + 1 == nl - 1)
     return gene, cre
 
 

@@ -429,6 +429,43 @@ def test_fp16_operand_mode_production_width_vs_oracle():
     check_signal("fp16 operands, production width vs pure fp32", out["pred_gene_exp"], f32["pred_gene_exp"])
 
 
+@pytest.mark.parametrize("precision", ["bf16-mixed", "16-mixed"])
+def test_trunk16_option_vs_oracle_and_fp32(precision, monkeypatch):
+    """VF_TRUNK16=1 (off by default): layer outputs travel to the next layer as 16-bit copy + row statistics only -- the
+    rounding point of the reference's own autocast (`x = linear_geglu_2(x)` is a 16-bit tensor, `x += res_long` adds in
+    place: reference layers.py:161-165, seq2reg/modules.py:186-190); the last layer of each stack keeps fp32.  Production
+    widths, 3 layers, ragged genes, both operand types: expression within the north-star bar of the oracle with the same
+    rounding points (Rounding(trunk16=True)) AND of pure fp32 arithmetic; the embedding bound is the 16-bit one (a trunk
+    element that rounds the other way in the two implementations stays one 16-bit ulp apart for the rest of the stack),
+    and the default mode stays the more exact one against fp32."""
+    kw = seq2gene_kw(layers=3)
+    model = build_model(SEQ2REG_512, kw, seed=515)
+    sd = state_dict_cpu(model)
+    model = model.cuda()
+    model.precision = precision
+    mode = "bf16" if precision == "bf16-mixed" else "fp16"
+    batch = make_batch(31, [7, 40, 1], [3, 9, 2], [[7], TISSUES_54[:5], [62, 10]], 200)
+    monkeypatch.setenv("VF_TRUNK16", "0")
+    base = model.predict_step(batch, 0)
+    monkeypatch.setenv("VF_TRUNK16", "1")
+    out = model.predict_step(batch, 0)
+    hp = O.Seq2RegHP.from_hparams(SEQ2REG_512)
+    ghp = O.Seq2GeneHP.from_kwargs(kw)
+    orc = O.predict_step(batch, sd, hp, hp, ghp, rounding=O.Rounding(mode, trunk16=True), share_cre_stream=True)
+    f32 = O.predict_step(batch, sd, hp, hp, ghp, rounding=None, share_cre_stream=True)
+    ulp = 2.0 ** -8 if mode == "bf16" else 2.0 ** -11
+    for i in range(3):
+        assert not np.array_equal(out["embeddings"][i], base["embeddings"][i])          # the switch does switch
+        assert prel(out["pred_gene_exp"][i], orc["pred_gene_exp"][i]) < NORTH_STAR_RTOL
+        assert prel(out["pred_gene_exp"][i], f32["pred_gene_exp"][i]) < NORTH_STAR_RTOL
+        assert _erel(out["embeddings"][i], orc["embeddings"][i]) < 4 * ulp
+        e16, e32 = _erel(out["embeddings"][i], f32["embeddings"][i]), _erel(base["embeddings"][i], f32["embeddings"][i])
+        print(f"[trunk16 {mode}] gene {i}: embedding vs pure fp32: 16-bit trunk {e16:.2e}, fp32 trunk {e32:.2e}; expression "
+              f"{prel(out['pred_gene_exp'][i], f32['pred_gene_exp'][i]):.2e} vs {prel(base['pred_gene_exp'][i], f32['pred_gene_exp'][i]):.2e}")
+        assert e16 < 8 * ulp
+    check_signal(f"trunk16 {mode} vs oracle(trunk16)", out["pred_gene_exp"], orc["pred_gene_exp"])
+
+
 def test_seq2reg_options_vs_reference_golden():
     """seq_pool max / linear, use_context (with and without expand_context), head dims 96 / 128 on the HIP path: vs the
     reference's own Seq2RegPredictor outputs (fp32 fixture) and vs the same-rounding oracle."""

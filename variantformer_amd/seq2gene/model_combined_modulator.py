@@ -30,7 +30,7 @@ from .. import ops
 from ..utils.constants import REF_CREs
 from ..utils.functions import precision2dtype
 from .modules.layers import (AddContext, ContextFlashAttentionEncoderLayer, ContextFlashCrossAttentionEncoderLayer,
-                             FlashAttentionEncoderLayer, MultiRegistry, StartToken, TissueExpressionHeads, ln_fold_enabled,
+                             FlashAttentionEncoderLayer, MultiRegistry, StartToken, TissueExpressionHeads, ln_fold_enabled, trunk16_enabled,
                              packed_linear, pad_input, unpad_input)
 
 logger = logging.getLogger(__name__)
@@ -129,6 +129,9 @@ def modulator_forward_packed(ctx_embedding, cre_layers, gene_layers, cre_x, gene
     ck = cu_cre if cu_cre_for_gene is None else cu_cre_for_gene
     cre, gene = cre_x, gene_x
     n = len(gene_layers)
+    # 16-bit trunk (layers.trunk16_enabled): a layer's result goes to the next layer of its stack as 16-bit copy + row
+    # statistics only; the last layer of each stack (returned below) and a stream that `use_res` adds to keep fp32 rows
+    t16 = trunk16_enabled() and ln_fold_enabled(cre_x.shape[1])
     if ln_fold_enabled(cre_x.shape[1]):
         # LayerNorm folded into the GEMMs: the streams travel as (fp32, bf16 copy, row statistics); one pass makes the
         # triple for the raw CRE embeddings (gene layer 0 projects K/V from the copy, CRE layer 0 consumes all three)
@@ -151,23 +154,26 @@ def modulator_forward_packed(ctx_embedding, cre_layers, gene_layers, cre_x, gene
             qkv0 = gene_layers[0].self_qkv_of_unique_rows(*gene_unique)
         kw0 = {} if qkv0 is None else {"self_qkv": qkv0}
         gene = gene_layers[0].forward_packed(gene, cu_gene_self, max_gene, context=cre, cu_ctx=ck, max_ctx=max_cre,
-                                             cu_cross_q=cq, max_cross_q=mq, **kw0)
+                                             cu_cross_q=cq, max_cross_q=mq, keep_x=not t16 or use_res or n == 1, **kw0)
     if use_res:                                     # gene-stream input added back after every gene layer (:253-254)
         gene = ops.add_rows(_t(gene), gene_x)
     for i in range(n - 1):
         if overlap:
             with torch.cuda.stream(side):
                 kv = None if ctx_embedding is None else ops.gather_rows_bf16(_context_kv_table(ctx_embedding, cre_layers[i]), labels)
-                cre = cre_layers[i].forward_packed(cre, cu_cre, max_cre, context_kv=kv, cu_ctx=cu_cre, max_ctx=max_cre)
+                cre = cre_layers[i].forward_packed(cre, cu_cre, max_cre, context_kv=kv, cu_ctx=cu_cre, max_ctx=max_cre,
+                                                   keep_x=not t16 or i == n - 2)
                 done = torch.cuda.Event()
                 done.record(side)
             for t in ((cre.x, cre.x16, cre.stats) if isinstance(cre, ops.LnStream) else (cre,)):
-                t.record_stream(main)               # allocated on `side`, read by the gene layer on `main`
+                if t is not None:
+                    t.record_stream(main)               # allocated on `side`, read by the gene layer on `main`
             main.wait_event(done)
         else:
             with ops.scope("cre_stream"):
                 kv = None if ctx_embedding is None else ops.gather_rows_bf16(_context_kv_table(ctx_embedding, cre_layers[i]), labels)
-                cre = cre_layers[i].forward_packed(cre, cu_cre, max_cre, context_kv=kv, cu_ctx=cu_cre, max_ctx=max_cre)
+                cre = cre_layers[i].forward_packed(cre, cu_cre, max_cre, context_kv=kv, cu_ctx=cu_cre, max_ctx=max_cre,
+                                                   keep_x=not t16 or i == n - 2)
         with ops.scope("gene_stream"):
             if final_rows is not None and i + 1 == n - 1:
                 # last gene layer: only the registry rows are consumed downstream -> compact [R, D] result
@@ -176,7 +182,8 @@ def modulator_forward_packed(ctx_embedding, cre_layers, gene_layers, cre_x, gene
                                                               cu_cross_rows, max_cross_rows)
             else:
                 gene = gene_layers[i + 1].forward_packed(gene, cu_gene_self, max_gene, context=cre, cu_ctx=ck,
-                                                         max_ctx=max_cre, cu_cross_q=cq, max_cross_q=mq)
+                                                         max_ctx=max_cre, cu_cross_q=cq, max_cross_q=mq,
+                                                         keep_x=not t16 or use_res or i + 1 == n - 1)
                 if use_res:                             # :284-285
                     gene = ops.add_rows(_t(gene), gene_x)
     return _t(gene), _t(cre)

@@ -37,18 +37,21 @@ def get_alibi_slopes(n: int) -> torch.Tensor:
 # ---------------------------------------------------------------------------------------------
 # weight packing (fp32 master parameters -> bf16 kernel operands), cached per parameter version
 # ---------------------------------------------------------------------------------------------
-def packed_linear(lin: nn.Linear, geglu: bool = False):
+def packed_linear(lin: nn.Linear, geglu: bool = False, wscale: float = 1.0):
     """(16-bit weight [N,K] in the current compute dtype, fp32 bias [N]) for vf_gemm_*; `geglu` applies the GEGLU row
     interleave.  Rebuilt whenever the parameter is modified in place (load_state_dict), moved, or the compute dtype
-    changes (one cached copy per module: a model runs in one precision at a time)."""
+    changes (one cached copy per module: a model runs in one precision at a time).  `wscale` (a power of two): the
+    16-bit weights are 16bit(W * wscale) -- the operand of a GEMM whose OTHER operand is a stream copy stored scaled by
+    1 / wscale (ops.LnStream.scale, fp16 mode); the product is then the unscaled one, exactly."""
     w = lin.weight
-    key = (w.data_ptr(), w._version, str(w.device), geglu, ops.cdt(),
+    key = (w.data_ptr(), w._version, str(w.device), geglu, ops.cdt(), float(wscale),
            None if lin.bias is None else (lin.bias.data_ptr(), lin.bias._version))
     cache = getattr(lin, "_vf_packed", None)
     if cache is not None and cache[0] == key:
         return cache[1], cache[2]
     with torch.no_grad():
-        wb = ops.cast16(w.detach().float().contiguous())
+        wf = w.detach().float()
+        wb = ops.cast16((wf if wscale == 1.0 else wf * float(wscale)).contiguous())
         b = None if lin.bias is None else lin.bias.detach().float().contiguous()
         if geglu:
             wb, b = ops.pack_geglu_rows(wb, b)
@@ -105,6 +108,28 @@ def res16_enabled() -> bool:
     oracle.Rounding(res16=True) restates the rounding points."""
     import os
     return os.environ.get("VF_RES16", "1") != "0"
+
+
+def trunk16_enabled() -> bool:
+    """A layer's OUTPUT (the trunk: W2.h + layer input) travels to the next layer of its stack in 16 bits only: the
+    down-projection epilogue reads the layer input from the 16-bit stream copy and writes the 16-bit copy + row
+    statistics of the sum, no fp32 rows in either direction (4 instead of 10 bytes per element; the kernel the attention
+    out-projections already use).  This is where the reference's own autocast rounds: `x = linear_geglu_2(x)` is a
+    16-bit tensor there and `x += res_long` adds in place (layers.py:161-165, seq2reg/modules.py:186-190), so every
+    layer hands a 16-bit stream to the next one.  The LAST layer of a stack (its output is pooled / returned, not fed to
+    a LayerNorm -> Linear pair) keeps its fp32 result.  Needs the LayerNorm fold and res16.
+    OFF by default (VF_TRUNK16=1 turns it on): measured at full depth it takes 3.2 % off
+    the step but the expression's distance from pure fp32 arithmetic grows from 3.4e-4 to 8.8e-4 -- inside the 1e-3 bar
+    without margin -- and a same-rounding oracle no longer tracks the kernels (one-ulp flips of the trunk persist).
+    oracle.Rounding(trunk16=True) restates the rounding points."""
+    import os
+    return os.environ.get("VF_TRUNK16", "0") != "0" and res16_enabled()
+
+
+def _ffn_residual(s):
+    """The layer input as the residual of the down-projection: its fp32 rows when they exist (the first layer of a stack,
+    or VF_TRUNK16=0), else the stream itself = its 16-bit copy."""
+    return s.x if s.x is not None else s
 
 
 def _as_stream(x):
@@ -171,6 +196,17 @@ class MHA(nn.Module):
         """bf16 [tokens_k, 2D] = Wkv(x_kv): exposed so that a caller can compute it once and share it."""
         w, b = packed_linear(self.Wkv)
         return ops.gemm(x_kv_bf16, w, b, ops.EPI_BF16)
+
+    def project_kv_of(self, ctx) -> torch.Tensor:
+        """project_kv of a context stream: an fp32 tensor (cast here), or an ops.LnStream, whose 16-bit copy is the
+        operand -- un-normalised use, so a SCALED copy (fp16 mode) meets weights scaled by the inverse power of two:
+        (x * s) . (W / s) = x . W in the fp32 accumulator, with the mantissas of fp16(x) and fp16(W)."""
+        if not isinstance(ctx, ops.LnStream):
+            return self.project_kv(ops.cast16(ctx))
+        if ctx.scale == 1.0:
+            return self.project_kv(ctx.x16)
+        w, b = packed_linear(self.Wkv, wscale=1.0 / ctx.scale)
+        return ops.gemm(ctx.x16, w, b, ops.EPI_BF16)
 
     def attend(self, x_bf16, kv_bf16, cu_q, max_q, cu_k, max_k) -> torch.Tensor:
         """bf16 attention output [tokens_q, D] (before out_proj)."""
@@ -323,11 +359,13 @@ class ContextFlashAttentionEncoderLayer(nn.Module):
         return ops.gather_rows_bf16(both, idx2)
 
     def forward_packed(self, src, cu_src, max_src, context=None, cu_ctx=None, max_ctx=None, context_kv=None,
-                       cu_cross_q=None, max_cross_q=None, self_qkv=None):
+                       cu_cross_q=None, max_cross_q=None, self_qkv=None, keep_x=True):
         """src fp32 [tokens, D] packed residual stream.  Cross-attention keys/values come either from
         `context` (fp32 packed stream, projected here) or from a precomputed bf16 `context_kv` [tokens_k, 2D].
         `cu_cross_q` lets several self-attention sequences share one K/V block (tissue copies of a gene).
-        `self_qkv`: precomputed LayerNorm1 -> Wqkv projection of src (self_qkv_of_unique_rows)."""
+        `self_qkv`: precomputed LayerNorm1 -> Wqkv projection of src (self_qkv_of_unique_rows).
+        `keep_x=False` (LayerNorm fold only): the result's fp32 rows have no reader (the next layer of the stack takes
+        the 16-bit copy, trunk16_enabled) and are not stored."""
         assert not self.make_data_kv
         cq = cu_src if cu_cross_q is None else cu_cross_q
         mq = max_src if max_cross_q is None else max_cross_q
@@ -343,16 +381,16 @@ class ContextFlashAttentionEncoderLayer(nn.Module):
             else:
                 s = _as_stream(src)
                 a = self.mixer.MHA.attend_ln(s, self.norm1, None, cu_src, max_src, None, None)
+            r16 = r16 or s.x is None
             x1 = self.mixer.MHA.out_ln(a, s if r16 else s.x, need_x=not r16)
             if context_kv is None:
-                ctx16 = context.operand16() if isinstance(context, ops.LnStream) else ops.cast16(context)
-                context_kv = self.crossMHA.MHA.project_kv(ctx16)
+                context_kv = self.crossMHA.MHA.project_kv_of(context)
             a = self.crossMHA.MHA.attend_ln(x1, self.norm2, context_kv, cq, mq, cu_ctx, max_ctx)
             x2 = self.crossMHA.MHA.out_ln(a, x1 if r16 else x1.x, need_x=False)
             w1, b1, c1 = packed_linear_ln(self.linear_geglu_1, self.norm3, geglu=True)
             hg = ops.gemm_ln_consumer(x2, w1, b1, c1, ops.EPI_GEGLU_BF16)
             w2, b2 = packed_linear(self.linear_geglu_2)
-            return ops.gemm_ln_producer(hg, w2, b2, s.x)
+            return ops.gemm_ln_producer(hg, w2, b2, _ffn_residual(s), need_x=keep_x)
         src, context = _as_tensor(src), _as_tensor(context)
         h = ops.layernorm(src, self.norm1.weight, self.norm1.bias)
         x1 = self.mixer.MHA.fused(h, src, cu_src, max_src)
@@ -378,22 +416,23 @@ class ContextFlashAttentionEncoderLayer(nn.Module):
         mha = self.mixer.MHA
         if ln_fold_enabled(self.norm1.weight.numel(), self.linear_geglu_2.in_features):
             s = _as_stream(src)
-            D = s.x.shape[1]
+            D = s.x16.shape[1]
             w, b, c = packed_linear_ln(mha.Wqkv, self.norm1)
             kv = ops.gemm_ln_consumer(s, w[D:], b[D:], c[D:], ops.EPI_BF16)            # all rows (K/V need them)
             sr = ops.ln_stream_rows(s, rows)
             q = ops.gemm_ln_consumer(sr, w[:D], b[:D], c[:D], ops.EPI_BF16)            # [R, D]
             a = ops.attn_varlen(q, kv[:, :D], kv[:, D:], cu_rows, cu_src, 1, max_src, mha.num_heads, mha.head_dim,
                                 mha.alibi_slopes, q_at_start=True, family=mha.family + "_registry_rows")
-            r16 = res16_enabled()
+            r16 = res16_enabled() or sr.x is None
             x1 = mha.out_ln(a, sr if r16 else sr.x, need_x=not r16)
-            ctx16 = context.operand16() if isinstance(context, ops.LnStream) else ops.cast16(context)
-            ckv = self.crossMHA.MHA.project_kv(ctx16)
+            ckv = self.crossMHA.MHA.project_kv_of(context)
             a = self.crossMHA.MHA.attend_ln(x1, self.norm2, ckv, cu_cross_rows, max_cross_rows, cu_ctx, max_ctx)
             x2 = self.crossMHA.MHA.out_ln(a, x1 if r16 else x1.x, need_x=False)
             w1, b1, c1 = packed_linear_ln(self.linear_geglu_1, self.norm3, geglu=True)
             hg = ops.gemm_ln_consumer(x2, w1, b1, c1, ops.EPI_GEGLU_BF16)
             w2, b2 = packed_linear(self.linear_geglu_2)
+            if sr.x is None:                 # 16-bit trunk: the registry rows' residual is their 16-bit copy
+                return ops.gemm_ln_producer(hg, w2, b2, sr).x
             return ops.gemm(hg, w2, b2, ops.EPI_RES_F32, residual=sr.x)
         ctx16 = context.operand16() if isinstance(context, ops.LnStream) else None
         src, context = _as_tensor(src), _as_tensor(context)
@@ -468,15 +507,15 @@ class FlashAttentionEncoderLayer(nn.Module):
         if use_alibi:
             self.register_buffer("m", get_alibi_slopes(self.num_heads))
 
-    def forward_packed(self, src, cu_src, max_src, **_):
+    def forward_packed(self, src, cu_src, max_src, keep_x=True, **_):
         if ln_fold_enabled(self.norm1.weight.numel(), self.linear_geglu_2.in_features):
             s = _as_stream(src)
             a = self.mixer.MHA.attend_ln(s, self.norm1, None, cu_src, max_src, None, None)
-            x1 = self.mixer.MHA.out_ln(a, s if res16_enabled() else s.x, need_x=False)
+            x1 = self.mixer.MHA.out_ln(a, s if (res16_enabled() or s.x is None) else s.x, need_x=False)
             w1, b1, c1 = packed_linear_ln(self.linear_geglu_1, self.norm2, geglu=True)
             hg = ops.gemm_ln_consumer(x1, w1, b1, c1, ops.EPI_GEGLU_BF16)
             w2, b2 = packed_linear(self.linear_geglu_2)
-            return ops.gemm_ln_producer(hg, w2, b2, s.x)
+            return ops.gemm_ln_producer(hg, w2, b2, _ffn_residual(s), need_x=keep_x)
         src = _as_tensor(src)
         h = ops.layernorm(src, self.norm1.weight, self.norm1.bias)
         x1 = self.mixer.MHA.fused(h, src, cu_src, max_src)
@@ -507,21 +546,20 @@ class ContextFlashCrossAttentionEncoderLayer(nn.Module):
             self.register_buffer("m", get_alibi_slopes(self.num_heads))
 
     def forward_packed(self, src, cu_src, max_src, context=None, cu_ctx=None, max_ctx=None, context_kv=None,
-                       cu_cross_q=None, max_cross_q=None):
+                       cu_cross_q=None, max_cross_q=None, keep_x=True):
         assert not self.make_data_kv
         cq = cu_src if cu_cross_q is None else cu_cross_q
         mq = max_src if max_cross_q is None else max_cross_q
         if ln_fold_enabled(self.norm1.weight.numel(), self.linear_geglu_2.in_features):
             s = _as_stream(src)
             if context_kv is None:
-                ctx16 = context.operand16() if isinstance(context, ops.LnStream) else ops.cast16(context)
-                context_kv = self.crossMHA.MHA.project_kv(ctx16)
+                context_kv = self.crossMHA.MHA.project_kv_of(context)
             a = self.crossMHA.MHA.attend_ln(s, self.norm1, context_kv, cq, mq, cu_ctx, max_ctx)
-            x1 = self.crossMHA.MHA.out_ln(a, s if res16_enabled() else s.x, need_x=False)
+            x1 = self.crossMHA.MHA.out_ln(a, s if (res16_enabled() or s.x is None) else s.x, need_x=False)
             w1, b1, c1 = packed_linear_ln(self.linear_geglu_1, self.norm2, geglu=True)
             hg = ops.gemm_ln_consumer(x1, w1, b1, c1, ops.EPI_GEGLU_BF16)
             w2, b2 = packed_linear(self.linear_geglu_2)
-            return ops.gemm_ln_producer(hg, w2, b2, s.x)
+            return ops.gemm_ln_producer(hg, w2, b2, _ffn_residual(s), need_x=keep_x)
         src, context = _as_tensor(src), _as_tensor(context)
         h = ops.layernorm(src, self.norm1.weight, self.norm1.bias)
         if context_kv is None:

@@ -110,12 +110,16 @@ class Seq2RegPredictor(nn.Module):
                         "a use_context tokenizer needs integer cCRE labels as context; the gene branch of the reference "
                         "passes a float zero tensor (model_combined_modulator.py:575-577), which nn.Embedding rejects there too")
                 ctx = self._context_rows(pad, cu, context.to(ids.device).long().reshape(-1), n_tokens)
-                for layer in self.transformer_encoder:
-                    x = layer.forward_packed(x, cu, Lmax, context=ctx, cu_ctx=cu, max_ctx=Lmax)
-            else:
+                from ..seq2gene.modules.layers import trunk16_enabled
                 n_layers = len(self.transformer_encoder)
                 for li, layer in enumerate(self.transformer_encoder):
-                    x = layer.forward_packed(x, cu, Lmax, last=li + 1 == n_layers)
+                    x = layer.forward_packed(x, cu, Lmax, context=ctx, cu_ctx=cu, max_ctx=Lmax,
+                                             keep_x=not trunk16_enabled() or li + 1 == n_layers)
+            else:
+                from ..seq2gene.modules.layers import trunk16_enabled
+                n_layers = len(self.transformer_encoder)
+                for li, layer in enumerate(self.transformer_encoder):
+                    x = layer.forward_packed(x, cu, Lmax, last=li + 1 == n_layers, keep_x=not trunk16_enabled())
             if isinstance(x, ops.LnStream):                           # layers exchange (x, bf16 copy, row statistics)
                 x = x.x
             if self.seq_pool == "mean":                               # :263-267

@@ -26,21 +26,26 @@ class FlashTransformerLayer(nn.Module):
         self.dropout = nn.Dropout(mlp_dout)
         self.linear_geglu_2 = nn.Linear(hidden_dim // 2, d_model)
 
-    def forward_packed(self, src, cu: torch.Tensor, max_seqlen: int, last: bool = False):
+    def forward_packed(self, src, cu: torch.Tensor, max_seqlen: int, last: bool = False, keep_x: bool = True):
         """src: fp32 [tokens, d] or an ops.LnStream; returns the same kind (an LnStream when LayerNorm is folded into
-        the GEMMs, see seq2gene.modules.layers.ln_fold_enabled; a plain tensor from the `last` layer)."""
-        from ..seq2gene.modules.layers import _as_stream, _as_tensor, ln_fold_enabled, packed_linear_ln, res16_enabled
+        the GEMMs, see seq2gene.modules.layers.ln_fold_enabled; a plain tensor from the `last` layer).  keep_x=False: the
+        result's fp32 rows have no reader (16-bit trunk, layers.trunk16_enabled) and are not stored."""
+        from ..seq2gene.modules.layers import (_as_stream, _as_tensor, _ffn_residual, ln_fold_enabled, packed_linear_ln,
+                                               res16_enabled)
         if ln_fold_enabled(self.norm1.weight.numel(), self.linear_geglu_2.in_features):
             s = _as_stream(src)
             a = self.MHA.attend_ln(s, self.norm1, None, cu, max_seqlen, None, None)
             # x1 is read only through norm2 -> linear_geglu_1: no fp32 store, and (res16) its residual is the 16-bit copy
-            x1 = self.MHA.out_ln(a, s if res16_enabled() else s.x, need_x=False)
+            x1 = self.MHA.out_ln(a, s if (res16_enabled() or s.x is None) else s.x, need_x=False)
             w1, b1, c1 = packed_linear_ln(self.linear_geglu_1, self.norm2, geglu=True)
             hg = ops.gemm_ln_consumer(x1, w1, b1, c1, ops.EPI_GEGLU_BF16)
             w2, b2 = packed_linear(self.linear_geglu_2)
-            if last:        # the encoder's last layer feeds the pooling, not a LayerNorm: plain fp32 result, no copy / statistics
+            if last:        # the encoder's last layer feeds the pooling, not a LayerNorm: plain fp32 result
+                if s.x is None:                  # 16-bit trunk: the layer input exists as its 16-bit copy only
+                    return ops.gemm_ln_producer(hg, w2, b2, s).x
                 return ops.gemm(hg, w2, b2, ops.EPI_RES_F32, residual=s.x)
-            return ops.gemm_ln_producer(hg, w2, b2, s.x)
+            # 16-bit trunk (layers.trunk16_enabled): the next layer reads the 16-bit copy + statistics only
+            return ops.gemm_ln_producer(hg, w2, b2, _ffn_residual(s), need_x=keep_x)
         src = _as_tensor(src)
         h = ops.layernorm(src, self.norm1.weight, self.norm1.bias)
         x1 = self.MHA.fused(h, src, cu, max_seqlen)
