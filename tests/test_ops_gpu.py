@@ -181,6 +181,55 @@ def test_attention_matches_oracle(ops, dh, H, ql, kl, alibi):
     np.testing.assert_allclose(got.numpy(), _bf(ref).numpy(), rtol=2 ** -7, atol=6e-3)
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("alibi,cross", [(True, False), (False, False), (False, True)])
+def test_attention_short_kernel_ragged_batch(ops, dtype, alibi, cross):
+    """The one-block-per-(sequence, head) kernel (dh <= 48, 128 < max_q <= 256) on a ragged batch of 70 sequences: lengths
+    1, 16-row and 64-row boundaries (every size of the 16 / 32 / 64-key tail tile), 256, an empty key sequence and an empty
+    query sequence; both operand types, with ALiBi, without, and as a cross attention.  Deterministic across repeats."""
+    dh, H = 48, 8
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float16
+    rng = np.random.default_rng(5)
+    ql = [256, 201, 129, 1, 16, 17, 64, 65, 128, 192, 193, 255, 0, 80, 81, 96, 97, 208, 209, 224, 225] + list(rng.integers(1, 257, 49))
+    kl = ql
+    if cross:
+        kl = [200, 256, 1, 63, 0, 64, 65, 129, 7, 255, 128, 31, 40, 16, 17, 32, 33, 48, 49, 80, 81] + list(rng.integers(1, 257, 49))
+    D = H * dh
+    tq, tk = sum(ql), sum(kl)
+    cu_q = torch.tensor([0] + list(np.cumsum(ql)), dtype=torch.int32)
+    cu_k = torch.tensor([0] + list(np.cumsum(kl)), dtype=torch.int32)
+    slopes = torch.tensor(O.alibi_slopes(H), dtype=torch.float32) if alibi else None
+    rd = (lambda t: t.to(tdt).float())
+    if not cross:
+        qkv = rd(_rand((tq, 3 * D), 31, 2.0))
+        q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+        dev = qkv.cuda().to(tdt)
+        dq, dk, dv = dev[:, :D], dev[:, D:2 * D], dev[:, 2 * D:]
+    else:
+        q = rd(_rand((tq, D), 32, 2.0))
+        kv = rd(_rand((tk, 2 * D), 33, 2.0))
+        k, v = kv[:, :D], kv[:, D:]
+        dq = q.cuda().to(tdt)
+        dkv = kv.cuda().to(tdt)
+        dk, dv = dkv[:, :D], dkv[:, D:]
+    args = (dq, dk, dv, cu_q.cuda(), cu_k.cuda(), max(ql), max(kl), H, dh, slopes.cuda() if alibi else None)
+    outs = [ops.attn_varlen(*args).clone() for _ in range(3)]
+    torch.cuda.synchronize()
+    for o in outs[1:]:
+        assert torch.equal(o.view(torch.int16), outs[0].view(torch.int16))
+    rnd = O.Rounding(dtype)
+    got = outs[0].float().cpu()
+    for b in list(range(21)) + [30, 50]:
+        a, e, ka, ke = int(cu_q[b]), int(cu_q[b + 1]), int(cu_k[b]), int(cu_k[b + 1])
+        if e == a:
+            continue
+        if ke == ka:
+            assert float(got[a:e].abs().max()) == 0.0
+            continue
+        ref = O.attention(q[a:e].view(-1, H, dh), k[ka:ke].view(-1, H, dh), v[ka:ke].view(-1, H, dh), slopes, rnd)
+        np.testing.assert_allclose(got[a:e].numpy(), rd(ref.reshape(e - a, D)).numpy(), rtol=2 ** -7, atol=6e-3)
+
+
 def test_attention_online_softmax_rescale_branch(ops):
     """Force the running max to jump at a late key tile (guide rule 26): one key far larger than the rest."""
     dh, H, n = 64, 1, 200

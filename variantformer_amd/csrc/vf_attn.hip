@@ -128,7 +128,11 @@ __device__ __forceinline__ s16x4_t lds_tr_read(const char* p) {
 // sK / sV point at the tile's first key row in LDS.  All state is per lane (r = query, g = key sub-block).
 // DBGT (diagnostic builds of the long-stream kernel only): 1 = no softmax VALU work (P = S), 2 = additionally no LDS
 // fragment reads (operands reused), used to locate the binding ceiling; results are meaningless.
-template <int DH, int QG, bool ALIBI, int DT, int DBGT = 0>
+// NKT (4, 2 or 1): number of 16-key sub-tiles that can hold a valid key -- the LAST tile of a sequence whose remainder is
+// <= 32 / <= 16 keys runs the 2 / 1 sub-tile form: no K fragments, QK^T MFMAs, bias, maximum, exponentials for the rest, and
+// for NKT <= 2 no second 32-key PV block either.  Bit-identical to the full tile (whose masked keys contribute p = 0 exactly,
+// and x + 0 = x in the accumulators); a 201-key sequence (3 tiles + 9 keys) saves 3/16 of its arithmetic.
+template <int DH, int QG, bool ALIBI, int DT, int DBGT = 0, int NKT = 4>
 __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, int kb0, int len_k, int r, int g, float c,
                                           float slope2, const typename Op16<DT>::frag (&qf)[QG][KLayout<DH>::KS], const float (&q_pos)[QG],
                                           f32x4_t (&o)[QG][DH / 16], float (&m_run)[QG], f32x4_t (&l_acc)[QG]) {
@@ -145,9 +149,9 @@ __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, int kb
     // all 8 K fragments of the tile are requested before the first MFMA and the V fragments of the first 32-key
     // block right after, so LDS latency overlaps the MFMAs and the softmax arithmetic instead of preceding every
     // MFMA pair (diagnostic builds: just-in-time fragment reads cost ~70 of 150 us on the gene->CRE shape)
-    frag_t kf[4][KS];
+    frag_t kf[NKT][KS];
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
+    for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
             kf[kt][ks] = DBGT >= 2 ? qf[0][ks] : *reinterpret_cast<const frag_t*>(
@@ -163,7 +167,7 @@ __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, int kb
         }
     };
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
+    for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -188,9 +192,9 @@ __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, int kb
     constexpr unsigned int one2 = Op16<DT>::ONE * 0x10001u;
     const u32x4_t ones_bits = {one2, one2, one2, one2};
     const frag_t ones = __builtin_bit_cast(frag_t, ones_bits);
-    auto pack_p = [&](int qg) {
+    auto pack_p = [&](int qg) {                        // sub-tiles kt >= NKT still hold their initial zeros = 16-bit zeros
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < (NKT > 2 ? 2 : 1); ++kb) {
             u32x4_t pk;
             pk[0] = Op16<DT>::pack2(s[qg][2 * kb][0], s[qg][2 * kb][1]);
             pk[1] = Op16<DT>::pack2(s[qg][2 * kb][2], s[qg][2 * kb][3]);
@@ -208,11 +212,13 @@ __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, int kb
     auto pv = [&](int qg) {
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) o[qg][dt] = Op16<DT>::mfma(vf0[dt], pf[qg][0], o[qg][dt]);
+        if (NKT > 2) {
 #pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) o[qg][dt] = Op16<DT>::mfma(vf1[dt], pf[qg][1], o[qg][dt]);
+            for (int dt = 0; dt < NDT; ++dt) o[qg][dt] = Op16<DT>::mfma(vf1[dt], pf[qg][1], o[qg][dt]);
+        }
         if (DBGT == 0) {
             l_acc[qg] = Op16<DT>::mfma(ones, pf[qg][0], l_acc[qg]);
-            l_acc[qg] = Op16<DT>::mfma(ones, pf[qg][1], l_acc[qg]);
+            if (NKT > 2) l_acc[qg] = Op16<DT>::mfma(ones, pf[qg][1], l_acc[qg]);
         }
     };
     if (DBGT >= 1) {                                  // diagnostic: P = S, no softmax arithmetic
@@ -232,26 +238,33 @@ __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, int kb
         if (ALIBI) {
             const float dq = q_pos[qg] - k_pos0;
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
+            for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     s[qg][kt][e] = fmaf(s[qg][kt][e], c, -slope2 * fabsf(dq - (float)(16 * kt + e)));
         }
         if (tail && !HwMask<DH>::value) {
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
+            for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) s[qg][kt][e] = (16 * kt + e) < klim ? s[qg][kt][e] : -INFINITY;
         }
         // 16 scores -> 1 maximum in 8 v_max3_f32 + 1 v_max_f32 (two chains of max(max(a, b), c) for instruction-level
         // parallelism; a pairwise tree compiled to 24 v_max / v_max3 per query group: the loop is VALU-issue bound)
-        float mxa = max3f(s[qg][0][0], s[qg][0][1], s[qg][0][2]);
-        float mxb = max3f(s[qg][2][0], s[qg][2][1], s[qg][2][2]);
-        mxa = max3f(mxa, s[qg][0][3], s[qg][1][0]);
-        mxb = max3f(mxb, s[qg][2][3], s[qg][3][0]);
-        mxa = max3f(mxa, s[qg][1][1], s[qg][1][2]);
-        mxb = max3f(mxb, s[qg][3][1], s[qg][3][2]);
-        mxa = max3f(mxa, s[qg][1][3], s[qg][3][3]);
+        float mxa = max3f(s[qg][0][0], s[qg][0][1], s[qg][0][2]), mxb;
+        if (NKT == 4) {
+            mxb = max3f(s[qg][2][0], s[qg][2][1], s[qg][2][2]);
+            mxa = max3f(mxa, s[qg][0][3], s[qg][1][0]);
+            mxb = max3f(mxb, s[qg][2][3], s[qg][3][0]);
+            mxa = max3f(mxa, s[qg][1][1], s[qg][1][2]);
+            mxb = max3f(mxb, s[qg][3][1], s[qg][3][2]);
+            mxa = max3f(mxa, s[qg][1][3], s[qg][3][3]);
+        } else if (NKT == 2) {
+            mxb = max3f(s[qg][1][0], s[qg][1][1], s[qg][1][2]);
+            mxa = max3f(mxa, s[qg][0][3], s[qg][1][3]);
+        } else {
+            mxb = s[qg][0][3];
+        }
         const float mx = max_over_g(max2f(mxa, mxb));
         m_new[qg] = max2f(m_run[qg], mx);           // finite: tile 0 always holds a valid key
         moved = moved || (m_new[qg] > m_run[qg]);
@@ -265,7 +278,7 @@ __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, int kb
             for (int dt = 0; dt < NDT; ++dt) o[qg][dt] *= alpha;
         }
     }
-    read_v(1, vf1);
+    if (NKT > 2) read_v(1, vf1);
 #pragma unroll
     for (int qg = 0; qg < QG; ++qg) {
         m_run[qg] = m_new[qg];
@@ -273,7 +286,7 @@ __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, int kb
         const float mc = ALIBI ? -m_new[qg] : -m_new[qg] * c;
         const float cc = ALIBI ? 1.0f : c;
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
+        for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
             for (int e = 0; e < 4; ++e) s[qg][kt][e] = __builtin_amdgcn_exp2f(fmaf(s[qg][kt][e], cc, mc));
         pack_p(qg);
@@ -285,6 +298,17 @@ __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, int kb
 #pragma unroll
         for (int qg = 0; qg < QG; ++qg) pv(qg);
     }
+}
+
+// The last key tile of a sequence in its short form: `rem` = keys it holds, <= 32 (the caller's tile loop stops one tile
+// early for such a remainder; a longer one is an ordinary full tile of that loop -- no second copy of the full tile body).
+template <int DH, int QG, bool ALIBI, int DT>
+__device__ __forceinline__ void attn_tile_short(int rem, const char* sK, const char* sV, int kb0, int len_k, int r, int g, float c,
+                                                float slope2, const typename Op16<DT>::frag (&qf)[QG][KLayout<DH>::KS],
+                                                const float (&q_pos)[QG], f32x4_t (&o)[QG][DH / 16], float (&m_run)[QG],
+                                                f32x4_t (&l_acc)[QG]) {
+    if (rem <= 16) attn_tile<DH, QG, ALIBI, DT, 0, 1>(sK, sV, kb0, len_k, r, g, c, slope2, qf, q_pos, o, m_run, l_acc);
+    else attn_tile<DH, QG, ALIBI, DT, 0, 2>(sK, sV, kb0, len_k, r, g, c, slope2, qf, q_pos, o, m_run, l_acc);
 }
 
 template <int DH, int QG, bool ALIBI, int DT = VF_BF16, int DBG = 0>
@@ -439,8 +463,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P) {
     if (active) {
         const int t = nkv - 1;
         const char* sK = smem + (t & 1) * STAGE;
-        attn_tile<DH, QG, ALIBI, DT, (DBG > 2 ? 0 : DBG)>(sK, sK + K_TILE_BYTES, t * BKV, len_k, r, g, c, slope2, qf, q_pos,
-                                                       o, m_run, l_acc);
+        // short sequences (one query group per wave: seq2reg windows of 70-200 tokens, 2-4 tiles): the last tile in its
+        // 16 / 32-key form when the remainder allows (a 100-token window: 64 + 36 keys; a 200-token chunk: 3 x 64 + 8)
+        if (QG == 1 && DBG == 0 && len_k - t * BKV <= 32)
+            attn_tile_short<DH, QG, ALIBI, DT>(len_k - t * BKV, sK, sK + K_TILE_BYTES, t * BKV, len_k, r, g, c, slope2, qf,
+                                               q_pos, o, m_run, l_acc);
+        else
+            attn_tile<DH, QG, ALIBI, DT, (DBG > 2 ? 0 : DBG)>(sK, sK + K_TILE_BYTES, t * BKV, len_k, r, g, c, slope2, qf, q_pos,
+                                                           o, m_run, l_acc);
     }
 
     // ---- normalise and store: lane (r,g) holds O[q = r][d = 16dt + 4g .. +3]
@@ -795,10 +825,16 @@ __global__ __launch_bounds__(256, (QG >= 2 ? 2 : 4)) void attn_short_kernel(Attn
     // rows nobody stores: 19 % of the block's matrix and vector work at the gene stream's 201-token sequences.  The
     // arrays of the first QG - 1 groups are prefixes of the QG-group arrays.
     const bool last_group_valid = (wave + 4 * (QG - 1)) * 16 < len_q;             // wave-uniform
+    // the last tile in its 16 / 32-key form when the remainder allows (201 keys = 3 tiles + 9 keys: 3/16 of the arithmetic)
+    const int tl = nkv - 1, rem = len_k - tl * BKV;
+    const int n_full = rem <= 32 ? tl : nkv;
     if (QG == 1 || last_group_valid) {
-        for (int t = 0; t < nkv; ++t)
+        for (int t = 0; t < n_full; ++t)
             attn_tile<DH, QG, ALIBI, DT>(sK0 + t * BKV * K_ROW_BYTES, sV0 + t * BKV * VROW, t * BKV, len_k, r, g, c, slope2,
                                          qf, q_pos, o, m_run, l_acc);
+        if (rem <= 32)
+            attn_tile_short<DH, QG, ALIBI, DT>(rem, sK0 + tl * BKV * K_ROW_BYTES, sV0 + tl * BKV * VROW, tl * BKV, len_k, r, g, c,
+                                               slope2, qf, q_pos, o, m_run, l_acc);
     } else {
         constexpr int Q1 = QG > 1 ? QG - 1 : 1;
         auto& qf1 = reinterpret_cast<const frag_t(&)[Q1][KS]>(qf);
@@ -806,9 +842,12 @@ __global__ __launch_bounds__(256, (QG >= 2 ? 2 : 4)) void attn_short_kernel(Attn
         auto& o1 = reinterpret_cast<f32x4_t(&)[Q1][NDT]>(o);
         auto& m_run1 = reinterpret_cast<float(&)[Q1]>(m_run);
         auto& l_acc1 = reinterpret_cast<f32x4_t(&)[Q1]>(l_acc);
-        for (int t = 0; t < nkv; ++t)
+        for (int t = 0; t < n_full; ++t)
             attn_tile<DH, Q1, ALIBI, DT>(sK0 + t * BKV * K_ROW_BYTES, sV0 + t * BKV * VROW, t * BKV, len_k, r, g, c, slope2,
                                          qf1, q_pos1, o1, m_run1, l_acc1);
+        if (rem <= 32)
+            attn_tile_short<DH, Q1, ALIBI, DT>(rem, sK0 + tl * BKV * K_ROW_BYTES, sV0 + tl * BKV * VROW, tl * BKV, len_k, r, g, c,
+                                               slope2, qf1, q_pos1, o1, m_run1, l_acc1);
     }
 
 #pragma unroll
