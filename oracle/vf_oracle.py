@@ -115,8 +115,9 @@ class Rounding:
     input as its residual (layers.res16_enabled, VF_RES16 != 0).
     `trunk16` (needs res16): a layer's output reaches the NEXT LAYER of its stack rounded to the operand type -- where the
     reference's autocast rounds it too (`x = linear_geglu_2(x)` is a 16-bit tensor there and `x += res_long` adds in
-    place, layers.py:161-165, seq2reg/modules.py:186-190); the last layer of a stack keeps fp32
-    (layers.trunk16_enabled; off unless VF_TRUNK16=1)."""
+    place, layers.py:161-165, seq2reg/modules.py:186-190); the last layer of a stack keeps fp32.  False (default), "s2r"
+    (the 6-layer seq2reg encoders only, whose output is mean-pooled over the window and rounded to 16 bits anyway) or
+    "all" / True (the 25 + 24 modulator layers too); layers.trunk16_enabled, VF_TRUNK16 = 0 | s2r | 1."""
 
     def __init__(self, mode: str | None, fold_ln: bool | None = None, res16: bool | None = None,
                  trunk16: bool | None = None):
@@ -132,17 +133,23 @@ class Rounding:
         self.res16 = bool(res16) and self.fold_ln
         trunk16 = self._trunk16_arg
         if trunk16 is None:
-            trunk16 = os.environ.get("VF_TRUNK16", "0") != "0"
-        self.trunk16 = bool(trunk16) and self.res16
+            trunk16 = os.environ.get("VF_TRUNK16", "0")
+        if isinstance(trunk16, str):
+            trunk16 = {"0": False, "": False, "s2r": "s2r"}.get(trunk16, True)
+        if trunk16 is True or trunk16 == 1:
+            trunk16 = "all"
+        self.trunk16 = trunk16 if (trunk16 and self.res16) else False           # False | "s2r" | "all"
 
     def res(self, x1: torch.Tensor) -> torch.Tensor:
         """x1 as the residual of the cross-attention out-projection (see `res16`)."""
         return self.r(x1) if (self.res16 and x1.shape[-1] % 64 == 0) else x1
 
-    def out(self, x: torch.Tensor, last: bool = False) -> torch.Tensor:
+    def out(self, x: torch.Tensor, last: bool = False, s2r: bool = False) -> torch.Tensor:
         """A layer's output (the trunk) on its way to the next layer of the stack: fp32, or rounded to the operand type
-        (`trunk16`).  The `last` layer of a stack keeps its fp32 result (it is pooled / returned, not fed to a layer)."""
-        return self.r(x) if (self.trunk16 and not last and x.shape[-1] % 64 == 0) else x
+        (`trunk16`: "s2r" = in the seq2reg encoders only, "all" = in the modulator stacks too).  The `last` layer of a stack
+        keeps its fp32 result (it is pooled / returned, not fed to a layer)."""
+        on = self.trunk16 == "all" or (self.trunk16 == "s2r" and s2r)
+        return self.r(x) if (on and not last and x.shape[-1] % 64 == 0) else x
 
     def r(self, x: torch.Tensor) -> torch.Tensor:
         if self.mode is None:
@@ -265,7 +272,7 @@ def seq2reg_layer(x, cu, sd, pfx, hp: Seq2RegHP, slopes, rnd: Rounding, last=Fal
     a = mha_self(h, sd, pfx + "MHA.", hp.num_heads, cu, slopes, rnd)
     x1 = a + rnd.res(x)                                              # :179  x += res_short (16-bit copy: Rounding.res16)
     h = rnd.ln(x1, sd[pfx + "norm2.weight"], sd[pfx + "norm2.bias"])
-    return rnd.out(geglu_ffn(h, sd, pfx, rnd) + x, last)                            # :188  x += res_long (= layer input)
+    return rnd.out(geglu_ffn(h, sd, pfx, rnd) + x, last, s2r=True)                  # :188  x += res_long (= layer input)
 
 
 def seq2reg_context_layer(x, ctx, cu, sd, pfx, hp: Seq2RegHP, slopes, rnd: Rounding, last=False):
@@ -277,7 +284,7 @@ def seq2reg_context_layer(x, ctx, cu, sd, pfx, hp: Seq2RegHP, slopes, rnd: Round
     h = rnd.ln(x1, sd[pfx + "norm2.weight"], sd[pfx + "norm2.bias"])
     x2 = mha_cross(h, ctx, sd, pfx + "crossMHA.MHA.", hp.num_heads, cu, cu, rnd) + rnd.res(x1)
     h = rnd.ln(x2, sd[pfx + "norm3.weight"], sd[pfx + "norm3.bias"])
-    return rnd.out(geglu_ffn(h, sd, pfx, rnd) + x, last)
+    return rnd.out(geglu_ffn(h, sd, pfx, rnd) + x, last, s2r=True)
 
 
 def seq2reg_embed(ids, pad_mask, sd, pfx, hp: Seq2RegHP, rnd: Rounding, context=None):

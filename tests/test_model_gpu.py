@@ -429,9 +429,10 @@ def test_fp16_operand_mode_production_width_vs_oracle():
     check_signal("fp16 operands, production width vs pure fp32", out["pred_gene_exp"], f32["pred_gene_exp"])
 
 
+@pytest.mark.parametrize("scope", ["1", "s2r"])
 @pytest.mark.parametrize("precision", ["bf16-mixed", "16-mixed"])
-def test_trunk16_option_vs_oracle_and_fp32(precision, monkeypatch):
-    """VF_TRUNK16=1 (off by default): layer outputs travel to the next layer as 16-bit copy + row statistics only -- the
+def test_trunk16_option_vs_oracle_and_fp32(precision, scope, monkeypatch):
+    """VF_TRUNK16=1 / s2r (off by default; s2r = in the seq2reg encoders only): layer outputs travel to the next layer as 16-bit copy + row statistics only -- the
     rounding point of the reference's own autocast (`x = linear_geglu_2(x)` is a 16-bit tensor, `x += res_long` adds in
     place: reference layers.py:161-165, seq2reg/modules.py:186-190); the last layer of each stack keeps fp32.  Production
     widths, 3 layers, ragged genes, both operand types: expression within the north-star bar of the oracle with the same
@@ -447,11 +448,12 @@ def test_trunk16_option_vs_oracle_and_fp32(precision, monkeypatch):
     batch = make_batch(31, [7, 40, 1], [3, 9, 2], [[7], TISSUES_54[:5], [62, 10]], 200)
     monkeypatch.setenv("VF_TRUNK16", "0")
     base = model.predict_step(batch, 0)
-    monkeypatch.setenv("VF_TRUNK16", "1")
+    monkeypatch.setenv("VF_TRUNK16", scope)
     out = model.predict_step(batch, 0)
     hp = O.Seq2RegHP.from_hparams(SEQ2REG_512)
     ghp = O.Seq2GeneHP.from_kwargs(kw)
-    orc = O.predict_step(batch, sd, hp, hp, ghp, rounding=O.Rounding(mode, trunk16=True), share_cre_stream=True)
+    orc = O.predict_step(batch, sd, hp, hp, ghp, rounding=O.Rounding(mode, trunk16="all" if scope == "1" else "s2r"),
+                         share_cre_stream=True)
     f32 = O.predict_step(batch, sd, hp, hp, ghp, rounding=None, share_cre_stream=True)
     ulp = 2.0 ** -8 if mode == "bf16" else 2.0 ** -11
     for i in range(3):

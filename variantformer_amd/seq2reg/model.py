@@ -114,12 +114,12 @@ class Seq2RegPredictor(nn.Module):
                 n_layers = len(self.transformer_encoder)
                 for li, layer in enumerate(self.transformer_encoder):
                     x = layer.forward_packed(x, cu, Lmax, context=ctx, cu_ctx=cu, max_ctx=Lmax,
-                                             keep_x=not trunk16_enabled() or li + 1 == n_layers)
+                                             keep_x=not trunk16_enabled("seq2reg") or li + 1 == n_layers)
             else:
                 from ..seq2gene.modules.layers import trunk16_enabled
                 n_layers = len(self.transformer_encoder)
                 for li, layer in enumerate(self.transformer_encoder):
-                    x = layer.forward_packed(x, cu, Lmax, last=li + 1 == n_layers, keep_x=not trunk16_enabled())
+                    x = layer.forward_packed(x, cu, Lmax, last=li + 1 == n_layers, keep_x=not trunk16_enabled("seq2reg"))
             if isinstance(x, ops.LnStream):                           # layers exchange (x, bf16 copy, row statistics)
                 x = x.x
             if self.seq_pool == "mean":                               # :263-267
