@@ -18,6 +18,12 @@
 #include <type_traits>
 #include "vf_common.h"
 
+#ifndef VF_G8_RES_ALL
+#define VF_G8_RES_ALL 0          // gemm8_kernel, 16-bit residual: 1 = request every epilogue pass's residual rows up front.
+                                 // Measured (profiles/r03_i_producer_epilogue_experiments.log): 417 -> 422 ... 435 us on the gene
+                                 // out-projection -- the epilogue is not waiting for its residual; left off.
+#endif
+
 namespace {
 
 // Bank-conflict swizzle of a [rows][BK] bf16 tile read with ds_read_b128 by lane (r = row & 15, g):
@@ -775,8 +781,13 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const unsigned short* __r
     // XCD-aware bijective remap + grouped order (same as gemm_mfma_kernel)
     const int bid = blockIdx.x;
 #ifdef VF_TUNING   // cost-centre probes of the epilogue (VF_G8_DBG bit mask, scripts/gemm_bench.py; results meaningless)
-    const int dbg = GROUP_M >> 8;
+    const int dbg = (GROUP_M >> 8) & 255;
+    // start-up stagger experiment (VF_G8_STAGGER = units of ~4 us): every other CU of an XCD starts its FIRST tile late, so
+    // that the epilogue bursts of the two halves do not coincide (later blocks inherit the phase of the CU they land on)
+    const int stagger = GROUP_M >> 16;
     GROUP_M &= 255;
+    if (stagger && bid < 256 && ((bid >> 3) & 1))
+        for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(127);
 #else
     constexpr int dbg = 0;
 #endif
@@ -997,7 +1008,11 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const unsigned short* __r
     char* out_run = out_p;
     unsigned short* o16_run = o16_p;
     float* part_run = part_p;
-    res_t rbuf[2][RES ? NI : 1];
+    // VF_G8_RES_ALL (experiment, off): 16-bit residual rows of ALL passes requested up front (NPASS * NI items of 2 registers
+    // = 64 of the registers the operand fragments no longer need) instead of one pass ahead.
+    constexpr bool RES_ALL = R16 && RES && (VF_G8_RES_ALL != 0);
+    constexpr int NRB = RES_ALL ? NPASS : 2;
+    res_t rbuf[NRB][RES ? NI : 1];
     auto load_res_pass = [&](int ps, res_t (&dst)[RES ? NI : 1]) {
         if (RES) {
 #pragma unroll
@@ -1015,6 +1030,10 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const unsigned short* __r
         else return v;
     };
     load_res_pass(0, rbuf[0]);
+    if (RES_ALL) {
+#pragma unroll
+        for (int ps = 1; ps < NPASS; ++ps) load_res_pass(ps, rbuf[ps < NRB ? ps : 0]);
+    }
     // bias of the wave's columns, from the side area (requested before the first K-tile)
     f32x4_t bvec[TN];
     if (bias) {
@@ -1052,7 +1071,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const unsigned short* __r
     char* const region = smem + wave * REGION;
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
-        if (ps + 1 < NPASS) load_res_pass(ps + 1, rbuf[(ps + 1) & 1]);
+        if (!RES_ALL && ps + 1 < NPASS) load_res_pass(ps + 1, rbuf[(ps + 1) & 1]);
 #pragma unroll
         for (int iml = 0; iml < IMP; ++iml) {
             const int im = ps * IMP + iml;
@@ -1104,7 +1123,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const unsigned short* __r
                 u32x4_t d = dd[k];
                 if (RES) {
                     f32x4_t f = __builtin_bit_cast(f32x4_t, d);
-                    f += res_value(rbuf[ps & 1][RES ? k0 + k : 0]);
+                    f += res_value(rbuf[RES_ALL ? (ps < NRB ? ps : 0) : (ps & 1)][RES ? k0 + k : 0]);
                     d = __builtin_bit_cast(u32x4_t, f);
                 }
                 const bool ok = j * RI + ep_row < WT_M && j * RI < rows_left && ep_col < n_out_total;
@@ -2217,6 +2236,7 @@ int launch_gemm8(const void* A, int64_t lda, const void* W, const float* bias, c
 #ifdef VF_TUNING
     if (const char* e = getenv("VF_G8_GROUP_M")) group_m = atoi(e);     // tile-walk sweep (scripts/gemm_bench.py)
     if (const char* e = getenv("VF_G8_DBG")) group_m |= atoi(e) << 8;   // epilogue cost-centre probes
+    if (const char* e = getenv("VF_G8_STAGGER")) group_m |= atoi(e) << 16;
 #endif
     hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(512), Cfg8::LDS_BYTES + Cfg8::SIDE_BYTES, st, (const unsigned short*)A, lda,
                        (const unsigned short*)W, bias, res, ldr, out, ldo, M, N, K, tiles_n, n_blocks, group_m, ln);
