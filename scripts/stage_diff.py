@@ -81,7 +81,7 @@ with torch.no_grad():
     x1_o = O.seq2reg_layer(xop, cuo, sd, pfx, hp, slopes, rnd)
     x1_32 = O.seq2reg_layer(xop, cuo, sd, pfx, hp, slopes, O.Rounding(None))
     print(" layer0 out hip-vs-o16", rel(x1_h.cpu(), x1_o), " o16-vs-o32", rel(x1_o, x1_32))
-    pred, emb, gene_out, cre_out = model.forward_prepared(pb, return_cre=True)
+    pred, emb, gene_out, cre_out = model.forward_prepared(pb, return_cre=True)[:4]
 print("first_gene_layer n/a; final gene_out hip-vs-o16", rel(gene_out.cpu(), torch.cat([m.reshape(-1, m.shape[-1]) for m in col["modulator_gene_out"]])),
       " o16-vs-o32", rel(torch.cat([m.reshape(-1, m.shape[-1]) for m in col["modulator_gene_out"]]), torch.cat([m.reshape(-1, m.shape[-1]) for m in col32["modulator_gene_out"]])))
 print("emb  hip-vs-o16", rel(emb.cpu(), emb_o), " o16-vs-o32", rel(emb_o, emb_32))

@@ -38,15 +38,16 @@ def load_fixture(name):
     return meta, arrays, sd, batch
 
 
-def load_vep_model_fixture():
-    """(meta, arrays, state_dict, vep_batch) of tests/golden/vep_model.*: outputs of the reference's own
-    variant_prediction on a seeded ref / het / hom batch."""
+def load_vep_model_fixture(name: str = "vep_model"):
+    """(meta, arrays, state_dict, vep_batch) of tests/golden/<name>.*: outputs of the reference's own
+    variant_prediction on a seeded ref / het / hom batch (vep_model: shipped options; vep_model_opts_a / _b: option sets
+    the shipped configuration leaves off)."""
     from variantformer_amd.utils.synthetic import make_tensor, make_vep_batch
     from oracle.vf_oracle import alibi_slopes
 
-    with open(os.path.join(GOLDEN, "vep_model.json")) as f:
+    with open(os.path.join(GOLDEN, f"{name}.json")) as f:
         meta = json.load(f)
-    arrays = dict(np.load(os.path.join(GOLDEN, "vep_model.npz")))
+    arrays = dict(np.load(os.path.join(GOLDEN, f"{name}.npz")))
     sd = {k: (torch.tensor(alibi_slopes(shape[0]), dtype=torch.float32) if k.endswith(".m")
               else torch.from_numpy(make_tensor(k, shape, meta["seed"]))) for k, shape in meta["state_dict_shapes"].items()}
     chk = float(sum(float(v.double().abs().sum()) for v in sd.values()))

@@ -251,6 +251,14 @@ FIXTURES["small_opts_c"] = dict(_with("small_sin", multi_head=True, use_bigger_h
 FIXTURES["small_opts_d"] = dict(_with("small_alibi", use_context=False, head_type="linear", use_bigger_head=False), seed=707)
 FIXTURES["small_twomod"] = dict(FIXTURES["small_sin"], seed=303, model_class="Seq2GenePredictor",
                                 n_cres=[6, 3], n_chunks=[2, 4], tissues=[[62, 7], [20, 33, 59]])
+# the older class with ITS constructor defaults' gene layers (only_cross_attention=True, reference layers.py:753) and ALiBi on the
+# cross attention (use_res=True fails inside the reference itself there: padded `res` + unpadded stream, layers.py:912);
+# and with context-free CRE layers (use_context=False, layers.py:612-624)
+FIXTURES["small_twomod_b"] = dict(_with("small_alibi", only_cross_attention=True, cross_alibi=True), seed=909,
+                                  model_class="Seq2GenePredictor", n_cres=[4, 9, 2], n_chunks=[3, 1, 2],
+                                  tissues=[[5, 6], [62], [7, 30, 31]])
+FIXTURES["small_twomod_c"] = dict(_with("small_sin", use_context=False), seed=1010, model_class="Seq2GenePredictor",
+                                  n_cres=[7, 2], n_chunks=[2, 3], tissues=[[1, 2, 3], [40]])
 
 
 def run_fixture(name, fx):
@@ -317,14 +325,26 @@ def run_fixture(name, fx):
 
 
 VEP_MODEL = dict(base="small_sin", seed=808, n_cre=7, n_chunks=5, tissues=[7, 20, 62], cre_index=2, gene_index=[1, 1, 3])
+# the same call on option sets the shipped configuration leaves off: (a) cross-attention-only gene layers, gene residual,
+# ALiBi on the cross attention, one shared start token; (b) tissue embedding added to the CRE tokens, max pooling (no token in
+# front of the gene chunks: the +1 of :665-666 does not apply)
+VEP_MODEL_OPTS = {
+    "vep_model_opts_a": dict(base="small_opts_a", seed=818, n_cre=6, n_chunks=4, tissues=[20, 62], cre_index=1, gene_index=[0, 2, 2]),
+    "vep_model_opts_b": dict(base="small_opts_b", seed=828, n_cre=5, n_chunks=3, tissues=[7, 8, 9], cre_index=4, gene_index=[1, 1, 1]),
+}
 
 
-def vep_model_fixture():
+def vep_model_opts_fixture():
+    for name, v in VEP_MODEL_OPTS.items():
+        vep_model_fixture(name, v)
+
+
+def vep_model_fixture(name="vep_model", v=None):
     """The reference's own variant_prediction (seq2gene/model_combined_modulator.py:909-1004) on a ref / het / hom
     batch with token positions: pred_gene_exp, embd and the token-position gathers (:296-326, +1 for the registry
     token :665-666).  Also one run with NaN positions (the reference then returns zero token embeddings, :936-939)."""
     from variantformer_amd.utils.synthetic import make_vep_batch
-    v = VEP_MODEL
+    v = VEP_MODEL if v is None else v
     fx = dict(FIXTURES[v["base"]], seed=v["seed"])
     torch.manual_seed(0)
     model = build_reference_model(fx)
@@ -342,16 +362,16 @@ def vep_model_fixture():
             for i, a in enumerate(o[k]):
                 arrays[f"{tag}.{k}_{i}"] = np.asarray(a, np.float32)
     sd = model.state_dict()
-    meta = dict(VEP_MODEL, seq2reg=fx["seq2reg"], seq2gene=fx["seq2gene"], token_length=fx["token_length"],
+    meta = dict(v, seq2reg=fx["seq2reg"], seq2gene=fx["seq2gene"], token_length=fx["token_length"],
                 cre_len_range=list(fx["cre_len_range"]), state_dict_shapes={k: list(t.shape) for k, t in sd.items()},
                 weight_abs_sum=float(sum(float(t.double().abs().sum()) for t in sd.values() if torch.is_floating_point(t))),
                 variant_type=out["variant_type"],
                 generated_by="tests/golden/make_golden.py: reference Seq2GenePredictorCombinedModulator.variant_prediction "
                              "(fp32, CPU, stubbed flash_attn) on variantformer_amd.utils.synthetic.make_vep_batch")
-    np.savez_compressed(os.path.join(HERE, "vep_model.npz"), **arrays)
-    with open(os.path.join(HERE, "vep_model.json"), "w") as f:
+    np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **arrays)
+    with open(os.path.join(HERE, f"{name}.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)
-    print("[golden] vep_model: gene_tok", arrays["pos.gene_token_embedding_1"][0, :3], "cre_tok", arrays["pos.cre_token_embedding_2"][0, :3],
+    print(f"[golden] {name}: gene_tok", arrays["pos.gene_token_embedding_1"][0, :3], "cre_tok", arrays["pos.cre_token_embedding_2"][0, :3],
           "nan ->", float(np.abs(arrays["nan.gene_token_embedding_0"]).max()))
 
 
@@ -578,6 +598,7 @@ def main():
     for name, fx in FIXTURES.items():
         run_fixture(name, fx)
     vep_model_fixture()
+    vep_model_opts_fixture()
     s2r_opts_fixture()
     bpe_fixture()
     misc_fixture()

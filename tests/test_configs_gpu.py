@@ -406,6 +406,39 @@ def test_variant_prediction_vs_reference_golden():
         np.testing.assert_array_equal(out_nan["pred_gene_exp"][i], out["pred_gene_exp"][i])
 
 
+@pytest.mark.parametrize("name", ["vep_model_opts_a", "vep_model_opts_b"])
+def test_variant_prediction_option_sets_vs_reference_golden(name):
+    """variant_prediction on option sets the shipped configuration leaves off -- (a) one shared start token,
+    cross-attention-only gene layers, gene residual, ALiBi on the cross attention; (b) tissue embedding added to the CRE
+    tokens, max pooling (no token in front of the chunks: the +1 of reference :665-666 does not apply) -- all four outputs
+    against the reference's own variant_prediction (tests/golden/vep_model_opts_*.*) and the same-rounding oracle."""
+    meta, arrays, sd, vb = load_vep_model_fixture(name)
+    model = build_model(meta["seq2reg"], meta["seq2gene"], sd).cuda()
+    model.vep = True
+    hp = O.Seq2RegHP.from_hparams(meta["seq2reg"])
+    ghp = O.Seq2GeneHP.from_kwargs(meta["seq2gene"])
+    out = model.predict_step(vb, 0)
+    orc = O.variant_prediction(vb, sd, hp, hp, ghp, rounding="bf16", share_cre_stream=False)
+    for i in range(3):
+        assert prel(out["pred_gene_exp"][i], arrays[f"pos.pred_gene_exp_{i}"]) < NORTH_STAR_RTOL
+        assert prel(out["pred_gene_exp"][i], orc["pred_gene_exp"][i]) < NORTH_STAR_RTOL
+        for k in ("embd", "gene_token_embedding", "cre_token_embedding"):
+            got = out[k][i]
+            assert got.shape == arrays[f"pos.{k}_{i}"].shape
+            # the bounds of tests/test_model_gpu.py::test_non_shipped_options_vs_reference_golden for these small fixtures
+            # (max norm; max pooling keeps per-column extremes of bf16-noisy rows): bf16 operands vs the fp32 reference
+            # run, then vs the oracle with the same rounding points
+            mx = lambda a, b: float(np.abs(a - b).max() / np.abs(b).max())  # noqa: E731
+            assert mx(got, arrays[f"pos.{k}_{i}"]) < 2e-2, (k, i)
+            assert mx(got, orc[k][i]) < (1e-2 if meta["seq2gene"]["gene_pooling"] == "max" else 5e-3), (k, i)
+    assert np.abs(out["cre_token_embedding"][1] - out["cre_token_embedding"][0]).max() > 1e-3
+    nan_b = dict(vb, cre_token_position=torch.full((3, 1), float("nan")), gene_token_position=torch.full((3, 1), float("nan")))
+    out_nan = model.predict_step(nan_b, 0)
+    for i in range(3):
+        assert float(np.abs(out_nan["gene_token_embedding"][i]).max()) == 0.0
+        assert float(np.abs(out_nan["cre_token_embedding"][i]).max()) == 0.0
+
+
 def test_variant_prediction_production_width_vs_oracle():
     """Same outputs at production widths (D = 1536, H = 32, seq2reg d = 512), 3 modulator layers, 200-token windows."""
     kw = seq2gene_kw(layers=3)

@@ -19,11 +19,13 @@ def test_state_dict_keys_and_shapes_match_reference(golden):
     model.load_state_dict(sd, strict=True)
 
 
-def test_two_module_variant_keys_match_reference():
-    """Seq2GenePredictor (epigenetics_modulator + gene_modulator prefixes, reference seq2gene/model.py:147-168)."""
+@pytest.mark.parametrize("name", ["small_twomod", "small_twomod_b", "small_twomod_c"])
+def test_two_module_variant_keys_match_reference(name):
+    """Seq2GenePredictor (epigenetics_modulator + gene_modulator prefixes, reference seq2gene/model.py:147-168), also with
+    the class's own default gene layers (only_cross_attention=True) + cross_alibi (b) and with context-free CRE layers (c)."""
     from variantformer_amd.seq2gene.model import Seq2GenePredictor
     from variantformer_amd.seq2reg.model import Seq2RegPredictor
-    meta, arrays, sd, batch = load_fixture("small_twomod")
+    meta, arrays, sd, batch = load_fixture(name)
     assert meta["model_class"] == "Seq2GenePredictor"
     m = Seq2GenePredictor(cre_tokenizer=Seq2RegPredictor(**meta["seq2reg"]), gene_tokenizer=Seq2RegPredictor(**meta["seq2reg"]),
                           **meta["seq2gene"])

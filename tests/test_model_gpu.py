@@ -251,12 +251,14 @@ def test_vep_window_dedupe_is_exact():
     assert torch.equal(a[0], d[0]) and torch.equal(a[1], d[1])
 
 
-def test_two_module_variant_vs_reference_golden():
+@pytest.mark.parametrize("name", ["small_twomod", "small_twomod_b", "small_twomod_c"])
+def test_two_module_variant_vs_reference_golden(name):
     """model_class Seq2GenePredictor: same network under the older module layout; outputs vs the reference's own
-    Seq2GenePredictor (fixture small_twomod)."""
+    Seq2GenePredictor -- shipped options (small_twomod), the class's default cross-attention-only gene layers with
+    cross_alibi (small_twomod_b), context-free CRE layers (small_twomod_c)."""
     from variantformer_amd.seq2gene.model import Seq2GenePredictor
     from variantformer_amd.seq2reg.model import Seq2RegPredictor
-    meta, arrays, sd, batch = load_fixture("small_twomod")
+    meta, arrays, sd, batch = load_fixture(name)
     m = Seq2GenePredictor(cre_tokenizer=Seq2RegPredictor(**meta["seq2reg"]), gene_tokenizer=Seq2RegPredictor(**meta["seq2reg"]),
                           **meta["seq2gene"])
     m.load_state_dict(sd, strict=True)
@@ -267,7 +269,7 @@ def test_two_module_variant_vs_reference_golden():
     for i in range(len(meta["n_cres"])):
         assert prel(out["pred_gene_exp"][i], arrays[f"pred_gene_exp_{i}"]) < NORTH_STAR_RTOL
         assert _rel(out["embeddings"][i], arrays[f"embeddings_{i}"]) < 5e-3
-    check_signal("two-module class vs reference fp32", out["pred_gene_exp"],
+    check_signal(f"two-module class ({name}) vs reference fp32", out["pred_gene_exp"],
                  [arrays[f"pred_gene_exp_{i}"] for i in range(len(meta["n_cres"]))])
 
 
@@ -358,10 +360,15 @@ def test_non_shipped_options_vs_reference_golden(name):
                  [arrays[f"pred_gene_exp_{i}"] for i in range(len(meta["n_cres"]))])
     if not general:
         return
-    model.vep = True
-    with pytest.raises(NotImplementedError, match="shipped configuration"):
-        model.forward(batch["cre_sequences"], batch["cre_attention_masks"], batch["tissue_context"], batch["ref_cre_labels"],
-                      batch["strand_val"], batch["gene_embeddings"], batch["gene_attention_masks"], return_embedding=True)
+    # the reference-signature forward with return_embedding (the VEP call) works for these option sets too; its
+    # token-position outputs are pinned by tests/test_configs_gpu.py::test_variant_prediction_option_sets_vs_reference_golden
+    pred, donors, emb, gtok, ctok = model.forward(
+        batch["cre_sequences"], batch["cre_attention_masks"], batch["tissue_context"], batch["ref_cre_labels"],
+        batch["strand_val"], batch["gene_embeddings"], batch["gene_attention_masks"], return_embedding=True)
+    rows = sum(len(t) for t in meta["tissues"])
+    assert pred.shape == (rows, 1) and emb.shape == gtok.shape == ctok.shape == (rows, meta["seq2gene"]["emb_dim"])
+    assert float(gtok.abs().max()) == 0.0 and float(ctok.abs().max()) == 0.0      # no positions given (reference :296-326)
+    np.testing.assert_allclose(emb.cpu().numpy(), np.concatenate(out["embeddings"]), rtol=1e-5, atol=1e-6)
 
 
 def test_run_to_run_determinism_and_sequence_permutation():

@@ -152,12 +152,14 @@ def test_oracle_matches_reference_with_non_shipped_options(name):
         O.predict_step(batch, sd, cre_hp, gene_hp, hp, share_cre_stream=True)
 
 
-@pytest.mark.parametrize("share", [False, True])
-def test_oracle_variant_prediction_matches_reference(share):
+@pytest.mark.parametrize("name,share", [("vep_model", False), ("vep_model", True), ("vep_model_opts_a", False),
+                                        ("vep_model_opts_b", False)])
+def test_oracle_variant_prediction_matches_reference(name, share):
     """VEP token-position outputs: the oracle's variant_prediction against the reference's own
-    variant_prediction run on CPU (tests/golden/vep_model.*), with positions and with NaN positions."""
+    variant_prediction run on CPU (tests/golden/vep_model*.*), with positions and with NaN positions; shipped options and
+    two option sets (start token + cross-attention-only + use_res + cross_alibi; add_context_to_cres + max pooling)."""
     from tests.conftest import load_vep_model_fixture
-    meta, arrays, sd, vb = load_vep_model_fixture()
+    meta, arrays, sd, vb = load_vep_model_fixture(name)
     hp = O.Seq2RegHP.from_hparams(meta["seq2reg"])
     ghp = O.Seq2GeneHP.from_kwargs(meta["seq2gene"])
     for tag, batch in (("pos", vb), ("nan", dict(vb, cre_token_position=torch.full((3, 1), float("nan")),

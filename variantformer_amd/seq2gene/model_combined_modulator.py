@@ -470,9 +470,7 @@ class Seq2GenePredictorCombinedModulator(nn.Module):
         w, b = packed_linear(self.gene_map)
         gene_x = ops.gemm(gene_tok, w, b, ops.EPI_F32)
         if self._general:
-            if return_cre:
-                raise NotImplementedError("token-position outputs (VEP) are implemented for the shipped configuration")
-            return self._forward_general(pb, cre_x, gene_x)
+            return self._forward_general(pb, cre_x, gene_x, return_cre)
         # registry token per (gene, tissue) + that gene's chunk rows (:357-366, layers.py:508-521)
         gene_stream = ops.gather_rows_f32(gene_x, self.start_tkn.registry_tokens.weight, pb.gene_stream_idx)
         uniq = (gene_x, self.start_tkn.registry_tokens.weight, pb.gene_stream_idx)     # what gene_stream's rows are copies of
@@ -489,10 +487,14 @@ class Seq2GenePredictorCombinedModulator(nn.Module):
             gene_out = None
         pred = self.tissue_heads(emb, [t for ts in pb.tissues for t in ts])
         if return_cre:
-            return pred, emb, gene_out, cre_out
+            # row of gene chunk 0 / of CRE 0 of every (gene, tissue) output row inside gene_out / cre_out (the shared CRE
+            # stream holds one copy per gene; +1: the registry token in front of the chunks, reference :665-666)
+            gene_base = pb.registry_rows_host + 1
+            cre_base = np.repeat(np.asarray(pb.cu_cre_host[:-1], dtype=np.int64), [len(t) for t in pb.tissues])
+            return pred, emb, gene_out, cre_out, gene_base, cre_base
         return pred, emb
 
-    def _forward_general(self, pb: PreparedBatch, cre_x: torch.Tensor, gene_x: torch.Tensor):
+    def _forward_general(self, pb: PreparedBatch, cre_x: torch.Tensor, gene_x: torch.Tensor, return_cre: bool = False):
         """Literal evaluation order of the reference for the options the shipped configuration leaves off
         (reference :614-700): every (gene, tissue) pair owns a copy of the gene's CRE stream (plus the tissue embedding
         when add_context_to_cres) and a gene sequence (start / registry token in front, or none for max pooling); cross
@@ -530,13 +532,18 @@ class Seq2GenePredictorCombinedModulator(nn.Module):
             table = None
         gene_stream = ops.gather_rows_f32(gene_x, None if table is None else table.float().contiguous(),
                                           to(np.concatenate(gene_idx)))
-        gene_out, _ = self._modulator_forward_packed(cre_rep, gene_stream, labels_rep, cu_cre, max(cre_lens), cu_gene,
-                                                     max(gene_lens))
+        gene_out, cre_out = self._modulator_forward_packed(cre_rep, gene_stream, labels_rep, cu_cre, max(cre_lens), cu_gene,
+                                                           max(gene_lens))
         if self.gene_pooling == "max":                    # pool_outputs (:380-389)
             emb = ops.segment_max(gene_out, cu_gene)
         else:                                             # start / registry token (:391-392)
             emb = ops.gather_rows_f32(gene_out, None, cu_gene[:-1].long().contiguous())
-        return self.tissue_heads(emb, [t for ts in pb.tissues for t in ts]), emb
+        pred = self.tissue_heads(emb, [t for ts in pb.tissues for t in ts])
+        if return_cre:       # every (gene, tissue) row owns a gene sequence (start token in front iff there is one, :665-666)
+            gene_base = np.concatenate([[0], np.cumsum(gene_lens)])[:-1].astype(np.int64) + prefix
+            cre_base = np.concatenate([[0], np.cumsum(cre_lens)])[:-1].astype(np.int64)
+            return pred, emb, gene_out, cre_out, gene_base, cre_base
+        return pred, emb
 
     def forward(self, inp, attention_mask, tissue_vector, cre_context, strand, gene_embedding, gene_att_mask,
                 return_embedding=False, get_all=False, **kwargs):
@@ -549,19 +556,19 @@ class Seq2GenePredictorCombinedModulator(nn.Module):
         cre_pos, gene_pos = kwargs.get("cre_token_position"), kwargs.get("gene_token_position")
         if kwargs.get("only_embedding", False):
             return {"embedding": self.forward_prepared(pb)[1], "donors": donors}
-        pred, emb, gene_out, cre_out = self.forward_prepared(pb, return_cre=True)
         if not return_embedding:
-            return pred, donors
+            return self.forward_prepared(pb)[0], donors
+        pred, emb, gene_out, cre_out, gene_base, cre_base = self.forward_prepared(pb, return_cre=True)
         gene_tok_emb = torch.zeros(pb.total_tissue_rows, self.emb_dim, device=pred.device)
         cre_tok_emb = torch.zeros(pb.total_tissue_rows, self.emb_dim, device=pred.device)
         if gene_pos is not None or cre_pos is not None:
             g_rows, c_rows, r = [], [], 0
             for i in range(pb.n_genes):
                 for _ in pb.tissues[i]:
-                    if gene_pos is not None:     # +1: registry token (:665-666)
-                        g_rows.append(int(pb.registry_rows_host[r]) + 1 + int(torch.as_tensor(gene_pos[i]).reshape(-1)[0]))
+                    if gene_pos is not None:
+                        g_rows.append(int(gene_base[r]) + int(torch.as_tensor(gene_pos[i]).reshape(-1)[0]))
                     if cre_pos is not None:
-                        c_rows.append(int(pb.cu_cre_host[i]) + int(torch.as_tensor(cre_pos[i]).reshape(-1)[0]))
+                        c_rows.append(int(cre_base[r]) + int(torch.as_tensor(cre_pos[i]).reshape(-1)[0]))
                     r += 1
             if g_rows:
                 gene_tok_emb = ops.gather_rows_f32(gene_out, None, torch.tensor(g_rows, device=pred.device))
