@@ -97,6 +97,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // then c * (x . w'), so the pair it needs is (mean * c, rstd / c).  alert (optional): set to 1 when a row's |mean| exceeds
 // ratio_limit standard deviations, the regime in which the folded form's 16-bit rounding of the UNCENTRED row costs
 // accuracy (tests/test_ops_gpu.py::test_ln_fold_rows_with_large_mean); the model reads the flag back with its outputs.
+// NP > 0: n_parts == NP, every part of the row is loaded ONCE, all loads in flight together (one HBM latency per thread; the
+// round-2 form swept the parts twice, 8 loads at a time: 15 us for 33 MB on the gene stream).  NP = 0: any part count, two
+// sweeps.  Same additions in the same order either way.
+template <int NP>
 __global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restrict__ part, float* __restrict__ row_stats,
                                                          int64_t rows, int n_parts, int D, float eps, float x16_scale,
                                                          float ratio_limit, int* __restrict__ alert) {
@@ -104,16 +108,29 @@ __global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restric
     // are added in index order, so the result does not depend on the GEMM tile configuration that wrote them
     const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (row >= rows) return;
-    float s1 = 0.f;
+    float s1 = 0.f, m2 = 0.f, mean;
+    if constexpr (NP > 0) {
+        f32x2_t v[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) v[p] = *reinterpret_cast<const f32x2_t*>(part + ((int64_t)p * rows + row) * 2);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) s1 += v[p][0];
+        mean = s1 / (float)D;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const float d = v[p][0] * (1.0f / 32.0f) - mean;
+            m2 += v[p][1] + 32.0f * d * d;
+        }
+    } else {
 #pragma unroll 8
-    for (int p = 0; p < n_parts; ++p) s1 += part[((int64_t)p * rows + row) * 2];
-    const float mean = s1 / (float)D;
-    float m2 = 0.f;
+        for (int p = 0; p < n_parts; ++p) s1 += part[((int64_t)p * rows + row) * 2];
+        mean = s1 / (float)D;
 #pragma unroll 8
-    for (int p = 0; p < n_parts; ++p) {                  // second sweep: the same lines, L2-resident
-        const f32x2_t v = *reinterpret_cast<const f32x2_t*>(part + ((int64_t)p * rows + row) * 2);
-        const float d = v[0] * (1.0f / 32.0f) - mean;
-        m2 += v[1] + 32.0f * d * d;
+        for (int p = 0; p < n_parts; ++p) {                  // second sweep: the same lines, L2-resident
+            const f32x2_t v = *reinterpret_cast<const f32x2_t*>(part + ((int64_t)p * rows + row) * 2);
+            const float d = v[0] * (1.0f / 32.0f) - mean;
+            m2 += v[1] + 32.0f * d * d;
+        }
     }
     const float rstd = rsqrtf(m2 / (float)D + eps);
     *reinterpret_cast<f32x2_t*>(row_stats + 2 * row) = (f32x2_t){mean * x16_scale, rstd / x16_scale};
@@ -472,8 +489,14 @@ extern "C" int vf_ln_finalize2(const float* part_stats, int64_t rows, int n_part
                                float ratio_limit, int* alert, float* row_stats, void* stream) {
     VF_REQUIRE(part_stats && row_stats && n_parts > 0 && D > 0 && x16_scale > 0.f, "vf_ln_finalize: bad arguments");
     if (rows <= 0) return VF_OK;
-    hipLaunchKernelGGL(ln_finalize_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, part_stats,
-                       row_stats, rows, n_parts, D, eps, x16_scale, ratio_limit, alert);
+    const dim3 grid((unsigned)((rows + 255) / 256));
+    hipStream_t st = (hipStream_t)stream;
+    if (n_parts == 48)            // D = 1536: the modulator streams
+        hipLaunchKernelGGL(ln_finalize_kernel<48>, grid, dim3(256), 0, st, part_stats, row_stats, rows, n_parts, D, eps, x16_scale, ratio_limit, alert);
+    else if (n_parts == 16)       // D = 512: seq2reg
+        hipLaunchKernelGGL(ln_finalize_kernel<16>, grid, dim3(256), 0, st, part_stats, row_stats, rows, n_parts, D, eps, x16_scale, ratio_limit, alert);
+    else
+        hipLaunchKernelGGL(ln_finalize_kernel<0>, grid, dim3(256), 0, st, part_stats, row_stats, rows, n_parts, D, eps, x16_scale, ratio_limit, alert);
     VF_CHECK_LAUNCH("vf_ln_finalize");
     return VF_OK;
 }
