@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define VF_ABI_VERSION 3
+#define VF_ABI_VERSION 4
 
 enum vf_status {
     VF_OK = 0,
@@ -156,6 +156,24 @@ int vf_attn_varlen_fwd_qstart_f16(const void* q, const void* k, const void* v, v
                                   const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k,
                                   int n_seq, int max_seqlen_q, int max_seqlen_k,
                                   int H, int dh, const float* alibi_slopes, float scale, void* stream);
+
+/* General form (ABI 4): operand_dtype VF_BF16 / VF_F16 and a flag word.
+ *   VF_ATTN_Q_AT_START  the _qstart alignment of the ALiBi query positions;
+ *   VF_ATTN_Q_LOG2      Q was projected with weights (and bias) pre-multiplied by scale * log2(e) -- the caller folds the
+ *                       softmax scale of flash-attn's MHA (softmax_scale = 1 / sqrt(dh), flash_attn.modules.mha [3p], as
+ *                       the reference constructs it, seq2gene/modules/layers.py:344-351) into the Wq rows at weight-load
+ *                       time, so q . k already is the base-2 logit and `scale` is ignored.  The long-stream dh = 48
+ *                       kernel then runs its softmax without a running maximum (p = exp2(q . k), unnormalised sums,
+ *                       one division at the end; softmax is invariant under the offset) and recomputes, inside the same
+ *                       launch, any block whose denominator left the range [2^-100, 2^100] with the running-maximum
+ *                       form: the result never depends on the magnitude of the logits, only the speed of such a block. */
+enum vf_attn_flags { VF_ATTN_Q_AT_START = 1, VF_ATTN_Q_LOG2 = 2 };
+int vf_attn_varlen_fwd_v2(const void* q, const void* k, const void* v, void* out,
+                          int64_t q_stride, int64_t k_stride, int64_t v_stride, int64_t o_stride,
+                          const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k,
+                          int n_seq, int max_seqlen_q, int max_seqlen_k,
+                          int H, int dh, const float* alibi_slopes, float scale,
+                          int operand_dtype, int flags, void* stream);
 
 /* y = LayerNorm(x) * gamma + beta over the last dim (eps inside sqrt, biased variance), optional
  * exact-erf GELU, output fp32, bf16 or fp16 (out_dtype = vf_dtype).  x fp32 [rows, D], D % 4 == 0, D <= 8192.

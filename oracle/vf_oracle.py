@@ -113,6 +113,8 @@ class Rounding:
     `res16`: with the fold on, every attention out-projection takes its residual from a 16-bit stream copy -- x1 = attn(..)
     + r(src), x2 = cross(..) + r(x1) -- and those sums' fp32 rows are never stored; a layer's OUTPUT keeps the fp32 layer
     input as its residual (layers.res16_enabled, VF_RES16 != 0).
+    `q_prescale`: a cross attention's Wq (and bias) carry softmax_scale * log2(e) before they are rounded, q . k is the
+    base-2 logit (layers.q_prescale_enabled, VF_Q_PRESCALE != 0; never without rounding: it is the same function then).
     `trunk16` (needs res16): a layer's output reaches the NEXT LAYER of its stack rounded to the operand type -- where the
     reference's autocast rounds it too (`x = linear_geglu_2(x)` is a 16-bit tensor there and `x += res_long` adds in
     place, layers.py:161-165, seq2reg/modules.py:186-190); the last layer of a stack keeps fp32.  False (default), "s2r"
@@ -120,11 +122,14 @@ class Rounding:
     "all" / True (the 25 + 24 modulator layers too); layers.trunk16_enabled, VF_TRUNK16 = 0 | s2r | 1."""
 
     def __init__(self, mode: str | None, fold_ln: bool | None = None, res16: bool | None = None,
-                 trunk16: bool | None = None):
+                 trunk16: bool | None = None, q_prescale: bool | None = None):
         assert mode in (None, "bf16", "fp16")
         self.mode = mode
         import os
         self._trunk16_arg = trunk16
+        if q_prescale is None:
+            q_prescale = os.environ.get("VF_Q_PRESCALE", "1") != "0"
+        self.q_prescale = bool(q_prescale) and mode is not None
         if fold_ln is None:
             fold_ln = mode is not None and os.environ.get("VF_LN_FOLD", "1") != "0"
         self.fold_ln = bool(fold_ln)
@@ -163,20 +168,27 @@ class Rounding:
         return self.r(layer_norm(x, w, b))
 
 
-def linear(x, w, b, rnd: Rounding):
+def linear(x, w, b, rnd: Rounding, wscale: float = 1.0):
     """nn.Linear under the kernel contract: bf16 operands (x already rounded by its
     producer, w rounded once at load), fp32 accumulate, fp32 bias.
     With a pending LayerNorm:  LN(x) W^T + b = rstd * (x W'^T - mean * rowsum(W')) + (W beta + b),  W' = gamma (.) W,
-    operands x and W' rounded, statistics and the correction in fp32."""
+    operands x and W' rounded, statistics and the correction in fp32.
+    `wscale`: the projection multiplied by a constant that is folded into the weights BEFORE they are rounded (and into the
+    fp32 bias): Rounding.q_prescale."""
     if isinstance(x, LnPending):
         xs = x.x
         mean = xs.mean(dim=-1, keepdim=True)
         rstd = torch.rsqrt(xs.var(dim=-1, unbiased=False, keepdim=True) + 1e-5)
-        wp = rnd.r(w * x.gamma[None, :])
+        wg = w * x.gamma[None, :]
+        wp = rnd.r(wg if wscale == 1.0 else wg * wscale)
         bias = w @ x.beta
         if b is not None:
             bias = bias + b
+        if wscale != 1.0:
+            bias = bias * wscale
         return (F.linear(rnd.r(xs), wp) - mean * wp.sum(dim=1)[None, :]) * rstd + bias
+    if wscale != 1.0:
+        return F.linear(rnd.r(x), rnd.r(w * wscale), None if b is None else b * wscale)
     return F.linear(rnd.r(x), rnd.r(w), b)
 
 
@@ -184,12 +196,26 @@ def layer_norm(x, w, b):
     return F.layer_norm(x, (x.shape[-1],), w, b, 1e-5)
 
 
-def attention(q, k, v, slopes, rnd: Rounding):
+def attention(q, k, v, slopes, rnd: Rounding, q_log2: bool = False):
     """Textbook restatement of flash-attn's varlen forward for ONE sequence [3p].
     q [sq,H,dh], k/v [sk,H,dh] (already rounded to the storage dtype by their producer).
     scores fp32, ALiBi bias -slope*|i + (sk - sq) - j|, softmax fp32; P is rounded to the
-    operand dtype before PV while the normaliser is summed from the unrounded P."""
+    operand dtype before PV while the normaliser is summed from the unrounded P.
+    q_log2: q already carries softmax_scale * log2(e) (Rounding.q_prescale): q . k is the base-2 logit."""
     dh = q.shape[-1]
+    if q_log2:
+        # base-2 logits as the matrix pipe delivers them; the kernels exponentiate them directly (or, for rows outside the
+        # representable range, after an INTEGER offset: a power of two does not move a rounding), round P to the operand
+        # type and divide by the sum of the ROUNDED P (the denominator runs on the matrix pipe next to P . V)
+        s2 = torch.einsum("qhd,khd->hqk", q, k)
+        if slopes is not None:
+            sq, sk = q.shape[0], k.shape[0]
+            i = torch.arange(sq)[:, None] + (sk - sq)
+            j = torch.arange(sk)[None, :]
+            s2 = s2 - (slopes.to(s2.dtype) * math.log2(math.e))[:, None, None] * (i - j).abs().to(s2.dtype)[None]
+        pr = rnd.r(torch.exp2(s2 - torch.ceil(s2.max(dim=-1, keepdim=True).values)))
+        o = torch.einsum("hqk,khd->hqd", pr, v) / pr.sum(dim=-1, keepdim=True)
+        return o.permute(1, 0, 2)
     s = torch.einsum("qhd,khd->hqk", q, k) * (1.0 / math.sqrt(dh))
     if slopes is not None:
         sq, sk = q.shape[0], k.shape[0]
@@ -231,14 +257,16 @@ def mha_cross(xq, xkv, sd, pfx, H, cu_q, cu_k, rnd: Rounding, slopes=None):
     no ALiBi in the shipped configuration (cross_alibi: false, configs/vf_model.yaml:13)."""
     D = xq.shape[-1]
     dh = D // H
-    q = rnd.r(linear(xq, sd[pfx + "Wq.weight"], sd[pfx + "Wq.bias"], rnd)).view(-1, H, dh)
+    pre = rnd.q_prescale                 # the softmax scale, in base 2, folded into Wq before its rounding (layers.q_prescale_enabled)
+    q = rnd.r(linear(xq, sd[pfx + "Wq.weight"], sd[pfx + "Wq.bias"], rnd,
+                     wscale=math.log2(math.e) / math.sqrt(dh) if pre else 1.0)).view(-1, H, dh)
     kv = rnd.r(linear(xkv, sd[pfx + "Wkv.weight"], sd[pfx + "Wkv.bias"], rnd)).view(-1, 2, H, dh)
     out = torch.empty(xq.shape[0], D)
     for b in range(len(cu_q) - 1):
         a, e = int(cu_q[b]), int(cu_q[b + 1])
         ka, ke = int(cu_k[b]), int(cu_k[b + 1])
         if e > a:
-            out[a:e] = attention(q[a:e], kv[ka:ke, 0], kv[ka:ke, 1], slopes, rnd).reshape(e - a, D)
+            out[a:e] = attention(q[a:e], kv[ka:ke, 0], kv[ka:ke, 1], slopes, rnd, q_log2=pre).reshape(e - a, D)
     out = rnd.r(out)
     return linear(out, sd[pfx + "out_proj.weight"], sd[pfx + "out_proj.bias"], rnd)
 

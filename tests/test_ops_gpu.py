@@ -286,6 +286,71 @@ def test_attention_long_stream_32x32_kernel(ops, dtype):
     np.testing.assert_allclose(got.numpy(), rnd.r(ref).numpy(), **tol)
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("big_batch", [True, False])
+def test_attention_prescaled_q_without_running_maximum(ops, dtype, big_batch):
+    """VF_ATTN_Q_LOG2 (q projected with weights pre-multiplied by softmax_scale * log2 e): the long-stream dh = 48 kernel
+    takes p = exp2(q . k) with NO running maximum and recomputes, in the same launch, every block whose denominator left
+    [2^-100, 2^100].  Ordinary sequences (fast path), a sequence whose logits reach +-400 (overflow -> recomputed), one
+    whose logits are all below -300 (every key underflows -> recomputed), a mixed block (one extreme query among ordinary
+    ones), ragged tails, an empty key sequence; 64 queries per wave (>= 2048 blocks) and 32 per wave; both operand types.
+    Every element against the oracle evaluated on the same (pre-scaled, rounded) q."""
+    td = torch.bfloat16 if dtype == "bf16" else torch.float16
+    rnd = O.Rounding(dtype)
+    dh, H = 48, 32
+    D = H * dh
+    c = math.log2(math.e) / math.sqrt(dh)
+    ql = [3000, 33, 2049, 700, 1, 2500, 600, 300, 256] if big_batch else [300, 33, 129, 1]
+    kl = [1024, 70, 63, 64, 200, 65, 0, 31, 1000] if big_batch else [260, 1, 0, 64]
+    if big_batch:
+        assert len(ql) * H * ((max(ql) + 255) // 256) >= 2048
+    else:
+        assert len(ql) * H * ((max(ql) + 255) // 256) < 2048
+    tq, tk = sum(ql), sum(kl)
+    cu_q = torch.tensor([0] + list(np.cumsum(ql)), dtype=torch.int32)
+    cu_k = torch.tensor([0] + list(np.cumsum(kl)), dtype=torch.int32)
+    q = _rand((tq, D), 44, 2.0)
+    kv = rnd.r(_rand((tk, 2 * D), 45, 2.0))
+    k, v = kv[:, :D].clone(), kv[:, D:].clone()
+    s1 = int(cu_q[1])
+    q[s1:s1 + 33] *= 12.0                         # sequence 1: logits up to several hundred in either direction (overflow)
+    if big_batch:
+        # sequence 3: every key is the same direction and every query points the other way -> all logits << -126
+        k3a, k3e = int(cu_k[3]), int(cu_k[4])
+        base = _rand((1, D), 46, 2.0)
+        k[k3a:k3e] = rnd.r(base.repeat(k3e - k3a, 1) * (1.0 + 0.01 * torch.arange(k3e - k3a)[:, None]))
+        q3a, q3e = int(cu_q[3]), int(cu_q[4])
+        q[q3a:q3e] = -6.0 * base
+        q[100] *= 15.0                            # one extreme query inside an ordinary block of sequence 0
+    qs = rnd.r(q * c)                             # what the pre-scaled Wq projection hands over (one rounding)
+    ref = torch.zeros(tq, D)
+    for b in range(len(ql)):
+        a, e, ka, ke = int(cu_q[b]), int(cu_q[b + 1]), int(cu_k[b]), int(cu_k[b + 1])
+        if ke > ka:
+            ref[a:e] = O.attention(qs[a:e].view(-1, H, dh), k[ka:ke].view(-1, H, dh), v[ka:ke].view(-1, H, dh), None,
+                                   rnd, q_log2=True).reshape(e - a, D)
+    dkv = torch.cat([k, v], dim=1).cuda().to(td)
+    out = torch.full((tq, D), float("nan"), device="cuda").to(td)
+    ops.attn_varlen(qs.cuda().to(td), dkv[:, :D], dkv[:, D:], cu_q.cuda(), cu_k.cuda(), max(ql), max(kl), H, dh, out=out,
+                    q_log2=True)
+    torch.cuda.synchronize()
+    got = out.float().cpu()
+    assert torch.isfinite(got).all()
+    tol = dict(rtol=2 ** -7, atol=6e-3) if dtype == "bf16" else dict(rtol=2 ** -9, atol=2e-3)
+    np.testing.assert_allclose(got.numpy(), rnd.r(ref).numpy(), **tol)
+    # the flag on the other kernels (here: dh = 64 cross attention, 16x16x32 tiles) only moves the scale
+    dh2, H2 = 64, 4
+    q2 = _rand((150, H2 * dh2), 47, 2.0)
+    kv2 = rnd.r(_rand((90, 2 * H2 * dh2), 48, 2.0))
+    c2 = math.log2(math.e) / math.sqrt(dh2)
+    cu2q, cu2k = torch.tensor([0, 150], dtype=torch.int32), torch.tensor([0, 90], dtype=torch.int32)
+    d2 = kv2.cuda().to(td)
+    plain = ops.attn_varlen(rnd.r(q2).cuda().to(td), d2[:, :H2 * dh2], d2[:, H2 * dh2:], cu2q.cuda(), cu2k.cuda(), 150, 90, H2, dh2)
+    pre = ops.attn_varlen(rnd.r(q2 * c2).cuda().to(td), d2[:, :H2 * dh2], d2[:, H2 * dh2:], cu2q.cuda(), cu2k.cuda(), 150, 90, H2,
+                          dh2, q_log2=True)
+    np.testing.assert_allclose(pre.float().cpu().numpy(), plain.float().cpu().numpy(), rtol=2 ** -5, atol=2e-2)
+
+
 def test_attention_uniform_values_property(ops):
     """Size-independent property at full size: with V constant along keys the output equals that
     constant row exactly up to bf16 rounding of P (softmax weights sum to one)."""

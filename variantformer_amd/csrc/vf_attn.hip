@@ -88,6 +88,8 @@ struct AttnParams {
     int total;          // n_seq * H * nqb
     int q_at_start;     // ALiBi query positions: 0 = queries are the LAST len_q positions of the key sequence
                         // (flash-attn convention), 1 = query i sits at position i
+    int q_log2;         // 1: Q was projected with weights pre-multiplied by scale * log2(e) (VF_ATTN_Q_LOG2): scores are
+                        // base-2 logits as they leave the matrix pipe, scale_log2 = 1
 };
 
 
@@ -510,7 +512,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P) {
 // LDS: K rows 112 B (96 + 16: the ds_read_b128 lane groups {0-3, 12-15, 20-27} then hit 16 distinct 16-byte slots),
 // V rows 192 B (the 4 rows x 64 B a 32-lane half reads transposed fall on four distinct quarters of the 256-B bank row).
 // ---------------------------------------------------------------------------------------------------------------------
-template <int DT, int QB>
+// FAST (Q pre-scaled, AttnParams::q_log2): the accumulator of K . Q^T already is the base-2 logit, and the softmax runs
+// WITHOUT a running maximum: p = exp2(s), O^T and the denominator (row 48) accumulate unnormalised -- per score one v_exp and
+// half a v_cvt_pk instead of max3 + fma + exp + cvt (the kernel is bound by instruction issue; -14 % time).  Softmax is
+// invariant under the offset, and fp32 / bf16 / fp16-with-offset carry the dynamic range as long as every row's largest
+// logit stays inside (-100, +100 - log2(keys)): trained attention logits live within a few tens.  A block in which some
+// valid row's denominator is not a normal number of moderate size (overflow, or every key underflowed) is detected at the
+// end (one block-wide vote) and recomputed with the running-maximum form -- correctness never depends on the range, only
+// the speed of such a block does.  The recomputation uses INTEGER offsets (ceil of the maximum): powers of two commute with
+// the roundings, so both forms round the same probabilities.
+template <int DT, int QB, bool FAST = false>
 __global__ __launch_bounds__(256) void attn_x32_kernel(AttnParams P) {
     using frag_t = typename Op16<DT>::frag;
     constexpr int DH = 48, KSTEPS = 3, KROW = 112, VROW = 192;
@@ -604,8 +615,9 @@ __global__ __launch_bounds__(256) void attn_x32_kernel(AttnParams P) {
 
     // TAIL: the key tile may reach past len_k (only the last tile of a sequence; a compile-time flag, so that the
     // steady-state loop body carries no masking code at all)
-    auto tile = [&](const char* st, int kb0, auto tail_c) {
+    auto tile = [&](const char* st, int kb0, auto tail_c, auto fast_c) {
         constexpr bool TAIL = decltype(tail_c)::value;
+        constexpr bool NOMAX = decltype(fast_c)::value;
         // ---- S^T = K . Q^T
         frag_t kf[2][KSTEPS];
 #pragma unroll
@@ -649,6 +661,7 @@ __global__ __launch_bounds__(256) void attn_x32_kernel(AttnParams P) {
                     for (int i = 0; i < 16; ++i)
                         s[qb][kb][i] = (32 * kb + (i & 3) + 8 * (i >> 2)) < klim ? s[qb][kb][i] : -INFINITY;
             }
+            if (NOMAX) continue;
             float ma = max3f(s[qb][0][0], s[qb][0][1], s[qb][0][2]);
             float mb = max3f(s[qb][1][0], s[qb][1][1], s[qb][1][2]);
 #pragma unroll
@@ -656,13 +669,14 @@ __global__ __launch_bounds__(256) void attn_x32_kernel(AttnParams P) {
                 ma = max3f(ma, s[qb][0][i], s[qb][0][i + 1]);
                 mb = max3f(mb, s[qb][1][i], s[qb][1][i + 1]);
             }
-            const float mx = max3f(ma, mb, max2f(s[qb][0][15], s[qb][1][15]));
+            float mx = max3f(ma, mb, max2f(s[qb][0][15], s[qb][1][15]));
+            if (FAST) mx = __builtin_ceilf(mx);          // the recomputation pass of the FAST kernel: integer offsets (see above)
             const unsigned u = __float_as_uint(mx);
             auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
             m_new[qb] = max3f(m_run[qb], __uint_as_float(sw[0]), __uint_as_float(sw[1]));   // finite: tile 0 holds a valid key
             moved = moved || (m_new[qb] > m_run[qb]);
         }
-        if (__any(moved)) {                              // wave-uniform; rare after the first tiles of a sequence
+        if (!NOMAX && __any(moved)) {                    // wave-uniform; rare after the first tiles of a sequence
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) {
                 const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new[qb]) * c);
@@ -672,12 +686,19 @@ __global__ __launch_bounds__(256) void attn_x32_kernel(AttnParams P) {
         }
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
-            m_run[qb] = m_new[qb];
-            const float mc = -m_new[qb] * c;
+            if (NOMAX) {
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+                for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) s[qb][kb][i] = __builtin_amdgcn_exp2f(fmaf(s[qb][kb][i], c, mc));
+                    for (int i = 0; i < 16; ++i) s[qb][kb][i] = __builtin_amdgcn_exp2f(s[qb][kb][i]);
+            } else {
+                m_run[qb] = m_new[qb];
+                const float mc = -m_new[qb] * c;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) s[qb][kb][i] = __builtin_amdgcn_exp2f(fmaf(s[qb][kb][i], c, mc));
+            }
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -693,17 +714,44 @@ __global__ __launch_bounds__(256) void attn_x32_kernel(AttnParams P) {
     };
 
     const int nkv = (len_k + BKV - 1) / BKV;
-    load_regs(0);
-    write_lds(0);
-    __syncthreads();
     const bool active = qb0 + wave * QB * 32 < len_q;                 // wave-uniform
-    for (int t = 0; t + 1 < nkv; ++t) {
-        load_regs(t + 1);
-        if (active) tile(smem + (t & 1) * STAGE, t * BKV, std::false_type{});
-        write_lds((t + 1) & 1);
+    auto pass = [&](auto fast_c) {
+        load_regs(0);
+        write_lds(0);
         __syncthreads();
+        for (int t = 0; t + 1 < nkv; ++t) {
+            load_regs(t + 1);
+            if (active) tile(smem + (t & 1) * STAGE, t * BKV, std::false_type{}, fast_c);
+            write_lds((t + 1) & 1);
+            __syncthreads();
+        }
+        if (active) tile(smem + ((nkv - 1) & 1) * STAGE, (nkv - 1) * BKV, std::true_type{}, fast_c);
+    };
+    if (FAST) {
+        pass(std::true_type{});
+        // the denominators (row d = 48: element 8 of the dt = 1 tile in the h = 0 lanes) of the block's valid rows
+        bool bad = false;
+        if (active && h == 0) {
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                const float l = o[qb][1][8];
+                bad = bad || !(l > 7.8886e-31f && l < 1.2676e30f);    // 2^-100 .. 2^100; false for NaN
+            }
+        }
+        if (__syncthreads_or(bad)) {                                  // block-uniform (also orders the LDS stages)
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                m_run[qb] = -INFINITY;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) o[qb][dt][i] = 0.f;
+            }
+            pass(std::false_type{});
+        }
+    } else {
+        pass(std::false_type{});
     }
-    if (active) tile(smem + ((nkv - 1) & 1) * STAGE, (nkv - 1) * BKV, std::true_type{});
 
     // ---- normalise and store: lane (q, h) holds O[q][d = 32 dt + (i & 3) + 8 (i >> 2) + 4 h]; the denominator is row
     // d = 48 = element 8 of the dt = 1 tile in the h = 0 lane
@@ -926,7 +974,9 @@ int launch_short(AttnParams P, int n_seq, int max_k, hipStream_t st) {
 template <int DT, int QB>
 int launch_x32(const AttnParams& P, dim3 grid, hipStream_t st) {
     constexpr int lds = 2 * BKV * (112 + 192);
-    hipLaunchKernelGGL((attn_x32_kernel<DT, QB>), grid, dim3(256), lds, st, P);
+    static const int nomax = getenv("VF_ATTN_NOMAX") ? atoi(getenv("VF_ATTN_NOMAX")) : 1;    // 0: running maximum always (A/B)
+    if (P.q_log2 && nomax) hipLaunchKernelGGL((attn_x32_kernel<DT, QB, true>), grid, dim3(256), lds, st, P);
+    else hipLaunchKernelGGL((attn_x32_kernel<DT, QB, false>), grid, dim3(256), lds, st, P);
     VF_CHECK_LAUNCH("vf_attn_varlen_fwd");
     return VF_OK;
 }
@@ -991,7 +1041,9 @@ template <int DT>
 static int attn_dispatch(const void* q, const void* k, const void* v, void* out, int64_t q_stride,
                          int64_t k_stride, int64_t v_stride, int64_t o_stride, const int32_t* cu_seqlens_q,
                          const int32_t* cu_seqlens_k, int n_seq, int max_seqlen_q, int max_seqlen_k, int H,
-                         int dh, const float* alibi_slopes, float scale, int q_at_start, void* stream) {
+                         int dh, const float* alibi_slopes, float scale, int flags, void* stream) {
+    const int q_at_start = flags & VF_ATTN_Q_AT_START, q_log2 = (flags & VF_ATTN_Q_LOG2) ? 1 : 0;
+    VF_REQUIRE((flags & ~(VF_ATTN_Q_AT_START | VF_ATTN_Q_LOG2)) == 0, "vf_attn_varlen_fwd: unknown flag bits 0x%x", flags);
     VF_REQUIRE(q && k && v && out && cu_seqlens_q, "vf_attn_varlen_fwd: null pointer");
     VF_REQUIRE(dh == 32 || dh == 48 || dh == 64 || dh == 96 || dh == 128,
                "vf_attn_varlen_fwd: head_dim %d not supported (32/48/64/96/128)", dh);
@@ -1011,7 +1063,8 @@ static int attn_dispatch(const void* q, const void* k, const void* v, void* out,
     P.out = (unsigned short*)out;
     P.q_stride = q_stride; P.k_stride = k_stride; P.v_stride = v_stride; P.o_stride = o_stride;
     P.cu_q = cu_seqlens_q; P.cu_k = cu_seqlens_k ? cu_seqlens_k : cu_seqlens_q;
-    P.slopes = alibi_slopes; P.scale_log2 = scale * 1.4426950408889634f; P.H = H; P.q_at_start = q_at_start;
+    P.slopes = alibi_slopes; P.scale_log2 = q_log2 ? 1.0f : scale * 1.4426950408889634f; P.H = H;
+    P.q_at_start = q_at_start ? 1 : 0; P.q_log2 = q_log2;
     hipStream_t st = (hipStream_t)stream;
     const bool alibi = alibi_slopes != nullptr;
     switch (dh) {
@@ -1055,4 +1108,17 @@ extern "C" int vf_attn_varlen_fwd_qstart_f16(const void* q, const void* k, const
                                              float scale, void* stream) {
     return attn_dispatch<VF_F16>(q, k, v, out, q_stride, k_stride, v_stride, o_stride, cu_seqlens_q, cu_seqlens_k, n_seq,
                                  max_seqlen_q, max_seqlen_k, H, dh, alibi_slopes, scale, 1, stream);
+}
+
+extern "C" int vf_attn_varlen_fwd_v2(const void* q, const void* k, const void* v, void* out, int64_t q_stride,
+                                     int64_t k_stride, int64_t v_stride, int64_t o_stride, const int32_t* cu_seqlens_q,
+                                     const int32_t* cu_seqlens_k, int n_seq, int max_seqlen_q, int max_seqlen_k, int H,
+                                     int dh, const float* alibi_slopes, float scale, int operand_dtype, int flags,
+                                     void* stream) {
+    if (operand_dtype == VF_BF16)
+        return attn_dispatch<VF_BF16>(q, k, v, out, q_stride, k_stride, v_stride, o_stride, cu_seqlens_q, cu_seqlens_k, n_seq,
+                                      max_seqlen_q, max_seqlen_k, H, dh, alibi_slopes, scale, flags, stream);
+    VF_REQUIRE(operand_dtype == VF_F16, "vf_attn_varlen_fwd_v2: operand_dtype must be VF_BF16 or VF_F16");
+    return attn_dispatch<VF_F16>(q, k, v, out, q_stride, k_stride, v_stride, o_stride, cu_seqlens_q, cu_seqlens_k, n_seq,
+                                 max_seqlen_q, max_seqlen_k, H, dh, alibi_slopes, scale, flags, stream);
 }

@@ -343,13 +343,17 @@ def pack_geglu_rows(w: torch.Tensor, bias: torch.Tensor | None):
     return wo, bo
 
 
+ATTN_Q_AT_START, ATTN_Q_LOG2 = 1, 2          # enum vf_attn_flags
+
+
 def attn_varlen(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_q: torch.Tensor, cu_k: torch.Tensor | None,
                 max_q: int, max_k: int, n_heads: int, head_dim: int, slopes: torch.Tensor | None = None,
                 scale: float | None = None, out: torch.Tensor | None = None, q_at_start: bool = False,
-                family: str = "") -> torch.Tensor:
+                family: str = "", q_log2: bool = False) -> torch.Tensor:
     """q [tq, >=H*dh] / k, v [tk, >=H*dh] bf16 row-strided views whose first H*dh columns are the heads.
     q_at_start: ALiBi positions of the queries count from the start of the key sequence (default: flash-attn's
-    end alignment)."""
+    end alignment).  q_log2: q was projected with weights pre-multiplied by scale * log2(e) (layers.q_prescale): q . k is the
+    base-2 logit, `scale` is not applied again (VF_ATTN_Q_LOG2)."""
     _dev(q, k, v, cu_q, cu_k, slopes, out)
     for t in (q, k, v):
         assert _is16(t.dtype) and t.dtype == q.dtype and t.dim() == 2 and t.stride(1) == 1
@@ -363,14 +367,11 @@ def attn_varlen(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_q: torch.T
         assert slopes.dtype == torch.float32 and slopes.numel() == n_heads
     def launch():
         lib = _lib.load()
-        if q.dtype == torch.float16:
-            fn = lib.vf_attn_varlen_fwd_qstart_f16 if q_at_start else lib.vf_attn_varlen_fwd_f16
-        else:
-            fn = lib.vf_attn_varlen_fwd_qstart if q_at_start else lib.vf_attn_varlen_fwd
-        check(fn(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), q.stride(0),
-                                             k.stride(0), v.stride(0), out.stride(0), cu_q.data_ptr(), _ptr(cu_k),
-                                             cu_q.numel() - 1, int(max_q), int(max_k), n_heads, head_dim, _ptr(slopes),
-                                             float(scale), _stream()), "vf_attn_varlen_fwd")
+        flags = (ATTN_Q_AT_START if q_at_start else 0) | (ATTN_Q_LOG2 if q_log2 else 0)
+        check(lib.vf_attn_varlen_fwd_v2(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), q.stride(0), k.stride(0),
+                                        v.stride(0), out.stride(0), cu_q.data_ptr(), _ptr(cu_k), cu_q.numel() - 1, int(max_q),
+                                        int(max_k), n_heads, head_dim, _ptr(slopes), float(scale), _dt(q.dtype), flags,
+                                        _stream()), "vf_attn_varlen_fwd")
     if TIMER is not None:
         def flops():       # 4 * sum_seq(len_q * len_k) * H * dh (QK^T and PV), evaluated after the timed replay
             lq = (cu_q[1:] - cu_q[:-1]).double()

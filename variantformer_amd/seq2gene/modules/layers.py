@@ -37,14 +37,15 @@ def get_alibi_slopes(n: int) -> torch.Tensor:
 # ---------------------------------------------------------------------------------------------
 # weight packing (fp32 master parameters -> bf16 kernel operands), cached per parameter version
 # ---------------------------------------------------------------------------------------------
-def packed_linear(lin: nn.Linear, geglu: bool = False, wscale: float = 1.0):
+def packed_linear(lin: nn.Linear, geglu: bool = False, wscale: float = 1.0, bscale: float = 1.0):
     """(16-bit weight [N,K] in the current compute dtype, fp32 bias [N]) for vf_gemm_*; `geglu` applies the GEGLU row
     interleave.  Rebuilt whenever the parameter is modified in place (load_state_dict), moved, or the compute dtype
     changes (one cached copy per module: a model runs in one precision at a time).  `wscale` (a power of two): the
     16-bit weights are 16bit(W * wscale) -- the operand of a GEMM whose OTHER operand is a stream copy stored scaled by
-    1 / wscale (ops.LnStream.scale, fp16 mode); the product is then the unscaled one, exactly."""
+    1 / wscale (ops.LnStream.scale, fp16 mode); the product is then the unscaled one, exactly.  `bscale` multiplies the
+    bias (q_prescale passes wscale = bscale = softmax scale * log2 e: the whole projection is scaled)."""
     w = lin.weight
-    key = (w.data_ptr(), w._version, str(w.device), geglu, ops.cdt(), float(wscale),
+    key = (w.data_ptr(), w._version, str(w.device), geglu, ops.cdt(), float(wscale), float(bscale),
            None if lin.bias is None else (lin.bias.data_ptr(), lin.bias._version))
     cache = getattr(lin, "_vf_packed", None)
     if cache is not None and cache[0] == key:
@@ -52,7 +53,7 @@ def packed_linear(lin: nn.Linear, geglu: bool = False, wscale: float = 1.0):
     with torch.no_grad():
         wf = w.detach().float()
         wb = ops.cast16((wf if wscale == 1.0 else wf * float(wscale)).contiguous())
-        b = None if lin.bias is None else lin.bias.detach().float().contiguous()
+        b = None if lin.bias is None else (lin.bias.detach().float() * float(bscale)).contiguous()
         if geglu:
             wb, b = ops.pack_geglu_rows(wb, b)
     lin._vf_packed = (key, wb, b)
@@ -60,26 +61,31 @@ def packed_linear(lin: nn.Linear, geglu: bool = False, wscale: float = 1.0):
     return wb, b
 
 
-def packed_linear_ln(lin: nn.Linear, norm: nn.LayerNorm, geglu: bool = False):
+def packed_linear_ln(lin: nn.Linear, norm: nn.LayerNorm, geglu: bool = False, wscale: float = 1.0):
     """Operands of a GEMM that consumes LayerNorm(x) without a normalised copy of x (ops.gemm_ln_consumer):
          w'     = bf16(gamma (.) W)        [N, K]   (gamma scales the K columns)
          bias'  = W . beta + b             [N] fp32 (from the fp32 master weights)
          colsum = sum_k float(w'[n, k])    [N] fp32
        so that LN(x) W^T + b = rstd * (x w'^T - mean * colsum) + bias'.  `geglu` applies the GEGLU row interleave to all
-       three.  One-time weight preparation (cached per parameter versions), torch elementwise / reduce ops on the fp32
-       masters; nothing of this runs per batch."""
+       three.  `wscale`: the whole projection multiplied by a constant (q_prescale: the softmax scale of a cross
+       attention folded into its Wq): w' = 16bit(wscale * gamma (.) W), bias' = wscale * (W . beta + b).  One-time weight
+       preparation (cached per parameter versions), torch elementwise / reduce ops on the fp32 masters; nothing of this
+       runs per batch."""
     w, g, be = lin.weight, norm.weight, norm.bias
     key = (w.data_ptr(), w._version, g.data_ptr(), g._version, be.data_ptr(), be._version, str(w.device), geglu, ops.cdt(),
-           None if lin.bias is None else (lin.bias.data_ptr(), lin.bias._version))
+           float(wscale), None if lin.bias is None else (lin.bias.data_ptr(), lin.bias._version))
     cache = getattr(lin, "_vf_packed_ln", None)
     if cache is not None and cache[0] == key:
         return cache[1], cache[2], cache[3]
     with torch.no_grad():
         wf = w.detach().float()
-        wb = ops.cast16((wf * g.detach().float()[None, :]).contiguous())            # current operand type (bf16 / fp16)
+        wg = wf * g.detach().float()[None, :]
+        wb = ops.cast16((wg if wscale == 1.0 else wg * float(wscale)).contiguous())  # current operand type (bf16 / fp16)
         b = wf @ be.detach().float()
         if lin.bias is not None:
             b = b + lin.bias.detach().float()
+        if wscale != 1.0:
+            b = b * float(wscale)
         b = b.contiguous()
         if geglu:
             wb, b = ops.pack_geglu_rows(wb, b)
@@ -130,6 +136,17 @@ def trunk16_enabled(stack: str = "modulator") -> bool:
     mode = os.environ.get("VF_TRUNK16", "0")
     on = mode not in ("0", "") and (stack == "seq2reg" or mode != "s2r")
     return on and res16_enabled()
+
+
+def q_prescale_enabled() -> bool:
+    """Cross attentions (a Wq of their own): the softmax scale and the change to base 2, 1 / sqrt(dh) * log2(e), are folded
+    into the Wq rows (and bias) when the 16-bit weights are packed, so that q . k leaves the matrix pipe as the base-2
+    logit (ops.attn_varlen(q_log2=True), VF_ATTN_Q_LOG2): one rounding of the scaled weights instead of one of the
+    unscaled ones -- the same size of error, different rounding points; oracle.Rounding(q_prescale=...) restates them.
+    What it buys: the long-stream attention kernel drops the running maximum and the multiply-add in front of every
+    exponential (gene -> CRE cross attention -14 %).  VF_Q_PRESCALE=0 keeps the unscaled projection."""
+    import os
+    return os.environ.get("VF_Q_PRESCALE", "1") != "0"
 
 
 def _ffn_residual(s):
@@ -184,6 +201,7 @@ class MHA(nn.Module):
         assert embed_dim % num_heads == 0
         self.embed_dim, self.num_heads, self.cross_attn = embed_dim, num_heads, cross_attn
         self.head_dim = embed_dim // num_heads
+        self.q_log2_scale = math.log2(math.e) / math.sqrt(self.head_dim)     # softmax scale (1 / sqrt(dh)) in base 2
         self.use_alibi = use_alibi
         if cross_attn:
             self.Wq = nn.Linear(embed_dim, embed_dim)
@@ -218,10 +236,12 @@ class MHA(nn.Module):
         """bf16 attention output [tokens_q, D] (before out_proj)."""
         D = self.embed_dim
         if self.cross_attn:
-            w, b = packed_linear(self.Wq)
+            pre = q_prescale_enabled()
+            c = self.q_log2_scale if pre else 1.0
+            w, b = packed_linear(self.Wq, wscale=c, bscale=c)
             q = ops.gemm(x_bf16, w, b, ops.EPI_BF16)
             return ops.attn_varlen(q, kv_bf16[:, :D], kv_bf16[:, D:], cu_q, cu_k, max_q, max_k, self.num_heads,
-                                   self.head_dim, self.alibi_slopes, family=self.family)
+                                   self.head_dim, self.alibi_slopes, family=self.family, q_log2=pre)
         w, b = packed_linear(self.Wqkv)
         qkv = ops.gemm(x_bf16, w, b, ops.EPI_BF16)
         return ops.attn_varlen(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], cu_q, None, max_q, max_q,
@@ -231,10 +251,11 @@ class MHA(nn.Module):
         """attend(LayerNorm(s.x)) with the LayerNorm folded into the Wqkv / Wq projection."""
         D = self.embed_dim
         if self.cross_attn:
-            w, b, c = packed_linear_ln(self.Wq, norm)
+            pre = q_prescale_enabled()
+            w, b, c = packed_linear_ln(self.Wq, norm, wscale=self.q_log2_scale if pre else 1.0)
             q = ops.gemm_ln_consumer(s, w, b, c, ops.EPI_BF16)
             return ops.attn_varlen(q, kv_bf16[:, :D], kv_bf16[:, D:], cu_q, cu_k, max_q, max_k, self.num_heads,
-                                   self.head_dim, self.alibi_slopes, family=self.family)
+                                   self.head_dim, self.alibi_slopes, family=self.family, q_log2=pre)
         w, b, c = packed_linear_ln(self.Wqkv, norm)
         qkv = ops.gemm_ln_consumer(s, w, b, c, ops.EPI_BF16)
         return self.attend_qkv(qkv, cu_q, max_q)
