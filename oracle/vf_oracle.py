@@ -173,22 +173,27 @@ def linear(x, w, b, rnd: Rounding, wscale: float = 1.0):
     producer, w rounded once at load), fp32 accumulate, fp32 bias.
     With a pending LayerNorm:  LN(x) W^T + b = rstd * (x W'^T - mean * rowsum(W')) + (W beta + b),  W' = gamma (.) W,
     operands x and W' rounded, statistics and the correction in fp32.
-    `wscale`: the projection multiplied by a constant that is folded into the weights BEFORE they are rounded (and into the
-    fp32 bias): Rounding.q_prescale."""
+    `wscale`: the projection multiplied by a constant (a float, or one factor per output row [N, 1]) that is folded into
+    the weights BEFORE they are rounded (and into the fp32 bias): Rounding.q_prescale."""
+    scaled = None
+    if torch.is_tensor(wscale):
+        scaled = wscale.to(torch.float32).reshape(-1, 1)
+    elif wscale != 1.0:
+        scaled = torch.full((w.shape[0], 1), float(wscale))
     if isinstance(x, LnPending):
         xs = x.x
         mean = xs.mean(dim=-1, keepdim=True)
         rstd = torch.rsqrt(xs.var(dim=-1, unbiased=False, keepdim=True) + 1e-5)
         wg = w * x.gamma[None, :]
-        wp = rnd.r(wg if wscale == 1.0 else wg * wscale)
+        wp = rnd.r(wg if scaled is None else wg * scaled)
         bias = w @ x.beta
         if b is not None:
             bias = bias + b
-        if wscale != 1.0:
-            bias = bias * wscale
+        if scaled is not None:
+            bias = bias * scaled[:, 0]
         return (F.linear(rnd.r(xs), wp) - mean * wp.sum(dim=1)[None, :]) * rstd + bias
-    if wscale != 1.0:
-        return F.linear(rnd.r(x), rnd.r(w * wscale), None if b is None else b * wscale)
+    if scaled is not None:
+        return F.linear(rnd.r(x), rnd.r(w * scaled), None if b is None else b * scaled[:, 0])
     return F.linear(rnd.r(x), rnd.r(w), b)
 
 
@@ -242,12 +247,17 @@ def mha_self(x, sd, pfx, H, cu, slopes, rnd: Rounding):
     """flash_attn MHA self path [3p] on a packed stream x [tokens, D] with cu_seqlens."""
     D = x.shape[-1]
     dh = D // H
-    qkv = rnd.r(linear(x, sd[pfx + "Wqkv.weight"], sd[pfx + "Wqkv.bias"], rnd)).view(-1, 3, H, dh)
+    pre = rnd.q_prescale                 # the Q rows of Wqkv carry the base-2 softmax scale before their rounding
+    ws = 1.0
+    if pre:
+        ws = torch.ones(3 * D, 1)
+        ws[:D] = math.log2(math.e) / math.sqrt(dh)
+    qkv = rnd.r(linear(x, sd[pfx + "Wqkv.weight"], sd[pfx + "Wqkv.bias"], rnd, wscale=ws)).view(-1, 3, H, dh)
     out = torch.empty(x.shape[0], D)
     for b in range(len(cu) - 1):
         a, e = int(cu[b]), int(cu[b + 1])
         if e > a:
-            out[a:e] = attention(qkv[a:e, 0], qkv[a:e, 1], qkv[a:e, 2], slopes, rnd).reshape(e - a, D)
+            out[a:e] = attention(qkv[a:e, 0], qkv[a:e, 1], qkv[a:e, 2], slopes, rnd, q_log2=pre).reshape(e - a, D)
     out = rnd.r(out)
     return linear(out, sd[pfx + "out_proj.weight"], sd[pfx + "out_proj.bias"], rnd)
 

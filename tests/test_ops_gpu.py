@@ -230,6 +230,81 @@ def test_attention_short_kernel_ragged_batch(ops, dtype, alibi, cross):
         np.testing.assert_allclose(got[a:e].numpy(), rd(ref.reshape(e - a, D)).numpy(), rtol=2 ** -7, atol=6e-3)
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("alibi", [True, False])
+def test_attention_short_kernel_prescaled_q(ops, dtype, alibi):
+    """VF_ATTN_Q_LOG2 on the one-block-per-(sequence, head) kernel (the gene stream's self attention): q carries the base-2
+    softmax scale, the running maximum is rounded up to an integer (attn_tile mode 2).  Ragged batch (1 ... 256 tokens,
+    every tail-tile size) in which one sequence has logits of several hundred, one has a single extreme query among
+    ordinary ones, and one has every logit below -300; every element of those and of a sample of ordinary sequences
+    against the oracle evaluated on the same pre-scaled, rounded q."""
+    dh, H = 48, 8
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float16
+    rnd = O.Rounding(dtype)
+    rd = rnd.r
+    c = math.log2(math.e) / math.sqrt(dh)
+    rng = np.random.default_rng(6)
+    ql = [256, 201, 129, 1, 16, 17, 64, 65, 200, 193, 255, 80] + list(rng.integers(1, 257, 20))
+    D = H * dh
+    tq = sum(ql)
+    cu = torch.tensor([0] + list(np.cumsum(ql)), dtype=torch.int32)
+    x = _rand((tq, 3 * D), 51, 2.0)
+    q, k, v = x[:, :D].clone(), rd(x[:, D:2 * D]), rd(x[:, 2 * D:])
+    a1, e1 = int(cu[1]), int(cu[2])
+    q[a1:e1] *= 14.0                                   # sequence 1: logits of several hundred, both signs
+    q[int(cu[8]) + 77] *= 16.0                         # sequence 8: one extreme query
+    a2, e2 = int(cu[2]), int(cu[3])
+    base = _rand((1, D), 52, 2.0)
+    k[a2:e2] = rd(base.repeat(e2 - a2, 1) * (1.0 + 0.01 * torch.arange(e2 - a2)[:, None]))
+    q[a2:e2] = -7.0 * base                             # sequence 2: every logit << -126
+    qs = rd(q * c)
+    slopes = torch.tensor(O.alibi_slopes(H), dtype=torch.float32) if alibi else None
+    dev = torch.cat([qs, k, v], dim=1).cuda().to(tdt)
+    out = ops.attn_varlen(dev[:, :D], dev[:, D:2 * D], dev[:, 2 * D:], cu.cuda(), None, max(ql), max(ql), H, dh,
+                          slopes.cuda() if alibi else None, q_log2=True)
+    again = ops.attn_varlen(dev[:, :D], dev[:, D:2 * D], dev[:, 2 * D:], cu.cuda(), None, max(ql), max(ql), H, dh,
+                            slopes.cuda() if alibi else None, q_log2=True)
+    torch.cuda.synchronize()
+    assert torch.equal(out.view(torch.int16), again.view(torch.int16))
+    got = out.float().cpu()
+    assert torch.isfinite(got).all()
+    tol = dict(rtol=2 ** -7, atol=6e-3) if dtype == "bf16" else dict(rtol=2 ** -9, atol=2e-3)
+    for b in list(range(12)) + [15, 25]:
+        a, e = int(cu[b]), int(cu[b + 1])
+        ref = O.attention(qs[a:e].view(-1, H, dh), k[a:e].view(-1, H, dh), v[a:e].view(-1, H, dh), slopes, rnd, q_log2=True)
+        np.testing.assert_allclose(got[a:e].numpy(), rd(ref.reshape(e - a, D)).numpy(), **tol)
+
+
+@pytest.mark.parametrize("alibi", [True, False])
+def test_attention_prescaled_q_is_kernel_independent(ops, alibi):
+    """A query's result must not depend on which kernel its batch geometry selects (a gene must not change with the genes
+    it is batched with): with VF_ATTN_Q_LOG2 the one-block-per-sequence kernel and the tiled kernels run the same
+    arithmetic per query (attn_tile mode 2: one fused multiply-add for the ALiBi bias, integer running maxima), so they
+    produce the same bits.  Two sequences alone (short kernel) and next to a 300-token one (tiled kernel, 2 query groups
+    per wave); one sequence alone (tiled kernel, 64-query blocks) and next to a 201-token one (short kernel)."""
+    dh, H = 48, 8
+    D = H * dh
+    c = math.log2(math.e) / math.sqrt(dh)
+    slopes = torch.tensor(O.alibi_slopes(H), dtype=torch.float32).cuda() if alibi else None
+    ql = [201, 150, 300]
+    x = _bf(_rand((sum(ql), 3 * D), 61, 2.0))
+    x[:, :D] = _bf(x[:, :D] * c)
+    dev = x.cuda().bfloat16()
+
+    def run(lens):
+        n = sum(lens)
+        cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32).cuda()
+        return ops.attn_varlen(dev[:n, :D], dev[:n, D:2 * D], dev[:n, 2 * D:], cu, None, max(lens), max(lens), H, dh, slopes,
+                               q_log2=True)
+    short = run(ql[:2])                                   # max_q = 201: attn_short_kernel, no maximum
+    tiled = run(ql)                                       # max_q = 300: attn_fwd_kernel
+    torch.cuda.synchronize()
+    assert torch.equal(short.view(torch.int16), tiled[:351].view(torch.int16))
+    small = run([100])                                    # max_q = 100: attn_fwd_kernel, one query group per wave
+    alone = run([100, 201])[:100]
+    assert torch.equal(small.view(torch.int16), alone.view(torch.int16))
+
+
 def test_attention_online_softmax_rescale_branch(ops):
     """Force the running max to jump at a late key tile (guide rule 26): one key far larger than the rest."""
     dh, H, n = 64, 1, 200

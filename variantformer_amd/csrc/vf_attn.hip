@@ -134,7 +134,13 @@ __device__ __forceinline__ s16x4_t lds_tr_read(const char* p) {
 // <= 32 / <= 16 keys runs the 2 / 1 sub-tile form: no K fragments, QK^T MFMAs, bias, maximum, exponentials for the rest, and
 // for NKT <= 2 no second 32-key PV block either.  Bit-identical to the full tile (whose masked keys contribute p = 0 exactly,
 // and x + 0 = x in the accumulators); a 201-key sequence (3 tiles + 9 keys) saves 3/16 of its arithmetic.
-template <int DH, int QG, bool ALIBI, int DT, int DBGT = 0, int NKT = 4>
+// SM (softmax mode): 0 = online softmax with a running maximum, scale applied here; 1 and 2: q carries the base-2 softmax
+// scale (AttnParams::q_log2) -- 1 = NO maximum: p = exp2(s [+ bias]), unnormalised sums; the caller checks the denominators
+// and recomputes with mode 2 when one left the safe range (see attn_x32_kernel); 2 = running maximum rounded up to an
+// INTEGER: a power-of-two offset does not move the rounding of p, so modes 1 and 2 produce the same bits -- which is what
+// lets the kernels a query may be served by differ in mode (a gene's result must not depend on the batch geometry that picks
+// the kernel: the tiled kernels run mode 2, the one-block-per-sequence kernel mode 1).
+template <int DH, int QG, bool ALIBI, int DT, int DBGT = 0, int NKT = 4, int SM = 0>
 __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, int kb0, int len_k, int r, int g, float c,
                                           float slope2, const typename Op16<DT>::frag (&qf)[QG][KLayout<DH>::KS], const float (&q_pos)[QG],
                                           f32x4_t (&o)[QG][DH / 16], float (&m_run)[QG], f32x4_t (&l_acc)[QG]) {
@@ -239,11 +245,21 @@ __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, int kb
     for (int qg = 0; qg < QG; ++qg) {
         if (ALIBI) {
             const float dq = q_pos[qg] - k_pos0;
+            // q carries the scale (modes 1, 2, imax): bias and logit meet in ONE fused multiply-add, the same expression in
+            // every kernel; otherwise scale and bias are applied together (wave-uniform choice)
+            if (SM != 0) {
 #pragma unroll
-            for (int kt = 0; kt < NKT; ++kt)
+                for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    s[qg][kt][e] = fmaf(s[qg][kt][e], c, -slope2 * fabsf(dq - (float)(16 * kt + e)));
+                    for (int e = 0; e < 4; ++e)
+                        s[qg][kt][e] = fmaf(-slope2, fabsf(dq - (float)(16 * kt + e)), s[qg][kt][e]);
+            } else {
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        s[qg][kt][e] = fmaf(s[qg][kt][e], c, -slope2 * fabsf(dq - (float)(16 * kt + e)));
+            }
         }
         if (tail && !HwMask<DH>::value) {
 #pragma unroll
@@ -253,6 +269,7 @@ __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, int kb
         }
         // 16 scores -> 1 maximum in 8 v_max3_f32 + 1 v_max_f32 (two chains of max(max(a, b), c) for instruction-level
         // parallelism; a pairwise tree compiled to 24 v_max / v_max3 per query group: the loop is VALU-issue bound)
+        if (SM == 1) continue;
         float mxa = max3f(s[qg][0][0], s[qg][0][1], s[qg][0][2]), mxb;
         if (NKT == 4) {
             mxb = max3f(s[qg][2][0], s[qg][2][1], s[qg][2][2]);
@@ -267,11 +284,12 @@ __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, int kb
         } else {
             mxb = s[qg][0][3];
         }
-        const float mx = max_over_g(max2f(mxa, mxb));
+        float mx = max_over_g(max2f(mxa, mxb));
+        if (SM == 2) mx = __builtin_ceilf(mx);
         m_new[qg] = max2f(m_run[qg], mx);           // finite: tile 0 always holds a valid key
         moved = moved || (m_new[qg] > m_run[qg]);
     }
-    if (__any(moved)) {                              // wave-uniform; rare after the first tiles of a sequence
+    if (SM != 1 && __any(moved)) {                   // wave-uniform; rare after the first tiles of a sequence
 #pragma unroll
         for (int qg = 0; qg < QG; ++qg) {
             const float alpha = __builtin_amdgcn_exp2f(ALIBI ? (m_run[qg] - m_new[qg]) : (m_run[qg] - m_new[qg]) * c);
@@ -283,14 +301,21 @@ __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, int kb
     if (NKT > 2) read_v(1, vf1);
 #pragma unroll
     for (int qg = 0; qg < QG; ++qg) {
-        m_run[qg] = m_new[qg];
-        // p = exp2(c*s - c*m) (no ALiBi: scale folded into one FMA) or exp2(s - m) (ALiBi: already scaled)
-        const float mc = ALIBI ? -m_new[qg] : -m_new[qg] * c;
-        const float cc = ALIBI ? 1.0f : c;
+        if (SM == 1) {
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
+            for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) s[qg][kt][e] = __builtin_amdgcn_exp2f(fmaf(s[qg][kt][e], cc, mc));
+                for (int e = 0; e < 4; ++e) s[qg][kt][e] = __builtin_amdgcn_exp2f(s[qg][kt][e]);
+        } else {
+            m_run[qg] = m_new[qg];
+            // p = exp2(c*s - c*m) (no ALiBi: scale folded into one FMA) or exp2(s - m) (ALiBi: already scaled)
+            const float mc = ALIBI ? -m_new[qg] : -m_new[qg] * c;
+            const float cc = ALIBI ? 1.0f : c;
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s[qg][kt][e] = __builtin_amdgcn_exp2f(fmaf(s[qg][kt][e], cc, mc));
+        }
         pack_p(qg);
         if (VF_ATTN_PV_INTERLEAVE && qg > 0) pv(qg - 1);
     }
@@ -304,17 +329,19 @@ __device__ __forceinline__ void attn_tile(const char* sK, const char* sV, int kb
 
 // The last key tile of a sequence in its short form: `rem` = keys it holds, <= 32 (the caller's tile loop stops one tile
 // early for such a remainder; a longer one is an ordinary full tile of that loop -- no second copy of the full tile body).
-template <int DH, int QG, bool ALIBI, int DT>
+template <int DH, int QG, bool ALIBI, int DT, int SM = 0>
 __device__ __forceinline__ void attn_tile_short(int rem, const char* sK, const char* sV, int kb0, int len_k, int r, int g, float c,
                                                 float slope2, const typename Op16<DT>::frag (&qf)[QG][KLayout<DH>::KS],
                                                 const float (&q_pos)[QG], f32x4_t (&o)[QG][DH / 16], float (&m_run)[QG],
                                                 f32x4_t (&l_acc)[QG]) {
-    if (rem <= 16) attn_tile<DH, QG, ALIBI, DT, 0, 1>(sK, sV, kb0, len_k, r, g, c, slope2, qf, q_pos, o, m_run, l_acc);
-    else attn_tile<DH, QG, ALIBI, DT, 0, 2>(sK, sV, kb0, len_k, r, g, c, slope2, qf, q_pos, o, m_run, l_acc);
+    if (rem <= 16) attn_tile<DH, QG, ALIBI, DT, 0, 1, SM>(sK, sV, kb0, len_k, r, g, c, slope2, qf, q_pos, o, m_run, l_acc);
+    else attn_tile<DH, QG, ALIBI, DT, 0, 2, SM>(sK, sV, kb0, len_k, r, g, c, slope2, qf, q_pos, o, m_run, l_acc);
 }
 
-template <int DH, int QG, bool ALIBI, int DT = VF_BF16, int DBG = 0>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P) {
+// (2 query groups with ALiBi sit at the 170-register edge of three waves per SIMD -- the CRE stream's self attention; the
+// integer-maximum form compiles to 172 without the bound)
+template <int DH, int QG, bool ALIBI, int DT = VF_BF16, int DBG = 0, bool QL = false>
+__global__ __launch_bounds__(256, (QL && QG == 2 && ALIBI && DH <= 48 ? 3 : 1)) void attn_fwd_kernel(AttnParams P) {
     using frag_t = typename Op16<DT>::frag;
     constexpr int CPR = DH / 8;                       // 16-byte chunks per K/V row
     constexpr int NCHUNK = BKV * CPR;                 // chunks per tile
@@ -457,7 +484,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P) {
         if (DBG < 3) load_regs(t + 1);
         const char* sK = smem + (t & 1) * STAGE;
         if (active)
-            attn_tile<DH, QG, ALIBI, DT, (DBG > 2 ? 0 : DBG)>(sK, sK + K_TILE_BYTES, t * BKV, len_k, r, g, c, slope2, qf,
+            attn_tile<DH, QG, ALIBI, DT, (DBG > 2 ? 0 : DBG), 4, (QL ? 2 : 0)>(sK, sK + K_TILE_BYTES, t * BKV, len_k, r, g, c, slope2, qf,
                                                            q_pos, o, m_run, l_acc);
         if (DBG < 3) write_lds((t + 1) & 1, t + 1);
         if (DBG < 4) __syncthreads();
@@ -468,10 +495,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P) {
         // short sequences (one query group per wave: seq2reg windows of 70-200 tokens, 2-4 tiles): the last tile in its
         // 16 / 32-key form when the remainder allows (a 100-token window: 64 + 36 keys; a 200-token chunk: 3 x 64 + 8)
         if (QG == 1 && DBG == 0 && len_k - t * BKV <= 32)
-            attn_tile_short<DH, QG, ALIBI, DT>(len_k - t * BKV, sK, sK + K_TILE_BYTES, t * BKV, len_k, r, g, c, slope2, qf,
+            attn_tile_short<DH, QG, ALIBI, DT, (QL ? 2 : 0)>(len_k - t * BKV, sK, sK + K_TILE_BYTES, t * BKV, len_k, r, g, c, slope2, qf,
                                                q_pos, o, m_run, l_acc);
         else
-            attn_tile<DH, QG, ALIBI, DT, (DBG > 2 ? 0 : DBG)>(sK, sK + K_TILE_BYTES, t * BKV, len_k, r, g, c, slope2, qf, q_pos,
+            attn_tile<DH, QG, ALIBI, DT, (DBG > 2 ? 0 : DBG), 4, (QL ? 2 : 0)>(sK, sK + K_TILE_BYTES, t * BKV, len_k, r, g, c, slope2, qf, q_pos,
                                                            o, m_run, l_acc);
     }
 
@@ -670,7 +697,8 @@ __global__ __launch_bounds__(256) void attn_x32_kernel(AttnParams P) {
                 mb = max3f(mb, s[qb][1][i], s[qb][1][i + 1]);
             }
             float mx = max3f(ma, mb, max2f(s[qb][0][15], s[qb][1][15]));
-            if (FAST) mx = __builtin_ceilf(mx);          // the recomputation pass of the FAST kernel: integer offsets (see above)
+            if (P.q_log2) mx = __builtin_ceilf(mx);      // integer offsets whenever q carries the scale: the recomputation pass
+                                                         // of the FAST kernel and VF_ATTN_NOMAX=0 round what FAST rounds
             const unsigned u = __float_as_uint(mx);
             auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
             m_new[qb] = max3f(m_run[qb], __uint_as_float(sw[0]), __uint_as_float(sw[1]));   // finite: tile 0 holds a valid key
@@ -780,8 +808,13 @@ __global__ __launch_bounds__(256) void attn_x32_kernel(AttnParams P) {
 // no per-tile barriers) and is fetched once per (sequence, head) instead of once per 64-query block.
 // Wave w owns the query groups w, w+4, ... (16 queries each), QG = ceil(max_seqlen_q / 64) of them, processed
 // together so that every K / V fragment read from LDS feeds QG MFMAs.
-template <int DH, int QG, bool ALIBI, int DT = VF_BF16>
+// QL: q carries the softmax scale (AttnParams::q_log2) -> attn_tile mode 2 (integer running maxima), the arithmetic of the
+// tiled kernels, which serve the same queries in other batch geometries.  (The no-maximum form of attn_x32_kernel was
+// measured here too: -2 % on the gene stream's self attention -- this kernel waits for its loads, not for its exponentials --
+// and it cannot be bit-identical to mode 2, whose s - m rounds; not kept.)
+template <int DH, int QG, bool ALIBI, int DT = VF_BF16, bool QL = false>
 __global__ __launch_bounds__(256, (QG >= 2 ? 2 : 4)) void attn_short_kernel(AttnParams P, int k_rows) {
+    constexpr int SM = QL ? 2 : 0;
     using frag_t = typename Op16<DT>::frag;
     constexpr int CPR = DH / 8;
     constexpr int NDT = DH / 16;
@@ -878,11 +911,11 @@ __global__ __launch_bounds__(256, (QG >= 2 ? 2 : 4)) void attn_short_kernel(Attn
     const int n_full = rem <= 32 ? tl : nkv;
     if (QG == 1 || last_group_valid) {
         for (int t = 0; t < n_full; ++t)
-            attn_tile<DH, QG, ALIBI, DT>(sK0 + t * BKV * K_ROW_BYTES, sV0 + t * BKV * VROW, t * BKV, len_k, r, g, c, slope2,
-                                         qf, q_pos, o, m_run, l_acc);
+            attn_tile<DH, QG, ALIBI, DT, 0, 4, SM>(sK0 + t * BKV * K_ROW_BYTES, sV0 + t * BKV * VROW, t * BKV, len_k, r, g, c,
+                                                   slope2, qf, q_pos, o, m_run, l_acc);
         if (rem <= 32)
-            attn_tile_short<DH, QG, ALIBI, DT>(rem, sK0 + tl * BKV * K_ROW_BYTES, sV0 + tl * BKV * VROW, tl * BKV, len_k, r, g, c,
-                                               slope2, qf, q_pos, o, m_run, l_acc);
+            attn_tile_short<DH, QG, ALIBI, DT, SM>(rem, sK0 + tl * BKV * K_ROW_BYTES, sV0 + tl * BKV * VROW, tl * BKV, len_k,
+                                                   r, g, c, slope2, qf, q_pos, o, m_run, l_acc);
     } else {
         constexpr int Q1 = QG > 1 ? QG - 1 : 1;
         auto& qf1 = reinterpret_cast<const frag_t(&)[Q1][KS]>(qf);
@@ -891,11 +924,11 @@ __global__ __launch_bounds__(256, (QG >= 2 ? 2 : 4)) void attn_short_kernel(Attn
         auto& m_run1 = reinterpret_cast<float(&)[Q1]>(m_run);
         auto& l_acc1 = reinterpret_cast<f32x4_t(&)[Q1]>(l_acc);
         for (int t = 0; t < n_full; ++t)
-            attn_tile<DH, Q1, ALIBI, DT>(sK0 + t * BKV * K_ROW_BYTES, sV0 + t * BKV * VROW, t * BKV, len_k, r, g, c, slope2,
-                                         qf1, q_pos1, o1, m_run1, l_acc1);
+            attn_tile<DH, Q1, ALIBI, DT, 0, 4, SM>(sK0 + t * BKV * K_ROW_BYTES, sV0 + t * BKV * VROW, t * BKV, len_k, r, g, c,
+                                                   slope2, qf1, q_pos1, o1, m_run1, l_acc1);
         if (rem <= 32)
-            attn_tile_short<DH, Q1, ALIBI, DT>(rem, sK0 + tl * BKV * K_ROW_BYTES, sV0 + tl * BKV * VROW, tl * BKV, len_k, r, g, c,
-                                               slope2, qf1, q_pos1, o1, m_run1, l_acc1);
+            attn_tile_short<DH, Q1, ALIBI, DT, SM>(rem, sK0 + tl * BKV * K_ROW_BYTES, sV0 + tl * BKV * VROW, tl * BKV, len_k,
+                                                   r, g, c, slope2, qf1, q_pos1, o1, m_run1, l_acc1);
     }
 
 #pragma unroll
@@ -927,9 +960,9 @@ static unsigned set_grid(AttnParams& P, int n_seq, int nqb) {
 // dynamic LDS of the tiled kernel: two (K tile + V tile) stages
 template <int DH> constexpr int attn_fwd_lds() { return 2 * (KLayout<DH>::TILE + VLayout<DH>::TILE); }
 
-template <int DH, int QG, bool ALIBI, int DT, int DBG = 0>
-int launch_fwd(const AttnParams& P, dim3 grid, hipStream_t st) {
-    auto kern = attn_fwd_kernel<DH, QG, ALIBI, DT, DBG>;
+template <int DH, int QG, bool ALIBI, int DT, int DBG, bool QL>
+int launch_fwd_k(const AttnParams& P, dim3 grid, hipStream_t st) {
+    auto kern = attn_fwd_kernel<DH, QG, ALIBI, DT, DBG, QL>;
     constexpr int lds = attn_fwd_lds<DH>();
     if (lds > 65536) {                             // dh = 128 only: above the default dynamic-LDS limit
         static bool attr_set[VF_MAX_DEVICES] = {};
@@ -949,11 +982,18 @@ int launch_fwd(const AttnParams& P, dim3 grid, hipStream_t st) {
     return VF_OK;
 }
 
-template <int DH, int QG, bool ALIBI, int DT>
-int launch_short(AttnParams P, int n_seq, int max_k, hipStream_t st) {
+// q carrying the softmax scale (AttnParams::q_log2) selects the integer-maximum instantiation (attn_tile mode 2)
+template <int DH, int QG, bool ALIBI, int DT, int DBG = 0>
+int launch_fwd(const AttnParams& P, dim3 grid, hipStream_t st) {
+    if (DBG == 0 && P.q_log2) return launch_fwd_k<DH, QG, ALIBI, DT, 0, true>(P, grid, st);
+    return launch_fwd_k<DH, QG, ALIBI, DT, DBG, false>(P, grid, st);
+}
+
+template <int DH, int QG, bool ALIBI, int DT, bool QL>
+int launch_short_k(AttnParams P, int n_seq, int max_k, hipStream_t st) {
     const int k_rows = ((max_k + BKV - 1) / BKV) * BKV;
     const int lds = k_rows * (KLayout<DH>::ROW + VLayout<DH>::ROW);
-    auto kern = attn_short_kernel<DH, QG, ALIBI, DT>;
+    auto kern = attn_short_kernel<DH, QG, ALIBI, DT, QL>;
     static bool attr_set[VF_MAX_DEVICES] = {};    // the attribute is per device (and per instantiation)
     const int dev = vf_current_device();
     if (dev < 0 || !attr_set[dev]) {
@@ -969,6 +1009,12 @@ int launch_short(AttnParams P, int n_seq, int max_k, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), lds, st, P, k_rows);
     VF_CHECK_LAUNCH("vf_attn_varlen_fwd");
     return VF_OK;
+}
+
+template <int DH, int QG, bool ALIBI, int DT>
+int launch_short(AttnParams P, int n_seq, int max_k, hipStream_t st) {
+    if (P.q_log2) return launch_short_k<DH, QG, ALIBI, DT, true>(P, n_seq, max_k, st);
+    return launch_short_k<DH, QG, ALIBI, DT, false>(P, n_seq, max_k, st);
 }
 
 template <int DT, int QB>

@@ -37,23 +37,37 @@ def get_alibi_slopes(n: int) -> torch.Tensor:
 # ---------------------------------------------------------------------------------------------
 # weight packing (fp32 master parameters -> bf16 kernel operands), cached per parameter version
 # ---------------------------------------------------------------------------------------------
-def packed_linear(lin: nn.Linear, geglu: bool = False, wscale: float = 1.0, bscale: float = 1.0):
+def _row_scale(n_rows: int, scale: float, qrows: int, device):
+    """[n_rows, 1] factor: `scale` for the first `qrows` output rows (all rows when qrows = 0), 1 elsewhere."""
+    v = torch.full((n_rows, 1), float(scale), dtype=torch.float32, device=device)
+    if qrows:
+        v[qrows:] = 1.0
+    return v
+
+
+def packed_linear(lin: nn.Linear, geglu: bool = False, wscale: float = 1.0, bscale: float = 1.0, qrows: int = 0):
     """(16-bit weight [N,K] in the current compute dtype, fp32 bias [N]) for vf_gemm_*; `geglu` applies the GEGLU row
     interleave.  Rebuilt whenever the parameter is modified in place (load_state_dict), moved, or the compute dtype
     changes (one cached copy per module: a model runs in one precision at a time).  `wscale` (a power of two): the
     16-bit weights are 16bit(W * wscale) -- the operand of a GEMM whose OTHER operand is a stream copy stored scaled by
     1 / wscale (ops.LnStream.scale, fp16 mode); the product is then the unscaled one, exactly.  `bscale` multiplies the
-    bias (q_prescale passes wscale = bscale = softmax scale * log2 e: the whole projection is scaled)."""
+    bias (q_prescale passes wscale = bscale = softmax scale * log2 e: the whole projection is scaled).  `qrows` > 0: both
+    scales apply to the first `qrows` output rows only (the Q rows of a packed Wqkv)."""
     w = lin.weight
-    key = (w.data_ptr(), w._version, str(w.device), geglu, ops.cdt(), float(wscale), float(bscale),
+    key = (w.data_ptr(), w._version, str(w.device), geglu, ops.cdt(), float(wscale), float(bscale), int(qrows),
            None if lin.bias is None else (lin.bias.data_ptr(), lin.bias._version))
     cache = getattr(lin, "_vf_packed", None)
     if cache is not None and cache[0] == key:
         return cache[1], cache[2]
     with torch.no_grad():
         wf = w.detach().float()
-        wb = ops.cast16((wf if wscale == 1.0 else wf * float(wscale)).contiguous())
-        b = None if lin.bias is None else (lin.bias.detach().float() * float(bscale)).contiguous()
+        wb = ops.cast16((wf if wscale == 1.0 else wf * _row_scale(wf.shape[0], wscale, qrows, wf.device)).contiguous())
+        b = None
+        if lin.bias is not None:
+            b = lin.bias.detach().float()
+            if bscale != 1.0:
+                b = b * _row_scale(b.shape[0], bscale, qrows, b.device)[:, 0]
+            b = b.contiguous()
         if geglu:
             wb, b = ops.pack_geglu_rows(wb, b)
     lin._vf_packed = (key, wb, b)
@@ -61,31 +75,33 @@ def packed_linear(lin: nn.Linear, geglu: bool = False, wscale: float = 1.0, bsca
     return wb, b
 
 
-def packed_linear_ln(lin: nn.Linear, norm: nn.LayerNorm, geglu: bool = False, wscale: float = 1.0):
+def packed_linear_ln(lin: nn.Linear, norm: nn.LayerNorm, geglu: bool = False, wscale: float = 1.0, qrows: int = 0):
     """Operands of a GEMM that consumes LayerNorm(x) without a normalised copy of x (ops.gemm_ln_consumer):
          w'     = bf16(gamma (.) W)        [N, K]   (gamma scales the K columns)
          bias'  = W . beta + b             [N] fp32 (from the fp32 master weights)
          colsum = sum_k float(w'[n, k])    [N] fp32
        so that LN(x) W^T + b = rstd * (x w'^T - mean * colsum) + bias'.  `geglu` applies the GEGLU row interleave to all
-       three.  `wscale`: the whole projection multiplied by a constant (q_prescale: the softmax scale of a cross
-       attention folded into its Wq): w' = 16bit(wscale * gamma (.) W), bias' = wscale * (W . beta + b).  One-time weight
+       three.  `wscale`: the projection (its first `qrows` output rows; all of them when qrows = 0) multiplied by a constant
+       (q_prescale: the softmax scale folded into Wq / the Q rows of Wqkv): w' = 16bit(wscale * gamma (.) W), bias' =
+       wscale * (W . beta + b).  One-time weight
        preparation (cached per parameter versions), torch elementwise / reduce ops on the fp32 masters; nothing of this
        runs per batch."""
     w, g, be = lin.weight, norm.weight, norm.bias
     key = (w.data_ptr(), w._version, g.data_ptr(), g._version, be.data_ptr(), be._version, str(w.device), geglu, ops.cdt(),
-           float(wscale), None if lin.bias is None else (lin.bias.data_ptr(), lin.bias._version))
+           float(wscale), int(qrows), None if lin.bias is None else (lin.bias.data_ptr(), lin.bias._version))
     cache = getattr(lin, "_vf_packed_ln", None)
     if cache is not None and cache[0] == key:
         return cache[1], cache[2], cache[3]
     with torch.no_grad():
         wf = w.detach().float()
         wg = wf * g.detach().float()[None, :]
-        wb = ops.cast16((wg if wscale == 1.0 else wg * float(wscale)).contiguous())  # current operand type (bf16 / fp16)
+        rs = None if wscale == 1.0 else _row_scale(wf.shape[0], wscale, qrows, wf.device)   # first `qrows` rows (0: all)
+        wb = ops.cast16((wg if rs is None else wg * rs).contiguous())                # current operand type (bf16 / fp16)
         b = wf @ be.detach().float()
         if lin.bias is not None:
             b = b + lin.bias.detach().float()
-        if wscale != 1.0:
-            b = b * float(wscale)
+        if rs is not None:
+            b = b * rs[:, 0]
         b = b.contiguous()
         if geglu:
             wb, b = ops.pack_geglu_rows(wb, b)
@@ -139,9 +155,9 @@ def trunk16_enabled(stack: str = "modulator") -> bool:
 
 
 def q_prescale_enabled() -> bool:
-    """Cross attentions (a Wq of their own): the softmax scale and the change to base 2, 1 / sqrt(dh) * log2(e), are folded
-    into the Wq rows (and bias) when the 16-bit weights are packed, so that q . k leaves the matrix pipe as the base-2
-    logit (ops.attn_varlen(q_log2=True), VF_ATTN_Q_LOG2): one rounding of the scaled weights instead of one of the
+    """The softmax scale and the change to base 2, 1 / sqrt(dh) * log2(e), are folded into the rows (and bias) of the query
+    projection -- Wq of a cross attention, the Q rows of a packed Wqkv -- when the 16-bit weights are packed, so that q . k
+    leaves the matrix pipe as the base-2 logit (ops.attn_varlen(q_log2=True), VF_ATTN_Q_LOG2): one rounding of the scaled weights instead of one of the
     unscaled ones -- the same size of error, different rounding points; oracle.Rounding(q_prescale=...) restates them.
     What it buys: the long-stream attention kernel drops the running maximum and the multiply-add in front of every
     exponential (gene -> CRE cross attention -14 %).  VF_Q_PRESCALE=0 keeps the unscaled projection."""
@@ -215,6 +231,15 @@ class MHA(nn.Module):
         else:
             self.alibi_slopes = None
 
+    def packed_qkv(self):
+        """packed_linear(Wqkv) with the Q rows carrying the base-2 softmax scale (q_prescale_enabled)."""
+        c = self.q_log2_scale if q_prescale_enabled() else 1.0
+        return packed_linear(self.Wqkv, wscale=c, bscale=c, qrows=self.embed_dim)
+
+    def packed_qkv_ln(self, norm: nn.LayerNorm):
+        """packed_linear_ln(Wqkv, norm), Q rows as in packed_qkv."""
+        return packed_linear_ln(self.Wqkv, norm, wscale=self.q_log2_scale if q_prescale_enabled() else 1.0, qrows=self.embed_dim)
+
     # -- pieces -------------------------------------------------------------------------------
     def project_kv(self, x_kv_bf16: torch.Tensor) -> torch.Tensor:
         """bf16 [tokens_k, 2D] = Wkv(x_kv): exposed so that a caller can compute it once and share it."""
@@ -242,10 +267,9 @@ class MHA(nn.Module):
             q = ops.gemm(x_bf16, w, b, ops.EPI_BF16)
             return ops.attn_varlen(q, kv_bf16[:, :D], kv_bf16[:, D:], cu_q, cu_k, max_q, max_k, self.num_heads,
                                    self.head_dim, self.alibi_slopes, family=self.family, q_log2=pre)
-        w, b = packed_linear(self.Wqkv)
+        w, b = self.packed_qkv()
         qkv = ops.gemm(x_bf16, w, b, ops.EPI_BF16)
-        return ops.attn_varlen(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], cu_q, None, max_q, max_q,
-                               self.num_heads, self.head_dim, self.alibi_slopes, family=self.family)
+        return self.attend_qkv(qkv, cu_q, max_q)
 
     def attend_ln(self, s: "ops.LnStream", norm: nn.LayerNorm, kv_bf16, cu_q, max_q, cu_k, max_k) -> torch.Tensor:
         """attend(LayerNorm(s.x)) with the LayerNorm folded into the Wqkv / Wq projection."""
@@ -256,15 +280,17 @@ class MHA(nn.Module):
             q = ops.gemm_ln_consumer(s, w, b, c, ops.EPI_BF16)
             return ops.attn_varlen(q, kv_bf16[:, :D], kv_bf16[:, D:], cu_q, cu_k, max_q, max_k, self.num_heads,
                                    self.head_dim, self.alibi_slopes, family=self.family, q_log2=pre)
-        w, b, c = packed_linear_ln(self.Wqkv, norm)
+        w, b, c = self.packed_qkv_ln(norm)
         qkv = ops.gemm_ln_consumer(s, w, b, c, ops.EPI_BF16)
         return self.attend_qkv(qkv, cu_q, max_q)
 
     def attend_qkv(self, qkv, cu_q, max_q) -> torch.Tensor:
-        """self attention on a packed [tokens, 3D] 16-bit projection (rows ordered (three, head, dh))."""
+        """self attention on a packed [tokens, 3D] 16-bit projection (rows ordered (three, head, dh)) made with packed_qkv /
+        packed_qkv_ln (its Q third carries the softmax scale when q_prescale_enabled)."""
         D = self.embed_dim
         return ops.attn_varlen(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], cu_q, None, max_q, max_q,
-                               self.num_heads, self.head_dim, self.alibi_slopes, family=self.family)
+                               self.num_heads, self.head_dim, self.alibi_slopes, family=self.family,
+                               q_log2=q_prescale_enabled())
 
     def out_ln(self, a_bf16, residual_f32, need_x: bool = True) -> "ops.LnStream":
         """out_proj(a) + residual as an LnStream (fp32 stream, its 16-bit copy, row statistics for the next LayerNorm).
@@ -378,7 +404,7 @@ class ContextFlashAttentionEncoderLayer(nn.Module):
         Exact: LayerNorm and the projection are row-wise.  None when the LayerNorm fold is off (fp16 mode)."""
         if not ln_fold_enabled(self.norm1.weight.numel(), self.linear_geglu_2.in_features):
             return None
-        w, b, c = packed_linear_ln(self.mixer.MHA.Wqkv, self.norm1)
+        w, b, c = self.mixer.MHA.packed_qkv_ln(self.norm1)
         qa = ops.gemm_ln_consumer(ops.ln_stream(rows_a.float().contiguous()), w, b, c, ops.EPI_BF16)
         qb = ops.gemm_ln_consumer(ops.ln_stream(rows_b.float().contiguous()), w, b, c, ops.EPI_BF16)
         both = torch.cat([qa, qb], dim=0)                        # (a few thousand rows: index plumbing, not data movement)
@@ -444,12 +470,13 @@ class ContextFlashAttentionEncoderLayer(nn.Module):
         if ln_fold_enabled(self.norm1.weight.numel(), self.linear_geglu_2.in_features):
             s = _as_stream(src)
             D = s.x16.shape[1]
-            w, b, c = packed_linear_ln(mha.Wqkv, self.norm1)
+            w, b, c = mha.packed_qkv_ln(self.norm1)
             kv = ops.gemm_ln_consumer(s, w[D:], b[D:], c[D:], ops.EPI_BF16)            # all rows (K/V need them)
             sr = ops.ln_stream_rows(s, rows)
             q = ops.gemm_ln_consumer(sr, w[:D], b[:D], c[:D], ops.EPI_BF16)            # [R, D]
             a = ops.attn_varlen(q, kv[:, :D], kv[:, D:], cu_rows, cu_src, 1, max_src, mha.num_heads, mha.head_dim,
-                                mha.alibi_slopes, q_at_start=True, family=mha.family + "_registry_rows")
+                                mha.alibi_slopes, q_at_start=True, family=mha.family + "_registry_rows",
+                                q_log2=q_prescale_enabled())
             r16 = res16_enabled() or sr.x is None
             x1 = mha.out_ln(a, sr if r16 else sr.x, need_x=not r16)
             ckv = self.crossMHA.MHA.project_kv_of(context)
@@ -465,12 +492,13 @@ class ContextFlashAttentionEncoderLayer(nn.Module):
         src, context = _as_tensor(src), _as_tensor(context)
         D = src.shape[1]
         h = ops.layernorm(src, self.norm1.weight, self.norm1.bias)                       # all rows (K/V need them)
-        w, b = packed_linear(mha.Wqkv)
+        w, b = mha.packed_qkv()
         kv = ops.gemm(h, w[D:], None if b is None else b[D:], ops.EPI_BF16)             # [tokens, 2D]
         hq = ops.gather_rows_bf16(h, rows)
         q = ops.gemm(hq, w[:D], None if b is None else b[:D], ops.EPI_BF16)             # [R, D]
         a = ops.attn_varlen(q, kv[:, :D], kv[:, D:], cu_rows, cu_src, 1, max_src, mha.num_heads, mha.head_dim,
-                            mha.alibi_slopes, q_at_start=True, family=mha.family + "_registry_rows")
+                            mha.alibi_slopes, q_at_start=True, family=mha.family + "_registry_rows",
+                            q_log2=q_prescale_enabled())
         src_rows = ops.gather_rows_f32(src, None, rows)
         wo, bo = packed_linear(mha.out_proj)
         x1 = ops.gemm(a, wo, bo, ops.EPI_RES_F32, residual=src_rows)
