@@ -343,7 +343,10 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_mfma_kernel(const unsigned
         else return *reinterpret_cast<const f32x4_t*>(res + m * ldr + col);
     };
     auto res_value = [&](res_t v) -> f32x4_t {
-        if constexpr (R16) return cvt4_16<DT>(v) * ln.res16_scale;
+        if constexpr (R16) {             // bf16 stream copies are never scaled (checked at launch): no multiply by 1.0 per element
+            if constexpr (DT == VF_F16) return cvt4_16<DT>(v) * ln.res16_scale;
+            else return cvt4_16<DT>(v);
+        }
         else return v;
     };
     res_t resv[RES_PRE ? NPASS : 1][RES_PRE ? NI : 1];
@@ -1026,7 +1029,10 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const unsigned short* __r
         }
     };
     auto res_value = [&](res_t v) -> f32x4_t {
-        if constexpr (R16) return cvt4_16<DT>(v) * ln.res16_scale;
+        if constexpr (R16) {             // bf16 stream copies are never scaled (checked at launch): no multiply by 1.0 per element
+            if constexpr (DT == VF_F16) return cvt4_16<DT>(v) * ln.res16_scale;
+            else return cvt4_16<DT>(v);
+        }
         else return v;
     };
     load_res_pass(0, rbuf[0]);
@@ -2502,6 +2508,7 @@ static int gemm_ln_dispatch(const void* A, int64_t lda, const void* W, const flo
     }
     VF_REQUIRE(residual_dtype == DT, "vf_gemm_ln: a 16-bit residual must have the operand type");
     VF_REQUIRE(ldr % 4 == 0 && ((uintptr_t)residual % 8 == 0) && res16_scale > 0.f, "vf_gemm_ln: misaligned 16-bit residual");
+    VF_REQUIRE(DT == VF_F16 || res16_scale == 1.0f, "vf_gemm_ln: res16_scale must be 1 for bf16 streams");
     ln.res16 = (const unsigned short*)residual;
     ln.ldr16 = ldr;
     ln.res16_scale = res16_scale;
