@@ -397,6 +397,13 @@ def test_attention_prescaled_q_without_running_maximum(ops, dtype, big_batch):
         q3a, q3e = int(cu_q[3]), int(cu_q[4])
         q[q3a:q3e] = -6.0 * base
         q[100] *= 15.0                            # one extreme query inside an ordinary block of sequence 0
+        # sequence 7: every logit around -12 -- harmless for bf16 P, but an fp16 P would be subnormal (4 significant bits)
+        k7a, k7e = int(cu_k[7]), int(cu_k[8])
+        base7 = _rand((1, D), 49, 1.0)
+        k[k7a:k7e] = rnd.r(base7.repeat(k7e - k7a, 1) * (1.0 + 0.02 * torch.arange(k7e - k7a)[:, None]))
+        q7a, q7e = int(cu_q[7]), int(cu_q[8])
+        per_head = (base7.view(H, dh) ** 2).sum(dim=1)                      # q . k per head for q = base7
+        q[q7a:q7e] = (base7.view(H, dh) * (-12.0 / (per_head * c))[:, None]).reshape(1, D).repeat(q7e - q7a, 1)
     qs = rnd.r(q * c)                             # what the pre-scaled Wq projection hands over (one rounding)
     ref = torch.zeros(tq, D)
     for b in range(len(ql)):

@@ -762,8 +762,12 @@ __global__ __launch_bounds__(256) void attn_x32_kernel(AttnParams P) {
         if (active && h == 0) {
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) {
+                // 2^-100 .. 2^100 (false for NaN).  fp16 P: overflow shows as inf; at the low end the largest p of a row must
+                // still be a NORMAL half with room below it (subnormal P would pass a 2^-100 test with 4 significant bits):
+                // rows whose logits all lie below -6 are recomputed
+                constexpr float L_MIN = DT == VF_F16 ? 0.015625f : 7.8886e-31f;
                 const float l = o[qb][1][8];
-                bad = bad || !(l > 7.8886e-31f && l < 1.2676e30f);    // 2^-100 .. 2^100; false for NaN
+                bad = bad || !(l > L_MIN && l < 1.2676e30f);
             }
         }
         if (__syncthreads_or(bad)) {                                  // block-uniform (also orders the LDS stages)
