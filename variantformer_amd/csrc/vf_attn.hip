@@ -90,6 +90,9 @@ struct AttnParams {
                         // (flash-attn convention), 1 = query i sits at position i
     int q_log2;         // 1: Q was projected with weights pre-multiplied by scale * log2(e) (VF_ATTN_Q_LOG2): scores are
                         // base-2 logits as they leave the matrix pipe, scale_log2 = 1
+#ifdef VF_SHORT_PROF
+    unsigned long long* prof;   // scripts/probes/attn_short_probe.hip only
+#endif
 };
 
 
@@ -843,6 +846,12 @@ __global__ __launch_bounds__(256, (QG >= 2 ? 2 : 4)) void attn_short_kernel(Attn
     const int r = lane & 15, g = lane >> 4;
     const int nkv = (len_k + BKV - 1) / BKV;
     const int nchunks = nkv * BKV * 8;
+#ifdef VF_SHORT_PROF
+    unsigned long long pt0 = __builtin_readcyclecounter(), pt1, ptv[5] = {0, 0, 0, 0, 0};
+#define SH_MARK(i) { pt1 = __builtin_readcyclecounter(); ptv[i] = pt1 - pt0; pt0 = pt1; }
+#else
+#define SH_MARK(i)
+#endif
 
     // ---- Q fragments of this wave's query groups (issued before the K/V loads so that both are in flight together)
     frag_t qf[QG][KS];
@@ -879,6 +888,11 @@ __global__ __launch_bounds__(256, (QG >= 2 ? 2 : 4)) void attn_short_kernel(Attn
                 vbuf[it] = *reinterpret_cast<const u32x4_t*>(vbase + (int64_t)key * P.v_stride + cc * 8);
             }
         }
+        SH_MARK(0)                                   // loads issued
+#ifdef VF_SHORT_PROF
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        SH_MARK(1)                                   // loads landed
+#endif
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
             const int ci = tid + 256 * it;
@@ -903,6 +917,7 @@ __global__ __launch_bounds__(256, (QG >= 2 ? 2 : 4)) void attn_short_kernel(Attn
         for (int dt = 0; dt < NDT; ++dt) o[qg][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     }
     __syncthreads();
+    SH_MARK(2)                                       // LDS written, barrier passed
     if (wave * 16 >= len_q) return;                                // this wave owns no valid query (wave-uniform)
 
     // A wave whose LAST query group lies past the sequence (201 queries = 13 groups of 16 over 4 waves: waves 1-3 own 3
@@ -935,6 +950,7 @@ __global__ __launch_bounds__(256, (QG >= 2 ? 2 : 4)) void attn_short_kernel(Attn
                                                    r, g, c, slope2, qf1, q_pos1, o1, m_run1, l_acc1);
     }
 
+    SH_MARK(3)                                       // tiles computed
 #pragma unroll
     for (int qg = 0; qg < QG; ++qg) {
         const float l = l_acc[qg][0];
@@ -950,6 +966,16 @@ __global__ __launch_bounds__(256, (QG >= 2 ? 2 : 4)) void attn_short_kernel(Attn
             }
         }
     }
+#ifdef VF_SHORT_PROF
+    SH_MARK(4)                                       // stores issued
+    if (lane == 0 && wave == 0 && (blockIdx.x & 63) == 0) {
+        unsigned long long* pp = P.prof + (blockIdx.x >> 6) * 8;
+        for (int i = 0; i < 5; ++i) pp[i] = ptv[i];
+        pp[5] = pt0;                                 // end stamp
+        pp[6] = pt0 - (ptv[0] + ptv[1] + ptv[2] + ptv[3] + ptv[4]);      // start stamp
+    }
+#endif
+#undef SH_MARK
 }
 
 // fills the grid decomposition of block_coords; returns the (padded) 1-D grid size
