@@ -978,6 +978,143 @@ __global__ __launch_bounds__(256, (QG >= 2 ? 2 : 4)) void attn_short_kernel(Attn
 #undef SH_MARK
 }
 
+// The same kernel for THREE resident blocks per CU (the gene stream's 201-token sequences).  attn_short_kernel at 4 query
+// groups per wave needs 232 VGPRs and 57 KB of LDS: two blocks per CU, whose two long phases -- ~5 us waiting for 58 KB of
+// Q / K / V at the latency this kernel's own traffic produces, ~6 us of tile arithmetic on the wave that owns 4 of the 13 query
+// groups (profiles/r03_o_attn_short_phase_probe.log) -- hide behind each other and nothing else.  Here a wave makes TWO PASSES
+// over the keys with 2 query groups each (<= 170 VGPRs: three waves per SIMD; the K / V fragments are read twice from LDS,
+// which has the bandwidth), and the LDS image holds only the rows the tiles read -- keys rounded up to the tail tile's 16 /
+// 32 / 64 for K and to 32 / 64 for V (201 keys: 208 K rows + 224 V rows = 47 KB) -- so three blocks fit: a third block's loads
+// and a second computing wave per SIMD.  Arithmetic per query: attn_tile's, identical to every other kernel.
+template <int DH, bool ALIBI, int DT = VF_BF16, bool QL = false>
+__global__ __launch_bounds__(256, 3) void attn_short2_kernel(AttnParams P, int k_rows) {
+    constexpr int SM = QL ? 2 : 0;
+    using frag_t = typename Op16<DT>::frag;
+    constexpr int CPR = DH / 8, NDT = DH / 16, QG = 2, NPASS = 2;
+    constexpr int VROW = VLayout<DH>::ROW;
+    constexpr int K_ROW_BYTES = KLayout<DH>::ROW, KS = KLayout<DH>::KS;
+    static_assert(K_ROW_BYTES == 128, "the short-sequence kernel is written for dh <= 64");
+    constexpr int MAXIT = 8;                                      // 256 rows x 8 chunk slots / 256 threads
+    extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
+    char* const sK0 = smem_dyn;
+    char* const sV0 = smem_dyn + k_rows * K_ROW_BYTES;
+
+    int seq, h, qblk;
+    if (!block_coords(P, seq, h, qblk)) return;
+    const int q_tok0 = P.cu_q[seq], len_q = P.cu_q[seq + 1] - q_tok0;
+    const int k_tok0 = P.cu_k[seq], len_k = P.cu_k[seq + 1] - k_tok0;
+    if (len_q <= 0) return;
+    if (len_k <= 0) {
+        zero_rows<DH>(P, q_tok0, len_q, h);
+        return;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int nkv = (len_k + BKV - 1) / BKV;
+    const int tl = nkv - 1, rem = len_k - tl * BKV;               // the last tile and the keys it holds
+    const int n_full = rem <= 32 ? tl : nkv;
+    const int rows_k = tl * BKV + (rem <= 16 ? 16 : rem <= 32 ? 32 : BKV);     // K rows the tiles read
+    const int rows_v = tl * BKV + (rem <= 32 ? 32 : BKV);                      // V rows (a PV block spans 32 keys)
+
+    // ---- Q fragments of all four query groups of this wave (issued before the K/V loads: everything in flight together)
+    frag_t qf[NPASS][QG][KS];
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps)
+#pragma unroll
+        for (int qg = 0; qg < QG; ++qg) {
+            const int qa = (wave + 4 * (QG * ps + qg)) * 16 + r;
+            const int row = qa < len_q ? qa : len_q - 1;
+            const unsigned short* qp = P.q + (int64_t)(q_tok0 + row) * P.q_stride + h * DH;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int d0 = 32 * ks + 8 * g;
+                u32x4_t raw = q_pad_chunk<DT>(d0, DH);
+                if (d0 < DH) raw = *reinterpret_cast<const u32x4_t*>(qp + d0);
+                qf[ps][qg][ks] = *reinterpret_cast<frag_t*>(&raw);
+            }
+        }
+    // ---- stage K (swizzled, zero pad chunks) and V; rows >= len_k replicate the last key (finite, masked later)
+    const unsigned short* kbase = P.k + (int64_t)k_tok0 * P.k_stride + h * DH;
+    const unsigned short* vbase = P.v + (int64_t)k_tok0 * P.v_stride + h * DH;
+    {
+        u32x4_t kbuf[MAXIT], vbuf[MAXIT];
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            const int ci = tid + 256 * it;
+            const int row = ci >> 3, cc = ci & 7;
+            kbuf[it] = (HwMask<DH>::value && cc == CPR) ? mask_chunk<DT>(row < len_k) : (u32x4_t){0u, 0u, 0u, 0u};
+            vbuf[it] = (u32x4_t){0u, 0u, 0u, 0u};
+            if (row < rows_v && cc < CPR) {
+                const int key = row < len_k ? row : len_k - 1;
+                if (row < rows_k) kbuf[it] = *reinterpret_cast<const u32x4_t*>(kbase + (int64_t)key * P.k_stride + cc * 8);
+                vbuf[it] = *reinterpret_cast<const u32x4_t*>(vbase + (int64_t)key * P.v_stride + cc * 8);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            const int ci = tid + 256 * it;
+            const int row = ci >> 3, cc = ci & 7;
+            if (row < rows_k) *reinterpret_cast<u32x4_t*>(sK0 + row * K_ROW_BYTES + ((cc ^ ((row >> 1) & 7)) << 4)) = kbuf[it];
+            if (row < rows_v && cc < CPR) *reinterpret_cast<u32x4_t*>(sV0 + row * VROW + (cc << 4)) = vbuf[it];
+        }
+    }
+    const float c = P.scale_log2;
+    const float slope2 = ALIBI ? P.slopes[h] * 1.4426950408889634f : 0.f;
+    __syncthreads();
+
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        const int g0 = wave + 4 * QG * ps;                         // this pass's first query group (wave-uniform)
+        if (g0 * 16 >= len_q) break;
+        int q_abs[QG];
+        float q_pos[QG], m_run[QG];
+        f32x4_t o[QG][NDT], l_acc[QG];
+#pragma unroll
+        for (int qg = 0; qg < QG; ++qg) {
+            q_abs[qg] = (g0 + 4 * qg) * 16 + r;
+            q_pos[qg] = (float)(q_abs[qg] + (P.q_at_start ? 0 : len_k - len_q));
+            m_run[qg] = -INFINITY;
+            l_acc[qg] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) o[qg][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        }
+        if ((g0 + 4) * 16 < len_q) {                               // both groups hold valid queries
+            for (int t = 0; t < n_full; ++t)
+                attn_tile<DH, QG, ALIBI, DT, 0, 4, SM>(sK0 + t * BKV * K_ROW_BYTES, sV0 + t * BKV * VROW, t * BKV, len_k, r, g, c,
+                                                       slope2, qf[ps], q_pos, o, m_run, l_acc);
+            if (rem <= 32)
+                attn_tile_short<DH, QG, ALIBI, DT, SM>(rem, sK0 + tl * BKV * K_ROW_BYTES, sV0 + tl * BKV * VROW, tl * BKV, len_k,
+                                                       r, g, c, slope2, qf[ps], q_pos, o, m_run, l_acc);
+        } else {
+            auto& qf1 = reinterpret_cast<const frag_t(&)[1][KS]>(qf[ps]);
+            auto& q_pos1 = reinterpret_cast<const float(&)[1]>(q_pos);
+            auto& o1 = reinterpret_cast<f32x4_t(&)[1][NDT]>(o);
+            auto& m_run1 = reinterpret_cast<float(&)[1]>(m_run);
+            auto& l_acc1 = reinterpret_cast<f32x4_t(&)[1]>(l_acc);
+            for (int t = 0; t < n_full; ++t)
+                attn_tile<DH, 1, ALIBI, DT, 0, 4, SM>(sK0 + t * BKV * K_ROW_BYTES, sV0 + t * BKV * VROW, t * BKV, len_k, r, g, c,
+                                                      slope2, qf1, q_pos1, o1, m_run1, l_acc1);
+            if (rem <= 32)
+                attn_tile_short<DH, 1, ALIBI, DT, SM>(rem, sK0 + tl * BKV * K_ROW_BYTES, sV0 + tl * BKV * VROW, tl * BKV, len_k,
+                                                      r, g, c, slope2, qf1, q_pos1, o1, m_run1, l_acc1);
+        }
+#pragma unroll
+        for (int qg = 0; qg < QG; ++qg) {
+            const float inv = 1.0f / l_acc[qg][0];
+            if (q_abs[qg] < len_q) {
+                unsigned short* op = P.out + (int64_t)(q_tok0 + q_abs[qg]) * P.o_stride + h * DH + 4 * g;
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) {
+                    u32x2_t pk;
+                    pk[0] = Op16<DT>::pack2(o[qg][dt][0] * inv, o[qg][dt][1] * inv);
+                    pk[1] = Op16<DT>::pack2(o[qg][dt][2] * inv, o[qg][dt][3] * inv);
+                    *reinterpret_cast<u32x2_t*>(op + 16 * dt) = pk;
+                }
+            }
+        }
+    }
+}
+
 // fills the grid decomposition of block_coords; returns the (padded) 1-D grid size
 static unsigned set_grid(AttnParams& P, int n_seq, int nqb) {
     const long total = (long)n_seq * P.H * nqb;
@@ -1041,6 +1178,42 @@ int launch_short_k(AttnParams P, int n_seq, int max_k, hipStream_t st) {
     return VF_OK;
 }
 
+// rows of the LDS image for sequences of at most max_k keys (monotone in max_k: a shorter sequence never reads beyond them)
+static inline void short2_rows(int max_k, int& kr, int& vr) {
+    const int tl = (max_k - 1) / BKV, rem = max_k - tl * BKV;
+    kr = tl * BKV + (rem <= 16 ? 16 : rem <= 32 ? 32 : BKV);
+    vr = tl * BKV + (rem <= 32 ? 32 : BKV);
+}
+
+template <int DH, bool ALIBI, int DT, bool QL>
+int launch_short2_k(AttnParams P, int n_seq, int max_k, hipStream_t st) {
+    int kr, vr;
+    short2_rows(max_k, kr, vr);
+    const int lds = kr * KLayout<DH>::ROW + vr * VLayout<DH>::ROW;
+    auto kern = attn_short2_kernel<DH, ALIBI, DT, QL>;
+    static bool attr_set[VF_MAX_DEVICES] = {};
+    const int dev = vf_current_device();
+    if (dev < 0 || !attr_set[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                256 * (KLayout<DH>::ROW + VLayout<DH>::ROW)) != hipSuccess) {
+            (void)hipGetLastError();
+            vf_set_error("vf_attn_varlen_fwd: cannot reserve LDS");
+            return VF_ERR_LAUNCH;
+        }
+        if (dev >= 0) attr_set[dev] = true;
+    }
+    const unsigned nblk = set_grid(P, n_seq, 1);
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), lds, st, P, kr);
+    VF_CHECK_LAUNCH("vf_attn_varlen_fwd");
+    return VF_OK;
+}
+
+template <int DH, bool ALIBI, int DT>
+int launch_short2(AttnParams P, int n_seq, int max_k, hipStream_t st) {
+    if (P.q_log2) return launch_short2_k<DH, ALIBI, DT, true>(P, n_seq, max_k, st);
+    return launch_short2_k<DH, ALIBI, DT, false>(P, n_seq, max_k, st);
+}
+
 template <int DH, int QG, bool ALIBI, int DT>
 int launch_short(AttnParams P, int n_seq, int max_k, hipStream_t st) {
     if (P.q_log2) return launch_short_k<DH, QG, ALIBI, DT, true>(P, n_seq, max_k, st);
@@ -1077,6 +1250,13 @@ int launch_attn(AttnParams P, int n_seq, int max_q, int max_k, hipStream_t st) {
     }
     if constexpr (DH <= 48) {
         if (max_q > 128 && max_q <= 256 && max_k <= 256) {
+            // three resident blocks per CU (two passes of 2 query groups, trimmed LDS image) once the image leaves room
+            // for them; VF_ATTN_SHORT2=0: the one-pass kernel (A/B)
+            static const int short2 = getenv("VF_ATTN_SHORT2") ? atoi(getenv("VF_ATTN_SHORT2")) : 1;
+            int kr, vr;
+            short2_rows(max_k, kr, vr);
+            if (short2 && 3 * (kr * KLayout<DH>::ROW + vr * VLayout<DH>::ROW) <= 160 * 1024)
+                return launch_short2<DH, ALIBI, DT>(P, n_seq, max_k, st);
             if (max_q <= 192) return launch_short<DH, 3, ALIBI, DT>(P, n_seq, max_k, st);
             return launch_short<DH, 4, ALIBI, DT>(P, n_seq, max_k, st);
         }
