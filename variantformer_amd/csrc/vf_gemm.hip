@@ -770,6 +770,10 @@ struct Cfg8 {
     enum { WL = 0, AL = 1, WH = 2, AH = 3 };
 };
 
+#ifdef VF_G8_PROF
+__device__ unsigned long long* vf_g8_prof = nullptr;      // scripts/probes/gemm8_probe.hip: cycle stamps of every 16th block
+#endif
+
 template <int EPI, int DT = VF_BF16, int LN = VF_LN_NONE>
 __global__ __launch_bounds__(512, 2) void gemm8_kernel(const unsigned short* __restrict__ A, int64_t lda,
                                                        const unsigned short* __restrict__ W,
@@ -783,6 +787,13 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const unsigned short* __r
 
     // XCD-aware bijective remap + grouped order (same as gemm_mfma_kernel)
     const int bid = blockIdx.x;
+#ifdef VF_G8_PROF
+    unsigned long long g8t[8]; int g8n = 0;
+#define G8_MARK() { g8t[g8n < 8 ? g8n : 7] = __builtin_readcyclecounter(); ++g8n; }
+    G8_MARK()
+#else
+#define G8_MARK()
+#endif
 #ifdef VF_TUNING   // cost-centre probes of the epilogue (VF_G8_DBG bit mask, scripts/gemm_bench.py; results meaningless)
     const int dbg = (GROUP_M >> 8) & 255;
     // start-up stagger experiment (VF_G8_STAGGER = units of ~4 us): every other CU of an XCD starts its FIRST tile late, so
@@ -919,6 +930,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const unsigned short* __r
     }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    G8_MARK()                                        // 1: first K-tile in LDS
     if (wm == 1) __builtin_amdgcn_s_barrier();       // group 1 runs one barrier behind (matched after the loop)
 
     for (int t = 0; t < nkt; ++t) {
@@ -958,6 +970,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const unsigned short* __r
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();       // matches group 1's extra barrier: every wave is past its last MFMA
     asm volatile("" ::: "memory");
+    G8_MARK()                                        // 2: K loop done
 #undef VF_G8_SYNC_IN
 #undef VF_G8_SYNC_OUT
 #undef VF_G8_MMA
@@ -1144,7 +1157,15 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const unsigned short* __r
                 out_run += out_step;
             }
         }
+        G8_MARK()                                    // 3 .. 6: epilogue passes
     }
+#ifdef VF_G8_PROF
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    G8_MARK()                                        // 7: stores acknowledged
+    if (vf_g8_prof && lane == 0 && wave == 0 && (bid & 15) == 0)
+        for (int i = 0; i < 8; ++i) vf_g8_prof[(bid >> 4) * 8 + i] = g8t[i];
+#endif
+#undef G8_MARK
 }
 
 // ----------------------------------------------------------------------------------------------------------------------
