@@ -468,15 +468,18 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_mfma_kernel(const unsigned
             int64_t m = mw0 + im * 16 + r;
             m = m < M ? m : M - 1;
             const f32x2_t st = *reinterpret_cast<const f32x2_t*>(ln.row_stats + 2 * m);
-            ln_mu[LN == VF_LN_CONSUMER ? im : 0] = st[0];
+            ln_mu[LN == VF_LN_CONSUMER ? im : 0] = -st[0] * st[1];           // -mean * rstd
             ln_rs[LN == VF_LN_CONSUMER ? im : 0] = st[1];
         }
     }
+    // accumulator + bias, or the LayerNorm-consumer form  rstd * (acc - mean * colsum) + bias'  evaluated as
+    // acc * rstd + ((-mean * rstd) * colsum + bias'): two fused multiply-adds per element instead of sub, mul, mul, add (the
+    // same expression in every tile configuration: their results stay bit-identical)
     auto lnv = [&](int in, int im) -> f32x4_t {
         if (LN == VF_LN_CONSUMER)
-            return (acc[in][im] - ln_mu[LN == VF_LN_CONSUMER ? im : 0] * svec[LN == VF_LN_CONSUMER ? in : 0]) *
-                   ln_rs[LN == VF_LN_CONSUMER ? im : 0];
-        return acc[in][im];
+            return acc[in][im] * ln_rs[LN == VF_LN_CONSUMER ? im : 0] +
+                   (ln_mu[LN == VF_LN_CONSUMER ? im : 0] * svec[LN == VF_LN_CONSUMER ? in : 0] + bvec[in]);
+        return acc[in][im] + bvec[in];
     };
     char* const region = smem + wave * REGION;
 #pragma unroll
@@ -491,7 +494,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_mfma_kernel(const unsigned
                 if (EPI == VF_EPI_GEGLU_BF16) {
 #pragma unroll
                     for (int ip = 0; ip < TN / 2; ++ip) {
-                        const f32x4_t v = lnv(2 * ip, im) + bvec[2 * ip], gt = lnv(2 * ip + 1, im) + bvec[2 * ip + 1];
+                        const f32x4_t v = lnv(2 * ip, im), gt = lnv(2 * ip + 1, im);
                         u32x2_t pk;
                         const f32x4_t y = v * gelu_erf4(gt);
                         pk[0] = Op16<DT>::pack2(y[0], y[1]);
@@ -501,7 +504,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_mfma_kernel(const unsigned
                 } else {
 #pragma unroll
                     for (int in = 0; in < TN; ++in) {
-                        f32x4_t v = lnv(in, im) + bvec[in];
+                        f32x4_t v = lnv(in, im);
                         if (EPI == VF_EPI_GELU_F32 || EPI == VF_EPI_GELU_BF16) {
                             v = gelu_erf4(v);
                         }
@@ -1077,15 +1080,18 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const unsigned short* __r
 #pragma unroll
         for (int im = 0; im < TM; ++im) {
             const f32x2_t st = *reinterpret_cast<const f32x2_t*>(side + 2048 + (wm * WT_M + im * 16 + r) * 8);
-            ln_mu[LN == VF_LN_CONSUMER ? im : 0] = st[0];
+            ln_mu[LN == VF_LN_CONSUMER ? im : 0] = -st[0] * st[1];           // -mean * rstd
             ln_rs[LN == VF_LN_CONSUMER ? im : 0] = st[1];
         }
     }
+    // accumulator + bias, or the LayerNorm-consumer form  rstd * (acc - mean * colsum) + bias'  evaluated as
+    // acc * rstd + ((-mean * rstd) * colsum + bias'): two fused multiply-adds per element instead of sub, mul, mul, add (the
+    // same expression in every tile configuration: their results stay bit-identical)
     auto lnv = [&](int in, int im) -> f32x4_t {
         if (LN == VF_LN_CONSUMER)
-            return (acc[in][im] - ln_mu[LN == VF_LN_CONSUMER ? im : 0] * svec[LN == VF_LN_CONSUMER ? in : 0]) *
-                   ln_rs[LN == VF_LN_CONSUMER ? im : 0];
-        return acc[in][im];
+            return acc[in][im] * ln_rs[LN == VF_LN_CONSUMER ? im : 0] +
+                   (ln_mu[LN == VF_LN_CONSUMER ? im : 0] * svec[LN == VF_LN_CONSUMER ? in : 0] + bvec[in]);
+        return acc[in][im] + bvec[in];
     };
     char* const region = smem + wave * REGION;
 #pragma unroll
@@ -1099,7 +1105,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const unsigned short* __r
                 if (EPI == VF_EPI_GEGLU_BF16) {
 #pragma unroll
                     for (int ip = 0; ip < TN / 2; ++ip) {
-                        const f32x4_t v = lnv(2 * ip, im) + bvec[2 * ip], gt = lnv(2 * ip + 1, im) + bvec[2 * ip + 1];
+                        const f32x4_t v = lnv(2 * ip, im), gt = lnv(2 * ip + 1, im);
                         u32x2_t pk;
                         const f32x4_t y = v * gelu_erf4(gt);
                         pk[0] = Op16<DT>::pack2(y[0], y[1]);
@@ -1109,7 +1115,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const unsigned short* __r
                 } else {
 #pragma unroll
                     for (int in = 0; in < TN; ++in) {
-                        f32x4_t v = lnv(in, im) + bvec[in];
+                        f32x4_t v = lnv(in, im);
                         if (EPI == VF_EPI_GELU_F32 || EPI == VF_EPI_GELU_BF16) {
                             v = gelu_erf4(v);
                         }
@@ -1480,9 +1486,9 @@ __global__ __launch_bounds__(512, 2) void gemm8x_kernel(const unsigned short* __
         }
         // (mean, rstd) of a row group are read from the side area when its accumulators are staged: 2 live registers
         // instead of 16 (the persistent loop has none to spare)
-        auto lnv = [&](int in, int im, f32x2_t st) -> f32x4_t {
-            if (LN == VF_LN_CONSUMER) return (acc[in][im] - st[0] * svec[LN == VF_LN_CONSUMER ? in : 0]) * st[1];
-            return acc[in][im];
+        auto lnv = [&](int in, int im, f32x2_t st) -> f32x4_t {          // st = (-mean * rstd, rstd); see gemm8_kernel
+            if (LN == VF_LN_CONSUMER) return acc[in][im] * st[1] + (st[0] * svec[LN == VF_LN_CONSUMER ? in : 0] + bvec[in]);
+            return acc[in][im] + bvec[in];
         };
         char* const region = stage_buf + wave * REGION;
 #pragma unroll
@@ -1494,11 +1500,14 @@ __global__ __launch_bounds__(512, 2) void gemm8x_kernel(const unsigned short* __
                 if (im < TM) {
                     char* rowp = region + (iml * 16 + r) * PITCH;
                     f32x2_t st = {0.f, 1.f};
-                    if (LN == VF_LN_CONSUMER) st = *reinterpret_cast<const f32x2_t*>(side + 2048 + (wm * WT_M + im * 16 + r) * 8);
+                    if (LN == VF_LN_CONSUMER) {
+                        st = *reinterpret_cast<const f32x2_t*>(side + 2048 + (wm * WT_M + im * 16 + r) * 8);
+                        st[0] = -st[0] * st[1];                                   // (-mean * rstd, rstd)
+                    }
                     if (EPI == VF_EPI_GEGLU_BF16) {
 #pragma unroll
                         for (int ip = 0; ip < TN / 2; ++ip) {
-                            const f32x4_t v = lnv(2 * ip, im, st) + bvec[2 * ip], gt = lnv(2 * ip + 1, im, st) + bvec[2 * ip + 1];
+                            const f32x4_t v = lnv(2 * ip, im, st), gt = lnv(2 * ip + 1, im, st);
                             u32x2_t pk;
                             const f32x4_t y = v * gelu_erf4(gt);
                             pk[0] = Op16<DT>::pack2(y[0], y[1]);
@@ -1508,7 +1517,7 @@ __global__ __launch_bounds__(512, 2) void gemm8x_kernel(const unsigned short* __
                     } else {
 #pragma unroll
                         for (int in = 0; in < TN; ++in) {
-                            f32x4_t v = lnv(in, im, st) + bvec[in];
+                            f32x4_t v = lnv(in, im, st);
                             if (EPI == VF_EPI_GELU_F32 || EPI == VF_EPI_GELU_BF16) {
                                 v = gelu_erf4(v);
                             }
@@ -1990,7 +1999,7 @@ __global__ __launch_bounds__(512, 2) void xs_gemm_kernel(const unsigned short* _
     float mu = 0.f, rs = 1.f;
     if (LN == VF_LN_CONSUMER) {
         const f32x2_t st = *reinterpret_cast<const f32x2_t*>(ln.row_stats + 2 * row_c);
-        mu = st[0];
+        mu = -st[0] * st[1];                 // -mean * rstd (the two-FMA form of the tile kernels: bit-identical results)
         rs = st[1];
     }
 
@@ -2101,7 +2110,7 @@ __global__ __launch_bounds__(512, 2) void xs_gemm_kernel(const unsigned short* _
                 const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(side + col);
                 if (LN == VF_LN_CONSUMER) {
                     const f32x4_t c4 = *reinterpret_cast<const f32x4_t*>(side + N + col);
-                    v = (v - mu * c4) * rs + b4;
+                    v = v * rs + (mu * c4 + b4);
                 } else {
                     v += b4;
                 }
