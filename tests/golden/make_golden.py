@@ -76,7 +76,13 @@ class _MHA(nn.Module):
                                  persistent=False)
 
     def _attend(self, q, k, v):
-        # q [sq,H,dh], k,v [sk,H,dh]
+        # q [sq,H,dh], k,v [sk,H,dh]; flash-attn's contract for 16-bit inputs: fp32 scores / softmax / accumulation, output in
+        # the input dtype (a no-op for the fp32 fixtures; used by the precision="32" fixture, whose MHA modules run in fp16)
+        odt = q.dtype
+        q, k, v = q.float(), k.float(), v.float()
+        return self._attend32(q, k, v).to(odt)
+
+    def _attend32(self, q, k, v):
         s = torch.einsum("qhd,khd->hqk", q, k) / math.sqrt(self.head_dim)
         if self.use_alibi:
             sq, sk = q.shape[0], k.shape[0]
@@ -231,7 +237,8 @@ def build_reference_model(fx):
     fill_state_dict(model, fx["seed"])
     model.eval()
     model.vep = False
-    model.trainer = types.SimpleNamespace(precision="bf16-mixed")   # cast-free fp32 branch, no autocast
+    # "bf16-mixed": the cast-free fp32 branch (no autocast on CPU); "32": MHA modules in fp16, the rest fp32
+    model.trainer = types.SimpleNamespace(precision=fx.get("precision", "bf16-mixed"))
     return model
 
 
@@ -249,6 +256,9 @@ FIXTURES["small_opts_b"] = dict(_with("small_alibi", add_context_to_cres=True, g
 # per-tissue small MLP heads; context-free CRE layers with one shared linear head
 FIXTURES["small_opts_c"] = dict(_with("small_sin", multi_head=True, use_bigger_head=False), seed=606)
 FIXTURES["small_opts_d"] = dict(_with("small_alibi", use_context=False, head_type="linear", use_bigger_head=False), seed=707)
+# trainer.precision = "32" (reference utils/functions.py:28-30 -> torch.float32 -> layers.py:98-126: the MHA modules are cast
+# to fp16 for their forward -- weights included, in place -- and everything else stays fp32)
+FIXTURES["small_sin_p32"] = dict(FIXTURES["small_sin"], seed=111, precision="32")
 FIXTURES["small_twomod"] = dict(FIXTURES["small_sin"], seed=303, model_class="Seq2GenePredictor",
                                 n_cres=[6, 3], n_chunks=[2, 4], tissues=[[62, 7], [20, 33, 59]])
 # the older class with ITS constructor defaults' gene layers (only_cross_attention=True, reference layers.py:753) and ALiBi on the
@@ -312,7 +322,7 @@ def run_fixture(name, fx):
     sd = model.state_dict()
     inv = {k: list(v.shape) for k, v in sd.items()}
     chk = float(sum(float(v.double().abs().sum()) for v in sd.values() if torch.is_floating_point(v)))
-    meta = dict(name=name, seed=fx["seed"], seq2reg=fx["seq2reg"], seq2gene=fx["seq2gene"],
+    meta = dict(name=name, seed=fx["seed"], seq2reg=fx["seq2reg"], seq2gene=fx["seq2gene"], precision=fx.get("precision", "bf16-mixed"),
                 model_class=fx.get("model_class", "Seq2GenePredictorCombinedModulator"),
                 n_cres=fx["n_cres"], n_chunks=fx["n_chunks"], tissues=fx["tissues"],
                 token_length=fx["token_length"], cre_len_range=list(fx["cre_len_range"]),

@@ -423,6 +423,23 @@ def test_fp16_operand_mode_vs_oracle_and_reference_golden(golden):
     assert np.array_equal(again["pred_gene_exp"][0], bf["pred_gene_exp"][0])     # weight repack follows the precision
 
 
+def test_precision_32_mode_vs_reference_fixture():
+    """trainer.precision = "32" on the HIP path (fp16 operands for every GEMM) against the reference's own precision-"32" run
+    (MHA modules in fp16, everything else fp32: tests/golden/small_sin_p32.*): expression inside the north-star bar with a
+    wide margin, embeddings at fp16 level."""
+    import types
+    meta, arrays, sd, batch = load_fixture("small_sin_p32")
+    model = build_model(meta["seq2reg"], meta["seq2gene"], sd).cuda()
+    model.trainer = types.SimpleNamespace(precision="32")
+    assert model.operand_dtype() == torch.float16
+    out = model.predict_step(batch, 0)
+    for i in range(len(meta["n_cres"])):
+        assert prel(out["pred_gene_exp"][i], arrays[f"pred_gene_exp_{i}"]) < 2e-4
+        assert _rel(out["embeddings"][i], arrays[f"embeddings_{i}"]) < 2e-3
+    check_signal("precision 32 vs the reference's precision-32 run", out["pred_gene_exp"],
+                 [arrays[f"pred_gene_exp_{i}"] for i in range(len(meta["n_cres"]))])
+
+
 def test_fp16_operand_mode_production_width_vs_oracle():
     kw = seq2gene_kw(layers=3)
     model = build_model(SEQ2REG_512, kw, seed=4242)
