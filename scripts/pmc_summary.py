@@ -12,13 +12,17 @@ for f in glob.glob("gpurun_out/%s_fetch/**/*counter_collection.csv" % tag, recur
                ("attn_kernels" if "attn_" in name else ("layernorm_kernel" if "layernorm" in name else None)))
         if key is None:
             continue
+        keys = [key]
+        if key == "attn_kernels":          # also one entry per attention kernel instantiation (name up to the argument list)
+            keys.append(name.replace("void (anonymous namespace)::", "").split("(")[0])
         d = (f, r["Dispatch_Id"])
-        if r["Counter_Name"] == "FETCH_SIZE":
-            acc[key]["fetch_kib"] += float(r["Counter_Value"])
-            if d not in seen: acc[key]["launches_f"] += 1
-        elif r["Counter_Name"] == "WRITE_SIZE":
-            acc[key]["write_kib"] += float(r["Counter_Value"])
-            if d not in seen: acc[key]["launches_w"] += 1
+        for key in keys:
+            if r["Counter_Name"] == "FETCH_SIZE":
+                acc[key]["fetch_kib"] += float(r["Counter_Value"])
+                if d not in seen: acc[key]["launches_f"] += 1
+            elif r["Counter_Name"] == "WRITE_SIZE":
+                acc[key]["write_kib"] += float(r["Counter_Value"])
+                if d not in seen: acc[key]["launches_w"] += 1
         seen.add(d)
 res = {}
 for k, v in acc.items():
