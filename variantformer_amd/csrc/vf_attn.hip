@@ -986,11 +986,13 @@ __global__ __launch_bounds__(256, (QG >= 2 ? 2 : 4)) void attn_short_kernel(Attn
 // which has the bandwidth), and the LDS image holds only the rows the tiles read -- keys rounded up to the tail tile's 16 /
 // 32 / 64 for K and to 32 / 64 for V (201 keys: 208 K rows + 224 V rows = 47 KB) -- so three blocks fit: a third block's loads
 // and a second computing wave per SIMD.  Arithmetic per query: attn_tile's, identical to every other kernel.
-template <int DH, bool ALIBI, int DT = VF_BF16, bool QL = false>
+// NPASS = 1: sequences of <= 128 queries (seq2reg windows at dh = 64: one block per (window, head) instead of two 64-query
+// blocks of the tiled kernel that each fetch K / V and wait for it).
+template <int DH, bool ALIBI, int DT = VF_BF16, bool QL = false, int NPASS = 2>
 __global__ __launch_bounds__(256, 3) void attn_short2_kernel(AttnParams P, int k_rows) {
     constexpr int SM = QL ? 2 : 0;
     using frag_t = typename Op16<DT>::frag;
-    constexpr int CPR = DH / 8, NDT = DH / 16, QG = 2, NPASS = 2;
+    constexpr int CPR = DH / 8, NDT = DH / 16, QG = 2;
     constexpr int VROW = VLayout<DH>::ROW;
     constexpr int K_ROW_BYTES = KLayout<DH>::ROW, KS = KLayout<DH>::KS;
     static_assert(K_ROW_BYTES == 128, "the short-sequence kernel is written for dh <= 64");
@@ -1185,12 +1187,12 @@ static inline void short2_rows(int max_k, int& kr, int& vr) {
     vr = tl * BKV + (rem <= 32 ? 32 : BKV);
 }
 
-template <int DH, bool ALIBI, int DT, bool QL>
+template <int DH, bool ALIBI, int DT, bool QL, int NPASS>
 int launch_short2_k(AttnParams P, int n_seq, int max_k, hipStream_t st) {
     int kr, vr;
     short2_rows(max_k, kr, vr);
     const int lds = kr * KLayout<DH>::ROW + vr * VLayout<DH>::ROW;
-    auto kern = attn_short2_kernel<DH, ALIBI, DT, QL>;
+    auto kern = attn_short2_kernel<DH, ALIBI, DT, QL, NPASS>;
     static bool attr_set[VF_MAX_DEVICES] = {};
     const int dev = vf_current_device();
     if (dev < 0 || !attr_set[dev]) {
@@ -1208,10 +1210,10 @@ int launch_short2_k(AttnParams P, int n_seq, int max_k, hipStream_t st) {
     return VF_OK;
 }
 
-template <int DH, bool ALIBI, int DT>
+template <int DH, bool ALIBI, int DT, int NPASS = 2>
 int launch_short2(AttnParams P, int n_seq, int max_k, hipStream_t st) {
-    if (P.q_log2) return launch_short2_k<DH, ALIBI, DT, true>(P, n_seq, max_k, st);
-    return launch_short2_k<DH, ALIBI, DT, false>(P, n_seq, max_k, st);
+    if (P.q_log2) return launch_short2_k<DH, ALIBI, DT, true, NPASS>(P, n_seq, max_k, st);
+    return launch_short2_k<DH, ALIBI, DT, false, NPASS>(P, n_seq, max_k, st);
 }
 
 template <int DH, int QG, bool ALIBI, int DT>
@@ -1259,6 +1261,17 @@ int launch_attn(AttnParams P, int n_seq, int max_q, int max_k, hipStream_t st) {
                 return launch_short2<DH, ALIBI, DT>(P, n_seq, max_k, st);
             if (max_q <= 192) return launch_short<DH, 3, ALIBI, DT>(P, n_seq, max_k, st);
             return launch_short<DH, 4, ALIBI, DT>(P, n_seq, max_k, st);
+        }
+    }
+    if constexpr (DH == 64) {
+        // seq2reg windows (<= 128 tokens at dh = 64: a 36 KB image): one block per (window, head) with the whole K / V in
+        // LDS instead of two 64-query blocks that each fetch K / V and wait for it (VF_ATTN_SHORT64=0: the tiled kernel)
+        static const int short64 = getenv("VF_ATTN_SHORT64") ? atoi(getenv("VF_ATTN_SHORT64")) : 1;
+        if (short64 && max_q <= 128 && max_k <= 128 && (long)n_seq * P.H >= 1024) {
+            int kr, vr;
+            short2_rows(max_k, kr, vr);
+            if (3 * (kr * KLayout<DH>::ROW + vr * VLayout<DH>::ROW) <= 160 * 1024)
+                return launch_short2<DH, ALIBI, DT, 1>(P, n_seq, max_k, st);
         }
     }
     // long query streams: 2 query groups per wave (halves K/V LDS traffic per MFMA; for seq2reg windows, 70-200 queries,
