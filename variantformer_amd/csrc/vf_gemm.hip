@@ -1418,7 +1418,9 @@ __global__ __launch_bounds__(512, 2) void gemm8x_kernel(const unsigned short* __
         constexpr int RP_FIT = (((REGION / PITCH) < WT_M ? (REGION / PITCH) : WT_M) / 16) * 16;
         // fp32-residual epilogues: 16-row passes (two residual buffers of 16 registers; with 32-row passes the persistent
         // loop spills)
-        constexpr int RP = (EPI == VF_EPI_RES_F32 && RP_FIT > 16) ? 16 : RP_FIT;
+        // (a 16-bit residual, VF_LN_PRODUCER_R16, is half the registers: 32-row passes like the one-shot kernel)
+        constexpr bool R16 = LN == VF_LN_PRODUCER_R16;
+        constexpr int RP = (EPI == VF_EPI_RES_F32 && !R16 && RP_FIT > 16) ? 16 : RP_FIT;
         constexpr int IMP = RP / 16, NPASS = (TM + IMP - 1) / IMP;
         constexpr int CR = WT_NO * ES / 16, RI = 64 / CR, NI = RP / RI;
         static_assert(RP >= 16 && CR >= 1 && CR <= 64 && 64 % CR == 0, "epilogue geometry");
@@ -1435,9 +1437,14 @@ __global__ __launch_bounds__(512, 2) void gemm8x_kernel(const unsigned short* __
         const int rows_left = (int)(M - mw0) - ep_row;              // item j is a row of the matrix iff j * RI < rows_left
         const int64_t row0 = mw0 + ep_row;
         const int colc = ep_col < N ? ep_col : N - 4;
-        const float* const res_p = RES ? res + row0 * ldr + colc : nullptr;
-        const float* const res_last = RES ? res + (int64_t)(M - 1) * ldr + colc : nullptr;
-        const int64_t res_step = (int64_t)RI * ldr;
+        // the residual: fp32 rows, or (VF_LN_PRODUCER_R16) the 16-bit copy of a stream, converted where it is added
+        using res_t = typename std::conditional<R16, u32x2_t, f32x4_t>::type;
+        const char* const res_base = R16 ? reinterpret_cast<const char*>(ln.res16) : reinterpret_cast<const char*>(res);
+        const int64_t res_ld = R16 ? ln.ldr16 : ldr;
+        constexpr int RES_ES = R16 ? 2 : 4;
+        const char* const res_p = RES ? res_base + (row0 * res_ld + colc) * RES_ES : nullptr;
+        const char* const res_last = RES ? res_base + ((int64_t)(M - 1) * res_ld + colc) * RES_ES : nullptr;
+        const int64_t res_step = (int64_t)RI * res_ld * RES_ES;
         char* const out_p = reinterpret_cast<char*>(out) + (row0 * ldo + ep_col) * ES;
         const int64_t out_step = (int64_t)RI * ldo * ES;
         unsigned short* const o16_p = ln_is_producer(LN) ? reinterpret_cast<unsigned short*>(ln.out16) + row0 * ln.ld16 + ep_col : nullptr;
@@ -1445,22 +1452,29 @@ __global__ __launch_bounds__(512, 2) void gemm8x_kernel(const unsigned short* __
         float* const part_p = ln_is_producer(LN) ? ln.part_stats + ((int64_t)(ep_col >> 5) * ln.rows + row0) * 2 : nullptr;
         // the items are visited in increasing j, so each pointer is a running one: p += step per item (one 64-bit add)
         // instead of base + j * step (hipcc multiplies per item otherwise: 81 quarter-rate v_mad_u64_u32 in this epilogue)
-        const float* res_run = res_p;
+        const char* res_run = res_p;
         char* out_run = out_p;
         unsigned short* o16_run = o16_p;
         float* part_run = part_p;
-        f32x4_t rbuf[2][RES ? NI : 1];
-        auto load_res_pass = [&](int ps, f32x4_t (&dst)[RES ? NI : 1]) {
+        res_t rbuf[2][RES ? NI : 1];
+        auto load_res_pass = [&](int ps, res_t (&dst)[RES ? NI : 1]) {
             if (RES) {
 #pragma unroll
                 for (int k = 0; k < NI; ++k) {
                     const int j = ps * NI + k;
-                    const float* rp = (j * RI < rows_left) ? res_run : res_last;
+                    const char* rp = (j * RI < rows_left) ? res_run : res_last;
                     res_run += res_step;
-                    if (dbg & 8) { dst[RES ? k : 0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; continue; }
-                    dst[RES ? k : 0] = *reinterpret_cast<const f32x4_t*>(rp);
+                    if (dbg & 8) { dst[RES ? k : 0] = res_t{}; continue; }
+                    dst[RES ? k : 0] = *reinterpret_cast<const res_t*>(rp);
                 }
             }
+        };
+        auto res_value = [&](res_t v) -> f32x4_t {      // see gemm8_kernel
+            if constexpr (R16) {
+                if constexpr (DT == VF_F16) return cvt4_16<DT>(v) * ln.res16_scale;
+                else return cvt4_16<DT>(v);
+            }
+            else return v;
         };
         load_res_pass(0, rbuf[0]);
         // bias of the wave's columns, from the side area (requested before the first K-tile)
@@ -1550,7 +1564,7 @@ __global__ __launch_bounds__(512, 2) void gemm8x_kernel(const unsigned short* __
                     u32x4_t d = dd[k];
                     if (RES) {
                         f32x4_t f = __builtin_bit_cast(f32x4_t, d);
-                        f += rbuf[ps & 1][RES ? k0 + k : 0];
+                        f += res_value(rbuf[ps & 1][RES ? k0 + k : 0]);
                         d = __builtin_bit_cast(u32x4_t, f);
                     }
                     const bool ok = j * RI + ep_row < WT_M && j * RI < rows_left && ep_col < n_out_total;
@@ -2482,12 +2496,20 @@ static int launch_gemm_ln(const void* A, int64_t lda, const void* W, const float
         if (xs && xs_ok(N, K, EPI) && (xs >= 2 || M >= 256 * 256))
             return launch_xs<EPI, DT, LN>(A, lda, W, bias, out, ldo, M, N, st, ln);
     }
-    switch (pick_variant(M, N, K, EPI)) {
+    int variant = pick_variant(M, N, K, EPI);
+    if constexpr (LN == VF_LN_PRODUCER_R16) {
+        // A producer whose residual is a 16-bit stream copy fits the persistent form with the one-shot kernel's 32-row
+        // passes (half the residual registers of the fp32 one): first fill and block hand-over hidden, gene out-projection
+        // 428-439 -> 408-414 us, seq2reg out-projection 662-675 -> 621-636 us (profiles/r03_v_persist_r16_ab.log).
+        // VF_GEMM_PERSIST_R16 = 1 (default): when no fp32 rows are stored either (the attention out-projections),
+        // 2: every such producer, 0: never.
+        static const int pr16 = getenv("VF_GEMM_PERSIST_R16") ? atoi(getenv("VF_GEMM_PERSIST_R16")) : 1;
+        if (variant == 20 && K % 128 == 0 && (pr16 >= 2 || (pr16 == 1 && out == nullptr))) variant = 22;
+    }
+    switch (variant) {
         case 1: return launch_cfg<CfgA, EPI, DT, 0, LN>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, st, ln);
         case 5: return launch_cfg<CfgE, EPI, DT, 0, LN>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, st, ln);
-        case 22:
-            if constexpr (LN != VF_LN_PRODUCER_R16)      // (fp32 epilogues never take the persistent form by default)
-                return launch_gemm8x<EPI, DT, LN>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, st, ln);
+        case 22: return launch_gemm8x<EPI, DT, LN>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, st, ln);
         default: return launch_gemm8<EPI, DT, LN>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, st, ln);
     }
 }
