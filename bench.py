@@ -200,9 +200,13 @@ def timed_steps(step, steps: int, warmup: int, use_dist: bool, sync, dev):
     if use_dist:
         dist.barrier()
     sync()
+    n_alloc = (lambda: torch.cuda.memory_stats(dev)["num_device_alloc"]) if dev.type == "cuda" else (lambda: 0)
+    a0 = n_alloc()
     t0 = time.perf_counter()
+    marks = []
     for _ in range(steps):
         out = step()
+        marks.append(time.perf_counter())        # a step ends with the D2H of its result, so this is its completion time
     sync()
     if use_dist:
         dist.barrier()
@@ -212,6 +216,8 @@ def timed_steps(step, steps: int, warmup: int, use_dist: bool, sync, dev):
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    timed_steps.device_allocs = n_alloc() - a0     # hipMalloc calls of the caching allocator inside the timed region
+    timed_steps.last_step_ms = [round((b - a) * 1e3, 2) for a, b in zip([t0] + marks[:-1], marks)]   # this rank's steps
     return dt, out
 
 
@@ -438,7 +444,22 @@ def main():
                 expr = all_gather_expression(expr, owned, world * G)
             return expr.cpu(), emb                            # D2H of the expression matrix (sync point of a step)
 
+        # Set-up, before the contract's W warm-up steps: let torch's caching allocator reach its steady state.  It keeps
+        # adding multi-GiB segments for the first three passes (fragmentation: 37 GiB live, 61 GiB reserved at 32 genes),
+        # and one such hipMalloc costs 0 or ~220 ms at random (profiles/r03_y_bench_repeat.log: the first timed step of
+        # 2 runs in 6 with W = 2).  Local passes only (no collective), until a pass makes no device allocation.
+        n_alloc = lambda: torch.cuda.memory_stats(dev)["num_device_alloc"]      # noqa: E731
+        priming = 0
+        while priming < 6:
+            before = n_alloc()
+            step_local()[0].cpu()
+            priming += 1
+            if n_alloc() == before:
+                break
+
         dt, (expr, _) = timed_steps(step, args.steps, args.warmup, use_dist, torch.cuda.synchronize, dev)
+        each_step_ms = timed_steps.last_step_ms
+        allocs_in_timed_region = timed_steps.device_allocs
         assert torch.isfinite(expr).all() and tuple(expr.shape) == (world * G, len(tissues))
 
         roof = None
@@ -525,6 +546,8 @@ def main():
             "reference_executed_tflop_per_gene": round(executed_step / G / 1e12, 3),
             "achieved_algorithmic_tflops_whole_step": round(world * flops_step * args.steps / dt / 1e12, 1),
             "roofline": roof, "kernel_families": kernels, "source_sha": source_sha(),
+            "ms_of_each_timed_step_rank0": each_step_ms, "device_allocations_inside_timed_region": allocs_in_timed_region,
+            "allocator_priming_passes_before_warmup": priming,
         }
         if small is not None:
             out["batch_of_8"] = small

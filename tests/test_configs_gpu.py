@@ -107,6 +107,24 @@ def test_cfg3_256_ragged_genes_lpt_shards(full_model):
     print(f"[cfg3] LPT imbalance max/mean = {max(loads) / (sum(loads) / 8):.4f}; genes per rank {[len(o) for o in owned]}")
 
 
+def test_bench_step_of_32_headline_genes_equals_batches_of_8(full_model):
+    """bench.py's step: 32 headline-size genes (1024 cCRE windows, 200 gene chunks, 54 tissues) in ONE pass -- 3.1 M seq2reg
+    tokens, GEMM outputs of up to 4.7e9 elements (row offsets past 2^32 bytes) -- must give every gene the expression it
+    gets in a batch of 8 (the reference DataLoader's batch size; the size every other full-size test runs at)."""
+    from variantformer_amd.utils.synthetic import collate, make_gene
+    model, hp, kw, sd = full_model
+    genes = [make_gene(977 * 1000003 + g, 1024, 200, TISSUES_54, 200) for g in range(32)]
+    with torch.no_grad():
+        big = model.forward_prepared(model.prepare_batch(collate(genes)))[0].view(32, 54).float().cpu().numpy()
+        parts = [model.forward_prepared(model.prepare_batch(collate(genes[s:s + 8])))[0].view(8, 54).float().cpu().numpy()
+                 for s in range(0, 32, 8)]
+    small = np.concatenate(parts)
+    assert np.isfinite(big).all() and (big > 0).all()
+    np.testing.assert_allclose(big, small, rtol=1e-5, atol=1e-6)
+    assert len({tuple(r) for r in np.round(big, 5)}) == 32, "distinct genes must give distinct rows"
+    torch.cuda.empty_cache()
+
+
 def make_batch_by_gene(ids, n, c):
     """collate of the cfg-3 genes `ids`: gene g is always built from seed (20251205, g), whatever batch it lands in."""
     from variantformer_amd.utils.synthetic import collate, make_gene
