@@ -23,3 +23,8 @@ cp $(find $O/prof -name '*kernel_stats.csv' | head -1) $O/kernel_stats.csv 2>/de
 rm -rf gpurun_out/${TAG}_pmc_fetch gpurun_out/${TAG}_pmc_write gpurun_out/${TAG}_pmc_sq
 find $O -name '*kernel_trace.csv' -delete; find $O -name '*.db' -delete
 du -sh $O
+if [ "$2" != "--pmc-only" ]; then
+python bench.py --dtype fp16 --no-cpu-baseline --no-pipelined > $O/bench_fp16.json 2>> $O/bench.err
+python bench.py --workload cfg3 --steps 2 --warmup 1 > $O/bench_cfg3_1gpu.json 2>> $O/bench.err
+python scripts/shape_breakdown.py 32 > $O/shape_breakdown.txt 2>&1
+fi
