@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define VF_ABI_VERSION 4
+#define VF_ABI_VERSION 5
 
 enum vf_status {
     VF_OK = 0,
@@ -103,6 +103,17 @@ int vf_gemm_ln(const void* A, int64_t lda, const void* W, const float* bias, con
                int residual_dtype, void* out, int64_t ldo, int M, int N, int K, int epilogue, int operand_dtype,
                const float* row_stats, const float* colsum, void* out16, int64_t ld16, float* part_stats,
                float x16_scale, float res16_scale, void* stream);
+/* ABI 5 -- the layer trunk as a scaled fp16 copy.  A layer's output x_out = linear_geglu_2(h) + x_in
+ * (seq2gene/modules/layers.py:161-165, seq2reg/modules.py:186-190) travels to the next layer of its stack as
+ * t16 = fp16(x * t16_scale) [M, ldt16] -- 11 significant bits whatever the operand type (bf16 has 8), so the per-layer
+ * rounding of the trunk stays below the operand roundings -- instead of fp32 rows: this producer (epilogue VF_EPI_RES_F32
+ * with the LayerNorm-producer outputs out16 / part_stats as above) reads its residual as float(residual_f16) * res_scale
+ * and writes t16_out (NULL: not written -- the last layer of a stack, which passes `out` for its fp32 rows instead;
+ * out may be NULL otherwise).  6 instead of 10 bytes per element through the down-projection epilogue. */
+int vf_gemm_ln_t16(const void* A, int64_t lda, const void* W, const float* bias, const void* residual_f16, int64_t ldr,
+                   float res_scale, void* out, int64_t ldo, int M, int N, int K, int operand_dtype, void* out16,
+                   int64_t ld16, float* part_stats, float x16_scale, void* t16_out, int64_t ldt16, float t16_scale,
+                   void* stream);
 int vf_ln_finalize(const float* part_stats, int64_t rows, int n_parts, int D, float eps, float* row_stats, void* stream);
 /* ..2 forms: x16_scale as above; alert (optional, device int): set to 1 when some row has |mean| > ratio_limit standard
  * deviations -- the regime where rounding the UNCENTRED row to 16 bits costs the folded form accuracy; callers read it back

@@ -119,7 +119,9 @@ class Rounding:
     reference's autocast rounds it too (`x = linear_geglu_2(x)` is a 16-bit tensor there and `x += res_long` adds in
     place, layers.py:161-165, seq2reg/modules.py:186-190); the last layer of a stack keeps fp32.  False (default), "s2r"
     (the 6-layer seq2reg encoders only, whose output is mean-pooled over the window and rounded to 16 bits anyway) or
-    "all" / True (the 25 + 24 modulator layers too); layers.trunk16_enabled, VF_TRUNK16 = 0 | s2r | 1."""
+    "all" / True (the 25 + 24 modulator layers too); layers.trunk16_enabled, VF_TRUNK16 = 0 | s2r | 1.
+    "f16" (the default): no rounding of the stream itself; each layer's down-projection adds the scaled FP16 copy of its
+    input (`trunk` below) -- 11 significant bits, so the trunk's per-layer rounding stays below the operand roundings."""
 
     def __init__(self, mode: str | None, fold_ln: bool | None = None, res16: bool | None = None,
                  trunk16: bool | None = None, q_prescale: bool | None = None):
@@ -138,12 +140,25 @@ class Rounding:
         self.res16 = bool(res16) and self.fold_ln
         trunk16 = self._trunk16_arg
         if trunk16 is None:
-            trunk16 = os.environ.get("VF_TRUNK16", "0")
+            trunk16 = os.environ.get("VF_TRUNK16", "f16")
         if isinstance(trunk16, str):
-            trunk16 = {"0": False, "": False, "s2r": "s2r"}.get(trunk16, True)
+            trunk16 = {"0": False, "": False, "s2r": "s2r", "f16": "f16"}.get(trunk16, True)
         if trunk16 is True or trunk16 == 1:
             trunk16 = "all"
-        self.trunk16 = trunk16 if (trunk16 and self.res16) else False           # False | "s2r" | "all"
+        if trunk16 == "f16" and mode == "fp16":
+            trunk16 = "all"            # an fp16 operand copy already is the fp16 trunk (layers.trunk_f16_active)
+        if trunk16 == "f16" and mode is None:
+            trunk16 = False
+        self.trunk16 = trunk16 if (trunk16 and self.res16) else False           # False | "s2r" | "all" | "f16"
+
+    def trunk(self, src: torch.Tensor) -> torch.Tensor:
+        """The layer input as the residual of the layer's down-projection (x_out = linear_geglu_2(h) + src).  trunk16 ==
+        "f16" (the default of variantformer_amd, VF_TRUNK16): every layer of a LayerNorm-folded stack adds the scaled fp16
+        copy of its input, fp16(src * 2^-4) * 2^4 (layers.down_projection / vf_gemm_ln_t16) -- the 16-bit OPERAND copy and
+        the row statistics still come from the unrounded sum."""
+        if self.trunk16 == "f16" and src.shape[-1] % 64 == 0:
+            return (src * 0.0625).to(torch.float16).to(torch.float32) * 16.0
+        return src
 
     def res(self, x1: torch.Tensor) -> torch.Tensor:
         """x1 as the residual of the cross-attention out-projection (see `res16`)."""
@@ -310,7 +325,7 @@ def seq2reg_layer(x, cu, sd, pfx, hp: Seq2RegHP, slopes, rnd: Rounding, last=Fal
     a = mha_self(h, sd, pfx + "MHA.", hp.num_heads, cu, slopes, rnd)
     x1 = a + rnd.res(x)                                              # :179  x += res_short (16-bit copy: Rounding.res16)
     h = rnd.ln(x1, sd[pfx + "norm2.weight"], sd[pfx + "norm2.bias"])
-    return rnd.out(geglu_ffn(h, sd, pfx, rnd) + x, last, s2r=True)                  # :188  x += res_long (= layer input)
+    return rnd.out(geglu_ffn(h, sd, pfx, rnd) + rnd.trunk(x), last, s2r=True)                  # :188  x += res_long (= layer input)
 
 
 def seq2reg_context_layer(x, ctx, cu, sd, pfx, hp: Seq2RegHP, slopes, rnd: Rounding, last=False):
@@ -322,7 +337,7 @@ def seq2reg_context_layer(x, ctx, cu, sd, pfx, hp: Seq2RegHP, slopes, rnd: Round
     h = rnd.ln(x1, sd[pfx + "norm2.weight"], sd[pfx + "norm2.bias"])
     x2 = mha_cross(h, ctx, sd, pfx + "crossMHA.MHA.", hp.num_heads, cu, cu, rnd) + rnd.res(x1)
     h = rnd.ln(x2, sd[pfx + "norm3.weight"], sd[pfx + "norm3.bias"])
-    return rnd.out(geglu_ffn(h, sd, pfx, rnd) + x, last, s2r=True)
+    return rnd.out(geglu_ffn(h, sd, pfx, rnd) + rnd.trunk(x), last, s2r=True)
 
 
 def seq2reg_embed(ids, pad_mask, sd, pfx, hp: Seq2RegHP, rnd: Rounding, context=None):
@@ -421,7 +436,7 @@ def modulator_layer(src, ctx, cu_src, cu_ctx, sd, pfx, H, slopes, rnd: Rounding,
     h = rnd.ln(x1, sd[pfx + "norm2.weight"], sd[pfx + "norm2.bias"])
     x2 = mha_cross(h, ctx, sd, pfx + "crossMHA.MHA.", H, cu_src, cu_ctx, rnd, cross_slopes) + rnd.res(x1)
     h = rnd.ln(x2, sd[pfx + "norm3.weight"], sd[pfx + "norm3.bias"])
-    return rnd.out(geglu_ffn(h, sd, pfx, rnd) + src, last)
+    return rnd.out(geglu_ffn(h, sd, pfx, rnd) + rnd.trunk(src), last)
 
 
 def self_only_layer(src, cu_src, sd, pfx, H, slopes, rnd: Rounding, last=False):
@@ -430,7 +445,7 @@ def self_only_layer(src, cu_src, sd, pfx, H, slopes, rnd: Rounding, last=False):
     h = rnd.ln(src, sd[pfx + "norm1.weight"], sd[pfx + "norm1.bias"])
     x1 = mha_self(h, sd, pfx + "mixer.MHA.", H, cu_src, slopes, rnd) + rnd.res(src)
     h = rnd.ln(x1, sd[pfx + "norm2.weight"], sd[pfx + "norm2.bias"])
-    return rnd.out(geglu_ffn(h, sd, pfx, rnd) + src, last)
+    return rnd.out(geglu_ffn(h, sd, pfx, rnd) + rnd.trunk(src), last)
 
 
 def cre_layer(cre, ctx, cu_cre, sd, pfx, hp, slopes, rnd: Rounding, last=False):
@@ -446,7 +461,7 @@ def cross_only_layer(src, ctx, cu_src, cu_ctx, sd, pfx, H, rnd: Rounding, cross_
     h = rnd.ln(src, sd[pfx + "norm1.weight"], sd[pfx + "norm1.bias"])
     x1 = mha_cross(h, ctx, sd, pfx + "crossMHA.MHA.", H, cu_src, cu_ctx, rnd, cross_slopes) + rnd.res(src)
     h = rnd.ln(x1, sd[pfx + "norm2.weight"], sd[pfx + "norm2.bias"])
-    return rnd.out(geglu_ffn(h, sd, pfx, rnd) + src, last)
+    return rnd.out(geglu_ffn(h, sd, pfx, rnd) + rnd.trunk(src), last)
 
 
 def combined_modulator(cre_x, gene_x, ctx_labels, cu_cre, cu_gene, sd, pfx, hp: Seq2GeneHP, rnd: Rounding,
@@ -614,7 +629,7 @@ def _modulator_shared(cre_x, gene_x, labels, T, G, sd, hp: Seq2GeneHP, rnd: Roun
         x2 = mha_cross(h, kvsrc, sd, p + "crossMHA.MHA.", H, torch.tensor([0, T * G], dtype=torch.int32), cu_c, rnd) \
             + rnd.res(x1)
         h = rnd.ln(x2, sd[p + "norm3.weight"], sd[p + "norm3.bias"])
-        return rnd.out(geglu_ffn(h, sd, p, rnd) + src, last)
+        return rnd.out(geglu_ffn(h, sd, p, rnd) + rnd.trunk(src), last)
 
     nl = hp.num_layers
     cre, gene = cre_x, gene_x

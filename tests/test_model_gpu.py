@@ -498,6 +498,41 @@ def test_trunk16_option_vs_oracle_and_fp32(precision, scope, monkeypatch):
     check_signal(f"trunk16 {mode} vs oracle(trunk16)", out["pred_gene_exp"], orc["pred_gene_exp"])
 
 
+def test_fp16_trunk_copy_default_vs_fp32_trunk_and_oracle(monkeypatch):
+    """VF_TRUNK16=f16 (the default): between the layers of a stack the trunk exists as a scaled FP16 copy (11 significant
+    bits) that the next down-projection adds as its residual (vf_gemm_ln_t16), not as fp32 rows; VF_TRUNK16=0 keeps fp32
+    rows.  Production widths, 3 layers, ragged genes, bf16 operands: each mode within the north-star bar of the oracle
+    with ITS rounding points (Rounding(trunk16="f16" / False)) and of pure fp32 arithmetic, and the fp16 copy costs no
+    accuracy against fp32 that the operand roundings have not already spent (embedding error within 1.5x of the fp32
+    trunk's; the bf16 trunk of VF_TRUNK16=1 is ~4x, test above)."""
+    kw = seq2gene_kw(layers=3)
+    model = build_model(SEQ2REG_512, kw, seed=515)
+    sd = state_dict_cpu(model)
+    model = model.cuda()
+    batch = make_batch(31, [7, 40, 1], [3, 9, 2], [[7], TISSUES_54[:5], [62, 10]], 200)
+    hp = O.Seq2RegHP.from_hparams(SEQ2REG_512)
+    ghp = O.Seq2GeneHP.from_kwargs(kw)
+    f32 = O.predict_step(batch, sd, hp, hp, ghp, rounding=None, share_cre_stream=True)
+    outs, errs = {}, {}
+    for mode, trunk in (("0", False), ("f16", "f16")):
+        monkeypatch.setenv("VF_TRUNK16", mode)
+        out = outs[mode] = model.predict_step(batch, 0)
+        orc = O.predict_step(batch, sd, hp, hp, ghp, rounding=O.Rounding("bf16", trunk16=trunk), share_cre_stream=True)
+        for i in range(3):
+            assert prel(out["pred_gene_exp"][i], orc["pred_gene_exp"][i]) < NORTH_STAR_RTOL, (mode, i)
+            assert prel(out["pred_gene_exp"][i], f32["pred_gene_exp"][i]) < NORTH_STAR_RTOL, (mode, i)
+            assert _erel(out["embeddings"][i], orc["embeddings"][i]) < 3 * NORTH_STAR_RTOL, (mode, i)
+        errs[mode] = [_erel(out["embeddings"][i], f32["embeddings"][i]) for i in range(3)]
+        check_signal(f"trunk mode {mode} vs its oracle", out["pred_gene_exp"], orc["pred_gene_exp"])
+    monkeypatch.delenv("VF_TRUNK16")
+    dflt = model.predict_step(batch, 0)
+    for i in range(3):
+        assert np.array_equal(dflt["embeddings"][i], outs["f16"]["embeddings"][i]), "f16 must be the default mode"
+        assert not np.array_equal(outs["0"]["embeddings"][i], outs["f16"]["embeddings"][i])
+        print(f"[trunk] gene {i}: embedding vs pure fp32: fp32 trunk {errs['0'][i]:.2e}, fp16 copy {errs['f16'][i]:.2e}")
+    assert max(errs["f16"]) < 1.5 * max(errs["0"])
+
+
 def test_seq2reg_options_vs_reference_golden():
     """seq_pool max / linear, use_context (with and without expand_context), head dims 96 / 128 on the HIP path: vs the
     reference's own Seq2RegPredictor outputs (fp32 fixture) and vs the same-rounding oracle."""

@@ -854,6 +854,44 @@ def test_gemm_ln_producer_with_16bit_residual(ops, M, N, K, dtype):
         np.testing.assert_allclose(s.stats[:, 1].double().cpu().numpy(), (rstd / scale).cpu().numpy(), rtol=2e-5)
 
 
+@pytest.mark.parametrize("M,N,K", [(515, 1536, 1024), (10854, 1536, 1024), (16387, 1536, 1024), (40000, 512, 1024), (300, 128, 128)])
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_gemm_ln_producer_with_fp16_trunk(ops, M, N, K, dtype):
+    """vf_gemm_ln_t16 (every tile configuration): the layer trunk as a scaled fp16 copy whatever the operand type.
+    x = a @ w^T + b + float(t16_in) / T16_SCALE must be bit-identical to the plain fp32-residual GEMM fed with that value;
+    the operand-type copy and the statistics follow from x as in every producer; t16_out = fp16(x * T16_SCALE), round to
+    nearest even; need_x=False / need_t16=False drop only their stores."""
+    td = torch.bfloat16 if dtype == "bf16" else torch.float16
+    with ops.compute_dtype(td):
+        a = _rand((M, K), 361).to(td)
+        w = (_rand((N, K), 362, 1.0 / math.sqrt(K))).to(td)
+        b = _rand((N,), 363, 0.5)
+        res = (_rand((M, N), 364, 3.0) + 0.7) * (10.0 ** _rand((M, 1), 365, 1.5))     # rows over three decades
+        t_in = ops.trunk16_of(res.cuda())
+        assert t_in.dtype == torch.float16 and torch.equal(t_in, (res.cuda() * ops.T16_SCALE).half())
+        res_val = t_in.float() / ops.T16_SCALE                                       # what the kernel must add
+        s = ops.gemm_ln_producer(a.cuda(), w.cuda(), b.cuda(), None, trunk16=t_in, need_t16=True)
+        plain = ops.gemm(a.cuda(), w.cuda(), b.cuda(), ops.EPI_RES_F32, residual=res_val.contiguous())
+        torch.cuda.synchronize()
+        scale = ops.x16_scale_for(td)
+        assert torch.equal(s.x, plain)
+        assert torch.equal(s.x16, (s.x * scale).to(td))
+        assert s.t16.dtype == torch.float16 and torch.equal(s.t16, (s.x * ops.T16_SCALE).half())
+        t = ops.gemm_ln_producer(a.cuda(), w.cuda(), b.cuda(), None, need_x=False, trunk16=t_in, need_t16=True)
+        u = ops.gemm_ln_producer(a.cuda(), w.cuda(), b.cuda(), None, need_x=True, trunk16=t_in, need_t16=False)
+        torch.cuda.synchronize()
+        assert t.x is None and torch.equal(t.x16, s.x16) and torch.equal(t.stats, s.stats) and torch.equal(t.t16, s.t16)
+        assert u.t16 is None and torch.equal(u.x, s.x) and torch.equal(u.x16, s.x16) and torch.equal(u.stats, s.stats)
+        xd = s.x.double()
+        mean = xd.mean(dim=1)
+        rstd = 1.0 / torch.sqrt(xd.var(dim=1, unbiased=False) + 1e-5)
+        np.testing.assert_allclose(s.stats[:, 0].double().cpu().numpy(), (mean * scale).cpu().numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(s.stats[:, 1].double().cpu().numpy(), (rstd / scale).cpu().numpy(), rtol=2e-5)
+        rows = torch.tensor([0, M // 2, M - 1])
+        sr = ops.ln_stream_rows(t, rows.cuda())
+        assert torch.equal(sr.t16, s.t16[rows.cuda()])
+
+
 @pytest.mark.parametrize("M,N,K", [(515, 4608, 1536), (16387, 1536, 512), (10854, 2048, 1536)])
 def test_gemm_ln_fp16_consumer_matches_folded_oracle_and_unfolded_pair(ops, M, N, K):
     """The LayerNorm fold for fp16 operands (BASELINE configs[4]): the stream copy is fp16(x * 2^-4) and the statistics are

@@ -68,10 +68,18 @@ struct LnArgs {
     float res16_scale;        // VF_LN_PRODUCER_R16: residual = float(res16) * res16_scale (= 1 / x16_scale of that stream)
     const unsigned short* res16;   // VF_LN_PRODUCER_R16: the residual as the 16-bit copy of a stream [M][ldr16] instead of
     int64_t ldr16;                 // its fp32 rows (a stream that is otherwise only read through LayerNorm -> Linear)
+    unsigned short* t16_out;       // VF_LN_PRODUCER_T16: fp16(x * t16_scale) [M][ldt16], the trunk copy the NEXT layer's
+    int64_t ldt16;                 // down-projection reads as its residual (may be null: last layer of a stack)
+    float t16_scale;
 };
-// VF_LN_PRODUCER_R16 = producer whose residual is read from a 16-bit stream copy (EPI is VF_EPI_RES_F32; `res` unused)
-enum { VF_LN_NONE = 0, VF_LN_CONSUMER = 1, VF_LN_PRODUCER = 2, VF_LN_PRODUCER_R16 = 3 };
-constexpr bool ln_is_producer(int ln) { return ln == VF_LN_PRODUCER || ln == VF_LN_PRODUCER_R16; }
+// VF_LN_PRODUCER_R16 = producer whose residual is read from a 16-bit stream copy (EPI is VF_EPI_RES_F32; `res` unused).
+// VF_LN_PRODUCER_T16 = the same with the residual in FP16 WHATEVER THE OPERAND TYPE (value = float(half) * res16_scale): the
+// layer trunk (x_out = W2 . h + x_in) travels between the layers of a stack as a scaled fp16 copy -- 11 significant bits
+// against bf16's 8, so the per-layer rounding of the trunk stays below the operand roundings -- and
+// the producer writes that copy of its own output (t16_out) beside the operand-type copy and the statistics.
+enum { VF_LN_NONE = 0, VF_LN_CONSUMER = 1, VF_LN_PRODUCER = 2, VF_LN_PRODUCER_R16 = 3, VF_LN_PRODUCER_T16 = 4 };
+constexpr bool ln_is_producer(int ln) { return ln == VF_LN_PRODUCER || ln == VF_LN_PRODUCER_R16 || ln == VF_LN_PRODUCER_T16; }
+constexpr bool ln_res_is_16(int ln) { return ln == VF_LN_PRODUCER_R16 || ln == VF_LN_PRODUCER_T16; }
 
 // 4 consecutive 16-bit values (8 bytes) -> fp32
 template <int DT>
@@ -93,7 +101,8 @@ __device__ __forceinline__ float dpp_f32(float v) {
 // lane's 16-bit values and its part's (sum, M2 about the part mean) go
 template <int DT>
 __device__ __forceinline__ void ln_emit(f32x4_t f, bool valid, unsigned short* p16, float* ppart, int lane,
-                                        float x16_scale = 1.0f, bool st16 = true, bool stpart = true) {
+                                        float x16_scale = 1.0f, bool st16 = true, bool stpart = true,
+                                        unsigned short* pt16 = nullptr, float t16_scale = 1.0f) {
     // no masking of the sums: N % 32 == 0 (checked at launch), so the 8 lanes of a part are all inside the matrix or
     // all outside, and a row past M only ever feeds its own (never stored) part
     float s1 = (f[0] + f[1]) + (f[2] + f[3]);
@@ -113,6 +122,12 @@ __device__ __forceinline__ void ln_emit(f32x4_t f, bool valid, unsigned short* p
     s2 += dpp_f32<0x141>(s2);
     if (valid) {
         u32x2_t pk;
+        if (pt16) {                                       // VF_LN_PRODUCER_T16: the fp16 trunk copy (null pointer constant otherwise)
+            const f32x4_t t = f * t16_scale;
+            pk[0] = pack2h(t[0], t[1]);
+            pk[1] = pack2h(t[2], t[3]);
+            *reinterpret_cast<u32x2_t*>(pt16) = pk;
+        }
         if (DT == VF_F16) f *= x16_scale;                 // statistics above are those of the UNSCALED row
         pk[0] = Op16<DT>::pack2(f[0], f[1]);
         pk[1] = Op16<DT>::pack2(f[2], f[3]);
@@ -336,14 +351,15 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_mfma_kernel(const unsigned
     constexpr bool RES_PRE = (EPI == VF_EPI_RES_F32) && (TN * TM <= 16);
     // the residual: fp32 rows, or (VF_LN_PRODUCER_R16) the 16-bit copy of a stream -- 8 instead of 16 bytes per item,
     // converted (and unscaled) where it is added
-    constexpr bool R16 = LN == VF_LN_PRODUCER_R16;
+    constexpr bool R16 = ln_res_is_16(LN), T16 = LN == VF_LN_PRODUCER_T16;
     using res_t = typename std::conditional<R16, u32x2_t, f32x4_t>::type;
     auto res_load = [&](int64_t m, int col) -> res_t {
         if constexpr (R16) return *reinterpret_cast<const u32x2_t*>(ln.res16 + m * ln.ldr16 + col);
         else return *reinterpret_cast<const f32x4_t*>(res + m * ldr + col);
     };
     auto res_value = [&](res_t v) -> f32x4_t {
-        if constexpr (R16) {             // bf16 stream copies are never scaled (checked at launch): no multiply by 1.0 per element
+        if constexpr (T16) return cvt4_16<VF_F16>(v) * ln.res16_scale;
+        else if constexpr (R16) {        // bf16 stream copies are never scaled (checked at launch): no multiply by 1.0 per element
             if constexpr (DT == VF_F16) return cvt4_16<DT>(v) * ln.res16_scale;
             else return cvt4_16<DT>(v);
         }
@@ -544,7 +560,8 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_mfma_kernel(const unsigned
                 if (ln_is_producer(LN) && OUT_F32)
                     ln_emit<DT>(__builtin_bit_cast(f32x4_t, d), ok,
                                 reinterpret_cast<unsigned short*>(ln.out16) + m * ln.ld16 + ep_col,
-                                ln.part_stats + ((int64_t)(ep_col >> 5) * ln.rows + m) * 2, lane, ln.x16_scale);
+                                ln.part_stats + ((int64_t)(ep_col >> 5) * ln.rows + m) * 2, lane, ln.x16_scale, true, true,
+                                (T16 && ln.t16_out) ? ln.t16_out + m * ln.ldt16 + ep_col : nullptr, ln.t16_scale);
                 if (ok && (!ln_is_producer(LN) || out != nullptr))
                     *reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(out) + (m * ldo + ep_col) * ES) = d;
             }
@@ -1008,7 +1025,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const unsigned short* __r
     const int colc = ep_col < N ? ep_col : N - 4;
     // the residual: fp32 rows, or (VF_LN_PRODUCER_R16) the 16-bit copy of a stream: 8 instead of 16 bytes per item,
     // converted (and unscaled) where it is added.  Byte pointers so that both forms share the running-pointer scheme.
-    constexpr bool R16 = LN == VF_LN_PRODUCER_R16;
+    constexpr bool R16 = ln_res_is_16(LN), T16 = LN == VF_LN_PRODUCER_T16;
     using res_t = typename std::conditional<R16, u32x2_t, f32x4_t>::type;
     const char* const res_base = R16 ? reinterpret_cast<const char*>(ln.res16) : reinterpret_cast<const char*>(res);
     const int64_t res_ld = R16 ? ln.ldr16 : ldr;                // elements per residual row
@@ -1027,6 +1044,8 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const unsigned short* __r
     char* out_run = out_p;
     unsigned short* o16_run = o16_p;
     float* part_run = part_p;
+    unsigned short* t16_run = T16 ? ln.t16_out + row0 * ln.ldt16 + ep_col : nullptr;
+    const int64_t t16_step = (int64_t)RI * ln.ldt16;
     // VF_G8_RES_ALL (experiment, off): 16-bit residual rows of ALL passes requested up front (NPASS * NI items of 2 registers
     // = 64 of the registers the operand fragments no longer need) instead of one pass ahead.
     constexpr bool RES_ALL = R16 && RES && (VF_G8_RES_ALL != 0);
@@ -1045,7 +1064,8 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const unsigned short* __r
         }
     };
     auto res_value = [&](res_t v) -> f32x4_t {
-        if constexpr (R16) {             // bf16 stream copies are never scaled (checked at launch): no multiply by 1.0 per element
+        if constexpr (T16) return cvt4_16<VF_F16>(v) * ln.res16_scale;
+        else if constexpr (R16) {        // bf16 stream copies are never scaled (checked at launch): no multiply by 1.0 per element
             if constexpr (DT == VF_F16) return cvt4_16<DT>(v) * ln.res16_scale;
             else return cvt4_16<DT>(v);
         }
@@ -1153,9 +1173,11 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const unsigned short* __r
                 }
                 const bool ok = j * RI + ep_row < WT_M && j * RI < rows_left && ep_col < n_out_total;
                 if (ln_is_producer(LN) && OUT_F32) {
-                    ln_emit<DT>(__builtin_bit_cast(f32x4_t, d), ok, o16_run, part_run, lane, ln.x16_scale, !(dbg & 2), !(dbg & 4));
+                    ln_emit<DT>(__builtin_bit_cast(f32x4_t, d), ok, o16_run, part_run, lane, ln.x16_scale, !(dbg & 2), !(dbg & 4),
+                                (T16 && ln.t16_out) ? t16_run : nullptr, ln.t16_scale);
                     o16_run += o16_step;
                     part_run += RI * 2;
+                    if (T16) t16_run += t16_step;
                 }
                 // a LayerNorm producer whose fp32 result has no reader (only its 16-bit copy and statistics do) passes
                 // out = NULL: the 16-byte store -- 4 of the 10 bytes the epilogue moves per element -- is dropped
@@ -1419,7 +1441,7 @@ __global__ __launch_bounds__(512, 2) void gemm8x_kernel(const unsigned short* __
         // fp32-residual epilogues: 16-row passes (two residual buffers of 16 registers; with 32-row passes the persistent
         // loop spills)
         // (a 16-bit residual, VF_LN_PRODUCER_R16, is half the registers: 32-row passes like the one-shot kernel)
-        constexpr bool R16 = LN == VF_LN_PRODUCER_R16;
+        constexpr bool R16 = ln_res_is_16(LN), T16 = LN == VF_LN_PRODUCER_T16;
         constexpr int RP = (EPI == VF_EPI_RES_F32 && !R16 && RP_FIT > 16) ? 16 : RP_FIT;
         constexpr int IMP = RP / 16, NPASS = (TM + IMP - 1) / IMP;
         constexpr int CR = WT_NO * ES / 16, RI = 64 / CR, NI = RP / RI;
@@ -1456,6 +1478,8 @@ __global__ __launch_bounds__(512, 2) void gemm8x_kernel(const unsigned short* __
         char* out_run = out_p;
         unsigned short* o16_run = o16_p;
         float* part_run = part_p;
+        unsigned short* t16_run = T16 ? ln.t16_out + row0 * ln.ldt16 + ep_col : nullptr;
+        const int64_t t16_step = (int64_t)RI * ln.ldt16;
         res_t rbuf[2][RES ? NI : 1];
         auto load_res_pass = [&](int ps, res_t (&dst)[RES ? NI : 1]) {
             if (RES) {
@@ -1470,7 +1494,8 @@ __global__ __launch_bounds__(512, 2) void gemm8x_kernel(const unsigned short* __
             }
         };
         auto res_value = [&](res_t v) -> f32x4_t {      // see gemm8_kernel
-            if constexpr (R16) {
+            if constexpr (T16) return cvt4_16<VF_F16>(v) * ln.res16_scale;
+            else if constexpr (R16) {
                 if constexpr (DT == VF_F16) return cvt4_16<DT>(v) * ln.res16_scale;
                 else return cvt4_16<DT>(v);
             }
@@ -1569,9 +1594,11 @@ __global__ __launch_bounds__(512, 2) void gemm8x_kernel(const unsigned short* __
                     }
                     const bool ok = j * RI + ep_row < WT_M && j * RI < rows_left && ep_col < n_out_total;
                     if (ln_is_producer(LN) && OUT_F32) {
-                        ln_emit<DT>(__builtin_bit_cast(f32x4_t, d), ok, o16_run, part_run, lane, ln.x16_scale, !(dbg & 2), !(dbg & 4));
+                        ln_emit<DT>(__builtin_bit_cast(f32x4_t, d), ok, o16_run, part_run, lane, ln.x16_scale, !(dbg & 2), !(dbg & 4),
+                                    (T16 && ln.t16_out) ? t16_run : nullptr, ln.t16_scale);
                         o16_run += o16_step;
                         part_run += RI * 2;
+                        if (T16) t16_run += t16_step;
                     }
                     // a LayerNorm producer whose fp32 result has no reader (only its 16-bit copy and statistics do) passes
                     // out = NULL: the 16-byte store -- 4 of the 10 bytes the epilogue moves per element -- is dropped
@@ -2497,6 +2524,11 @@ static int launch_gemm_ln(const void* A, int64_t lda, const void* W, const float
             return launch_xs<EPI, DT, LN>(A, lda, W, bias, out, ldo, M, N, st, ln);
     }
     int variant = pick_variant(M, N, K, EPI);
+    if constexpr (LN == VF_LN_PRODUCER_T16) {
+        // the fp16-trunk down-projection: persistent form when no fp32 rows are stored (VF_GEMM_PERSIST_T16, default on: gene down-projection 829 -> 857, seq2reg 858 -> 897 TFLOP/s)
+        static const int pt16 = getenv("VF_GEMM_PERSIST_T16") ? atoi(getenv("VF_GEMM_PERSIST_T16")) : 1;
+        if (variant == 20 && K % 128 == 0 && pt16 && out == nullptr) variant = 22;
+    }
     if constexpr (LN == VF_LN_PRODUCER_R16) {
         // A producer whose residual is a 16-bit stream copy fits the persistent form with the one-shot kernel's 32-row
         // passes (half the residual registers of the fp32 one): first fill and block hand-over hidden, gene out-projection
@@ -2518,7 +2550,8 @@ template <int DT>
 static int gemm_ln_dispatch(const void* A, int64_t lda, const void* W, const float* bias, const void* residual, int64_t ldr,
                             int residual_dtype, void* out, int64_t ldo, int M, int N, int K, int epilogue,
                             const float* row_stats, const float* colsum, void* out16, int64_t ld16, float* part_stats,
-                            float x16_scale, float res16_scale, void* stream) {
+                            float x16_scale, float res16_scale, void* stream, bool trunk = false, void* t16_out = nullptr,
+                            int64_t ldt16 = 0, float t16_scale = 1.0f) {
     VF_REQUIRE(A && W && (out || (out16 && part_stats)), "vf_gemm_ln: null pointer");
     VF_REQUIRE(M >= 0 && N > 0 && K > 0 && K % 64 == 0 && N % 8 == 0, "vf_gemm_ln: needs K %% 64 == 0, N %% 8 == 0 (N=%d K=%d)", N, K);
     VF_REQUIRE(lda % 8 == 0 && lda >= K, "vf_gemm_ln: lda=%lld must be >= K and a multiple of 8", (long long)lda);
@@ -2558,6 +2591,20 @@ static int gemm_ln_dispatch(const void* A, int64_t lda, const void* W, const flo
         VF_REQUIRE(ldr % 4 == 0 && ((uintptr_t)residual % 16 == 0), "vf_gemm_ln: misaligned fp32 residual");
         return launch_gemm_ln<VF_EPI_RES_F32, DT, VF_LN_PRODUCER>(A, lda, W, bias, (const float*)residual, ldr, out, ldo, M, N, K, ln, st);
     }
+    if (trunk) {
+        // the layer trunk as a scaled fp16 copy, whatever the operand type (VF_LN_PRODUCER_T16)
+        VF_REQUIRE(residual_dtype == VF_F16, "vf_gemm_ln_t16: the trunk residual is fp16");
+        VF_REQUIRE(ldr % 4 == 0 && ((uintptr_t)residual % 8 == 0) && res16_scale > 0.f, "vf_gemm_ln_t16: misaligned fp16 residual");
+        VF_REQUIRE(!t16_out || (ldt16 % 4 == 0 && ldt16 >= N && ((uintptr_t)t16_out % 8 == 0) && t16_scale > 0.f),
+                   "vf_gemm_ln_t16: the fp16 trunk output must keep 8-byte alignment (ldt16=%lld)", (long long)ldt16);
+        ln.res16 = (const unsigned short*)residual;
+        ln.ldr16 = ldr;
+        ln.res16_scale = res16_scale;
+        ln.t16_out = (unsigned short*)t16_out;
+        ln.ldt16 = ldt16;
+        ln.t16_scale = t16_scale;
+        return launch_gemm_ln<VF_EPI_RES_F32, DT, VF_LN_PRODUCER_T16>(A, lda, W, bias, (const float*)residual, ldr, out, ldo, M, N, K, ln, st);
+    }
     VF_REQUIRE(residual_dtype == DT, "vf_gemm_ln: a 16-bit residual must have the operand type");
     VF_REQUIRE(ldr % 4 == 0 && ((uintptr_t)residual % 8 == 0) && res16_scale > 0.f, "vf_gemm_ln: misaligned 16-bit residual");
     VF_REQUIRE(DT == VF_F16 || res16_scale == 1.0f, "vf_gemm_ln: res16_scale must be 1 for bf16 streams");
@@ -2578,6 +2625,20 @@ extern "C" int vf_gemm_ln(const void* A, int64_t lda, const void* W, const float
     VF_REQUIRE(operand_dtype == VF_F16, "vf_gemm_ln: operand_dtype must be VF_BF16 or VF_F16");
     return gemm_ln_dispatch<VF_F16>(A, lda, W, bias, residual, ldr, residual_dtype, out, ldo, M, N, K, epilogue, row_stats,
                                     colsum, out16, ld16, part_stats, x16_scale, res16_scale, stream);
+}
+
+extern "C" int vf_gemm_ln_t16(const void* A, int64_t lda, const void* W, const float* bias, const void* residual_f16,
+                              int64_t ldr, float res_scale, void* out, int64_t ldo, int M, int N, int K, int operand_dtype,
+                              void* out16, int64_t ld16, float* part_stats, float x16_scale, void* t16_out, int64_t ldt16,
+                              float t16_scale, void* stream) {
+    VF_REQUIRE(residual_f16, "vf_gemm_ln_t16: null residual");
+    if (operand_dtype == VF_BF16)
+        return gemm_ln_dispatch<VF_BF16>(A, lda, W, bias, residual_f16, ldr, VF_F16, out, ldo, M, N, K, VF_EPI_RES_F32, nullptr,
+                                         nullptr, out16, ld16, part_stats, x16_scale, res_scale, stream, true, t16_out, ldt16,
+                                         t16_scale);
+    VF_REQUIRE(operand_dtype == VF_F16, "vf_gemm_ln_t16: operand_dtype must be VF_BF16 or VF_F16");
+    return gemm_ln_dispatch<VF_F16>(A, lda, W, bias, residual_f16, ldr, VF_F16, out, ldo, M, N, K, VF_EPI_RES_F32, nullptr, nullptr,
+                                    out16, ld16, part_stats, x16_scale, res_scale, stream, true, t16_out, ldt16, t16_scale);
 }
 
 extern "C" int vf_gemm_ln_bf16(const void* A, int64_t lda, const void* W, const float* bias, const float* residual,

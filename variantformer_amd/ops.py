@@ -183,10 +183,13 @@ class LnStream:
     reader), x16 its 16-bit copy -- for fp16 streams stored SCALED, x16 = fp16(x * scale) --, stats fp32 [M, 2] =
     (mean * scale, rstd / scale) of every row: exactly the pair the consumer GEMM applies to its accumulator of the
     scaled operand (vf_gemm_ln / vf_ln_finalize2 / vf_row_stats_cast2).  scale = 1 for bf16 streams."""
-    __slots__ = ("x", "x16", "stats", "scale")
+    __slots__ = ("x", "x16", "stats", "scale", "t16")
 
-    def __init__(self, x, x16, stats, scale: float = 1.0):
+    def __init__(self, x, x16, stats, scale: float = 1.0, t16=None):
         self.x, self.x16, self.stats, self.scale = x, x16, stats, float(scale)
+        # fp16 trunk copy fp16(x * T16_SCALE) (layers.trunk16_mode() == "f16"): what the NEXT layer's down-projection adds
+        # as its residual when the fp32 rows are not stored (vf_gemm_ln_t16)
+        self.t16 = t16
 
     def operand16(self):
         """The stream as a plain 16-bit GEMM operand (un-normalised use: the K/V projection of a cross attention):
@@ -253,7 +256,30 @@ def ln_stream(x: torch.Tensor, eps: float = 1e-5) -> LnStream:
 def ln_stream_rows(s: LnStream, rows: torch.Tensor) -> LnStream:
     """The rows `rows` (int64) of a stream, statistics included (bit-identical to the full stream's)."""
     return LnStream(None if s.x is None else gather_rows_f32(s.x, None, rows), gather_rows_bf16(s.x16, rows),
-                    gather_rows_f32(s.stats, None, rows), s.scale)
+                    gather_rows_f32(s.stats, None, rows), s.scale,
+                    None if s.t16 is None else gather_rows_bf16(s.t16, rows))
+
+
+T16_SCALE = 2.0 ** -4          # the fp16 trunk copy is fp16(x * 2^-4): |x| < 1e6 representable (x16_scale_for(fp16))
+
+
+def trunk16_of(x: torch.Tensor) -> torch.Tensor:
+    """fp16(x * T16_SCALE) of an fp32 stream no trunk-writing GEMM produced (a stack's input): one pass
+    (vf_row_stats_cast2 with an fp16 output; its statistics are not used)."""
+    _dev(x)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 2
+    M, D = x.shape
+    t16 = torch.empty((M, D), dtype=torch.float16, device=x.device)
+    stats = torch.empty((M, 2), dtype=torch.float32, device=x.device)
+
+    def launch():
+        check(_lib.load().vf_row_stats_cast2(x.data_ptr(), M, D, 1e-5, t16.data_ptr(), VF_F16, T16_SCALE, 0.0, 0,
+                                             stats.data_ptr(), _stream()), "vf_row_stats_cast")
+    if TIMER is not None:
+        TIMER.time("layernorm", 0.0, float(M) * D * 6, launch, f"trunk16_of D={D}", _SCOPE)
+    else:
+        launch()
+    return t16
 
 
 def gemm_ln_consumer(s: LnStream, w: torch.Tensor, bias: torch.Tensor, colsum: torch.Tensor, epilogue: int,
@@ -282,11 +308,18 @@ def gemm_ln_consumer(s: LnStream, w: torch.Tensor, bias: torch.Tensor, colsum: t
 
 
 def gemm_ln_producer(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None, residual,
-                     eps: float = 1e-5, family: str = "", need_x: bool = True) -> LnStream:
+                     eps: float = 1e-5, family: str = "", need_x: bool = True, trunk16: torch.Tensor | None = None,
+                     need_t16: bool = False) -> LnStream:
     """x = a @ w^T + bias (+ residual), fp32, returned together with its 16-bit copy and row statistics (the next
     LayerNorm's): EPI_RES_F32 when a residual is given, else EPI_F32.  `residual`: an fp32 tensor [M, N], or an LnStream
     whose 16-BIT COPY is the residual (its fp32 rows need not exist).  need_x=False: the fp32 x itself has no reader (a
-    layer's intermediate stream feeds only the next LayerNorm -> Linear pair) and is not stored; .x is None."""
+    layer's intermediate stream feeds only the next LayerNorm -> Linear pair) and is not stored; .x is None.
+    `trunk16` (instead of `residual`): the residual as the fp16 trunk copy fp16(r * T16_SCALE) of the layer input
+    (vf_gemm_ln_t16); need_t16: also write that copy of the result (.t16) for the next layer."""
+    if trunk16 is not None:
+        assert residual is None
+        return _gemm_ln_producer_t16(a, w, bias, trunk16, eps, family, need_x, need_t16)
+    assert not need_t16
     res16 = residual if isinstance(residual, LnStream) else None
     res32 = None if res16 is not None else residual
     _dev(a, w, bias, res32, None if res16 is None else res16.x16)
@@ -330,6 +363,42 @@ def gemm_ln_producer(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None
         launch()
         finalize()
     return LnStream(out, x16, stats, scale)
+
+
+def _gemm_ln_producer_t16(a, w, bias, t_in, eps, family, need_x, need_t16) -> LnStream:
+    _dev(a, w, bias, t_in)
+    assert _is16(a.dtype) and w.dtype == a.dtype and a.shape[1] == w.shape[1] and a.stride(1) == 1
+    M, K = a.shape
+    N = w.shape[0]
+    assert t_in.dtype == torch.float16 and t_in.shape == (M, N) and t_in.stride(1) == 1
+    out = torch.empty((M, N), dtype=torch.float32, device=a.device) if need_x else None
+    t_out = torch.empty((M, N), dtype=torch.float16, device=a.device) if need_t16 else None
+    x16 = torch.empty((M, N), dtype=a.dtype, device=a.device)
+    n_parts = (N + 31) // 32
+    part = torch.empty((n_parts, M, 2), dtype=torch.float32, device=a.device)
+    stats = torch.empty((M, 2), dtype=torch.float32, device=a.device)
+    scale = x16_scale_for(a.dtype)
+    alert = _alert_flag(a.device)
+    lib = _lib.load()
+
+    def launch():
+        check(lib.vf_gemm_ln_t16(a.data_ptr(), a.stride(0) if M > 1 else max(a.stride(0), K), w.data_ptr(), _ptr(bias),
+                                 t_in.data_ptr(), t_in.stride(0), 1.0 / T16_SCALE, _ptr(out), N, M, N, K, _dt(a.dtype),
+                                 x16.data_ptr(), N, part.data_ptr(), scale, _ptr(t_out), N, T16_SCALE, _stream()),
+              "vf_gemm_ln_t16")
+
+    def finalize():
+        check(lib.vf_ln_finalize2(part.data_ptr(), M, n_parts, N, eps, scale, LN_FOLD_RATIO_LIMIT, alert.data_ptr(),
+                                  stats.data_ptr(), _stream()), "vf_ln_finalize")
+    if TIMER is not None:
+        nbytes = 2.0 * (M * K + N * K) + M * N * ((4.0 if need_x else 0.0) + (2.0 if need_t16 else 0.0) + 2.0 + 2.0) + 8.0 * M * n_parts
+        tag = "producer" + ("" if need_x else "-nox") + "-t16" + ("" if need_t16 else "-in")
+        TIMER.time("gemm", 2.0 * M * N * K, nbytes, launch, f"M={M} N={N} K={K} epi={EPI_RES_F32} ln={tag}", family or _SCOPE)
+        TIMER.time("layernorm", 0.0, 8.0 * M * (n_parts + 1), finalize, f"finalize D={N}", _SCOPE)
+    else:
+        launch()
+        finalize()
+    return LnStream(out, x16, stats, scale, t_out)
 
 
 def pack_geglu_rows(w: torch.Tensor, bias: torch.Tensor | None):

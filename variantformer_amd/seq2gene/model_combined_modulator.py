@@ -165,7 +165,7 @@ def modulator_forward_packed(ctx_embedding, cre_layers, gene_layers, cre_x, gene
                                                    keep_x=not t16 or i == n - 2)
                 done = torch.cuda.Event()
                 done.record(side)
-            for t in ((cre.x, cre.x16, cre.stats) if isinstance(cre, ops.LnStream) else (cre,)):
+            for t in ((cre.x, cre.x16, cre.stats, cre.t16) if isinstance(cre, ops.LnStream) else (cre,)):
                 if t is not None:
                     t.record_stream(main)               # allocated on `side`, read by the gene layer on `main`
             main.wait_event(done)

@@ -148,10 +148,36 @@ def trunk16_enabled(stack: str = "modulator") -> bool:
     without margin, and a same-rounding oracle no longer tracks the kernels (one-ulp flips of the trunk persist).
     DESIGN.md section 6 (round 3) has the measurements; oracle.Rounding(trunk16="s2r" | "all") restates the rounding
     points."""
-    import os
-    mode = os.environ.get("VF_TRUNK16", "0")
+    mode = trunk16_mode()
     on = mode not in ("0", "") and (stack == "seq2reg" or mode != "s2r")
     return on and res16_enabled()
+
+
+def trunk16_mode() -> str:
+    """VF_TRUNK16: "f16" (default) -- the trunk travels between the layers of a stack as a scaled FP16 copy whatever the
+    operand type (down_projection below; with fp16 operands that is the operand-type copy itself, i.e. mode "1");
+    "0" -- fp32 rows; "s2r" / "1" -- the operand-type (bf16) copy in the seq2reg encoders / everywhere (trunk16_enabled)."""
+    import os
+    return os.environ.get("VF_TRUNK16", "f16")
+
+
+def trunk_f16_active() -> bool:
+    """The fp16 trunk copy is in use: mode "f16", 16-bit residual exchange on, bf16 operands (an fp16 operand copy already
+    IS the fp16 trunk: trunk16_enabled's plain 16-bit path serves it)."""
+    return trunk16_mode() == "f16" and res16_enabled() and ops.cdt() == torch.bfloat16
+
+
+def down_projection(hg, w2, b2, s, keep_x: bool = True, need_t16: bool | None = None):
+    """The layer's output stream x = linear_geglu_2(hg) + (layer input s) with its 16-bit copy and row statistics
+    (LayerNorm fold).  The residual is, in this order: the fp16 trunk copy of the layer input (trunk_f16_active: taken
+    from the stream, or made from its fp32 rows for the first layer of a stack -- EVERY layer of a folded stack then adds
+    fp16(x_in * 2^-4) * 2^4, oracle.Rounding.trunk), its fp32 rows, or its operand-type copy (trunk16 modes "s2r" / "1").
+    keep_x: store the fp32 rows (the last layer of a stack); otherwise the next layer reads the copies only."""
+    if trunk_f16_active():
+        t = s.t16 if s.t16 is not None else ops.trunk16_of(s.x)
+        return ops.gemm_ln_producer(hg, w2, b2, None, need_x=keep_x, trunk16=t,
+                                    need_t16=(not keep_x) if need_t16 is None else need_t16)
+    return ops.gemm_ln_producer(hg, w2, b2, _ffn_residual(s), need_x=keep_x)
 
 
 def q_prescale_enabled() -> bool:
@@ -443,7 +469,7 @@ class ContextFlashAttentionEncoderLayer(nn.Module):
             w1, b1, c1 = packed_linear_ln(self.linear_geglu_1, self.norm3, geglu=True)
             hg = ops.gemm_ln_consumer(x2, w1, b1, c1, ops.EPI_GEGLU_BF16)
             w2, b2 = packed_linear(self.linear_geglu_2)
-            return ops.gemm_ln_producer(hg, w2, b2, _ffn_residual(s), need_x=keep_x)
+            return down_projection(hg, w2, b2, s, keep_x)
         src, context = _as_tensor(src), _as_tensor(context)
         h = ops.layernorm(src, self.norm1.weight, self.norm1.bias)
         x1 = self.mixer.MHA.fused(h, src, cu_src, max_src)
@@ -485,8 +511,8 @@ class ContextFlashAttentionEncoderLayer(nn.Module):
             w1, b1, c1 = packed_linear_ln(self.linear_geglu_1, self.norm3, geglu=True)
             hg = ops.gemm_ln_consumer(x2, w1, b1, c1, ops.EPI_GEGLU_BF16)
             w2, b2 = packed_linear(self.linear_geglu_2)
-            if sr.x is None:                 # 16-bit trunk: the registry rows' residual is their 16-bit copy
-                return ops.gemm_ln_producer(hg, w2, b2, sr).x
+            if sr.x is None or trunk_f16_active():     # 16-bit trunk: the registry rows' residual is their trunk copy
+                return down_projection(hg, w2, b2, sr, keep_x=True, need_t16=False).x
             return ops.gemm(hg, w2, b2, ops.EPI_RES_F32, residual=sr.x)
         ctx16 = context.operand16() if isinstance(context, ops.LnStream) else None
         src, context = _as_tensor(src), _as_tensor(context)
@@ -570,7 +596,7 @@ class FlashAttentionEncoderLayer(nn.Module):
             w1, b1, c1 = packed_linear_ln(self.linear_geglu_1, self.norm2, geglu=True)
             hg = ops.gemm_ln_consumer(x1, w1, b1, c1, ops.EPI_GEGLU_BF16)
             w2, b2 = packed_linear(self.linear_geglu_2)
-            return ops.gemm_ln_producer(hg, w2, b2, _ffn_residual(s), need_x=keep_x)
+            return down_projection(hg, w2, b2, s, keep_x)
         src = _as_tensor(src)
         h = ops.layernorm(src, self.norm1.weight, self.norm1.bias)
         x1 = self.mixer.MHA.fused(h, src, cu_src, max_src)
@@ -614,7 +640,7 @@ class ContextFlashCrossAttentionEncoderLayer(nn.Module):
             w1, b1, c1 = packed_linear_ln(self.linear_geglu_1, self.norm2, geglu=True)
             hg = ops.gemm_ln_consumer(x1, w1, b1, c1, ops.EPI_GEGLU_BF16)
             w2, b2 = packed_linear(self.linear_geglu_2)
-            return ops.gemm_ln_producer(hg, w2, b2, _ffn_residual(s), need_x=keep_x)
+            return down_projection(hg, w2, b2, s, keep_x)
         src, context = _as_tensor(src), _as_tensor(context)
         h = ops.layernorm(src, self.norm1.weight, self.norm1.bias)
         if context_kv is None:

@@ -30,8 +30,8 @@ class FlashTransformerLayer(nn.Module):
         """src: fp32 [tokens, d] or an ops.LnStream; returns the same kind (an LnStream when LayerNorm is folded into
         the GEMMs, see seq2gene.modules.layers.ln_fold_enabled; a plain tensor from the `last` layer).  keep_x=False: the
         result's fp32 rows have no reader (16-bit trunk, layers.trunk16_enabled) and are not stored."""
-        from ..seq2gene.modules.layers import (_as_stream, _as_tensor, _ffn_residual, ln_fold_enabled, packed_linear_ln,
-                                               res16_enabled)
+        from ..seq2gene.modules.layers import (_as_stream, _as_tensor, down_projection, ln_fold_enabled, packed_linear_ln,
+                                               res16_enabled, trunk_f16_active)
         if ln_fold_enabled(self.norm1.weight.numel(), self.linear_geglu_2.in_features):
             s = _as_stream(src)
             a = self.MHA.attend_ln(s, self.norm1, None, cu, max_seqlen, None, None)
@@ -41,11 +41,11 @@ class FlashTransformerLayer(nn.Module):
             hg = ops.gemm_ln_consumer(x1, w1, b1, c1, ops.EPI_GEGLU_BF16)
             w2, b2 = packed_linear(self.linear_geglu_2)
             if last:        # the encoder's last layer feeds the pooling, not a LayerNorm: plain fp32 result
-                if s.x is None:                  # 16-bit trunk: the layer input exists as its 16-bit copy only
-                    return ops.gemm_ln_producer(hg, w2, b2, s).x
+                if s.x is None or trunk_f16_active():    # 16-bit trunk: the layer input exists as its trunk copy only
+                    return down_projection(hg, w2, b2, s, keep_x=True, need_t16=False).x
                 return ops.gemm(hg, w2, b2, ops.EPI_RES_F32, residual=s.x)
-            # 16-bit trunk (layers.trunk16_enabled): the next layer reads the 16-bit copy + statistics only
-            return ops.gemm_ln_producer(hg, w2, b2, _ffn_residual(s), need_x=keep_x)
+            # 16-bit trunk (layers.trunk16_enabled): the next layer reads the 16-bit copies + statistics only
+            return down_projection(hg, w2, b2, s, keep_x)
         src = _as_tensor(src)
         h = ops.layernorm(src, self.norm1.weight, self.norm1.bias)
         x1 = self.MHA.fused(h, src, cu, max_seqlen)
