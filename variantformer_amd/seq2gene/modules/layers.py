@@ -133,21 +133,22 @@ def res16_enabled() -> bool:
 
 
 def trunk16_enabled(stack: str = "modulator") -> bool:
-    """A layer's OUTPUT (the trunk: W2.h + layer input) travels to the next layer of its stack in 16 bits only: the
-    down-projection epilogue reads the layer input from the 16-bit stream copy and writes the 16-bit copy + row
-    statistics of the sum, no fp32 rows in either direction (4 instead of 10 bytes per element; the kernel the attention
-    out-projections already use).  This is where the reference's own autocast rounds: `x = linear_geglu_2(x)` is a
-    16-bit tensor there and `x += res_long` adds in place (layers.py:161-165, seq2reg/modules.py:186-190), so every
-    layer hands a 16-bit stream to the next one.  The LAST layer of a stack (its output is pooled / returned, not fed to
-    a LayerNorm -> Linear pair) keeps its fp32 result.  Needs the LayerNorm fold and res16.
-    OFF by default.  VF_TRUNK16 = s2r: the seq2reg encoders only (`stack="seq2reg"`: 6 layers whose output is mean-pooled
-    over the window and rounded to 16 bits anyway) -- 1.2 % off the step; at production widths the outputs' distance from
-    pure fp32 arithmetic does not move, but on the small reference fixtures the expression error grows from 2.0e-2 to
-    3.1e-2 of the across-tissue spread (tests' signal-relative bound: 3e-2).  = 1: the modulator stacks too -- 3.2 % off
-    the step, but over 25 + 24 layers the expression's distance from fp32 grows from 3.4e-4 to 8.8e-4, inside the 1e-3 bar
-    without margin, and a same-rounding oracle no longer tracks the kernels (one-ulp flips of the trunk persist).
-    DESIGN.md section 6 (round 3) has the measurements; oracle.Rounding(trunk16="s2r" | "all") restates the rounding
-    points."""
+    """A layer's OUTPUT (the trunk: W2.h + layer input) travels to the next layer of its stack as 16-bit copies + row
+    statistics only, no fp32 rows in either direction; the LAST layer of a stack (its output is pooled / returned, not fed
+    to a LayerNorm -> Linear pair) keeps its fp32 result.  Needs the LayerNorm fold and res16.  VF_TRUNK16 selects what the
+    next down-projection adds as its residual (trunk16_mode):
+      f16 (default)  a scaled FP16 copy of the trunk written beside the operand-type copy (down_projection,
+                     vf_gemm_ln_t16): 6 instead of 10 bytes per element through the epilogue, 11 significant bits -- the
+                     embeddings' distance from pure fp32 arithmetic stays at the fp32 trunk's (3.3e-3 vs 3.4e-3 on a
+                     full-depth gene; the bf16 copy: 1.3e-2), step +1 %;
+      1 / s2r        the operand-type (bf16) copy itself, everywhere / in the seq2reg encoders only: 4 bytes per element,
+                     where the reference's own autocast rounds (`x = linear_geglu_2(x)` is a 16-bit tensor there and
+                     `x += res_long` adds in place, layers.py:161-165, seq2reg/modules.py:186-190) -- 3.2 % / 1.2 % off the
+                     step, but over 25 + 24 layers the expression's distance from fp32 grows from 3.4e-4 to 8.8e-4, inside
+                     the 1e-3 bar without margin, and a same-rounding oracle no longer tracks the kernels (one-ulp flips of
+                     the trunk persist);
+      0              fp32 rows.
+    DESIGN.md section 6 (round 3) has the measurements; oracle.Rounding(trunk16=...) restates the rounding points."""
     mode = trunk16_mode()
     on = mode not in ("0", "") and (stack == "seq2reg" or mode != "s2r")
     return on and res16_enabled()
