@@ -202,6 +202,14 @@ int vf_layernorm(const float* x, const float* gamma, const float* beta, void* ou
 int vf_embed_pack(const int64_t* ids, const uint8_t* pad, const int32_t* cu,
                   const float* table, const float* pos_table, float* out,
                   int W, int L, int d, int vocab, void* stream);
+/* The same rows as a LayerNorm-fold stream (ABI 5): out16 = 16-bit(x * x16_scale) [n_tokens, d] in out_dtype, row_stats
+ * [n_tokens, 2] = (mean * x16_scale, rstd / x16_scale) exactly as vf_row_stats_cast2 would compute them from vf_embed_pack's
+ * rows, t16 (optional) = fp16(x * t16_scale) the trunk copy of vf_gemm_ln_t16, out (optional) the fp32 rows.  Fuses
+ * token_embedding + position_encoding (seq2reg/model.py:203-221) with the first layer's LayerNorm statistics: the fp32
+ * rows of the encoder input never reach HBM.  d <= 2048. */
+int vf_embed_stream(const int64_t* ids, const uint8_t* pad, const int32_t* cu, const float* table, const float* pos_table,
+                    float* out, void* out16, int out_dtype, float x16_scale, void* t16, float t16_scale, float* row_stats,
+                    float eps, float ratio_limit, int* alert, int W, int L, int d, int vocab, void* stream);
 
 /* Per-window valid-token count and exclusive prefix sum: cu[0]=0, cu[w+1]=cu[w]+#valid(w).
  * Replaces the cu_seqlens half of unpad_input [3p].  Single-block scan; W <= 2^24. */

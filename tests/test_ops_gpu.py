@@ -525,6 +525,38 @@ def test_embed_pack_and_cu_seqlens_bit_exact(ops):
     assert torch.equal(out_nopos.cpu(), table[ids][keep])
 
 
+@pytest.mark.parametrize("d,dtype", [(512, "bf16"), (128, "bf16"), (1536, "bf16"), (512, "fp16")])
+def test_embed_stream_equals_embed_pack_then_stream_passes(ops, d, dtype):
+    """vf_embed_stream (embedding + positional table -> 16-bit operand copy, fp16 trunk copy, row statistics, no fp32 rows)
+    against the three kernels it replaces -- vf_embed_pack, vf_row_stats_cast2, the fp16 trunk cast: bit-identical copies and
+    statistics (same lane / column mapping, same reduction order); ragged, arbitrary (non-suffix) masks, an empty window."""
+    td = torch.bfloat16 if dtype == "bf16" else torch.float16
+    W, L, V = 41, 200, 500
+    g = torch.Generator().manual_seed(17)
+    ids = torch.randint(0, V, (W, L), generator=g)
+    pad = torch.rand((W, L), generator=g) < 0.4
+    pad[0] = True
+    pad[0, 7] = False
+    pad[1] = False
+    pad[2] = True
+    table = _rand((V, d), 18, 2.0)
+    pos = _rand((L, d), 19)
+    with ops.compute_dtype(td):
+        cu = ops.mask_to_cu_seqlens(pad.cuda())
+        n = int(cu[-1])
+        for p in (pos.cuda(), None):
+            x = ops.embed_pack(ids.cuda(), pad.cuda(), cu, table.cuda(), p, n)
+            want = ops.ln_stream(x)
+            t_want = ops.trunk16_of(x)
+            got = ops.embed_stream(ids.cuda(), pad.cuda(), cu, table.cuda(), p, n, need_x=True, need_t16=True)
+            lean = ops.embed_stream(ids.cuda(), pad.cuda(), cu, table.cuda(), p, n, need_x=False, need_t16=False)
+            torch.cuda.synchronize()
+            assert got.scale == want.scale and torch.equal(got.x, x)
+            assert got.x16.dtype == td and torch.equal(got.x16, want.x16) and torch.equal(got.stats, want.stats)
+            assert torch.equal(got.t16, t_want)
+            assert lean.x is None and lean.t16 is None and torch.equal(lean.x16, want.x16) and torch.equal(lean.stats, want.stats)
+
+
 def test_mask_to_cu_seqlens_many_windows(ops):
     W, L = 5000, 40
     pad = torch.rand((W, L), generator=torch.Generator().manual_seed(1)) < 0.5

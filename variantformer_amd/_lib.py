@@ -41,6 +41,7 @@ SIGNATURES = {
     "vf_attn_varlen_fwd_qstart_f16": [_p, _p, _p, _p, _l, _l, _l, _l, _p, _p, _i, _i, _i, _i, _i, _p, _f, _p],
     "vf_attn_varlen_fwd_v2": [_p, _p, _p, _p, _l, _l, _l, _l, _p, _p, _i, _i, _i, _i, _i, _p, _f, _i, _i, _p],
     "vf_layernorm": [_p, _p, _p, _p, _l, _i, _f, _i, _i, _p],
+    "vf_embed_stream": [_p, _p, _p, _p, _p, _p, _p, _i, _f, _p, _f, _p, _f, _f, _p, _i, _i, _i, _i, _p],
     "vf_embed_pack": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "vf_mask_to_cu_seqlens": [_p, _p, _i, _i, _p],
     "vf_segment_mean": [_p, _p, _p, _i, _i, _i, _p],

@@ -261,6 +261,91 @@ __global__ __launch_bounds__(256) void embed_pack_kernel(const int64_t* __restri
     }
 }
 
+// The same embedding, handed to the first encoder layer as the LayerNorm-folding GEMMs exchange a stream: per valid token
+// row x = table[id] + pos_table[pos] never reaches HBM as fp32 (unless `out` is given) -- the kernel writes its 16-bit
+// operand copy, its scaled fp16 trunk copy and its (mean, rstd), with exactly the arithmetic of embed_pack_kernel followed
+// by row_stats_cast_kernel (one wave per row, lane i owns the float4 columns i, i + 64, ...).
+template <int MAXC>
+__global__ __launch_bounds__(256) void embed_stream_kernel(const int64_t* __restrict__ ids, const uint8_t* __restrict__ pad,
+                                                          const int32_t* __restrict__ cu, const float* __restrict__ table,
+                                                          const float* __restrict__ pos_table, float* __restrict__ out,
+                                                          void* __restrict__ out16, unsigned short* __restrict__ t16,
+                                                          float* __restrict__ row_stats, int L, int d, int vocab, float eps,
+                                                          int out_dt, float x16_scale, float t16_scale, float ratio_limit,
+                                                          int* __restrict__ alert) {
+    extern __shared__ int sh[];          // [L] position of the k-th valid token, [L] its token id
+    int* vpos = sh;
+    int* vid = sh + L;
+    __shared__ int nvalid_s;
+    const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid < 64) {                      // wave 0 compacts the valid positions in order (as embed_pack_kernel)
+        int base = 0;
+        for (int p0 = 0; p0 < L; p0 += 64) {
+            const int p = p0 + tid;
+            const bool valid = p < L && pad[(int64_t)w * L + p] == 0;
+            const unsigned long long bal = __ballot(valid);
+            if (valid) {
+                const int rank = __popcll(bal & ((1ull << tid) - 1ull));
+                long long id = ids[(int64_t)w * L + p];
+                id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+                vpos[base + rank] = p;
+                vid[base + rank] = (int)id;
+            }
+            base += __popcll(bal);
+        }
+        if (tid == 0) nvalid_s = base;
+    }
+    __syncthreads();
+    const int nvalid = nvalid_s;
+    const int64_t row0 = cu[w];
+    const int n4 = d >> 2;
+    for (int k = wv; k < nvalid; k += 4) {
+        const f32x4_t* er = reinterpret_cast<const f32x4_t*>(table + (int64_t)vid[k] * d);
+        const f32x4_t* pr = pos_table ? reinterpret_cast<const f32x4_t*>(pos_table + (int64_t)vpos[k] * d) : nullptr;
+        const int64_t row = row0 + k;
+        f32x4_t v[MAXC];
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int i = lane + 64 * c;
+            v[c] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            if (i < n4) {
+                v[c] = er[i];
+                if (pr) v[c] += pr[i];
+            }
+            s += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
+        }
+        const float mean = wave_sum(s) / (float)d;
+        float ss = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int i = lane + 64 * c;
+            if (i < n4) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float dd = v[c][e] - mean;
+                    ss += dd * dd;
+                }
+                u32x2_t p;
+                p[0] = pack2_dt(v[c][0] * x16_scale, v[c][1] * x16_scale, out_dt);
+                p[1] = pack2_dt(v[c][2] * x16_scale, v[c][3] * x16_scale, out_dt);
+                reinterpret_cast<u32x2_t*>(reinterpret_cast<unsigned short*>(out16) + row * d)[i] = p;
+                if (t16) {
+                    p[0] = pack2_dt(v[c][0] * t16_scale, v[c][1] * t16_scale, VF_F16);
+                    p[1] = pack2_dt(v[c][2] * t16_scale, v[c][3] * t16_scale, VF_F16);
+                    reinterpret_cast<u32x2_t*>(t16 + row * d)[i] = p;
+                }
+                if (out) reinterpret_cast<f32x4_t*>(out + row * d)[i] = v[c];
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(ss) / (float)d + eps);
+        if (lane == 0) {
+            *reinterpret_cast<f32x2_t*>(row_stats + 2 * row) = (f32x2_t){mean * x16_scale, rstd / x16_scale};
+            if (alert && fabsf(mean) * rstd > ratio_limit) *alert = 1;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // segment mean (masked mean pool): one block per window, threads over float4 columns
 // ---------------------------------------------------------------------------------------------
@@ -543,6 +628,26 @@ extern "C" int vf_embed_pack(const int64_t* ids, const uint8_t* pad, const int32
     hipLaunchKernelGGL(embed_pack_kernel, dim3(W), dim3(256), 2 * L * sizeof(int), (hipStream_t)stream, ids, pad, cu,
                        table, pos_table, out, L, d, vocab);
     VF_CHECK_LAUNCH("vf_embed_pack");
+    return VF_OK;
+}
+
+extern "C" int vf_embed_stream(const int64_t* ids, const uint8_t* pad, const int32_t* cu, const float* table,
+                               const float* pos_table, float* out, void* out16, int out_dtype, float x16_scale, void* t16,
+                               float t16_scale, float* row_stats, float eps, float ratio_limit, int* alert, int W, int L,
+                               int d, int vocab, void* stream) {
+    VF_REQUIRE(ids && pad && cu && table && out16 && row_stats, "vf_embed_stream: null pointer");
+    VF_REQUIRE(L > 0 && L <= 4096 && d > 0 && d % 4 == 0 && d <= 2048 && vocab > 0, "vf_embed_stream: bad shape L=%d d=%d vocab=%d", L, d, vocab);
+    VF_REQUIRE(out_dtype == VF_BF16 || out_dtype == VF_F16, "vf_embed_stream: bad out_dtype %d", out_dtype);
+    VF_REQUIRE(x16_scale > 0.f && t16_scale > 0.f, "vf_embed_stream: scales must be positive");
+    if (W <= 0) return VF_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (d <= 512)
+        hipLaunchKernelGGL(embed_stream_kernel<2>, dim3(W), dim3(256), 2 * L * sizeof(int), st, ids, pad, cu, table, pos_table, out,
+                           out16, (unsigned short*)t16, row_stats, L, d, vocab, eps, out_dtype, x16_scale, t16_scale, ratio_limit, alert);
+    else
+        hipLaunchKernelGGL(embed_stream_kernel<8>, dim3(W), dim3(256), 2 * L * sizeof(int), st, ids, pad, cu, table, pos_table, out,
+                           out16, (unsigned short*)t16, row_stats, L, d, vocab, eps, out_dtype, x16_scale, t16_scale, ratio_limit, alert);
+    VF_CHECK_LAUNCH("vf_embed_stream");
     return VF_OK;
 }
 

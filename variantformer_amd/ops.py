@@ -498,6 +498,38 @@ def embed_pack(ids: torch.Tensor, pad: torch.Tensor, cu: torch.Tensor, table: to
     return out
 
 
+def embed_stream(ids: torch.Tensor, pad: torch.Tensor, cu: torch.Tensor, table: torch.Tensor,
+                 pos_table: torch.Tensor | None, n_tokens: int, need_x: bool = False, need_t16: bool = True,
+                 eps: float = 1e-5) -> LnStream:
+    """embed_pack + ln_stream (+ trunk16_of) in one kernel (vf_embed_stream): the encoder input as an LnStream whose fp32
+    rows exist only on request; bit-identical copies and statistics to the three-step form."""
+    _dev(ids, pad, cu, table, pos_table)
+    pad = pad.view(torch.uint8) if pad.dtype == torch.bool else pad
+    assert ids.dtype == torch.int64 and ids.is_contiguous() and ids.dim() == 2 and pad.shape == ids.shape
+    assert table.dtype == torch.float32 and table.is_contiguous()
+    W, L = ids.shape
+    d = table.shape[1]
+    dev = ids.device
+    x = torch.empty((n_tokens, d), dtype=torch.float32, device=dev) if need_x else None
+    x16 = torch.empty((n_tokens, d), dtype=_CDT, device=dev)
+    t16 = torch.empty((n_tokens, d), dtype=torch.float16, device=dev) if need_t16 else None
+    stats = torch.empty((n_tokens, 2), dtype=torch.float32, device=dev)
+    scale = x16_scale_for(_CDT)
+    alert = _alert_flag(dev)
+
+    def launch():
+        check(_lib.load().vf_embed_stream(ids.data_ptr(), pad.data_ptr(), cu.data_ptr(), table.data_ptr(), _ptr(pos_table),
+                                          _ptr(x), x16.data_ptr(), _dt(_CDT), scale, _ptr(t16), T16_SCALE, stats.data_ptr(),
+                                          eps, LN_FOLD_RATIO_LIMIT, alert.data_ptr(), W, L, d, table.shape[0], _stream()),
+              "vf_embed_stream")
+    if TIMER is not None:
+        TIMER.time("layernorm", 0.0, float(n_tokens) * d * (2 + (2 if need_t16 else 0) + (4 if need_x else 0)), launch,
+                   f"embed_stream D={d}", _SCOPE)
+    else:
+        launch()
+    return LnStream(x, x16, stats, scale, t16)
+
+
 def segment_mean(x: torch.Tensor, cu: torch.Tensor, out_dtype=None) -> torch.Tensor:
     _dev(x, cu)
     out_dtype = _CDT if out_dtype is None else out_dtype

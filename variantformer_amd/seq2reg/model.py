@@ -103,7 +103,13 @@ class Seq2RegPredictor(nn.Module):
         Lmax = max_len if 0 < max_len < L else L
         with ops.scope("seq2reg"):
             cu = ops.mask_to_cu_seqlens(pad)
-            x = ops.embed_pack(ids, pad, cu, self.token_embedding.weight, self._pos_table(ids.device), n_tokens)
+            from ..seq2gene.modules.layers import ln_fold_enabled, trunk_f16_active
+            l0 = self.transformer_encoder[0]
+            if trunk_f16_active() and ln_fold_enabled(l0.norm1.weight.numel(), l0.linear_geglu_2.in_features):
+                # the encoder input as (16-bit copy, fp16 trunk copy, row statistics): its fp32 rows have no reader
+                x = ops.embed_stream(ids, pad, cu, self.token_embedding.weight, self._pos_table(ids.device), n_tokens)
+            else:
+                x = ops.embed_pack(ids, pad, cu, self.token_embedding.weight, self._pos_table(ids.device), n_tokens)
             if self.use_context:
                 if context is None or torch.is_floating_point(context):
                     raise NotImplementedError(
