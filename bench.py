@@ -512,15 +512,20 @@ def main():
                 kernels[f"{kind}/{fam}"] = ent
 
         small = None
-        if rank == 0 and world == 1 and G != 8 and not args.no_kernel_timing:
-            # the same step at the reference's own DataLoader batch size (8 genes), inputs resident, same K / W
-            b8 = make_batch(20251205 + rank, [args.n_cre] * 8, [args.n_chunks] * 8, [tissues] * 8, 200)
-            pb8 = model.prepare_batch(b8)
-            dt8, _ = timed_steps(lambda: model.forward_prepared(pb8)[0].view(8, len(tissues)).cpu(), args.steps, args.warmup,
-                                 False, torch.cuda.synchronize, dev)
-            small = {"genes_per_step": 8, "value": round(8 * args.steps / dt8, 4), "unit": "genes/sec",
-                     "ms_per_step": round(dt8 / args.steps * 1e3, 3)}
-            del pb8, b8
+        if rank == 0 and world == 1 and not args.no_kernel_timing:
+            # the same step at the reference's own DataLoader batch size (8 genes, configs/vcfloader.yaml:5) and for one
+            # gene alone (SURVEY 8d's cfg-2 row: B = 1), inputs resident, same K / W
+            small = {}
+            for g in (8, 1):
+                if g == G:
+                    continue
+                bg = make_batch(20251205 + rank, [args.n_cre] * g, [args.n_chunks] * g, [tissues] * g, 200)
+                pbg = model.prepare_batch(bg)
+                dtg, _ = timed_steps(lambda: model.forward_prepared(pbg)[0].view(g, len(tissues)).cpu(), args.steps,
+                                     args.warmup, False, torch.cuda.synchronize, dev)
+                small[g] = {"genes_per_step": g, "value": round(g * args.steps / dtg, 4), "unit": "genes/sec",
+                            "ms_per_step": round(dtg / args.steps * 1e3, 3)}
+                del pbg, bg
 
         strong = None
         if world > 1 and not args.no_cfg3:
@@ -549,8 +554,8 @@ def main():
             "ms_of_each_timed_step_rank0": each_step_ms, "device_allocations_inside_timed_region": allocs_in_timed_region,
             "allocator_priming_passes_before_warmup": priming,
         }
-        if small is not None:
-            out["batch_of_8"] = small
+        for g, rec in (small or {}).items():
+            out[f"batch_of_{g}"] = rec
         out["peak_hbm_allocated_gb"] = round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2)
         if strong is not None:
             out["cfg3_strong_scaling"] = strong
