@@ -1,7 +1,7 @@
 """End-to-end vcf2exp throughput on a synthetic genome at headline size: FASTA + donor VCF + per-gene cCRE tables ->
 VCFDataset (in-process consensus + C++ BPE) in DataLoader workers -> collate -> HIP model (full 1.2B architecture,
 random weights) -> expression matrix.  Shows whether the host-side sample builder keeps the GPU fed.
-usage: python scripts/vcf2exp_e2e.py [n_genes] [num_workers]"""
+usage: python scripts/vcf2exp_e2e.py [n_genes] [num_workers] [batch_size]"""
 import os, sys, tempfile, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, pandas as pd, torch
@@ -14,6 +14,7 @@ from variantformer_amd.utils.synthetic import TISSUES_54
 
 n_genes = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 workers = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+batch_size = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 rng = np.random.default_rng(0)
 n = 3_000_000
 genome = "".join(np.array(list("ACGT"))[rng.integers(0, 4, n)])
@@ -36,7 +37,7 @@ for g in range(n_genes):
 query = pd.DataFrame({"gene_id": [g["gene_id"] for g in genes], "tissues": [",".join(tissue_names)] * n_genes})
 ds = VCFDataset(200, 200, 50, pd.DataFrame(genes), LocalManifest(paths), 1000, 300000, query, fasta, os.path.join(root, "d.vcf.gz"))
 model, hp, kw = bench.build_model(torch.device("cuda:0"))
-loader = DataLoader(ds, batch_size=8, num_workers=workers, collate_fn=collate_fn_batching,
+loader = DataLoader(ds, batch_size=batch_size, num_workers=workers, collate_fn=collate_fn_batching,
                     prefetch_factor=2 if workers else None, persistent_workers=bool(workers))
 from variantformer_amd.processors.trainer import Trainer
 trainer = Trainer(precision="bf16-mixed")
