@@ -1618,6 +1618,434 @@ __global__ __launch_bounds__(512, 2) void gemm8x_kernel(const unsigned short* __
 #undef VF_G8_MMA
 }
 
+#ifdef VF_TUNING   // measured 15-20 % SLOWER than the 8-wave 256x256 kernels on every shape of the workload (profiles/r04_a_gemm4_two_blocks_per_cu.log):
+                   // the 256x128 tiles need 1.5x the L2 -> LDS bytes per flop and the LDS-DMA fill rate (~46 GB/s per CU) is what
+                   // bounds these kernels; kept for scripts/gemm4_probe.py in libvf_hip_tuning.so only
+// ======================================================================================================================
+// gemm4_kernel: TWO INDEPENDENT 4-WAVE BLOCKS PER CU, each persistent over its own 256 (m) x 128 (n) output tiles.
+//
+// Why: in the 8-wave kernels above both wave groups work on the SAME output tile, so all eight waves reach the epilogue
+// (VALU + LDS transpose + stores, 4-8 k cycles) together and the matrix pipe idles for 20-40 % of a K = 512 tile; nothing
+// else is resident on the CU to fill the gap.  Here a CU holds two blocks of 256 threads (one wave per SIMD each, 256
+// registers per wave, 80 KiB of LDS each).  The blocks share nothing and meet at no barrier, so they drift out of phase:
+// while one block runs its epilogue, requests its next tile or waits at a barrier, the other block's wave on the same
+// SIMD has the matrix pipe to itself.  The hardware's wave arbitration does what the two-group schedule does by hand,
+// and it also covers the epilogue.
+//
+// Wave (wm = wave / 2, wn = wave % 2) owns the same contiguous 128 (m) x 64 (n) block as in gemm8_kernel, computed in the
+// same four quadrants with the same fragment reads, so every accumulator sees the K-steps in the same order: results are
+// bit-identical to the other tile configurations.
+//
+// LDS ring: three BANKS of 24 KiB, each one PAIR = [W half-tile 64 rows x 128 B | A half-tile 128 rows x 128 B]; pair
+// 2 kt is (WL, AL) of K-tile kt, pair 2 kt + 1 is (WH, AH) (half-tile row <-> matrix row as in gemm8_kernel, XOR swizzle on
+// the LDS-DMA source side).  The pair stream runs across K-tiles AND across output tiles; pair q lives in bank q % 3.
+// Per K-tile g of the stream (pairs 2g in bank b0, 2g + 1 in b1):
+//     reads WL, AL (b0)                  vmcnt: pair 2g+1 landed     lgkmcnt(0)   s_barrier B1    -> b0 is free
+//     request pair 2g+3 into b0;  reads WH (b1);  32 MFMAs (m-lo x n-lo, m-lo x n-hi);  reads AH (b1)
+//                                        vmcnt: pair 2g+2 landed     lgkmcnt(0)   s_barrier B3    -> b1 is free
+//     request pair 2g+4 into b1;  32 MFMAs (m-hi x n-hi, m-hi x n-lo)
+//   RAW  a pair is read only after the barrier that follows every wave's counted wait for its own pieces of it.
+//   WAR  a bank is re-requested only after the barrier that follows every wave's lgkmcnt(0) behind its last read of it.
+//   The counted waits always leave exactly the youngest pair (6 LDS-DMA instructions per wave) in flight; the epilogue
+//   operands of the next tile (bias, colsum, row statistics) are requested just BEFORE a pair, so they never are among
+//   the youngest six.
+// Tile boundary: during the last K-tile of a tile the pair that would go into b1 ((WL, AL) of the next tile's K-tile 1)
+// is held back; b1 is free after B3 and is the epilogue's staging area (6 KiB per wave).  The next tile's K-tile 0 is
+// complete in the other two banks before the epilogue starts (vmcnt(0) behind the last MFMA), one barrier ends the
+// epilogue, then the held-back pair is requested and the K loop restarts without a first fill.
+// ======================================================================================================================
+struct Cfg4 {
+    static constexpr int BM = 256, BN = 128, BK = 64, NW = 4, THREADS = 256;
+    static constexpr int TM = 8, TN = 4;                            // 16x16 tiles per wave: 128 x 64
+    static constexpr int WHALF = 64 * 128, AHALF = 128 * 128;       // half-tiles: 8 KiB, 16 KiB
+    static constexpr int BANK = WHALF + AHALF, RING = 3 * BANK;     // 24 KiB, 72 KiB
+    static constexpr int SIDE = 4096;                               // bias | colsum | (mean, rstd) of a tile, double-buffered
+    static constexpr int LDS_BYTES = RING + 2 * SIDE;               // 80 KiB: two blocks per CU
+};
+
+// Epilogue of one wave's 128 (m) x 64 (n) accumulator block (lane holds out[m = mw0 + im*16 + r][n = nw0 + in*16 + 4g .. +3]):
+// staged through `region` (REGION bytes of LDS private to the wave) in passes of RP rows and written as whole rows, 16
+// bytes per lane; residual, LayerNorm producer / consumer forms as in gemm8x_kernel (same arithmetic, same order).
+// side: [0, 1K) bias, [1K, 2K) colsum, [2K, 4K) (mean, rstd) of the tile's rows; side_m / side_n = the wave tile's first
+// row / column inside the block tile.
+template <int EPI, int DT, int LN, int REGION>
+__device__ __forceinline__ void wave_tile_epilogue(f32x4_t (&acc)[4][8], char* region, const char* side, int side_m, int side_n,
+                                                   int64_t mw0, int nw0, bool has_bias, const float* __restrict__ res,
+                                                   int64_t ldr, void* out, int64_t ldo, int M, int N, const LnArgs& ln) {
+    constexpr int TM = 8, TN = 4;
+    // lane-derived addresses from a lane id the compiler cannot hoist out of the caller's tile loop (see gemm8x_kernel)
+    int lane_e;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+    const int lane = lane_e, r = lane & 15, g = lane >> 4;
+    constexpr bool OUT_F32 = (EPI == VF_EPI_F32 || EPI == VF_EPI_RES_F32 || EPI == VF_EPI_GELU_F32);
+    constexpr int ES = OUT_F32 ? 4 : 2;
+    constexpr int WT_M = 128, WT_N = 64;
+    constexpr int WT_NO = (EPI == VF_EPI_GEGLU_BF16) ? WT_N / 2 : WT_N;
+    constexpr int PITCH = WT_NO * ES + 16;
+    constexpr int RP = (((REGION / PITCH) < WT_M ? (REGION / PITCH) : WT_M) / 16) * 16;
+    constexpr int IMP = RP / 16, NPASS = (TM + IMP - 1) / IMP;
+    constexpr int CR = WT_NO * ES / 16, RI = 64 / CR, NI = RP / RI;
+    static_assert(RP >= 16 && CR >= 1 && CR <= 64 && 64 % CR == 0, "epilogue geometry");
+    constexpr bool RES = (EPI == VF_EPI_RES_F32);
+    constexpr bool R16 = ln_res_is_16(LN), T16 = LN == VF_LN_PRODUCER_T16;
+    const int n_out_total = (EPI == VF_EPI_GEGLU_BF16) ? N / 2 : N;
+    const int no0 = (EPI == VF_EPI_GEGLU_BF16) ? nw0 / 2 : nw0;
+    const int ep_row = lane / CR, ep_col = no0 + (lane % CR) * (16 / ES);
+    const int rows_left = (int)(M - mw0) - ep_row;              // item j is a row of the matrix iff j * RI < rows_left
+    const int64_t row0 = mw0 + ep_row;
+    const int colc = ep_col < N ? ep_col : N - 4;
+    using res_t = typename std::conditional<R16, u32x2_t, f32x4_t>::type;
+    const char* const res_base = R16 ? reinterpret_cast<const char*>(ln.res16) : reinterpret_cast<const char*>(res);
+    const int64_t res_ld = R16 ? ln.ldr16 : ldr;
+    constexpr int RES_ES = R16 ? 2 : 4;
+    const char* const res_last = RES ? res_base + ((int64_t)(M - 1) * res_ld + colc) * RES_ES : nullptr;
+    const int64_t res_step = (int64_t)RI * res_ld * RES_ES;
+    const int64_t out_step = (int64_t)RI * ldo * ES;
+    const int64_t o16_step = (int64_t)RI * ln.ld16;
+    const int64_t t16_step = (int64_t)RI * ln.ldt16;
+    // running pointers: one 64-bit add per item instead of a multiply (see gemm8_kernel)
+    const char* res_run = RES ? res_base + (row0 * res_ld + colc) * RES_ES : nullptr;
+    char* out_run = reinterpret_cast<char*>(out) + (row0 * ldo + ep_col) * ES;
+    unsigned short* o16_run = ln_is_producer(LN) ? reinterpret_cast<unsigned short*>(ln.out16) + row0 * ln.ld16 + ep_col : nullptr;
+    float* part_run = ln_is_producer(LN) ? ln.part_stats + ((int64_t)(ep_col >> 5) * ln.rows + row0) * 2 : nullptr;
+    unsigned short* t16_run = T16 ? ln.t16_out + row0 * ln.ldt16 + ep_col : nullptr;
+    res_t rbuf[2][RES ? NI : 1];
+    auto load_res_pass = [&](int ps, res_t (&dst)[RES ? NI : 1]) {
+        if (RES) {
+#pragma unroll
+            for (int k = 0; k < NI; ++k) {
+                const int j = ps * NI + k;
+                const char* rp = (j * RI < rows_left) ? res_run : res_last;
+                res_run += res_step;
+                dst[RES ? k : 0] = *reinterpret_cast<const res_t*>(rp);
+            }
+        }
+    };
+    auto res_value = [&](res_t v) -> f32x4_t {      // see gemm8_kernel
+        if constexpr (T16) return cvt4_16<VF_F16>(v) * ln.res16_scale;
+        else if constexpr (R16) {
+            if constexpr (DT == VF_F16) return cvt4_16<DT>(v) * ln.res16_scale;
+            else return cvt4_16<DT>(v);
+        }
+        else return v;
+    };
+    load_res_pass(0, rbuf[0]);
+    f32x4_t bvec[TN];
+    if (has_bias) {
+#pragma unroll
+        for (int in = 0; in < TN; ++in) {
+            const int nl = side_n + ((EPI == VF_EPI_GEGLU_BF16) ? (in >> 1) * 32 + (in & 1) * 16 + 4 * g : in * 16 + 4 * g);
+            bvec[in] = *reinterpret_cast<const f32x4_t*>(side + nl * 4);
+        }
+    } else {
+#pragma unroll
+        for (int in = 0; in < TN; ++in) bvec[in] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
+    f32x4_t svec[LN == VF_LN_CONSUMER ? TN : 1];
+    if (LN == VF_LN_CONSUMER) {
+#pragma unroll
+        for (int in = 0; in < TN; ++in) {
+            const int nl = side_n + ((EPI == VF_EPI_GEGLU_BF16) ? (in >> 1) * 32 + (in & 1) * 16 + 4 * g : in * 16 + 4 * g);
+            svec[LN == VF_LN_CONSUMER ? in : 0] = *reinterpret_cast<const f32x4_t*>(side + 1024 + nl * 4);
+        }
+    }
+    auto lnv = [&](int in, int im, f32x2_t st) -> f32x4_t {          // st = (-mean * rstd, rstd); see gemm8_kernel
+        if (LN == VF_LN_CONSUMER) return acc[in][im] * st[1] + (st[0] * svec[LN == VF_LN_CONSUMER ? in : 0] + bvec[in]);
+        return acc[in][im] + bvec[in];
+    };
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        if (ps + 1 < NPASS) load_res_pass(ps + 1, rbuf[(ps + 1) & 1]);
+#pragma unroll
+        for (int iml = 0; iml < IMP; ++iml) {
+            const int im = ps * IMP + iml;
+            if (im < TM) {
+                char* rowp = region + (iml * 16 + r) * PITCH;
+                f32x2_t st = {0.f, 1.f};
+                if (LN == VF_LN_CONSUMER) {
+                    st = *reinterpret_cast<const f32x2_t*>(side + 2048 + (side_m + im * 16 + r) * 8);
+                    st[0] = -st[0] * st[1];                                   // (-mean * rstd, rstd)
+                }
+                if (EPI == VF_EPI_GEGLU_BF16) {
+#pragma unroll
+                    for (int ip = 0; ip < TN / 2; ++ip) {
+                        const f32x4_t v = lnv(2 * ip, im, st), gt = lnv(2 * ip + 1, im, st);
+                        u32x2_t pk;
+                        const f32x4_t y = v * gelu_erf4(gt);
+                        pk[0] = Op16<DT>::pack2(y[0], y[1]);
+                        pk[1] = Op16<DT>::pack2(y[2], y[3]);
+                        *reinterpret_cast<u32x2_t*>(rowp + (ip * 16 + 4 * g) * 2) = pk;
+                    }
+                } else {
+#pragma unroll
+                    for (int in = 0; in < TN; ++in) {
+                        f32x4_t v = lnv(in, im, st);
+                        if (EPI == VF_EPI_GELU_F32 || EPI == VF_EPI_GELU_BF16) v = gelu_erf4(v);
+                        if (OUT_F32) {
+                            *reinterpret_cast<f32x4_t*>(rowp + (in * 16 + 4 * g) * 4) = v;
+                        } else {
+                            u32x2_t pk;
+                            pk[0] = Op16<DT>::pack2(v[0], v[1]);
+                            pk[1] = Op16<DT>::pack2(v[2], v[3]);
+                            *reinterpret_cast<u32x2_t*>(rowp + (in * 16 + 4 * g) * 2) = pk;
+                        }
+                    }
+                }
+            }
+        }
+        // read the slice back row-wise: all LDS reads of a batch first, then the predicated stores
+        constexpr int KB = RES ? 4 : NI;
+#pragma unroll
+        for (int k0 = 0; k0 < NI; k0 += KB) {
+            u32x4_t dd[KB];
+#pragma unroll
+            for (int k = 0; k < KB; ++k)
+                if (k0 + k < NI)
+                    dd[k] = *reinterpret_cast<const u32x4_t*>(region + ((k0 + k) * RI + ep_row) * PITCH + (lane % CR) * 16);
+#pragma unroll
+            for (int k = 0; k < KB; ++k) {
+                if (k0 + k >= NI) continue;
+                const int j = ps * NI + k0 + k;                  // row j * RI + ep_row of the wave tile
+                u32x4_t d = dd[k];
+                if (RES) {
+                    f32x4_t f = __builtin_bit_cast(f32x4_t, d);
+                    f += res_value(rbuf[ps & 1][RES ? k0 + k : 0]);
+                    d = __builtin_bit_cast(u32x4_t, f);
+                }
+                const bool ok = j * RI + ep_row < WT_M && j * RI < rows_left && ep_col < n_out_total;
+                if (ln_is_producer(LN) && OUT_F32) {
+                    ln_emit<DT>(__builtin_bit_cast(f32x4_t, d), ok, o16_run, part_run, lane, ln.x16_scale, true, true,
+                                (T16 && ln.t16_out) ? t16_run : nullptr, ln.t16_scale);
+                    o16_run += o16_step;
+                    part_run += RI * 2;
+                    if (T16) t16_run += t16_step;
+                }
+                if (ok && (!ln_is_producer(LN) || out != nullptr)) *reinterpret_cast<u32x4_t*>(out_run) = d;
+                out_run += out_step;
+            }
+        }
+    }
+}
+
+template <int EPI, int DT = VF_BF16, int LN = VF_LN_NONE>
+__global__ __launch_bounds__(256, 2) void gemm4_kernel(const unsigned short* __restrict__ A, int64_t lda,
+                                                       const unsigned short* __restrict__ W,
+                                                       const float* __restrict__ bias, const float* __restrict__ res,
+                                                       int64_t ldr, void* out, int64_t ldo, int M, int N, int K,
+                                                       int tiles_n, int n_tiles, int GROUP_M, LnArgs ln) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using frag_t = typename Op16<DT>::frag;
+    using C = Cfg4;
+    constexpr int TM = C::TM, TN = C::TN, BK = C::BK;
+
+    const int bid = blockIdx.x, grid = gridDim.x;
+#ifdef VF_TUNING   // start-up stagger experiment (VF_G4_STAGGER, units of ~0.1 us): the second half of the grid starts late
+    const int stagger = GROUP_M >> 16;
+    GROUP_M &= 255;
+    if (stagger && bid >= (grid >> 1))
+        for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(3);
+#endif
+    const int my_tiles = (n_tiles - bid + grid - 1) / grid;          // output tiles bid, bid + grid, ... (>= 1)
+    auto tile_origin = [&](int t, int& m0, int& n0) {                 // XCD-contiguous runs, grouped order (see gemm_mfma_kernel)
+        const int q8 = n_tiles >> 3, r8 = n_tiles & 7, xcd = t & 7, loc = t >> 3;
+        const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+        const int tiles_m = n_tiles / tiles_n;
+        const int per_group = GROUP_M * tiles_n;
+        const int grp = wg / per_group, in_grp = wg - grp * per_group;
+        const int first_m = grp * GROUP_M;
+        const int gsz = (tiles_m - first_m) < GROUP_M ? (tiles_m - first_m) : GROUP_M;
+        m0 = (first_m + in_grp % gsz) * C::BM;
+        n0 = (in_grp / gsz) * C::BN;
+    };
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 15, g = lane >> 4;
+
+    // ---- LDS-DMA sources of ONE output tile.  A half-tile row i <-> m = m0 + (i / 64) * 128 + i % 64 (+ 64 for the hi half),
+    // W half-tile row i <-> n = n0 + (i / 32) * 64 + i % 32 (+ 32).  Wave w fills rows 32w .. 32w+31 of an A half (four 8-row
+    // pieces) and rows 16w .. 16w+15 of a W half (two pieces).  Recomputed in place when the stream crosses into the next tile.
+    const unsigned short* srcA[2][4];
+    const unsigned short* srcW[2][2];
+    auto set_src = [&](int m0, int n0) {
+#pragma unroll
+        for (int pi = 0; pi < 4; ++pi) {
+            const int i = 32 * wave + 8 * pi + (lane >> 3);
+            const int c = (lane & 7) ^ ((i >> 1) & 7);
+            const int am = m0 + (i >> 6) * 128 + (i & 63);
+            int v;
+            v = am;       v = v < M ? v : M - 1;  srcA[0][pi] = A + (int64_t)v * lda + c * 8;
+            v = am + 64;  v = v < M ? v : M - 1;  srcA[1][pi] = A + (int64_t)v * lda + c * 8;
+        }
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi) {
+            const int i = 16 * wave + 8 * pi + (lane >> 3);
+            const int c = (lane & 7) ^ ((i >> 1) & 7);
+            const int wr = n0 + (i >> 5) * 64 + (i & 31);
+            int v;
+            v = wr;       v = v < N ? v : N - 1;  srcW[0][pi] = W + (int64_t)v * K + c * 8;
+            v = wr + 32;  v = v < N ? v : N - 1;  srcW[1][pi] = W + (int64_t)v * K + c * 8;
+        }
+    };
+    // pair (h = 0: WL, AL; h = 1: WH, AH) of K-tile kt of the tile `src` points at, into the bank at byte offset boff
+#define VF_G4_ISSUE(H, BOFF, KT)                                                     \
+    do {                                                                             \
+        char* dw_ = smem + (BOFF) + wave * 2048;                                     \
+        glds16(srcW[H][0] + (KT) * BK, dw_);                                         \
+        glds16(srcW[H][1] + (KT) * BK, dw_ + 1024);                                  \
+        char* da_ = smem + (BOFF) + C::WHALF + wave * 4096;                          \
+        _Pragma("unroll") for (int pi_ = 0; pi_ < 4; ++pi_) glds16(srcA[H][pi_] + (KT) * BK, da_ + pi_ * 1024); \
+    } while (0)
+    // epilogue operands of a tile by LDS-DMA (bias | colsum | row statistics), double-buffered by tile parity
+    auto issue_side = [&](int m0, int n0, int seq) {
+        char* const sd = smem + C::RING + (seq & 1) * C::SIDE;
+        int ln_;                                     // not hoistable out of the tile loop
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln_));
+        if (bias && wave == 0) {
+            int n = n0 + 4 * ln_;
+            n = n < N ? n : N - 4;
+            glds16(bias + n, sd);
+        }
+        if (LN == VF_LN_CONSUMER) {
+            if (wave == 1) {
+                int n = n0 + 4 * ln_;
+                n = n < N ? n : N - 4;
+                glds16(ln.colsum + n, sd + 1024);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {            // every wave: 64 rows x (mean, rstd), one dword per lane, two instructions
+                int64_t m = m0 + 64 * wave + 32 * j + (ln_ >> 1);
+                m = m < M ? m : M - 1;
+                __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) void*)(ln.row_stats + 2 * m + (ln_ & 1)),
+                                                 (__attribute__((address_space(3))) void*)(sd + 2048 + wave * 512 + j * 256), 4, 0, 0);
+            }
+        }
+    };
+
+    f32x4_t acc[TN][TM];
+
+    // ---- fragment addresses (bytes inside a bank): row * 128 + ((4 ks + g) ^ swz(r)) * 16
+    const int sw = (r >> 1) & 7;
+    const int ck0 = ((g) ^ sw) << 4, ck1 = ((4 + g) ^ sw) << 4;
+    const int offW = (wn * 32 + r) * 128;                      // + in_local * 2048
+    const int offA = C::WHALF + (wm * 64 + r) * 128;           // + im_local * 2048
+    frag_t wlo[2][2], whi[2][2], af[4][2];                     // [fragment][k-step]
+    auto read_w = [&](int boff, frag_t (&f)[2][2]) {
+        const char* b = smem + boff + offW;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            f[i][0] = *reinterpret_cast<const frag_t*>(b + i * 2048 + ck0);
+            f[i][1] = *reinterpret_cast<const frag_t*>(b + i * 2048 + ck1);
+        }
+    };
+    auto read_a = [&](int boff) {
+        const char* b = smem + boff + offA;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            af[i][0] = *reinterpret_cast<const frag_t*>(b + i * 2048 + ck0);
+            af[i][1] = *reinterpret_cast<const frag_t*>(b + i * 2048 + ck1);
+        }
+    };
+    // every wave's reads of the bank retired (WAR) and its own pieces of the pair being waited for landed (RAW), then
+    // the barrier; the MFMA clusters stay between the synchronisation points (sched_barrier, priority: T5)
+#define VF_G4_BARRIER()                                          \
+    do {                                                         \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       \
+        __builtin_amdgcn_sched_barrier(0);                       \
+        __builtin_amdgcn_s_barrier();                            \
+        asm volatile("" ::: "memory");                           \
+        __builtin_amdgcn_sched_barrier(0);                       \
+    } while (0)
+#define VF_G4_MMA(WF, IN0, IM0)                                                                                      \
+    do {                                                                                                             \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                             \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                            \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                        \
+                    acc[IN0 + i][IM0 + j] =                                                                          \
+                        Op16<DT>::mfma(WF[i][ks], af[j][ks], acc[IN0 + i][IM0 + j]); \
+    } while (0)
+
+    // ---- first tile: its epilogue operands, K-tile 0 (pairs 0, 1) and (WL, AL) of K-tile 1 (pair 2)
+    const int nkt = K / BK;                                  // >= 2 (launcher)
+    int m0, n0;
+    tile_origin(bid, m0, n0);
+    set_src(m0, n0);
+    issue_side(m0, n0, 0);
+    int b0 = 0, b1 = C::BANK, b2 = 2 * C::BANK;              // banks of pairs 2g, 2g + 1, 2g + 2 (wave-uniform)
+    VF_G4_ISSUE(0, b0, 0);
+    VF_G4_ISSUE(1, b1, 0);
+    VF_G4_ISSUE(0, b2, 1);
+    wait_vmcnt<12>();                                        // pair 0 (and the side operands) landed
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    for (int ti = 0; ti < my_tiles; ++ti) {
+        const bool has_next = ti + 1 < my_tiles;             // block-uniform
+        tile_origin(bid + ti * grid, m0, n0);
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        // the pair held back under the previous tile's epilogue: (WL, AL) of this tile's K-tile 1, into the staging bank
+        if (ti > 0) VF_G4_ISSUE(0, b2, 1);
+
+        for (int t = 0; t < nkt; ++t) {
+            const bool e3 = t + 1 < nkt || has_next;                         // pairs 2g+2, 2g+3 (K-tile t+1 of the stream) exist
+            const bool i4 = t + 2 < nkt || (t + 2 == nkt && has_next);       // pair 2g+4 is requested inside the loop
+            const bool cross = t + 2 == nkt && has_next;                     // the stream crosses into the next output tile
+            int m1 = 0, n1 = 0;
+            // ---- (m-lo, n-lo): W-lo, A-lo
+            read_w(b0, wlo);
+            read_a(b0);
+            if (cross) {
+                tile_origin(bid + (ti + 1) * grid, m1, n1);
+                issue_side(m1, n1, ti + 1);                  // BEFORE the pair below: never among the youngest six
+            }
+            // pair 2g+1 landed (own pieces); the first K-tile of a later tile retired it behind the previous tile's last MFMA
+            if (!(t == 0 && ti > 0)) {
+                if (e3) wait_vmcnt<6>(); else wait_vmcnt<0>();
+            }
+            VF_G4_BARRIER();                                 // B1: b0 free, pair 2g+1 visible
+            if (e3) {
+                if (t + 1 < nkt) VF_G4_ISSUE(1, b0, t + 1); else VF_G4_ISSUE(1, b0, 0);
+            }
+            if (cross) set_src(m1, n1);
+            read_w(b1, whi);
+            __builtin_amdgcn_s_setprio(1);
+            VF_G4_MMA(wlo, 0, 0);
+            VF_G4_MMA(whi, 2, 0);
+            __builtin_amdgcn_s_setprio(0);
+            // ---- (m-hi, *): A-hi
+            read_a(b1);
+            if (e3) wait_vmcnt<6>(); else wait_vmcnt<0>();   // pair 2g+2 landed (own pieces)
+            VF_G4_BARRIER();                                 // B3: b1 free, pair 2g+2 visible
+            if (i4) {
+                if (t + 2 < nkt) VF_G4_ISSUE(0, b1, t + 2); else VF_G4_ISSUE(0, b1, 0);
+            }
+            __builtin_amdgcn_s_setprio(1);
+            VF_G4_MMA(whi, 2, 4);
+            VF_G4_MMA(wlo, 0, 4);
+            __builtin_amdgcn_s_setprio(0);
+            const int tb = b0; b0 = b2; b2 = b1; b1 = tb;    // pairs 2g+2, 2g+3, 2g+4 of the next K-tile
+        }
+        // the next tile's K-tile 0 complete (own pieces) before the epilogue; its barrier publishes them
+        wait_vmcnt<0>();
+        asm volatile("" ::: "memory");
+        // ---- epilogue through the free bank (b2 after the rotation = the bank of the last (WH, AH)), 6 KiB per wave
+        wave_tile_epilogue<EPI, DT, LN, C::BANK / C::NW>(acc, smem + b2 + wave * (C::BANK / C::NW),
+                                                         smem + C::RING + (ti & 1) * C::SIDE, wm * 128, wn * 64,
+                                                         (int64_t)m0 + wm * 128, n0 + wn * 64, bias != nullptr, res, ldr, out, ldo,
+                                                         M, N, ln);
+        // every wave's staging reads are done before the held-back pair is requested into this bank
+        VF_G4_BARRIER();
+    }
+#undef VF_G4_ISSUE
+#undef VF_G4_BARRIER
+#undef VF_G4_MMA
+}
+#endif  // VF_TUNING (gemm4_kernel)
+
 #ifdef VF_TUNING   // measured: +5 % on the seq2reg Wqkv shape, +1..2 % on Wq / 8192^3, -2..4 % on Wqkv / GeGLU / fp32-residual
                    // (gpurun_out/r2g/gemm_bench.log): not selected, kept for scripts/gemm_bench.py only
 // ----------------------------------------------------------------------------------------------------------------------
@@ -2352,6 +2780,7 @@ int launch_gemm8x(const void* A, int64_t lda, const void* W, const float* bias, 
     const int grid = n_tiles < cus ? n_tiles : cus;              // one resident block per CU
     int group_m = 8;
 #ifdef VF_TUNING
+    if (const char* e = getenv("VF_G8X_GROUP_M")) group_m = atoi(e);    // tile-walk sweep (scripts/gemm4_probe.py)
     if (const char* e = getenv("VF_G8_DBG")) group_m |= atoi(e) << 8;   // epilogue cost-centre probes
 #endif
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, st, (const unsigned short*)A, lda, (const unsigned short*)W, bias,
@@ -2359,6 +2788,55 @@ int launch_gemm8x(const void* A, int64_t lda, const void* W, const float* bias, 
     VF_CHECK_LAUNCH("vf_gemm_bf16");
     return VF_OK;
 }
+
+#ifdef VF_TUNING
+template <int EPI, int DT = VF_BF16, int LN = VF_LN_NONE>
+int launch_gemm4(const void* A, int64_t lda, const void* W, const float* bias, const float* res, int64_t ldr, void* out,
+                 int64_t ldo, int M, int N, int K, hipStream_t st, LnArgs ln = LnArgs{}) {
+    constexpr int LDS = Cfg4::LDS_BYTES;                         // 80 KiB: two blocks per CU
+    static bool attr_set[VF_MAX_DEVICES] = {};
+    static int n_cu[VF_MAX_DEVICES] = {};
+    auto kern = gemm4_kernel<EPI, DT, LN>;
+    const int dev = vf_current_device();
+    if (dev < 0 || !attr_set[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
+            hipSuccess) {
+            (void)hipGetLastError();
+            vf_set_error("vf_gemm: cannot reserve %d bytes of LDS", LDS);
+            return VF_ERR_LAUNCH;
+        }
+        if (dev >= 0) attr_set[dev] = true;
+    }
+    int cus = 256;
+    if (dev >= 0) {
+        if (n_cu[dev] == 0) {
+            int v = 0;
+            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+            n_cu[dev] = v;
+        }
+        cus = n_cu[dev];
+    }
+    const int tiles_m = (M + Cfg4::BM - 1) / Cfg4::BM, tiles_n = (N + Cfg4::BN - 1) / Cfg4::BN;
+    const int n_tiles = tiles_m * tiles_n;
+    int slots = 2 * cus;                                         // two resident blocks per CU
+    int lds = LDS;
+    int group_m = 8;
+#ifdef VF_TUNING
+    if (const char* e = getenv("VF_G4_GROUP_M")) group_m = atoi(e);
+    if (const char* e = getenv("VF_G4_STAGGER")) group_m |= atoi(e) << 16;
+    if (const char* e = getenv("VF_G4_BPC")) slots = atoi(e) * cus;      // residency probes: blocks per CU, LDS request
+    if (const char* e = getenv("VF_G4_LDS")) {
+        lds = atoi(e);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    }
+#endif
+    const int grid = n_tiles < slots ? n_tiles : slots;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, (const unsigned short*)A, lda, (const unsigned short*)W, bias,
+                       res, ldr, out, ldo, M, N, K, tiles_n, n_tiles, group_m, ln);
+    VF_CHECK_LAUNCH("vf_gemm");
+    return VF_OK;
+}
+#endif  // VF_TUNING
 
 #ifdef VF_TUNING
 template <int EPI, int DT = VF_BF16>
@@ -2439,6 +2917,8 @@ int launch_gemm(const void* A, int64_t lda, const void* W, const float* bias, co
             }
             break;
 #ifdef VF_TUNING
+        case 40: if (K % 128 == 0) return launch_gemm4<EPI, DT>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
+                 return launch_gemm8<EPI, DT>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
         case 21:
             if (K < 128) break;
             return launch_gemm8p<EPI, DT>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
@@ -2538,6 +3018,16 @@ static int launch_gemm_ln(const void* A, int64_t lda, const void* W, const float
         static const int pr16 = getenv("VF_GEMM_PERSIST_R16") ? atoi(getenv("VF_GEMM_PERSIST_R16")) : 1;
         if (variant == 20 && K % 128 == 0 && (pr16 >= 2 || (pr16 == 1 && out == nullptr))) variant = 22;
     }
+#ifdef VF_TUNING
+    {
+        // two 4-wave blocks per CU (gemm4_kernel) instead of the 8-wave 256x256 kernels: VF_GEMM4 bit mask, 1 = consumers,
+        // 2 = 16-bit-residual producers (R16 / T16), 4 = fp32-residual / plain producers
+        static const int g4 = getenv("VF_GEMM4") ? atoi(getenv("VF_GEMM4")) : 0;
+        const int bit = LN == VF_LN_CONSUMER ? 1 : (ln_res_is_16(LN) ? 2 : 4);
+        if ((variant == 20 || variant == 22) && K % 128 == 0 && (g4 & bit))
+            return launch_gemm4<EPI, DT, LN>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, st, ln);
+    }
+#endif
     switch (variant) {
         case 1: return launch_cfg<CfgA, EPI, DT, 0, LN>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, st, ln);
         case 5: return launch_cfg<CfgE, EPI, DT, 0, LN>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, st, ln);
