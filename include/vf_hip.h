@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define VF_ABI_VERSION 5
+#define VF_ABI_VERSION 6
 
 enum vf_status {
     VF_OK = 0,
@@ -115,13 +115,18 @@ int vf_gemm_ln_t16(const void* A, int64_t lda, const void* W, const float* bias,
                    int64_t ld16, float* part_stats, float x16_scale, void* t16_out, int64_t ldt16, float t16_scale,
                    void* stream);
 int vf_ln_finalize(const float* part_stats, int64_t rows, int n_parts, int D, float eps, float* row_stats, void* stream);
-/* ..2 forms: x16_scale as above; alert (optional, device int): set to 1 when some row has |mean| > ratio_limit standard
- * deviations -- the regime where rounding the UNCENTRED row to 16 bits costs the folded form accuracy; callers read it back
- * with their outputs and warn (variantformer_amd.ops.ln_fold_alert). */
+/* vf_ln_finalize consumes the ABI >= 5 part statistics only: per 32-column part (sum, second moment ABOUT THE PART'S MEAN),
+ * D == 32 * n_parts (checked).
+ * ..2 forms: x16_scale as above; alert (optional, device int, OR-ed): bit 0 when some row has |mean| > ratio_limit standard
+ * deviations -- the regime where rounding the UNCENTRED row to 16 bits costs the folded form accuracy; bit 1 (ABI 6) when
+ * some row may hold an element of magnitude >= abs_limit (|mean| + sqrt(D * var) >= abs_limit; 0 = no check) -- its scaled
+ * fp16 copies (fp16 operand copy, fp16 trunk copy of vf_gemm_ln_t16) could overflow.  Callers read the flag back with their
+ * outputs and recompute the batch with the separate LayerNorm (variantformer_amd.ops.ln_fold_alert; the reference's plain
+ * nn.LayerNorm has no such regime, seq2gene/modules/layers.py:75-77,99-163). */
 int vf_ln_finalize2(const float* part_stats, int64_t rows, int n_parts, int D, float eps, float x16_scale, float ratio_limit,
-                    int* alert, float* row_stats, void* stream);
+                    float abs_limit, int* alert, float* row_stats, void* stream);
 int vf_row_stats_cast2(const float* x, int64_t rows, int D, float eps, void* out16, int out_dtype, float x16_scale,
-                       float ratio_limit, int* alert, float* row_stats, void* stream);
+                       float ratio_limit, float abs_limit, int* alert, float* row_stats, void* stream);
 int vf_row_stats_cast(const float* x, int64_t rows, int D, float eps, void* out16, int out_dtype, float* row_stats,
                       void* stream);
 
@@ -209,7 +214,7 @@ int vf_embed_pack(const int64_t* ids, const uint8_t* pad, const int32_t* cu,
  * rows of the encoder input never reach HBM.  d <= 2048. */
 int vf_embed_stream(const int64_t* ids, const uint8_t* pad, const int32_t* cu, const float* table, const float* pos_table,
                     float* out, void* out16, int out_dtype, float x16_scale, void* t16, float t16_scale, float* row_stats,
-                    float eps, float ratio_limit, int* alert, int W, int L, int d, int vocab, void* stream);
+                    float eps, float ratio_limit, float abs_limit, int* alert, int W, int L, int d, int vocab, void* stream);
 
 /* Per-window valid-token count and exclusive prefix sum: cu[0]=0, cu[w+1]=cu[w]+#valid(w).
  * Replaces the cu_seqlens half of unpad_input [3p].  Single-block scan; W <= 2^24. */

@@ -130,13 +130,13 @@ class Rounding:
         import os
         self._trunk16_arg = trunk16
         if q_prescale is None:
-            q_prescale = os.environ.get("VF_Q_PRESCALE", "1") != "0"
+            q_prescale = True
         self.q_prescale = bool(q_prescale) and mode is not None
         if fold_ln is None:
             fold_ln = mode is not None and os.environ.get("VF_LN_FOLD", "1") != "0"
         self.fold_ln = bool(fold_ln)
         if res16 is None:
-            res16 = os.environ.get("VF_RES16", "1") != "0"
+            res16 = True
         self.res16 = bool(res16) and self.fold_ln
         trunk16 = self._trunk16_arg
         if trunk16 is None:

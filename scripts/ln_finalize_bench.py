@@ -14,7 +14,7 @@ for name, M, D in [("gene8", 86832, 1536), ("s2r8", 769460, 512), ("cre8", 8192,
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         for _ in range(10):
-            lib.vf_ln_finalize2(part.data_ptr(), M, n_parts, D, 1e-5, 1.0, 8.0, 0, stats.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            lib.vf_ln_finalize2(part.data_ptr(), M, n_parts, D, 1e-5, 1.0, 8.0, 0.0, 0, stats.data_ptr(), torch.cuda.current_stream().cuda_stream)
         e.record(); torch.cuda.synchronize()
         if r: best = min(best, s.elapsed_time(e) / 10)
     print("%-6s M=%7d D=%5d  %7.1f us  %6.2f TB/s  checksum %.6f" % (name, M, D, best * 1e3, part.numel() * 4 / best / 1e9, float(stats.double().sum())))

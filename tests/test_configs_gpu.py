@@ -210,8 +210,8 @@ def test_cfg4_paired_ref_alt_full_size(full_model):
     alone = model.predict_step(ref, 0)
     np.testing.assert_allclose(both["pred_gene_exp"][0], alone["pred_gene_exp"][0], rtol=1e-5, atol=1e-6)
     with torch.no_grad():
-        plain = model.forward_prepared(model.prepare_batch(pair))
-        dd = model.prepare_batch(pair, dedupe_windows=True)
+        plain = model.forward_prepared(model.prepare_batch(pair, dedupe_windows=False))
+        dd = model.prepare_batch(pair)                  # default: exact de-duplication on
         assert dd.cre_ids.shape[0] == 1024 + 5 and dd.gene_ids.shape[0] == 200 + 5
         dedup = model.forward_prepared(dd)
     assert torch.equal(plain[0], dedup[0]) and torch.equal(plain[1], dedup[1])

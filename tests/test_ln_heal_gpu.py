@@ -1,0 +1,164 @@
+"""The folded LayerNorm never hands back degraded numbers: when the statistics kernels flag a batch (a residual-stream row
+with |mean| beyond ops.LN_FOLD_RATIO_LIMIT standard deviations, or an element a scaled fp16 copy could not hold) the model
+recomputes that batch with the separate LayerNorm on fp32 rows before predict_step / variant_prediction return -- bit for
+bit what a VF_LN_FOLD=0 run returns (reference: plain nn.LayerNorm, seq2gene/modules/layers.py:75-77,99-163, no such
+regime).  Also the range half of the flag on the op level (round-3 advice: a 2e6 outlier against the fp16 trunk copy)."""
+import logging
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import SEQ2REG_512, build_model, seq2gene_kw
+from variantformer_amd.utils.synthetic import TISSUES_54, make_batch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def heal_state():
+    """The self-healing bookkeeping is per process (sticky after two alerting batches): isolate it."""
+    from variantformer_amd.seq2gene import model_combined_modulator as M
+    from variantformer_amd.seq2gene.modules import layers as L
+    saved = (dict(M._LN_HEAL), L._LN_FOLD_FORCED_OFF)
+    M._LN_HEAL.update(batches=0, logged=False)
+    L._LN_FOLD_FORCED_OFF = 0
+    yield M, L
+    M._LN_HEAL.clear()
+    M._LN_HEAL.update(saved[0])
+    L._LN_FOLD_FORCED_OFF = saved[1]
+
+
+def _forward_counter(model, monkeypatch):
+    calls = {"n": 0}
+    orig = model.forward_prepared
+
+    def counted(*a, **k):
+        calls["n"] += 1
+        return orig(*a, **k)
+    monkeypatch.setattr(model, "forward_prepared", counted)
+    return calls
+
+
+def test_alerting_batch_is_recomputed_and_equals_the_unfolded_run(heal_state, monkeypatch, caplog):
+    M, L = heal_state
+    from variantformer_amd import ops
+    tissues = [TISSUES_54[:3], [9]]
+    kw = seq2gene_kw(layers=2)                       # production widths: D = 1536 / 32 heads, seq2reg 512 / 8 heads
+    model = build_model(SEQ2REG_512, kw, seed=4242).cuda()
+    batch = make_batch(99, [12, 5], [5, 3], tissues, 200)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    ops.ln_fold_alert(dev)                                             # clear whatever earlier tests left
+    calls = _forward_counter(model, monkeypatch)
+
+    # an ordinary batch: one forward, nothing flagged
+    clean = model.predict_step(batch, 0)
+    assert calls["n"] == 1 and M._LN_HEAL["batches"] == 0
+
+    # registry rows of the tissues in use get a mean of 20 standard deviations: the first gene layer's LayerNorm sees them
+    with torch.no_grad():
+        w = model.start_tkn.registry_tokens.weight
+        for t in sorted({t for ts in tissues for t in ts}):
+            w[t] += 20.0 * w[t].std()
+    monkeypatch.setenv("VF_LN_FOLD", "0")
+    calls["n"] = 0
+    plain = model.predict_step(batch, 0)                               # the reference for "what must come back"
+    assert calls["n"] == 1
+    monkeypatch.delenv("VF_LN_FOLD")
+    assert ops.ln_fold_alert(dev) == 0                                 # the unfolded path raises nothing
+
+    calls["n"] = 0
+    with caplog.at_level(logging.INFO, logger="variantformer_amd"):
+        healed = model.predict_step(batch, 0)
+    assert calls["n"] == 2, "the flagged batch must have been recomputed once"
+    assert M._LN_HEAL["batches"] == 1 and any("recomputed" in r.getMessage() for r in caplog.records)
+    assert ops.ln_fold_alert(dev) == 0                                 # flag consumed
+    for i in range(len(tissues)):
+        assert np.array_equal(healed["pred_gene_exp"][i], plain["pred_gene_exp"][i])
+        assert np.array_equal(healed["embeddings"][i], plain["embeddings"][i])
+        assert not np.array_equal(healed["pred_gene_exp"][i], clean["pred_gene_exp"][i])     # the weights did change
+    assert L.ln_fold_enabled(1536, 1024)                               # one alert: the fold is still on for the next batch
+
+    # a second alerting batch switches the fold off for the process: from then on ONE forward per batch, same bits
+    calls["n"] = 0
+    again = model.predict_step(batch, 1)
+    assert calls["n"] == 2 and M._LN_HEAL["batches"] == 2 and not L.ln_fold_enabled(1536, 1024)
+    calls["n"] = 0
+    third = model.predict_step(batch, 2)
+    assert calls["n"] == 1
+    for i in range(len(tissues)):
+        assert np.array_equal(again["pred_gene_exp"][i], plain["pred_gene_exp"][i])
+        assert np.array_equal(third["pred_gene_exp"][i], plain["pred_gene_exp"][i])
+        assert np.array_equal(third["embeddings"][i], plain["embeddings"][i])
+
+
+def test_pipelined_trainer_heals_the_right_batch(heal_state, monkeypatch):
+    """Trainer.predict enqueues batch i, prepares batch i + 1 and only then finishes batch i: the flag read in
+    predict_finish belongs to batch i (nothing of batch i + 1 has been launched), and only that batch is recomputed."""
+    M, L = heal_state
+    from variantformer_amd import ops
+    from variantformer_amd.processors.trainer import Trainer
+    kw = seq2gene_kw(layers=2)
+    model = build_model(SEQ2REG_512, kw, seed=4242).cuda()
+    good = make_batch(5, [6], [3], [[8, 9]], 200)
+    bad = make_batch(6, [4], [2], [[30]], 200)
+    # token 499 occurs in the middle batch only, and its embedding row carries a mean of ~28 standard deviations of the
+    # encoder input row (embedding + sinusoidal table, std ~0.7): the seq2reg input statistics (width 512) flag that batch.
+    # (An anomalous REGISTRY row would flag every batch: gene layer 0 projects the whole 63-row table once per batch.)
+    for b in (good, bad):
+        for v in b["cre_sequences"] + b["gene_embeddings"]:
+            v[v == 499] = 498
+    assert not bool(bad["cre_attention_masks"][0][0, 0, 5])
+    bad["cre_sequences"][0][0, 0, 5] = 499
+    with torch.no_grad():
+        model.cre_tokenizer.token_embedding.weight[499] += 20.0
+    ops.ln_fold_alert(torch.device("cuda", torch.cuda.current_device()))
+    monkeypatch.setenv("VF_LN_FOLD", "0")
+    want = Trainer().predict(model, [good, bad, good])
+    monkeypatch.delenv("VF_LN_FOLD")
+    monkeypatch.setattr(M, "LN_HEAL_STICKY_AFTER", 10 ** 9)
+    calls = _forward_counter(model, monkeypatch)
+    got = Trainer().predict(model, [good, bad, good])
+    assert calls["n"] == 4 and M._LN_HEAL["batches"] == 1              # three batches + one recomputation
+    assert np.array_equal(got[1]["pred_gene_exp"][0], want[1]["pred_gene_exp"][0])
+    assert np.array_equal(got[1]["embeddings"][0], want[1]["embeddings"][0])
+    # the clean batches came from the folded path: same numbers as the unfolded run at 16-bit level, not bit for bit
+    for i in (0, 2):
+        np.testing.assert_allclose(got[i]["pred_gene_exp"][0], want[i]["pred_gene_exp"][0], rtol=1e-2)
+        assert [r["batch_idx"] for r in got] == [0, 1, 2]
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_range_bit_of_the_flag(dtype, monkeypatch):
+    """An element of 2e6 cannot be held by fp16(x * 2^-4): the producer's statistics bound it (|mean| + sqrt(D var)) and
+    raise bit 1 -- for the fp16 trunk copy of a bf16 model and for the scaled fp16 operand copy of an fp16 one; a bf16-only
+    configuration (VF_TRUNK16=0) has no fp16 copy and stays silent; ordinary rows never raise it."""
+    from variantformer_amd import ops
+    td = torch.bfloat16 if dtype == "bf16" else torch.float16
+    dev = torch.device("cuda", torch.cuda.current_device())
+    M_, N, K = 300, 1536, 1024
+    g = torch.Generator().manual_seed(3)
+    a = (torch.rand((M_, K), generator=g) * 2 - 1).cuda().to(td)
+    w = ((torch.rand((N, K), generator=g) * 2 - 1) / math.sqrt(K)).cuda().to(td)
+    res = (torch.rand((M_, N), generator=g) * 2 - 1).cuda()
+    with ops.compute_dtype(td):
+        ops.ln_fold_alert(dev)
+        s = ops.gemm_ln_producer(a, w, None, res)
+        torch.cuda.synchronize()
+        assert ops.ln_fold_alert(dev) == 0
+        res2 = res.clone()
+        res2[17, 100] = 2.0e6
+        s = ops.gemm_ln_producer(a, w, None, res2)
+        bits = ops.ln_fold_alert(dev)
+        assert bits & 2, bits
+        assert ops.ln_fold_alert(dev) == 0                             # reading resets
+        # the stream-input forms raise it too
+        ops.ln_stream(res2)
+        assert ops.ln_fold_alert(dev) & 2
+        if dtype == "bf16":
+            t = ops.trunk16_of(res2)
+            assert ops.ln_fold_alert(dev) & 2 and torch.isinf(t[17, 100])
+            monkeypatch.setenv("VF_TRUNK16", "0")                      # no fp16 copy anywhere: nothing to overflow
+            ops.gemm_ln_producer(a, w, None, res2)
+            assert ops.ln_fold_alert(dev) & 2 == 0

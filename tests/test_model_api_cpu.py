@@ -192,3 +192,42 @@ def test_seq2reg_option_state_dicts_match_reference():
         mine = {k: list(v.shape) for k, v in m.state_dict().items()}
         assert mine == {k: list(v.shape) for k, v in sd.items()}, name
         m.load_state_dict(sd, strict=True)
+
+
+def test_window_deduplication_is_exact_and_hash_independent():
+    """prepare_batch's exact window de-duplication: a 64-bit row hash proposes the groups, every group is verified element
+    by element, a collision falls back to the row-wise np.unique -- so the grouping never depends on the hash."""
+    from variantformer_amd.seq2gene.model_combined_modulator import Seq2GenePredictorCombinedModulator as M
+    rng = np.random.default_rng(3)
+    W, L = 300, 200
+    ids = rng.integers(4, 500, (W, L)).astype(np.int32)
+    pad = np.zeros((W, L), np.uint8)
+    lens = rng.integers(60, 130, W)
+    for i, n in enumerate(lens):
+        pad[i, n:] = 1
+        ids[i, n:] = 0
+    src = rng.integers(0, 40, W)                      # every row is a copy of one of the first 40 rows ...
+    ids[40:], pad[40:] = ids[src[40:]], pad[src[40:]]
+    ids[77, 5] ^= 1                                   # ... except two that differ in ONE element (token / mask bit)
+    pad[91, 3] ^= 1
+    extra = (np.arange(W) % 2).astype(np.int64)
+
+    def brute(extra=None):
+        key = np.concatenate([ids, pad.astype(np.int32)] + ([extra.reshape(-1, 1).astype(np.int32)] if extra is not None else []), axis=1)
+        seen, keep, inv = {}, [], []
+        for i, r in enumerate(map(bytes, key)):
+            if r not in seen:
+                seen[r] = len(keep)
+                keep.append(i)
+            inv.append(seen[r])
+        return np.array(keep), np.array(inv)
+    for ex in (None, extra):
+        want_keep, want_inv = brute(ex)
+        for forced in (False, True):
+            keep, inv = M._unique_windows(ids, pad, ex, _force_collisions=forced)
+            assert np.array_equal(keep, want_keep) and np.array_equal(inv, want_inv)
+            assert np.array_equal(ids[keep][inv], ids) and np.array_equal(pad[keep][inv], pad)
+    assert len(brute()[0]) == 42 and len(brute(extra)[0]) > 42
+    assert M._unique_windows(ids[:40], pad[:40]) is None             # all distinct: nothing to share
+    odd = M._unique_windows(np.concatenate([ids[:, :199]] * 1), pad[:, :199])      # odd row length (padding column)
+    assert odd is not None and np.array_equal(ids[:, :199][odd[0]][odd[1]], ids[:, :199])

@@ -766,11 +766,14 @@ __global__ __launch_bounds__(256) void attn_x32_kernel(AttnParams P) {
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) {
                 // 2^-100 .. 2^100 (false for NaN).  fp16 P: overflow shows as inf; at the low end the largest p of a row must
-                // still be a NORMAL half with room below it (subnormal P would pass a 2^-100 test with 4 significant bits):
-                // rows whose logits all lie below -6 are recomputed
-                constexpr float L_MIN = DT == VF_F16 ? 0.015625f : 7.8886e-31f;
+                // still be a NORMAL half with room below it (subnormal P would pass a 2^-100 test with 4 significant bits).
+                // The denominator bounds the largest p from below only through the key count, l <= len_k * p_max, so the
+                // test is on the MEAN p: l > len_k * 2^-11 guarantees p_max > 2^-11 (8 times the smallest normal half)
+                // however many keys share the sum -- thousands of keys at logits of -17 ... -20 add up to 2^-6 with every
+                // P subnormal (round-3 advice).  Conservative for peaked rows (recomputed although fine): never wrong.
+                const float l_min = DT == VF_F16 ? fmaxf(0.015625f, (float)len_k * 4.8828125e-4f) : 7.8886e-31f;
                 const float l = o[qb][1][8];
-                bad = bad || !(l > L_MIN && l < 1.2676e30f);
+                bad = bad || !(l > l_min && l < 1.2676e30f);
             }
         }
         if (__syncthreads_or(bad)) {                                  // block-uniform (also orders the LDS stages)
@@ -1225,7 +1228,7 @@ int launch_short(AttnParams P, int n_seq, int max_k, hipStream_t st) {
 template <int DT, int QB>
 int launch_x32(const AttnParams& P, dim3 grid, hipStream_t st) {
     constexpr int lds = 2 * BKV * (112 + 192);
-    static const int nomax = getenv("VF_ATTN_NOMAX") ? atoi(getenv("VF_ATTN_NOMAX")) : 1;    // 0: running maximum always (A/B)
+    static const int nomax = vf_tuning_env("VF_ATTN_NOMAX", 1);    // 0: running maximum always (A/B)
     if (P.q_log2 && nomax) hipLaunchKernelGGL((attn_x32_kernel<DT, QB, true>), grid, dim3(256), lds, st, P);
     else hipLaunchKernelGGL((attn_x32_kernel<DT, QB, false>), grid, dim3(256), lds, st, P);
     VF_CHECK_LAUNCH("vf_attn_varlen_fwd");
@@ -1243,7 +1246,7 @@ int launch_attn(AttnParams P, int n_seq, int max_q, int max_k, hipStream_t st) {
     // query, never the arithmetic of a query: tests test_cfg3 / test_headline batch independence at 1e-5).  64 queries
     // per wave once that leaves >= 8 blocks per CU (the batched gene -> CRE cross attention), else 32 (3 waves / SIMD).
     if constexpr (DH == 48 && !ALIBI) {
-        static const int x32 = getenv("VF_ATTN_X32") ? atoi(getenv("VF_ATTN_X32")) : 1;      // 0: the 16x16x32 kernels (A/B)
+        static const int x32 = vf_tuning_env("VF_ATTN_X32", 1);      // 0: the 16x16x32 kernels (A/B)
         if (x32) {
             if (x32 != 2 && (long)n_seq * P.H * ((max_q + 255) / 256) >= 2048)
                 return launch_x32<DT, 2>(P, dim3(set_grid(P, n_seq, (max_q + 255) / 256)), st);
@@ -1254,7 +1257,7 @@ int launch_attn(AttnParams P, int n_seq, int max_q, int max_k, hipStream_t st) {
         if (max_q > 128 && max_q <= 256 && max_k <= 256) {
             // three resident blocks per CU (two passes of 2 query groups, trimmed LDS image) once the image leaves room
             // for them; VF_ATTN_SHORT2=0: the one-pass kernel (A/B)
-            static const int short2 = getenv("VF_ATTN_SHORT2") ? atoi(getenv("VF_ATTN_SHORT2")) : 1;
+            static const int short2 = vf_tuning_env("VF_ATTN_SHORT2", 1);
             int kr, vr;
             short2_rows(max_k, kr, vr);
             if (short2 && 3 * (kr * KLayout<DH>::ROW + vr * VLayout<DH>::ROW) <= 160 * 1024)
@@ -1266,7 +1269,7 @@ int launch_attn(AttnParams P, int n_seq, int max_q, int max_k, hipStream_t st) {
     if constexpr (DH == 64) {
         // seq2reg windows (<= 128 tokens at dh = 64: a 36 KB image): one block per (window, head) with the whole K / V in
         // LDS instead of two 64-query blocks that each fetch K / V and wait for it (VF_ATTN_SHORT64=0: the tiled kernel)
-        static const int short64 = getenv("VF_ATTN_SHORT64") ? atoi(getenv("VF_ATTN_SHORT64")) : 1;
+        static const int short64 = vf_tuning_env("VF_ATTN_SHORT64", 1);
         if (short64 && max_q <= 128 && max_k <= 128 && (long)n_seq * P.H >= 1024) {
             int kr, vr;
             short2_rows(max_k, kr, vr);
@@ -1285,7 +1288,7 @@ int launch_attn(AttnParams P, int n_seq, int max_q, int max_k, hipStream_t st) {
             const dim3 grid(set_grid(P, n_seq, (max_q + 127) / 128));
 #ifdef VF_TUNING                                   // libvf_hip_tuning.so only (scripts/): ceiling-finding builds whose results are meaningless
             if constexpr (DH == 48 && !ALIBI && DT == VF_BF16) {
-                static const int dbg = getenv("VF_ATTN_DBG") ? atoi(getenv("VF_ATTN_DBG")) : 0;
+                static const int dbg = vf_tuning_env("VF_ATTN_DBG", 0);
                 if (dbg == 1) return launch_fwd<48, 2, false, VF_BF16, 1>(P, grid, st);
                 if (dbg == 2) return launch_fwd<48, 2, false, VF_BF16, 2>(P, grid, st);
                 if (dbg == 3) return launch_fwd<48, 2, false, VF_BF16, 3>(P, grid, st);

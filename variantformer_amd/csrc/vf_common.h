@@ -25,6 +25,18 @@ static inline int vf_current_device() {
     return (d >= 0 && d < VF_MAX_DEVICES) ? d : -1;
 }
 
+// A/B switches between kernel forms exist in the tuning library only (libvf_hip_tuning.so, -DVF_TUNING: scripts/ and the
+// tuning tests); the product library always takes the measured default, so no environment variable reaches a kernel choice.
+#ifdef VF_TUNING
+#include <stdlib.h>
+static inline int vf_tuning_env(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+#else
+#define vf_tuning_env(name, dflt) (dflt)
+#endif
+
 #define VF_REQUIRE(cond, ...)                        \
     do {                                             \
         if (!(cond)) {                               \

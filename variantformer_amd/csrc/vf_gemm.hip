@@ -2394,6 +2394,7 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(const unsigned short*
     }
 }
 
+#ifdef VF_TUNING   // measured 5-7 % slower than the persistent tile kernel on its own shapes (profiles/r03_e_xs_gemm.log); tuning library only
 // ======================================================================================================================
 // X-STATIONARY GEMM for K = 512 (the seq2reg consumers: Wqkv 512 -> 1536, GeGLU 512 -> 2048).
 // At K = 512 a 256x256 output tile lives for 8 K-tiles (11 us) and pays 4-7 us of ramp + epilogue around them, and the
@@ -2654,6 +2655,7 @@ int launch_xs(const void* A, int64_t lda, const void* W, const float* bias, void
 inline bool xs_ok(int N, int K, int epilogue) {
     return K == 512 && N % 128 == 0 && N <= CfgXS::MAX_N && (epilogue == VF_EPI_BF16 || epilogue == VF_EPI_GEGLU_BF16);
 }
+#endif  // VF_TUNING (xs_gemm_kernel)
 
 // The product library instantiates only the configurations pick_variant() can select.
 using CfgA = Cfg<128, 128, 2, 2, 2>;       // 64 KiB, 4 waves, 2 blocks/CU
@@ -2889,7 +2891,7 @@ int pick_variant(int M, int N, int K, int epilogue) {
     // 890 -> 953, GeGLU 893 -> 976, gene Wqkv / Wq / GeGLU +2-3 %, same box).  The fp32 epilogues stay on the one-shot
     // kernel: staged through half the ring (16-row passes) the seq2reg N = 512 producers lose 8 %, the gene ones gain
     // nothing.  VF_GEMM_PERSIST=0 switches the persistent form off (A/B runs).
-    static const int persist = getenv("VF_GEMM_PERSIST") ? atoi(getenv("VF_GEMM_PERSIST")) : 1;
+    static const int persist = vf_tuning_env("VF_GEMM_PERSIST", 1);
     const bool out16 = epilogue == VF_EPI_BF16 || epilogue == VF_EPI_GEGLU_BF16 || epilogue == VF_EPI_GELU_BF16;
     return (persist && (out16 || persist >= 2) && K % 128 == 0) ? 22 : 20;      // K / 64 even: see the kernel's staging
 }
@@ -2911,12 +2913,12 @@ int launch_gemm(const void* A, int64_t lda, const void* W, const float* bias, co
         case 20: return launch_gemm8<EPI, DT>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
         case 22: if (K % 128 == 0) return launch_gemm8x<EPI, DT>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
                  return launch_gemm8<EPI, DT>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
+#ifdef VF_TUNING
         case 30:
             if constexpr (EPI == VF_EPI_BF16 || EPI == VF_EPI_GEGLU_BF16) {
                 if (xs_ok(N, K, EPI)) return launch_xs<EPI, DT, VF_LN_NONE>(A, lda, W, bias, out, ldo, M, N, st);
             }
             break;
-#ifdef VF_TUNING
         case 40: if (K % 128 == 0) return launch_gemm4<EPI, DT>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
                  return launch_gemm8<EPI, DT>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
         case 21:
@@ -2996,17 +2998,19 @@ static int gemm_dispatch(const void* A, int64_t lda, const void* W, const float*
 template <int EPI, int DT, int LN>
 static int launch_gemm_ln(const void* A, int64_t lda, const void* W, const float* bias, const float* residual, int64_t ldr,
                           void* out, int64_t ldo, int M, int N, int K, const LnArgs& ln, hipStream_t st) {
+#ifdef VF_TUNING
     if constexpr (LN == VF_LN_CONSUMER) {
         // A/B switch (off by default: measured 906-942 against 955-1009 TFLOP/s for the persistent tile kernel on the
         // seq2reg shapes, profiles/r03_e_xs_gemm.log): 1 = grids of >= 256 blocks, 2 = every K = 512 consumer (tests)
-        static const int xs = getenv("VF_GEMM_XS") ? atoi(getenv("VF_GEMM_XS")) : 0;
+        static const int xs = vf_tuning_env("VF_GEMM_XS", 0);
         if (xs && xs_ok(N, K, EPI) && (xs >= 2 || M >= 256 * 256))
             return launch_xs<EPI, DT, LN>(A, lda, W, bias, out, ldo, M, N, st, ln);
     }
+#endif
     int variant = pick_variant(M, N, K, EPI);
     if constexpr (LN == VF_LN_PRODUCER_T16) {
         // the fp16-trunk down-projection: persistent form when no fp32 rows are stored (VF_GEMM_PERSIST_T16, default on: gene down-projection 829 -> 857, seq2reg 858 -> 897 TFLOP/s)
-        static const int pt16 = getenv("VF_GEMM_PERSIST_T16") ? atoi(getenv("VF_GEMM_PERSIST_T16")) : 1;
+        static const int pt16 = vf_tuning_env("VF_GEMM_PERSIST_T16", 1);
         if (variant == 20 && K % 128 == 0 && pt16 && out == nullptr) variant = 22;
     }
     if constexpr (LN == VF_LN_PRODUCER_R16) {
@@ -3015,7 +3019,7 @@ static int launch_gemm_ln(const void* A, int64_t lda, const void* W, const float
         // 428-439 -> 408-414 us, seq2reg out-projection 662-675 -> 621-636 us (profiles/r03_v_persist_r16_ab.log).
         // VF_GEMM_PERSIST_R16 = 1 (default): when no fp32 rows are stored either (the attention out-projections),
         // 2: every such producer, 0: never.
-        static const int pr16 = getenv("VF_GEMM_PERSIST_R16") ? atoi(getenv("VF_GEMM_PERSIST_R16")) : 1;
+        static const int pr16 = vf_tuning_env("VF_GEMM_PERSIST_R16", 1);
         if (variant == 20 && K % 128 == 0 && (pr16 >= 2 || (pr16 == 1 && out == nullptr))) variant = 22;
     }
 #ifdef VF_TUNING

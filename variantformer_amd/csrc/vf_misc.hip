@@ -100,10 +100,24 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // NP > 0: n_parts == NP, every part of the row is loaded ONCE, all loads in flight together (one HBM latency per thread; the
 // round-2 form swept the parts twice, 8 loads at a time: 15 us for 33 MB on the gene stream).  NP = 0: any part count, two
 // sweeps.  Same additions in the same order either way.
+// Device flag shared by the statistics kernels (read back with a batch's outputs, ops.ln_fold_alert):
+//   bit 0: a row's |mean| exceeds ratio_limit standard deviations -- rounding the UNCENTRED row to 16 bits costs the folded
+//          LayerNorm accuracy there;
+//   bit 1: a row may hold an element of magnitude >= abs_limit (|x_i - mean| <= sqrt(D * var), so |mean| + sqrt(D * var) bounds
+//          every element): its scaled fp16 copies (operand copy of an fp16 stream, the fp16 trunk copy) could overflow to inf.
+// Either bit makes the model recompute the batch with the separate-LayerNorm fp32-stream path.  Rare path: atomicOr.
+__device__ __forceinline__ void ln_alert(int* alert, float mean, float var, float rstd, int D, float ratio_limit, float abs_limit) {
+    if (!alert) return;
+    int bits = 0;
+    if (fabsf(mean) * rstd > ratio_limit) bits |= 1;
+    if (abs_limit > 0.f && !(fabsf(mean) + sqrtf((float)D * var) < abs_limit)) bits |= 2;     // also true for inf / NaN rows
+    if (bits) atomicOr(alert, bits);
+}
+
 template <int NP>
 __global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restrict__ part, float* __restrict__ row_stats,
                                                          int64_t rows, int n_parts, int D, float eps, float x16_scale,
-                                                         float ratio_limit, int* __restrict__ alert) {
+                                                         float ratio_limit, float abs_limit, int* __restrict__ alert) {
     // part is [n_parts][rows][2] (part-major): one thread per row, consecutive threads read consecutive rows; the parts
     // are added in index order, so the result does not depend on the GEMM tile configuration that wrote them
     const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -132,9 +146,10 @@ __global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restric
             m2 += v[1] + 32.0f * d * d;
         }
     }
-    const float rstd = rsqrtf(m2 / (float)D + eps);
+    const float var = m2 / (float)D;
+    const float rstd = rsqrtf(var + eps);
     *reinterpret_cast<f32x2_t*>(row_stats + 2 * row) = (f32x2_t){mean * x16_scale, rstd / x16_scale};
-    if (alert && fabsf(mean) * rstd > ratio_limit) *alert = 1;      // benign race: every writer stores the same value
+    ln_alert(alert, mean, var, rstd, D, ratio_limit, abs_limit);
 }
 
 // The same statistics for a stream that no GEMM produced (the first layer's input): one wave per row, two-pass
@@ -143,7 +158,7 @@ template <int MAXC>
 __global__ __launch_bounds__(256) void row_stats_cast_kernel(const float* __restrict__ x, void* __restrict__ out16,
                                                             float* __restrict__ row_stats, int64_t rows, int D, float eps,
                                                             int out_dt, float x16_scale, float ratio_limit,
-                                                            int* __restrict__ alert) {
+                                                            float abs_limit, int* __restrict__ alert) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -174,10 +189,11 @@ __global__ __launch_bounds__(256) void row_stats_cast_kernel(const float* __rest
             reinterpret_cast<u32x2_t*>(reinterpret_cast<unsigned short*>(out16) + row * D)[i] = p;
         }
     }
-    const float rstd = rsqrtf(wave_sum(ss) / (float)D + eps);
+    const float var = wave_sum(ss) / (float)D;
+    const float rstd = rsqrtf(var + eps);
     if (lane == 0) {
         *reinterpret_cast<f32x2_t*>(row_stats + 2 * row) = (f32x2_t){mean * x16_scale, rstd / x16_scale};
-        if (alert && fabsf(mean) * rstd > ratio_limit) *alert = 1;
+        ln_alert(alert, mean, var, rstd, D, ratio_limit, abs_limit);
     }
 }
 
@@ -272,7 +288,7 @@ __global__ __launch_bounds__(256) void embed_stream_kernel(const int64_t* __rest
                                                           void* __restrict__ out16, unsigned short* __restrict__ t16,
                                                           float* __restrict__ row_stats, int L, int d, int vocab, float eps,
                                                           int out_dt, float x16_scale, float t16_scale, float ratio_limit,
-                                                          int* __restrict__ alert) {
+                                                          float abs_limit, int* __restrict__ alert) {
     extern __shared__ int sh[];          // [L] position of the k-th valid token, [L] its token id
     int* vpos = sh;
     int* vid = sh + L;
@@ -338,10 +354,11 @@ __global__ __launch_bounds__(256) void embed_stream_kernel(const int64_t* __rest
                 if (out) reinterpret_cast<f32x4_t*>(out + row * d)[i] = v[c];
             }
         }
-        const float rstd = rsqrtf(wave_sum(ss) / (float)d + eps);
+        const float var = wave_sum(ss) / (float)d;
+        const float rstd = rsqrtf(var + eps);
         if (lane == 0) {
             *reinterpret_cast<f32x2_t*>(row_stats + 2 * row) = (f32x2_t){mean * x16_scale, rstd / x16_scale};
-            if (alert && fabsf(mean) * rstd > ratio_limit) *alert = 1;
+            ln_alert(alert, mean, var, rstd, d, ratio_limit, abs_limit);
         }
     }
 }
@@ -571,28 +588,30 @@ extern "C" int vf_layernorm(const float* x, const float* gamma, const float* bet
 }
 
 extern "C" int vf_ln_finalize2(const float* part_stats, int64_t rows, int n_parts, int D, float eps, float x16_scale,
-                               float ratio_limit, int* alert, float* row_stats, void* stream) {
+                               float ratio_limit, float abs_limit, int* alert, float* row_stats, void* stream) {
     VF_REQUIRE(part_stats && row_stats && n_parts > 0 && D > 0 && x16_scale > 0.f, "vf_ln_finalize: bad arguments");
+    // the merge assumes whole 32-column parts carrying (sum, M2 about the part mean) -- what the ABI >= 5 producers write
+    VF_REQUIRE(D == 32 * n_parts, "vf_ln_finalize: D=%d must be 32 * n_parts (n_parts=%d)", D, n_parts);
     if (rows <= 0) return VF_OK;
     const dim3 grid((unsigned)((rows + 255) / 256));
     hipStream_t st = (hipStream_t)stream;
     if (n_parts == 48)            // D = 1536: the modulator streams
-        hipLaunchKernelGGL(ln_finalize_kernel<48>, grid, dim3(256), 0, st, part_stats, row_stats, rows, n_parts, D, eps, x16_scale, ratio_limit, alert);
+        hipLaunchKernelGGL(ln_finalize_kernel<48>, grid, dim3(256), 0, st, part_stats, row_stats, rows, n_parts, D, eps, x16_scale, ratio_limit, abs_limit, alert);
     else if (n_parts == 16)       // D = 512: seq2reg
-        hipLaunchKernelGGL(ln_finalize_kernel<16>, grid, dim3(256), 0, st, part_stats, row_stats, rows, n_parts, D, eps, x16_scale, ratio_limit, alert);
+        hipLaunchKernelGGL(ln_finalize_kernel<16>, grid, dim3(256), 0, st, part_stats, row_stats, rows, n_parts, D, eps, x16_scale, ratio_limit, abs_limit, alert);
     else
-        hipLaunchKernelGGL(ln_finalize_kernel<0>, grid, dim3(256), 0, st, part_stats, row_stats, rows, n_parts, D, eps, x16_scale, ratio_limit, alert);
+        hipLaunchKernelGGL(ln_finalize_kernel<0>, grid, dim3(256), 0, st, part_stats, row_stats, rows, n_parts, D, eps, x16_scale, ratio_limit, abs_limit, alert);
     VF_CHECK_LAUNCH("vf_ln_finalize");
     return VF_OK;
 }
 
 extern "C" int vf_ln_finalize(const float* part_stats, int64_t rows, int n_parts, int D, float eps, float* row_stats,
                               void* stream) {
-    return vf_ln_finalize2(part_stats, rows, n_parts, D, eps, 1.0f, 0.f, nullptr, row_stats, stream);
+    return vf_ln_finalize2(part_stats, rows, n_parts, D, eps, 1.0f, 0.f, 0.f, nullptr, row_stats, stream);
 }
 
 extern "C" int vf_row_stats_cast2(const float* x, int64_t rows, int D, float eps, void* out16, int out_dtype, float x16_scale,
-                                  float ratio_limit, int* alert, float* row_stats, void* stream) {
+                                  float ratio_limit, float abs_limit, int* alert, float* row_stats, void* stream) {
     VF_REQUIRE(x && out16 && row_stats, "vf_row_stats_cast: null pointer");
     VF_REQUIRE(D > 0 && D % 4 == 0 && D <= 8192, "vf_row_stats_cast: D=%d must be a multiple of 4 and <= 8192", D);
     VF_REQUIRE(out_dtype == VF_BF16 || out_dtype == VF_F16, "vf_row_stats_cast: bad out_dtype %d", out_dtype);
@@ -600,16 +619,16 @@ extern "C" int vf_row_stats_cast2(const float* x, int64_t rows, int D, float eps
     if (rows <= 0) return VF_OK;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)((rows + 3) / 4));
-    if (D <= 512) hipLaunchKernelGGL(row_stats_cast_kernel<2>, grid, dim3(256), 0, st, x, out16, row_stats, rows, D, eps, out_dtype, x16_scale, ratio_limit, alert);
-    else if (D <= 2048) hipLaunchKernelGGL(row_stats_cast_kernel<8>, grid, dim3(256), 0, st, x, out16, row_stats, rows, D, eps, out_dtype, x16_scale, ratio_limit, alert);
-    else hipLaunchKernelGGL(row_stats_cast_kernel<32>, grid, dim3(256), 0, st, x, out16, row_stats, rows, D, eps, out_dtype, x16_scale, ratio_limit, alert);
+    if (D <= 512) hipLaunchKernelGGL(row_stats_cast_kernel<2>, grid, dim3(256), 0, st, x, out16, row_stats, rows, D, eps, out_dtype, x16_scale, ratio_limit, abs_limit, alert);
+    else if (D <= 2048) hipLaunchKernelGGL(row_stats_cast_kernel<8>, grid, dim3(256), 0, st, x, out16, row_stats, rows, D, eps, out_dtype, x16_scale, ratio_limit, abs_limit, alert);
+    else hipLaunchKernelGGL(row_stats_cast_kernel<32>, grid, dim3(256), 0, st, x, out16, row_stats, rows, D, eps, out_dtype, x16_scale, ratio_limit, abs_limit, alert);
     VF_CHECK_LAUNCH("vf_row_stats_cast");
     return VF_OK;
 }
 
 extern "C" int vf_row_stats_cast(const float* x, int64_t rows, int D, float eps, void* out16, int out_dtype,
                                  float* row_stats, void* stream) {
-    return vf_row_stats_cast2(x, rows, D, eps, out16, out_dtype, 1.0f, 0.f, nullptr, row_stats, stream);
+    return vf_row_stats_cast2(x, rows, D, eps, out16, out_dtype, 1.0f, 0.f, 0.f, nullptr, row_stats, stream);
 }
 
 extern "C" int vf_mask_to_cu_seqlens(const uint8_t* pad, int32_t* cu, int W, int L, void* stream) {
@@ -633,8 +652,8 @@ extern "C" int vf_embed_pack(const int64_t* ids, const uint8_t* pad, const int32
 
 extern "C" int vf_embed_stream(const int64_t* ids, const uint8_t* pad, const int32_t* cu, const float* table,
                                const float* pos_table, float* out, void* out16, int out_dtype, float x16_scale, void* t16,
-                               float t16_scale, float* row_stats, float eps, float ratio_limit, int* alert, int W, int L,
-                               int d, int vocab, void* stream) {
+                               float t16_scale, float* row_stats, float eps, float ratio_limit, float abs_limit, int* alert,
+                               int W, int L, int d, int vocab, void* stream) {
     VF_REQUIRE(ids && pad && cu && table && out16 && row_stats, "vf_embed_stream: null pointer");
     VF_REQUIRE(L > 0 && L <= 4096 && d > 0 && d % 4 == 0 && d <= 2048 && vocab > 0, "vf_embed_stream: bad shape L=%d d=%d vocab=%d", L, d, vocab);
     VF_REQUIRE(out_dtype == VF_BF16 || out_dtype == VF_F16, "vf_embed_stream: bad out_dtype %d", out_dtype);
@@ -643,10 +662,10 @@ extern "C" int vf_embed_stream(const int64_t* ids, const uint8_t* pad, const int
     hipStream_t st = (hipStream_t)stream;
     if (d <= 512)
         hipLaunchKernelGGL(embed_stream_kernel<2>, dim3(W), dim3(256), 2 * L * sizeof(int), st, ids, pad, cu, table, pos_table, out,
-                           out16, (unsigned short*)t16, row_stats, L, d, vocab, eps, out_dtype, x16_scale, t16_scale, ratio_limit, alert);
+                           out16, (unsigned short*)t16, row_stats, L, d, vocab, eps, out_dtype, x16_scale, t16_scale, ratio_limit, abs_limit, alert);
     else
         hipLaunchKernelGGL(embed_stream_kernel<8>, dim3(W), dim3(256), 2 * L * sizeof(int), st, ids, pad, cu, table, pos_table, out,
-                           out16, (unsigned short*)t16, row_stats, L, d, vocab, eps, out_dtype, x16_scale, t16_scale, ratio_limit, alert);
+                           out16, (unsigned short*)t16, row_stats, L, d, vocab, eps, out_dtype, x16_scale, t16_scale, ratio_limit, abs_limit, alert);
     VF_CHECK_LAUNCH("vf_embed_stream");
     return VF_OK;
 }

@@ -200,11 +200,8 @@ class LnStream:
 def x16_scale_for(dtype) -> float:
     """Power-of-two scale of the 16-bit copy of a residual stream: 1 for bf16 (fp32's exponent range); 2^-4 for fp16, which
     keeps |x| < 1e6 representable (the reference's own fp16 autocast overflows at 65504) at no cost in precision --
-    10 mantissa bits at every magnitude above 1e-3 -- and LayerNorm is scale-invariant.  VF_X16_SCALE_LOG2 overrides."""
-    import os
-    if dtype != torch.float16:
-        return 1.0
-    return 2.0 ** int(os.environ.get("VF_X16_SCALE_LOG2", "-4"))
+    10 mantissa bits at every magnitude above 1e-3 -- and LayerNorm is scale-invariant."""
+    return 1.0 if dtype != torch.float16 else 2.0 ** -4
 
 
 # Rows whose |mean| exceeds this many standard deviations make the folded LayerNorm -> Linear lose accuracy (it rounds
@@ -221,13 +218,29 @@ def _alert_flag(device) -> torch.Tensor:
     return _ALERT[key]
 
 
-def ln_fold_alert(device, reset: bool = True) -> bool:
-    """True when, since the last reset, some row of a LayerNorm-folded stream had |mean| > LN_FOLD_RATIO_LIMIT standard
-    deviations (synchronises: call it where the outputs are copied back).  VF_LN_FOLD=0 avoids the regime."""
+# Elements at or beyond this magnitude could overflow a scaled fp16 copy of a stream (65504 / 2^-4 with some margin): the
+# statistics kernels bound every element of a row by |mean| + sqrt(D * var) and raise bit 1 of the flag (ABI 6).
+def ln_fold_abs_limit() -> float:
+    """Largest |x| the 16-bit copies of a LayerNorm-folded stream represent: unbounded (0 = no check) when every copy is
+    bf16; 60000 / scale for the fp16 copy with the least headroom (fp16 operand copy, fp16 trunk copy)."""
+    scales = []
+    if _CDT == torch.float16:
+        scales.append(x16_scale_for(torch.float16))
+    import os
+    if os.environ.get("VF_TRUNK16", "f16") == "f16":
+        scales.append(T16_SCALE)
+    return 60000.0 / max(scales) if scales else 0.0
+
+
+def ln_fold_alert(device, reset: bool = True) -> int:
+    """Non-zero when, since the last reset, a LayerNorm-folded stream left the regime its 16-bit copies serve: bit 0 -- some
+    row had |mean| > LN_FOLD_RATIO_LIMIT standard deviations; bit 1 -- some row may hold an element beyond ln_fold_abs_limit()
+    (a scaled fp16 copy could overflow).  Synchronises: call it where the outputs are copied back.  The model then recomputes
+    the batch with the separate LayerNorm on fp32 rows (layers.ln_fold_forced_off) -- degraded numbers are never returned."""
     key = (device.type, device.index)
     if key not in _ALERT:
-        return False
-    hit = bool(int(_ALERT[key].item()))
+        return 0
+    hit = int(_ALERT[key].item())
     if hit and reset:
         _ALERT[key].zero_()
     return hit
@@ -245,7 +258,8 @@ def ln_stream(x: torch.Tensor, eps: float = 1e-5) -> LnStream:
 
     def launch():
         check(_lib.load().vf_row_stats_cast2(x.data_ptr(), M, D, eps, x16.data_ptr(), _dt(_CDT), scale, LN_FOLD_RATIO_LIMIT,
-                                             alert.data_ptr(), stats.data_ptr(), _stream()), "vf_row_stats_cast")
+                                             ln_fold_abs_limit(), alert.data_ptr(), stats.data_ptr(), _stream()),
+              "vf_row_stats_cast")
     if TIMER is not None:
         TIMER.time("layernorm", 0.0, float(M) * D * 6, launch, f"stats_cast D={D}", _SCOPE)
     else:
@@ -272,9 +286,12 @@ def trunk16_of(x: torch.Tensor) -> torch.Tensor:
     t16 = torch.empty((M, D), dtype=torch.float16, device=x.device)
     stats = torch.empty((M, 2), dtype=torch.float32, device=x.device)
 
-    def launch():
-        check(_lib.load().vf_row_stats_cast2(x.data_ptr(), M, D, 1e-5, t16.data_ptr(), VF_F16, T16_SCALE, 0.0, 0,
-                                             stats.data_ptr(), _stream()), "vf_row_stats_cast")
+    alert = _alert_flag(x.device)
+
+    def launch():       # ratio limit off (1e30): this stream's statistics are the caller's business; range check on
+        check(_lib.load().vf_row_stats_cast2(x.data_ptr(), M, D, 1e-5, t16.data_ptr(), VF_F16, T16_SCALE, 1e30,
+                                             60000.0 / T16_SCALE, alert.data_ptr(), stats.data_ptr(), _stream()),
+              "vf_row_stats_cast")
     if TIMER is not None:
         TIMER.time("layernorm", 0.0, float(M) * D * 6, launch, f"trunk16_of D={D}", _SCOPE)
     else:
@@ -351,8 +368,8 @@ def gemm_ln_producer(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None
                              part.data_ptr(), scale, r_scale, _stream()), "vf_gemm_ln")
 
     def finalize():
-        check(lib.vf_ln_finalize2(part.data_ptr(), M, n_parts, N, eps, scale, LN_FOLD_RATIO_LIMIT, alert.data_ptr(),
-                                  stats.data_ptr(), _stream()), "vf_ln_finalize")
+        check(lib.vf_ln_finalize2(part.data_ptr(), M, n_parts, N, eps, scale, LN_FOLD_RATIO_LIMIT, ln_fold_abs_limit(),
+                                  alert.data_ptr(), stats.data_ptr(), _stream()), "vf_ln_finalize")
     if TIMER is not None:
         res_bytes = 0.0 if residual is None else (4.0 if res32 is not None else 2.0) * M * N
         nbytes = 2.0 * (M * K + N * K) + M * N * ((4.0 if need_x else 0.0) + 2.0) + res_bytes + 8.0 * M * n_parts
@@ -388,8 +405,8 @@ def _gemm_ln_producer_t16(a, w, bias, t_in, eps, family, need_x, need_t16) -> Ln
               "vf_gemm_ln_t16")
 
     def finalize():
-        check(lib.vf_ln_finalize2(part.data_ptr(), M, n_parts, N, eps, scale, LN_FOLD_RATIO_LIMIT, alert.data_ptr(),
-                                  stats.data_ptr(), _stream()), "vf_ln_finalize")
+        check(lib.vf_ln_finalize2(part.data_ptr(), M, n_parts, N, eps, scale, LN_FOLD_RATIO_LIMIT, ln_fold_abs_limit(),
+                                  alert.data_ptr(), stats.data_ptr(), _stream()), "vf_ln_finalize")
     if TIMER is not None:
         nbytes = 2.0 * (M * K + N * K) + M * N * ((4.0 if need_x else 0.0) + (2.0 if need_t16 else 0.0) + 2.0 + 2.0) + 8.0 * M * n_parts
         tag = "producer" + ("" if need_x else "-nox") + "-t16" + ("" if need_t16 else "-in")
@@ -520,7 +537,8 @@ def embed_stream(ids: torch.Tensor, pad: torch.Tensor, cu: torch.Tensor, table: 
     def launch():
         check(_lib.load().vf_embed_stream(ids.data_ptr(), pad.data_ptr(), cu.data_ptr(), table.data_ptr(), _ptr(pos_table),
                                           _ptr(x), x16.data_ptr(), _dt(_CDT), scale, _ptr(t16), T16_SCALE, stats.data_ptr(),
-                                          eps, LN_FOLD_RATIO_LIMIT, alert.data_ptr(), W, L, d, table.shape[0], _stream()),
+                                          eps, LN_FOLD_RATIO_LIMIT, ln_fold_abs_limit(), alert.data_ptr(), W, L, d, table.shape[0],
+                                          _stream()),
               "vf_embed_stream")
     if TIMER is not None:
         TIMER.time("layernorm", 0.0, float(n_tokens) * d * (2 + (2 if need_t16 else 0) + (4 if need_x else 0)), launch,

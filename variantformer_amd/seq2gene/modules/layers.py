@@ -111,61 +111,84 @@ def packed_linear_ln(lin: nn.Linear, norm: nn.LayerNorm, geglu: bool = False, ws
     return wb, b, colsum
 
 
+_LN_FOLD_FORCED_OFF = 0        # > 0: inside ln_fold_forced_off() (or switched off for the process by ln_fold_disable())
+
+
+class ln_fold_forced_off:
+    """Context: every layer takes the separate-LayerNorm path on fp32 rows, exactly as with VF_LN_FOLD=0, whatever the
+    environment says.  The model recomputes a batch under it when the statistics kernels flagged rows the folded form does
+    not serve (ops.ln_fold_alert): the same kernels, the same arithmetic, the same bits as a VF_LN_FOLD=0 run."""
+
+    def __enter__(self):
+        global _LN_FOLD_FORCED_OFF
+        _LN_FOLD_FORCED_OFF += 1
+        return self
+
+    def __exit__(self, *exc):
+        global _LN_FOLD_FORCED_OFF
+        _LN_FOLD_FORCED_OFF -= 1
+        return False
+
+
+def ln_fold_disable():
+    """Switch the fold off for the rest of the process (a checkpoint that keeps tripping the alert: stop paying for two
+    forwards and two weight packings per batch)."""
+    global _LN_FOLD_FORCED_OFF
+    _LN_FOLD_FORCED_OFF += 1 << 20
+
+
 def ln_fold_enabled(*widths: int) -> bool:
     """LayerNorm folded into the neighbouring GEMMs when EVERY contraction width of the layer's
     folded GEMMs (d_model, and hidden_dim / 2 for the down-projection producer) is one the MFMA path takes (K % 64 == 0);
-    otherwise -- and with VF_LN_FOLD=0 -- the separate LayerNorm pass.  Both operand types: an fp16 stream's 16-bit copy
-    is stored scaled by a power of two (ops.x16_scale_for), so the raw residual cannot leave the fp16 range."""
+    otherwise -- and with VF_LN_FOLD=0, or inside ln_fold_forced_off() -- the separate LayerNorm pass.  Both operand types:
+    an fp16 stream's 16-bit copy is stored scaled by a power of two (ops.x16_scale_for), so the raw residual cannot leave
+    the fp16 range."""
     import os
-    return all(int(w) % 64 == 0 for w in widths) and os.environ.get("VF_LN_FOLD", "1") != "0"
+    return (_LN_FOLD_FORCED_OFF == 0 and all(int(w) % 64 == 0 for w in widths)
+            and os.environ.get("VF_LN_FOLD", "1") != "0")
 
 
 def res16_enabled() -> bool:
     """Every attention block's output sum (x1 = out_proj(attn) + src, x2 = out_proj(cross) + x1) is read only through the
-    next LayerNorm -> Linear pair and as the next attention block's residual; both read it in 16 bits.  With this on (default;
-    VF_RES16=0 restores fp32) the 16-bit copies serve as the residuals of the two attention out-projections -- x1 = ... +
-    float(src16), x2 = ... + float(x1_16) -- and x1's fp32 rows are never written: 8 bytes per element less traffic in
-    the two producer epilogues.  The trunk stays fp32: a layer's output is still W2.h + src with the fp32 layer input, so
-    the 16-bit roundings only ever enter branch inputs.  The reference's own autocast keeps these streams in 16 bits;
-    oracle.Rounding(res16=True) restates the rounding points."""
-    import os
-    return os.environ.get("VF_RES16", "1") != "0"
+    next LayerNorm -> Linear pair and as the next attention block's residual; both read it in 16 bits: the 16-bit copies
+    serve as the residuals of the two attention out-projections -- x1 = ... + float(src16), x2 = ... + float(x1_16) -- and
+    x1's fp32 rows are never written.  The trunk is unaffected: a layer's output is W2.h + (layer input), so these
+    roundings only ever enter branch inputs.  The reference's own autocast keeps these streams in 16 bits;
+    oracle.Rounding(res16=True) restates the rounding points.  Part of the LayerNorm fold (round 3 had a VF_RES16 switch;
+    the fp32 form was 3 % slower and no more accurate at the outputs, profiles/r03_c_*)."""
+    return True
 
 
 def trunk16_enabled(stack: str = "modulator") -> bool:
     """A layer's OUTPUT (the trunk: W2.h + layer input) travels to the next layer of its stack as 16-bit copies + row
     statistics only, no fp32 rows in either direction; the LAST layer of a stack (its output is pooled / returned, not fed
-    to a LayerNorm -> Linear pair) keeps its fp32 result.  Needs the LayerNorm fold and res16.  VF_TRUNK16 selects what the
-    next down-projection adds as its residual (trunk16_mode):
+    to a LayerNorm -> Linear pair) keeps its fp32 result.  Part of the LayerNorm fold.  VF_TRUNK16 selects what the next
+    down-projection adds as its residual (trunk16_mode):
       f16 (default)  a scaled FP16 copy of the trunk written beside the operand-type copy (down_projection,
                      vf_gemm_ln_t16): 6 instead of 10 bytes per element through the epilogue, 11 significant bits -- the
                      embeddings' distance from pure fp32 arithmetic stays at the fp32 trunk's (3.3e-3 vs 3.4e-3 on a
-                     full-depth gene; the bf16 copy: 1.3e-2), step +1 %;
-      1 / s2r        the operand-type (bf16) copy itself, everywhere / in the seq2reg encoders only: 4 bytes per element,
-                     where the reference's own autocast rounds (`x = linear_geglu_2(x)` is a 16-bit tensor there and
-                     `x += res_long` adds in place, layers.py:161-165, seq2reg/modules.py:186-190) -- 3.2 % / 1.2 % off the
-                     step, but over 25 + 24 layers the expression's distance from fp32 grows from 3.4e-4 to 8.8e-4, inside
-                     the 1e-3 bar without margin, and a same-rounding oracle no longer tracks the kernels (one-ulp flips of
-                     the trunk persist);
+                     full-depth gene), step +1 %; with fp16 operands the operand copy already is that trunk;
       0              fp32 rows.
-    DESIGN.md section 6 (round 3) has the measurements; oracle.Rounding(trunk16=...) restates the rounding points."""
-    mode = trunk16_mode()
-    on = mode not in ("0", "") and (stack == "seq2reg" or mode != "s2r")
-    return on and res16_enabled()
+    (Round 3 also measured the reference's own rounding point -- the trunk in the OPERAND type, bf16 -- as modes "1" / "s2r":
+    -3.2 % / -1.2 % step time, but expression error 3.4e-4 -> 8.8e-4 against a bar of 1e-3; removed in round 4, DESIGN.md
+    appendix.)  oracle.Rounding(trunk16=...) restates the rounding points."""
+    return trunk16_mode() == "f16"
 
 
 def trunk16_mode() -> str:
     """VF_TRUNK16: "f16" (default) -- the trunk travels between the layers of a stack as a scaled FP16 copy whatever the
-    operand type (down_projection below; with fp16 operands that is the operand-type copy itself, i.e. mode "1");
-    "0" -- fp32 rows; "s2r" / "1" -- the operand-type (bf16) copy in the seq2reg encoders / everywhere (trunk16_enabled)."""
+    operand type (down_projection below; with fp16 operands that is the operand-type copy itself); "0" -- fp32 rows."""
     import os
-    return os.environ.get("VF_TRUNK16", "f16")
+    mode = os.environ.get("VF_TRUNK16", "f16")
+    if mode not in ("f16", "0"):
+        raise ValueError(f"VF_TRUNK16={mode!r}: the supported values are 'f16' (default) and '0' (fp32 trunk)")
+    return mode
 
 
 def trunk_f16_active() -> bool:
-    """The fp16 trunk copy is in use: mode "f16", 16-bit residual exchange on, bf16 operands (an fp16 operand copy already
-    IS the fp16 trunk: trunk16_enabled's plain 16-bit path serves it)."""
-    return trunk16_mode() == "f16" and res16_enabled() and ops.cdt() == torch.bfloat16
+    """The fp16 trunk copy is in use: mode "f16" with bf16 operands (an fp16 operand copy already IS the fp16 trunk:
+    trunk16_enabled's plain 16-bit path serves it)."""
+    return trunk16_mode() == "f16" and ops.cdt() == torch.bfloat16
 
 
 def down_projection(hg, w2, b2, s, keep_x: bool = True, need_t16: bool | None = None):
@@ -184,12 +207,11 @@ def down_projection(hg, w2, b2, s, keep_x: bool = True, need_t16: bool | None = 
 def q_prescale_enabled() -> bool:
     """The softmax scale and the change to base 2, 1 / sqrt(dh) * log2(e), are folded into the rows (and bias) of the query
     projection -- Wq of a cross attention, the Q rows of a packed Wqkv -- when the 16-bit weights are packed, so that q . k
-    leaves the matrix pipe as the base-2 logit (ops.attn_varlen(q_log2=True), VF_ATTN_Q_LOG2): one rounding of the scaled weights instead of one of the
-    unscaled ones -- the same size of error, different rounding points; oracle.Rounding(q_prescale=...) restates them.
-    What it buys: the long-stream attention kernel drops the running maximum and the multiply-add in front of every
-    exponential (gene -> CRE cross attention -14 %).  VF_Q_PRESCALE=0 keeps the unscaled projection."""
-    import os
-    return os.environ.get("VF_Q_PRESCALE", "1") != "0"
+    leaves the matrix pipe as the base-2 logit (ops.attn_varlen(q_log2=True)): one rounding of the scaled weights instead
+    of one of the unscaled ones -- the same size of error, different rounding points; oracle.Rounding(q_prescale=...)
+    restates them.  What it buys: the long-stream attention kernel drops the running maximum and the multiply-add in front
+    of every exponential (gene -> CRE cross attention -14 %).  Always on (round 3's VF_Q_PRESCALE switch is gone)."""
+    return True
 
 
 def _ffn_residual(s):

@@ -105,7 +105,9 @@ class Seq2RegPredictor(nn.Module):
             cu = ops.mask_to_cu_seqlens(pad)
             from ..seq2gene.modules.layers import ln_fold_enabled, trunk_f16_active
             l0 = self.transformer_encoder[0]
-            if trunk_f16_active() and ln_fold_enabled(l0.norm1.weight.numel(), l0.linear_geglu_2.in_features):
+            # (vf_embed_stream serves d <= 2048; wider tokenizers keep the embed_pack + ln_stream form, which has no limit)
+            if (trunk_f16_active() and ln_fold_enabled(l0.norm1.weight.numel(), l0.linear_geglu_2.in_features)
+                    and self.token_embedding.weight.shape[1] <= 2048):
                 # the encoder input as (16-bit copy, fp16 trunk copy, row statistics): its fp32 rows have no reader
                 x = ops.embed_stream(ids, pad, cu, self.token_embedding.weight, self._pos_table(ids.device), n_tokens)
             else:
