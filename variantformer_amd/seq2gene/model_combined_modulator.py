@@ -491,13 +491,19 @@ class Seq2GenePredictorCombinedModulator(nn.Module):
         st.begin()
 
         def gather(name, parts, dtype):
-            """per-gene [n_i, 1, L] tensors -> one staged [sum n_i, L] array of `dtype` (one narrowing copy per gene)"""
+            """per-gene [n_i, 1, L] tensors -> one staged [sum n_i, L] array of `dtype`: one narrowing copy per gene, by numpy
+            (single-threaded: torch's copy_ forks an OpenMP team per call, which collides with the loader workers when a rank
+            has few host cores -- 170 ms instead of 25 per 32-gene batch on 2-4 cores, profiles/r04_c_host_capacity.log)"""
             L = int(parts[0].shape[2]) if len(parts) else 0
             buf = st.get(name, (sum(int(v.shape[0]) for v in parts), L), dtype)
+            dst = buf.numpy()
             off = 0
             for v in parts:
                 n = int(v.shape[0])
-                buf[off:off + n].copy_(v[:, 0, :])
+                if v.device.type == "cpu":
+                    np.copyto(dst[off:off + n], v.numpy()[:, 0, :], casting="unsafe")
+                else:
+                    buf[off:off + n].copy_(v[:, 0, :])
                 off += n
             return buf
         cre_ids, cre_pad = gather("cre_ids", x, torch.int32), gather("cre_pad", m, torch.uint8)
