@@ -18,6 +18,9 @@
 #include <type_traits>
 #include "vf_common.h"
 
+#ifndef VF_G8X_WIDE
+#define VF_G8X_WIDE 1            // persistent kernel, 16-bit-residual producers: 8-column read-back (0: the 4-column form; A/B builds)
+#endif
 #ifndef VF_G8_RES_ALL
 #define VF_G8_RES_ALL 0          // gemm8_kernel, 16-bit residual: 1 = request every epilogue pass's residual rows up front.
                                  // Measured (profiles/r03_i_producer_epilogue_experiments.log): 417 -> 422 ... 435 us on the gene
@@ -133,6 +136,127 @@ __device__ __forceinline__ void ln_emit(f32x4_t f, bool valid, unsigned short* p
         pk[1] = Op16<DT>::pack2(f[2], f[3]);
         if (st16) *reinterpret_cast<u32x2_t*>(p16) = pk;
         if (stpart && (lane & 7) == 0) *reinterpret_cast<f32x2_t*>(ppart) = (f32x2_t){s1, s2};
+    }
+}
+
+// ln_emit for a lane that holds EIGHT consecutive columns of a row (fa = columns 0-3, fb = columns 4-7; a 32-column part = 4
+// consecutive lanes): one 16-byte store per 16-bit copy instead of two 8-byte ones.  The sums run through the SAME balanced
+// tree as ln_emit's (4 values in a lane, then lane pairs, quads, the two quads of a part): fa / fb are what two neighbouring
+// lanes hold there and IEEE addition commutes, so (sum, M2) are bit-identical to the 4-column form.
+template <int DT>
+__device__ __forceinline__ void ln_emit8(f32x4_t fa, f32x4_t fb, bool valid, unsigned short* p16, float* ppart, int lane,
+                                         float x16_scale, unsigned short* pt16, float t16_scale) {
+    float s1 = ((fa[0] + fa[1]) + (fa[2] + fa[3])) + ((fb[0] + fb[1]) + (fb[2] + fb[3]));
+    s1 += dpp_f32<0xB1>(s1);                 // lane j <-> j ^ 1: ln_emit's quad_perm [2,3,0,1] step
+    s1 += dpp_f32<0x4E>(s1);                 // lane j <-> j ^ 2: ln_emit's row_half_mirror step (the part's two halves)
+    const float mp = s1 * (1.0f / 32.0f);
+    const float a0 = fa[0] - mp, a1 = fa[1] - mp, a2 = fa[2] - mp, a3 = fa[3] - mp;
+    const float b0 = fb[0] - mp, b1 = fb[1] - mp, b2 = fb[2] - mp, b3 = fb[3] - mp;
+    float s2 = __builtin_fmaf(a3, a3, __builtin_fmaf(a2, a2, __builtin_fmaf(a1, a1, a0 * a0))) +
+               __builtin_fmaf(b3, b3, __builtin_fmaf(b2, b2, __builtin_fmaf(b1, b1, b0 * b0)));
+    s2 += dpp_f32<0xB1>(s2);
+    s2 += dpp_f32<0x4E>(s2);
+    if (valid) {
+        u32x4_t pk;
+        if (pt16) {                                       // the fp16 trunk copy (VF_LN_PRODUCER_T16)
+            const f32x4_t ta = fa * t16_scale, tb = fb * t16_scale;
+            pk = (u32x4_t){pack2h(ta[0], ta[1]), pack2h(ta[2], ta[3]), pack2h(tb[0], tb[1]), pack2h(tb[2], tb[3])};
+            *reinterpret_cast<u32x4_t*>(pt16) = pk;
+        }
+        if (DT == VF_F16) { fa *= x16_scale; fb *= x16_scale; }           // statistics above are those of the UNSCALED row
+        pk = (u32x4_t){Op16<DT>::pack2(fa[0], fa[1]), Op16<DT>::pack2(fa[2], fa[3]), Op16<DT>::pack2(fb[0], fb[1]),
+                       Op16<DT>::pack2(fb[2], fb[3])};
+        *reinterpret_cast<u32x4_t*>(p16) = pk;
+        if ((lane & 3) == 0) *reinterpret_cast<f32x2_t*>(ppart) = (f32x2_t){s1, s2};
+    }
+}
+
+// Epilogue of one wave's 128 (m) x 64 (n) accumulator block for the LayerNorm producers whose residual is a 16-bit stream
+// copy (VF_LN_PRODUCER_R16 / _T16), "wide" read-back (round 4): the block is staged as fp32 through `region` in passes of 32
+// rows exactly as before, but a lane reads back EIGHT consecutive columns (two ds_read_b128) of a row instead of four, so the
+// residual load, the 16-bit copy, the fp16 trunk copy and the part statistics are 16-byte-per-lane operations on 8 rows per
+// wave-instruction: half the global memory instructions (and pointer steps) for the same bytes.  The producer epilogue was
+// 19-21 k cycles per tile against ~6 k of vector issue (scripts/probes/gemm8x_probe.hip): 288 global memory instructions of
+// 512 bytes per wave through the CU's one address / store path.  Same arithmetic, same summation tree: bit-identical.
+template <int DT, int LN, int REGION>
+__device__ __forceinline__ void producer16_epilogue_wide(f32x4_t (&acc)[4][8], char* region, const char* side, int side_n,
+                                                         int64_t mw0, int nw0, bool has_bias, void* out, int64_t ldo, int M,
+                                                         int N, const LnArgs& ln) {
+    constexpr int TM = 8, TN = 4, WT_M = 128, PITCH = 64 * 4 + 16, RP = 32, IMP = RP / 16, NPASS = TM / IMP;
+    constexpr int RI = 8, NI = RP / RI;                                 // 8 lanes x 32 B per row, 8 rows per wave-instruction
+    constexpr bool T16 = LN == VF_LN_PRODUCER_T16;
+    static_assert(REGION >= RP * PITCH, "wide producer epilogue: staging region too small");
+    int lane_e;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+    const int lane = lane_e, r = lane & 15, g = lane >> 4;
+    const int ep_row = lane >> 3, ep_col = nw0 + (lane & 7) * 8;
+    const int rows_left = (int)(M - mw0) - ep_row;                      // item j is a row of the matrix iff j * RI < rows_left
+    const int64_t row0 = mw0 + ep_row;
+    const int colc = ep_col < N ? ep_col : N - 8;
+    const char* res_run = reinterpret_cast<const char*>(ln.res16) + (row0 * ln.ldr16 + colc) * 2;
+    const char* const res_last = reinterpret_cast<const char*>(ln.res16) + ((int64_t)(M - 1) * ln.ldr16 + colc) * 2;
+    const int64_t res_step = (int64_t)RI * ln.ldr16 * 2;
+    char* out_run = reinterpret_cast<char*>(out) + (row0 * ldo + ep_col) * 4;
+    const int64_t out_step = (int64_t)RI * ldo * 4;
+    unsigned short* o16_run = reinterpret_cast<unsigned short*>(ln.out16) + row0 * ln.ld16 + ep_col;
+    const int64_t o16_step = (int64_t)RI * ln.ld16;
+    float* part_run = ln.part_stats + ((int64_t)(ep_col >> 5) * ln.rows + row0) * 2;
+    unsigned short* t16_run = T16 ? ln.t16_out + row0 * ln.ldt16 + ep_col : nullptr;
+    const int64_t t16_step = (int64_t)RI * ln.ldt16;
+    u32x4_t rbuf[2][NI];
+    auto load_res_pass = [&](int ps, u32x4_t (&dst)[NI]) {
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            const int j = ps * NI + k;
+            const char* rp = (j * RI < rows_left) ? res_run : res_last;
+            res_run += res_step;
+            dst[k] = *reinterpret_cast<const u32x4_t*>(rp);
+        }
+    };
+    auto res_value = [&](u32x2_t v) -> f32x4_t {         // see gemm8_kernel
+        if constexpr (T16) return cvt4_16<VF_F16>(v) * ln.res16_scale;
+        else if constexpr (DT == VF_F16) return cvt4_16<DT>(v) * ln.res16_scale;
+        else return cvt4_16<DT>(v);
+    };
+    load_res_pass(0, rbuf[0]);
+    f32x4_t bvec[TN];
+#pragma unroll
+    for (int in = 0; in < TN; ++in)
+        bvec[in] = has_bias ? *reinterpret_cast<const f32x4_t*>(side + (side_n + in * 16 + 4 * g) * 4) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        if (ps + 1 < NPASS) load_res_pass(ps + 1, rbuf[(ps + 1) & 1]);
+#pragma unroll
+        for (int iml = 0; iml < IMP; ++iml) {
+            const int im = ps * IMP + iml;
+            char* rowp = region + (iml * 16 + r) * PITCH;
+#pragma unroll
+            for (int in = 0; in < TN; ++in) *reinterpret_cast<f32x4_t*>(rowp + (in * 16 + 4 * g) * 4) = acc[in][im] + bvec[in];
+        }
+        u32x4_t da[NI], db[NI];
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            const char* p = region + (k * RI + ep_row) * PITCH + (lane & 7) * 32;
+            da[k] = *reinterpret_cast<const u32x4_t*>(p);
+            db[k] = *reinterpret_cast<const u32x4_t*>(p + 16);
+        }
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            const int j = ps * NI + k;                       // row j * RI + ep_row of the wave tile
+            const u32x4_t rv = rbuf[ps & 1][k];
+            const f32x4_t fa = __builtin_bit_cast(f32x4_t, da[k]) + res_value((u32x2_t){rv[0], rv[1]});
+            const f32x4_t fb = __builtin_bit_cast(f32x4_t, db[k]) + res_value((u32x2_t){rv[2], rv[3]});
+            const bool ok = j * RI + ep_row < WT_M && j * RI < rows_left && ep_col < N;
+            ln_emit8<DT>(fa, fb, ok, o16_run, part_run, lane, ln.x16_scale, (T16 && ln.t16_out) ? t16_run : nullptr, ln.t16_scale);
+            o16_run += o16_step;
+            part_run += RI * 2;
+            if (T16) t16_run += t16_step;
+            if (ok && out != nullptr) {                      // the fp32 rows, when somebody reads them (last layer of a stack)
+                *reinterpret_cast<f32x4_t*>(out_run) = fa;
+                *reinterpret_cast<f32x4_t*>(out_run + 16) = fb;
+            }
+            out_run += out_step;
+        }
     }
 }
 
@@ -1354,9 +1478,16 @@ __global__ __launch_bounds__(512, 2) void gemm8x_kernel(const unsigned short* __
     issue(0, 0, C::WL); issue(0, 0, C::AL); issue(0, 0, C::WH); issue(0, 0, C::AH);
 
     int g0 = 0;                                              // stream index of the current tile's K-tile 0
+#ifdef VF_G8_PROF   // scripts/probes/gemm8x_probe.hip: per block, cycles summed over its tiles (wave 0 = group 0, wave 4 = group 1)
+    unsigned long long px[6] = {0, 0, 0, 0, 0, 0}, pt0, pt1;
+#define G8X_T() __builtin_readcyclecounter()
+#endif
     for (int ti = 0; ti < my_tiles; ++ti) {
         const bool has_next = ti + 1 < my_tiles;             // block-uniform
         tile_origin(bid + ti * grid, m0, n0);
+#ifdef VF_G8_PROF
+        pt0 = G8X_T();
+#endif
 #pragma unroll
         for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -1369,8 +1500,14 @@ __global__ __launch_bounds__(512, 2) void gemm8x_kernel(const unsigned short* __
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (wm == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind (matched after the loop)
+#ifdef VF_G8_PROF
+        pt1 = G8X_T(); px[0] += pt1 - pt0; pt0 = pt1;        // 0: tile start (K-tile 1 requested, start barriers)
+#endif
 
         for (int t = 0; t < nkt; ++t) {
+#ifdef VF_G8_PROF
+            if (t == 1) { pt1 = G8X_T(); px[1] += pt1 - pt0; pt0 = pt1; }      // 1: the first K-tile of the tile
+#endif
             const char* buf = smem + ((g0 + t) & 1) * C::TILE_BYTES;
             // the stream continues into the NEXT output tile for exactly one K-tile: its K-tile 0 is "K-tile nkt"
             const bool pre1 = t + 1 < nkt || has_next;                       // AH of stream K-tile t+1
@@ -1416,6 +1553,9 @@ __global__ __launch_bounds__(512, 2) void gemm8x_kernel(const unsigned short* __
         }
         if (wm == 0) __builtin_amdgcn_s_barrier();   // matches group 1's extra barrier: every wave is past its last MFMA
         asm volatile("" ::: "memory");
+#ifdef VF_G8_PROF
+        pt1 = G8X_T(); px[2] += pt1 - pt0; pt0 = pt1;        // 2: K-tiles 1 .. nkt-1 (+ the group-sync barrier)
+#endif
         char* const side = smem + C::LDS_BYTES + C::SPARE_BYTES + (ti & 1) * C::SIDE_BYTES;
         // Staging: the last K-tile's buffer is free now (the other one holds, or is receiving, the next tile's K-tile 0).
         // K / 64 is even (launcher), so that is always buffer 1, and the 24 KiB of LDS that lie unused behind the ring
@@ -1428,6 +1568,13 @@ __global__ __launch_bounds__(512, 2) void gemm8x_kernel(const unsigned short* __
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
         const int lane = lane_e, r = lane & 15, g = lane >> 4;
 
+        // 16-bit-residual LayerNorm producers: the wide read-back form (producer16_epilogue_wide above)
+        constexpr bool WIDE = ln_res_is_16(LN) && EPI == VF_EPI_RES_F32 && (VF_G8X_WIDE != 0);
+        if constexpr (WIDE) {
+            producer16_epilogue_wide<DT, LN, (C::TILE_BYTES + C::SPARE_BYTES) / C::NW>(
+                acc, stage_buf + wave * ((C::TILE_BYTES + C::SPARE_BYTES) / C::NW), side, wn * 64, (int64_t)m0 + wm * 128,
+                n0 + wn * 64, bias != nullptr, out, ldo, M, N, ln);
+        } else {
         // ---- epilogue: each wave stages its 128 x 64 block through its own 8 KiB slice of the free half of the ring and
         // writes whole rows, 16 bytes per lane; the fp32 residual rows of pass p+1 are requested while pass p goes through
         // LDS (same scheme as gemm8_kernel).
@@ -1608,11 +1755,24 @@ __global__ __launch_bounds__(512, 2) void gemm8x_kernel(const unsigned short* __
             }
         }
 
+        }   // !WIDE
+
         // every wave's staging reads are done before the next tile's K-tile 1 is requested into this buffer
+#ifdef VF_G8_PROF
+        pt1 = G8X_T(); px[3] += pt1 - pt0; pt0 = pt1;        // 3: epilogue passes of this wave
+#endif
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+#ifdef VF_G8_PROF
+        pt1 = G8X_T(); px[4] += pt1 - pt0; px[5] += 1;       // 4: waiting for the other waves' epilogues
+#endif
         g0 += nkt;
     }
+#ifdef VF_G8_PROF
+    if (vf_g8_prof && (tid & 63) == 0 && (wave == 0 || wave == 4) && (bid & 7) == 0)
+        for (int i = 0; i < 6; ++i) vf_g8_prof[((bid >> 3) * 2 + (wave >> 2)) * 8 + i] = px[i];
+#undef G8X_T
+#endif
 #undef VF_G8_SYNC_IN
 #undef VF_G8_SYNC_OUT
 #undef VF_G8_MMA
