@@ -143,19 +143,22 @@ __device__ __forceinline__ void ln_emit(f32x4_t f, bool valid, unsigned short* p
 // consecutive lanes): one 16-byte store per 16-bit copy instead of two 8-byte ones.  The sums run through the SAME balanced
 // tree as ln_emit's (4 values in a lane, then lane pairs, quads, the two quads of a part): fa / fb are what two neighbouring
 // lanes hold there and IEEE addition commutes, so (sum, M2) are bit-identical to the 4-column form.
-template <int DT>
+template <int DT, int SKIP = 0>      // SKIP (probe builds): 1 = no statistics store, 2 = no 16-bit store, 16 = no statistics arithmetic
 __device__ __forceinline__ void ln_emit8(f32x4_t fa, f32x4_t fb, bool valid, unsigned short* p16, float* ppart, int lane,
                                          float x16_scale, unsigned short* pt16, float t16_scale) {
     float s1 = ((fa[0] + fa[1]) + (fa[2] + fa[3])) + ((fb[0] + fb[1]) + (fb[2] + fb[3]));
+    float s2 = s1;
+    if (!(SKIP & 16)) {
     s1 += dpp_f32<0xB1>(s1);                 // lane j <-> j ^ 1: ln_emit's quad_perm [2,3,0,1] step
     s1 += dpp_f32<0x4E>(s1);                 // lane j <-> j ^ 2: ln_emit's row_half_mirror step (the part's two halves)
     const float mp = s1 * (1.0f / 32.0f);
     const float a0 = fa[0] - mp, a1 = fa[1] - mp, a2 = fa[2] - mp, a3 = fa[3] - mp;
     const float b0 = fb[0] - mp, b1 = fb[1] - mp, b2 = fb[2] - mp, b3 = fb[3] - mp;
-    float s2 = __builtin_fmaf(a3, a3, __builtin_fmaf(a2, a2, __builtin_fmaf(a1, a1, a0 * a0))) +
-               __builtin_fmaf(b3, b3, __builtin_fmaf(b2, b2, __builtin_fmaf(b1, b1, b0 * b0)));
+    s2 = __builtin_fmaf(a3, a3, __builtin_fmaf(a2, a2, __builtin_fmaf(a1, a1, a0 * a0))) +
+         __builtin_fmaf(b3, b3, __builtin_fmaf(b2, b2, __builtin_fmaf(b1, b1, b0 * b0)));
     s2 += dpp_f32<0xB1>(s2);
     s2 += dpp_f32<0x4E>(s2);
+    }
     if (valid) {
         u32x4_t pk;
         if (pt16) {                                       // the fp16 trunk copy (VF_LN_PRODUCER_T16)
@@ -166,8 +169,10 @@ __device__ __forceinline__ void ln_emit8(f32x4_t fa, f32x4_t fb, bool valid, uns
         if (DT == VF_F16) { fa *= x16_scale; fb *= x16_scale; }           // statistics above are those of the UNSCALED row
         pk = (u32x4_t){Op16<DT>::pack2(fa[0], fa[1]), Op16<DT>::pack2(fa[2], fa[3]), Op16<DT>::pack2(fb[0], fb[1]),
                        Op16<DT>::pack2(fb[2], fb[3])};
-        *reinterpret_cast<u32x4_t*>(p16) = pk;
-        if ((lane & 3) == 0) *reinterpret_cast<f32x2_t*>(ppart) = (f32x2_t){s1, s2};
+        if (!(SKIP & 2)) *reinterpret_cast<u32x4_t*>(p16) = pk;
+        else asm volatile("" :: "v"(pk));
+        if (!(SKIP & 1) && (lane & 3) == 0) *reinterpret_cast<f32x2_t*>(ppart) = (f32x2_t){s1, s2};
+        else asm volatile("" :: "v"(s1), "v"(s2));
     }
 }
 
@@ -210,7 +215,11 @@ __device__ __forceinline__ void producer16_epilogue_wide(f32x4_t (&acc)[4][8], c
             const int j = ps * NI + k;
             const char* rp = (j * RI < rows_left) ? res_run : res_last;
             res_run += res_step;
+#if defined(VF_WIDE_SKIP) && (VF_WIDE_SKIP & 4)
+            dst[k] = (u32x4_t){(unsigned)(uintptr_t)rp, 0u, 0u, 0u};
+#else
             dst[k] = *reinterpret_cast<const u32x4_t*>(rp);
+#endif
         }
     };
     auto res_value = [&](u32x2_t v) -> f32x4_t {         // see gemm8_kernel
@@ -230,15 +239,22 @@ __device__ __forceinline__ void producer16_epilogue_wide(f32x4_t (&acc)[4][8], c
         for (int iml = 0; iml < IMP; ++iml) {
             const int im = ps * IMP + iml;
             char* rowp = region + (iml * 16 + r) * PITCH;
+#if !(defined(VF_WIDE_SKIP) && (VF_WIDE_SKIP & 8))
 #pragma unroll
             for (int in = 0; in < TN; ++in) *reinterpret_cast<f32x4_t*>(rowp + (in * 16 + 4 * g) * 4) = acc[in][im] + bvec[in];
+#endif
         }
         u32x4_t da[NI], db[NI];
 #pragma unroll
         for (int k = 0; k < NI; ++k) {
             const char* p = region + (k * RI + ep_row) * PITCH + (lane & 7) * 32;
+#if defined(VF_WIDE_SKIP) && (VF_WIDE_SKIP & 8)
+            da[k] = __builtin_bit_cast(u32x4_t, acc[k & 3][ps * IMP]);          // no LDS read-back (wrong values)
+            db[k] = __builtin_bit_cast(u32x4_t, acc[k & 3][ps * IMP + 1]);
+#else
             da[k] = *reinterpret_cast<const u32x4_t*>(p);
             db[k] = *reinterpret_cast<const u32x4_t*>(p + 16);
+#endif
         }
 #pragma unroll
         for (int k = 0; k < NI; ++k) {
@@ -247,7 +263,11 @@ __device__ __forceinline__ void producer16_epilogue_wide(f32x4_t (&acc)[4][8], c
             const f32x4_t fa = __builtin_bit_cast(f32x4_t, da[k]) + res_value((u32x2_t){rv[0], rv[1]});
             const f32x4_t fb = __builtin_bit_cast(f32x4_t, db[k]) + res_value((u32x2_t){rv[2], rv[3]});
             const bool ok = j * RI + ep_row < WT_M && j * RI < rows_left && ep_col < N;
+#ifdef VF_WIDE_SKIP   // cost-centre probes (scripts/probes/gemm8x_probe.hip builds only; results meaningless)
+            ln_emit8<DT, VF_WIDE_SKIP>(fa, fb, ok, o16_run, part_run, lane, ln.x16_scale, (T16 && ln.t16_out) ? t16_run : nullptr, ln.t16_scale);
+#else
             ln_emit8<DT>(fa, fb, ok, o16_run, part_run, lane, ln.x16_scale, (T16 && ln.t16_out) ? t16_run : nullptr, ln.t16_scale);
+#endif
             o16_run += o16_step;
             part_run += RI * 2;
             if (T16) t16_run += t16_step;
