@@ -48,6 +48,9 @@ static void run(const char* name, int M, int N, int K, int kind) {
             double s[5] = {0}, cnt = 0;
             for (int i = 0; i < 32; ++i) { const unsigned long long* r = &hp[(i * 2 + grp) * 8]; if (!r[5]) continue; for (int k = 0; k < 5; ++k) s[k] += (double)r[k]; cnt += (double)r[5]; }
             double tot = 0; for (int k = 0; k < 5; ++k) tot += s[k] / cnt;
+            double mt = 0, rt = 0;
+            for (int i = 0; i < 32; ++i) { const unsigned long long* r = &hp[(i * 2 + grp) * 8]; mt += (double)r[6]; rt += (double)r[7]; }
+            if (grp == 0 && rt > 0) printf("  clock held during the launch (d s_memtime / d s_memrealtime x 100 MHz): %.0f MHz\n", mt / rt * 100.0);
             printf("  wave %d (group %d), %.0f tiles sampled, %.0f cycles per tile:\n", grp * 4, grp, cnt, tot);
             for (int k = 0; k < 5; ++k) printf("    %-42s %8.0f  (%4.1f %%)\n", nm[k], s[k] / cnt, 100 * s[k] / cnt / tot);
         }

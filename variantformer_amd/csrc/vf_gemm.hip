@@ -1409,6 +1409,9 @@ __global__ __launch_bounds__(512, 2) void gemm8x_kernel(const unsigned short* __
     // half-tile `type` of the K-tile with index kt inside the tile `src` points at; gk = its index in the block's
     // K-tile stream (the ring buffer is the stream index's parity, so the stream runs across output tiles)
     auto issue = [&](int gk, int kt, int type) {
+#ifdef VF_G8X_NOFILL      // probe build: the K loop without its LDS-DMA stream (stale LDS contents; results meaningless)
+        if (gk > 1) return;
+#endif
         char* dst = lds_piece + (gk & 1) * C::TILE_BYTES + type * C::HALF_BYTES;
         glds16(src[type][0] + kt * BK, dst);
         glds16(src[type][1] + kt * BK, dst + 1024);
@@ -1501,7 +1504,8 @@ __global__ __launch_bounds__(512, 2) void gemm8x_kernel(const unsigned short* __
 #ifdef VF_G8_PROF   // scripts/probes/gemm8x_probe.hip: per block, cycles summed over its tiles (wave 0 = group 0, wave 4 = group 1)
     unsigned long long px[6] = {0, 0, 0, 0, 0, 0}, pt0, pt1;
 #define G8X_T() __builtin_readcyclecounter()
-#endif
+    const unsigned long long pc0 = __builtin_amdgcn_s_memtime(), pr0 = __builtin_amdgcn_s_memrealtime();   // clock held under load:
+#endif                                                                                                    // d(memtime) / d(memrealtime) x 100 MHz
     for (int ti = 0; ti < my_tiles; ++ti) {
         const bool has_next = ti + 1 < my_tiles;             // block-uniform
         tile_origin(bid + ti * grid, m0, n0);
@@ -1789,8 +1793,11 @@ __global__ __launch_bounds__(512, 2) void gemm8x_kernel(const unsigned short* __
         g0 += nkt;
     }
 #ifdef VF_G8_PROF
-    if (vf_g8_prof && (tid & 63) == 0 && (wave == 0 || wave == 4) && (bid & 7) == 0)
+    if (vf_g8_prof && (tid & 63) == 0 && (wave == 0 || wave == 4) && (bid & 7) == 0) {
         for (int i = 0; i < 6; ++i) vf_g8_prof[((bid >> 3) * 2 + (wave >> 2)) * 8 + i] = px[i];
+        vf_g8_prof[((bid >> 3) * 2 + (wave >> 2)) * 8 + 6] = __builtin_amdgcn_s_memtime() - pc0;
+        vf_g8_prof[((bid >> 3) * 2 + (wave >> 2)) * 8 + 7] = __builtin_amdgcn_s_memrealtime() - pr0;
+    }
 #undef G8X_T
 #endif
 #undef VF_G8_SYNC_IN
