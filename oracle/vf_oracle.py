@@ -427,13 +427,19 @@ class Seq2GeneHP:
                    use_bigger_head=kw.get("use_bigger_head", False), head_type=kw.get("head_type", "mlp"))
 
 
-def modulator_layer(src, ctx, cu_src, cu_ctx, sd, pfx, H, slopes, rnd: Rounding, cross_slopes=None, last=False):
+def modulator_layer(src, ctx, cu_src, cu_ctx, sd, pfx, H, slopes, rnd: Rounding, cross_slopes=None, last=False,
+                    make_data_kv=False):
     """ContextFlashAttentionEncoderLayer.forward (seq2gene/modules/layers.py:88-165) on packed
     streams: LN1 -> self-MHA(ALiBi) -> +src -> LN2 -> cross-MHA(q = x, kv = ctx RAW, no norm)
-    -> +res_short -> LN3 -> GeGLU -> + src (the LAYER INPUT, :99,163)."""
+    -> +res_short -> LN3 -> GeGLU -> + src (the LAYER INPUT, :99,163).
+    make_data_kv (:133-136; no reference call site enables it): q = ctx RAW, kv = LN2(x); ctx holds the stream's sequences."""
     h = rnd.ln(src, sd[pfx + "norm1.weight"], sd[pfx + "norm1.bias"])
     x1 = mha_self(h, sd, pfx + "mixer.MHA.", H, cu_src, slopes, rnd) + rnd.res(src)
     h = rnd.ln(x1, sd[pfx + "norm2.weight"], sd[pfx + "norm2.bias"])
+    if make_data_kv:
+        x2 = mha_cross(ctx, h, sd, pfx + "crossMHA.MHA.", H, cu_ctx, cu_src, rnd, cross_slopes) + rnd.res(x1)
+        h = rnd.ln(x2, sd[pfx + "norm3.weight"], sd[pfx + "norm3.bias"])
+        return rnd.out(geglu_ffn(h, sd, pfx, rnd) + rnd.trunk(src), last)
     x2 = mha_cross(h, ctx, sd, pfx + "crossMHA.MHA.", H, cu_src, cu_ctx, rnd, cross_slopes) + rnd.res(x1)
     h = rnd.ln(x2, sd[pfx + "norm3.weight"], sd[pfx + "norm3.bias"])
     return rnd.out(geglu_ffn(h, sd, pfx, rnd) + rnd.trunk(src), last)
@@ -455,11 +461,15 @@ def cre_layer(cre, ctx, cu_cre, sd, pfx, hp, slopes, rnd: Rounding, last=False):
     return self_only_layer(cre, cu_cre, sd, pfx, hp.num_heads, slopes, rnd, last=last)
 
 
-def cross_only_layer(src, ctx, cu_src, cu_ctx, sd, pfx, H, rnd: Rounding, cross_slopes=None, last=False):
+def cross_only_layer(src, ctx, cu_src, cu_ctx, sd, pfx, H, rnd: Rounding, cross_slopes=None, last=False,
+                     make_data_kv=False):
     """ContextFlashCrossAttentionEncoderLayer.forward (layers.py:231-325): LN1 -> cross-MHA(q = x, kv = ctx raw)
-    -> +src -> LN2 -> GeGLU -> + src (the layer input)."""
+    -> +src -> LN2 -> GeGLU -> + src (the layer input).  make_data_kv (:283-286): q = ctx raw, kv = LN1(x)."""
     h = rnd.ln(src, sd[pfx + "norm1.weight"], sd[pfx + "norm1.bias"])
-    x1 = mha_cross(h, ctx, sd, pfx + "crossMHA.MHA.", H, cu_src, cu_ctx, rnd, cross_slopes) + rnd.res(src)
+    if make_data_kv:
+        x1 = mha_cross(ctx, h, sd, pfx + "crossMHA.MHA.", H, cu_ctx, cu_src, rnd, cross_slopes) + rnd.res(src)
+    else:
+        x1 = mha_cross(h, ctx, sd, pfx + "crossMHA.MHA.", H, cu_src, cu_ctx, rnd, cross_slopes) + rnd.res(src)
     h = rnd.ln(x1, sd[pfx + "norm2.weight"], sd[pfx + "norm2.bias"])
     return rnd.out(geglu_ffn(h, sd, pfx, rnd) + rnd.trunk(src), last)
 

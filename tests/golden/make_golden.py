@@ -587,6 +587,53 @@ def variantprocessor_fixture():
     np.savez_compressed(os.path.join(HERE, "variantprocessor.npz"), **arrays)
 
 
+def layer_data_kv_fixture():
+    """make_data_kv=True: the option swaps the two streams of a layer's cross attention (queries from the raw context, keys /
+    values from the normalised stream; seq2gene/modules/layers.py:133-136,283-286, seq2reg/modules.py:97-100).  No reference
+    MODEL can enable it (the models build their layers with the default), so it is pinned at layer level: the reference's own
+    three layer classes, seeded weights, one padded batch with ragged masks, fp32 (precision=None: no casts)."""
+    from seq2gene.modules.layers import ContextFlashAttentionEncoderLayer as GeneLayer
+    from seq2gene.modules.layers import ContextFlashCrossAttentionEncoderLayer as CrossLayer
+    from seq2reg.modules import ContextFlashAttentionEncoderLayer as S2RLayer
+    g = torch.Generator().manual_seed(20251207)
+    D, H, F, B, S = 128, 4, 256, 3, 24
+    src = torch.randn((B, S, D), generator=g)
+    ctx = torch.randn((B, S, D), generator=g)
+    mask = torch.zeros((B, S), dtype=torch.bool)                 # True = pad
+    mask[0, 20:] = True
+    mask[1, 7:] = True
+    arrays = {"src": src.numpy(), "ctx": ctx.numpy(), "mask": mask.numpy()}
+    meta = {"d_model": D, "nhead": H, "hidden_dim": F, "layers": {}}
+    layers = {
+        "gene": (GeneLayer(D, H, hidden_dim=F, dropout=0.0, use_alibi=True, make_data_kv=True, mlp_dout=0.0),
+                 lambda m: m(src.clone(), ctx.clone(), src_key_padding_mask=mask.clone(), precision=None), True),
+        "cross": (CrossLayer(D, H, hidden_dim=F, dropout=0.0, use_alibi=False, make_data_kv=True, mlp_dout=0.0),
+                  lambda m: m(src.clone(), ctx.clone(), context_padding_mask=mask.clone(), src_key_padding_mask=mask.clone(),
+                              precision=None), False),
+        "s2r": (S2RLayer(D, H, hidden_dim=F, dropout=0.0, use_alibi=False, make_data_kv=True, mlp_dout=0.0),
+                lambda m: m(src.clone(), ctx.clone(), key_padding_mask=mask.clone(), precision=None), False),
+    }
+    for name, (layer, call, alibi) in layers.items():
+        layer.eval()
+        with torch.no_grad():
+            for k, p in layer.named_parameters():               # non-trivial LayerNorm affine parameters, O(1) activations
+                if "norm" in k:
+                    p.copy_((1.0 if k.endswith("weight") else 0.0) + 0.2 * torch.randn(p.shape, generator=g))
+                elif k.endswith("bias"):
+                    p.copy_(0.1 * torch.randn(p.shape, generator=g))
+                else:
+                    p.copy_(torch.randn(p.shape, generator=g) / math.sqrt(p.shape[-1]))
+            out = call(layer)
+        for k, v in layer.state_dict().items():
+            arrays[f"{name}.sd.{k}"] = v.numpy()
+        arrays[f"{name}.out"] = out.numpy()
+        meta["layers"][name] = {"use_alibi": alibi, "class": type(layer).__module__ + "." + type(layer).__name__}
+        print(f"[golden] layer_data_kv {name}: out {tuple(out.shape)} |out| {float(out.abs().mean()):.3f}")
+    np.savez_compressed(os.path.join(HERE, "layer_data_kv.npz"), **arrays)
+    with open(os.path.join(HERE, "layer_data_kv.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+
+
 def main():
     assert os.path.isdir(REF), "reference checkout not present: fixtures can only be generated in the dev container"
     sys.path.insert(0, REPO)
@@ -614,6 +661,7 @@ def main():
     misc_fixture()
     vep_fixture()
     variantprocessor_fixture()
+    layer_data_kv_fixture()
 
 
 if __name__ == "__main__":

@@ -537,3 +537,34 @@ def test_seq2reg_options_vs_reference_golden():
     with pytest.raises(NotImplementedError, match="integer cCRE labels"):
         m_ctx = Seq2RegPredictor(**load_s2r_opts()["ctx_max"][0]).cuda()
         m_ctx(g["cre_sequences"], g["cre_attention_masks"], None, context=torch.zeros(9), only_embed=True)
+
+
+def test_make_data_kv_layers_vs_reference_layer_fixture_and_oracle():
+    """The layer option the models never switch on (make_data_kv: cross-attention queries from the raw context, keys / values
+    from the normalised stream), for the three reference layer classes that carry it: HIP layers through the reference
+    signature (padded + masks) against the reference's own layer outputs (tests/golden/layer_data_kv.*, fp32) and against the
+    same-rounding oracle."""
+    from tests.test_oracle_golden import _data_kv_fixture, data_kv_oracle
+    from variantformer_amd.seq2gene.modules.layers import (ContextFlashAttentionEncoderLayer,
+                                                           ContextFlashCrossAttentionEncoderLayer)
+    z, meta, src, ctx, mask, keep, cu = _data_kv_fixture()
+    D, H, F = meta["d_model"], meta["nhead"], meta["hidden_dim"]
+    for name, info in meta["layers"].items():
+        cls = ContextFlashCrossAttentionEncoderLayer if name == "cross" else ContextFlashAttentionEncoderLayer
+        layer = cls(D, H, hidden_dim=F, dropout=0.0, use_alibi=info["use_alibi"], make_data_kv=True, mlp_dout=0.0)
+        sd = {k[len(name) + 4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(name + ".sd.")}
+        layer.load_state_dict(sd, strict=True)
+        layer = layer.cuda().eval()
+        xs, cs = src[keep].cuda().contiguous(), ctx[keep].cuda().contiguous()
+        with torch.no_grad():
+            got = layer.forward_packed(xs, cu.cuda(), int((cu[1:] - cu[:-1]).max()), context=cs, cu_ctx=cu.cuda(),
+                                       max_ctx=int((cu[1:] - cu[:-1]).max()))
+            got = (got.x if hasattr(got, "x") else got).float().cpu().numpy()
+            if name == "gene":          # the reference signature (padded tensors + masks) takes the same path
+                pad = layer(src.cuda(), ctx.cuda(), src_key_padding_mask=mask.cuda(), precision=None)
+                assert np.array_equal(pad.float().cpu().numpy()[keep.numpy()], got)
+            orc = data_kv_oracle(name, sd, src[keep], ctx[keep], cu, H, info["use_alibi"], O.Rounding("bf16", fold_ln=False))
+        want = z[f"{name}.out"][keep.numpy()]
+        assert _rel(got, want) < BF16_VS_FP32, (name, _rel(got, want))
+        assert _rel(got, orc.numpy()) < 5e-3, (name, _rel(got, orc.numpy()))
+        print(f"[make_data_kv] {name}: vs reference fp32 {_rel(got, want):.2e}, vs same-rounding oracle {_rel(got, orc.numpy()):.2e}")

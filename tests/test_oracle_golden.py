@@ -204,3 +204,33 @@ def test_oracle_seq2reg_options_match_reference():
                               context=g["ref_cre_labels"])
         assert got.shape == want.shape
         np.testing.assert_allclose(got.numpy(), want, rtol=2e-5, atol=2e-5, err_msg=name)
+
+
+def _data_kv_fixture():
+    z = np.load(os.path.join(GOLDEN, "layer_data_kv.npz"))
+    meta = json.load(open(os.path.join(GOLDEN, "layer_data_kv.json")))
+    src, ctx, mask = torch.from_numpy(z["src"]), torch.from_numpy(z["ctx"]), torch.from_numpy(z["mask"])
+    keep = ~mask
+    lens = keep.sum(dim=1)
+    cu = torch.cat([torch.zeros(1, dtype=torch.long), torch.cumsum(lens, 0)]).to(torch.int32)
+    return z, meta, src, ctx, mask, keep, cu
+
+
+def data_kv_oracle(name, sd, xs, cs, cu, H, alibi, rnd):
+    slopes = torch.tensor(O.alibi_slopes(H), dtype=torch.float32) if alibi else None
+    if name == "cross":
+        return O.cross_only_layer(xs, cs, cu, cu, sd, "", H, rnd, make_data_kv=True)
+    return O.modulator_layer(xs, cs, cu, cu, sd, "", H, slopes, rnd, make_data_kv=True)
+
+
+def test_make_data_kv_layers_match_the_reference_layer_classes():
+    """make_data_kv=True (queries of the cross attention from the raw context, keys / values from the normalised stream;
+    reference seq2gene/modules/layers.py:133-136,283-286, seq2reg/modules.py:97-100) is reachable only at layer level in the
+    reference: the oracle's layer functions against the outputs of the reference's own three layer classes."""
+    z, meta, src, ctx, mask, keep, cu = _data_kv_fixture()
+    H = meta["nhead"]
+    for name, info in meta["layers"].items():
+        sd = {k[len(name) + 4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(name + ".sd.")}
+        with torch.no_grad():
+            out = data_kv_oracle(name, sd, src[keep], ctx[keep], cu, H, info["use_alibi"], O.Rounding(None))
+        np.testing.assert_allclose(out.numpy(), z[f"{name}.out"][keep.numpy()], rtol=RTOL, atol=ATOL)

@@ -468,7 +468,8 @@ class ContextFlashAttentionEncoderLayer(nn.Module):
         `self_qkv`: precomputed LayerNorm1 -> Wqkv projection of src (self_qkv_of_unique_rows).
         `keep_x=False` (LayerNorm fold only): the result's fp32 rows have no reader (the next layer of the stack takes
         the 16-bit copy, trunk16_enabled) and are not stored."""
-        assert not self.make_data_kv
+        if self.make_data_kv:
+            return self._forward_packed_data_kv(src, cu_src, max_src, context, cu_ctx, max_ctx)
         cq = cu_src if cu_cross_q is None else cu_cross_q
         mq = max_src if max_cross_q is None else max_cross_q
         if ln_fold_enabled(self.norm1.weight.numel(), self.linear_geglu_2.in_features):
@@ -506,6 +507,29 @@ class ContextFlashAttentionEncoderLayer(nn.Module):
         w2, b2 = packed_linear(self.linear_geglu_2)
         return ops.gemm(hg, w2, b2, ops.EPI_RES_F32, residual=src)
 
+    def _forward_packed_data_kv(self, src, cu_src, max_src, context, cu_ctx, max_ctx):
+        """make_data_kv=True (reference layers.py:133-136, seq2reg/modules.py:97-100): the roles of the two streams in the
+        cross attention are swapped -- its QUERIES are the raw context rows, its keys / values come from norm2(x) -- so its
+        output has one row per CONTEXT token, which the reference then adds to the stream (`x += res_short`): context and
+        stream must hold the same sequences.  No reference call site enables the option (the models construct their layers
+        with the default); it runs on the separate-LayerNorm path (no fold: the normalised stream is a K/V operand here)."""
+        src, context = _as_tensor(src), _as_tensor(context)
+        if src is None or context is None:
+            raise RuntimeError("make_data_kv layers need the fp32 rows of their input streams (run them with VF_LN_FOLD=0 "
+                               "when they sit inside a LayerNorm-folded stack)")
+        assert context.shape == src.shape and (cu_ctx is None or cu_ctx is cu_src or torch.equal(cu_ctx, cu_src)), \
+            "make_data_kv: src and context must have the same shape (reference seq2reg/modules.py:79)"
+        h = ops.layernorm(src, self.norm1.weight, self.norm1.bias)
+        x1 = self.mixer.MHA.fused(h, src, cu_src, max_src)
+        h = ops.layernorm(x1, self.norm2.weight, self.norm2.bias)
+        kv = self.crossMHA.MHA.project_kv(h)                               # K / V from the NORMALISED stream
+        x2 = self.crossMHA.MHA.fused(ops.cast16(context), x1, cu_src, max_src, kv, cu_src, max_src)     # Q from the raw context
+        h = ops.layernorm(x2, self.norm3.weight, self.norm3.bias)
+        w1, b1 = packed_linear(self.linear_geglu_1, geglu=True)
+        hg = ops.gemm(h, w1, b1, ops.EPI_GEGLU_BF16)
+        w2, b2 = packed_linear(self.linear_geglu_2)
+        return ops.gemm(hg, w2, b2, ops.EPI_RES_F32, residual=src)
+
     def forward_packed_rows(self, src, cu_src, max_src, rows, cu_rows, context, cu_ctx, max_ctx, cu_cross_rows,
                             max_cross_rows):
         """Same layer, but only the output rows `rows` (int64 indices into src, at most one per self-attention
@@ -514,7 +538,8 @@ class ContextFlashAttentionEncoderLayer(nn.Module):
         cross attention, LayerNorm 2/3 and the GeGLU FFN run on the selected rows only.  Used for the LAST gene layer,
         whose output is consumed only through the registry token (pool_outputs row 0,
         model_combined_modulator.py:391-392): exact, and ~1/25 of the gene-stream work less."""
-        assert not self.make_data_kv
+        if self.make_data_kv:
+            raise NotImplementedError("make_data_kv: the cross attention's rows are context rows; no registry-only form")
         mha = self.mixer.MHA
         if ln_fold_enabled(self.norm1.weight.numel(), self.linear_geglu_2.in_features):
             s = _as_stream(src)
@@ -651,7 +676,20 @@ class ContextFlashCrossAttentionEncoderLayer(nn.Module):
 
     def forward_packed(self, src, cu_src, max_src, context=None, cu_ctx=None, max_ctx=None, context_kv=None,
                        cu_cross_q=None, max_cross_q=None, keep_x=True):
-        assert not self.make_data_kv
+        if self.make_data_kv:
+            # reference layers.py:283-286: Q from the raw context, K / V from norm1(x); context and stream hold the same
+            # sequences (the attention output is added to the stream).  Separate-LayerNorm path, as above.
+            src, context = _as_tensor(src), _as_tensor(context)
+            assert src is not None and context is not None and context.shape == src.shape, \
+                "make_data_kv: src and context must have the same shape"
+            h = ops.layernorm(src, self.norm1.weight, self.norm1.bias)
+            kv = self.crossMHA.MHA.project_kv(h)
+            x1 = self.crossMHA.MHA.fused(ops.cast16(context), src, cu_src, max_src, kv, cu_src, max_src)
+            h = ops.layernorm(x1, self.norm2.weight, self.norm2.bias)
+            w1, b1 = packed_linear(self.linear_geglu_1, geglu=True)
+            hg = ops.gemm(h, w1, b1, ops.EPI_GEGLU_BF16)
+            w2, b2 = packed_linear(self.linear_geglu_2)
+            return ops.gemm(hg, w2, b2, ops.EPI_RES_F32, residual=src)
         cq = cu_src if cu_cross_q is None else cu_cross_q
         mq = max_src if max_cross_q is None else max_cross_q
         if ln_fold_enabled(self.norm1.weight.numel(), self.linear_geglu_2.in_features):
