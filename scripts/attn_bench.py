@@ -6,6 +6,7 @@ from variantformer_amd import ops, _lib
 from variantformer_amd.seq2gene.modules.layers import get_alibi_slopes
 if os.environ.get("VF_LIB"):                 # A/B against another build of the library on the same box
     _lib.load(os.path.join(os.path.dirname(_lib.LIB_PATH), os.environ["VF_LIB"]))
+QLOG2 = os.environ.get("ATTN_QLOG2", "0") == "1"      # q already carries the softmax scale (the model's own call form)
 
 def run(name, H, dh, ql, kl, alibi, self_attn, reps=20):
     D = H * dh
@@ -21,11 +22,11 @@ def run(name, H, dh, ql, kl, alibi, self_attn, reps=20):
         kv = torch.randn((tk, 2 * D), device="cuda").bfloat16()
         k, v = kv[:, :D], kv[:, D:]
     for _ in range(3):
-        ops.attn_varlen(q, k, v, cu_q, cu_k, max(ql), max(kl), H, dh, slopes)
+        ops.attn_varlen(q, k, v, cu_q, cu_k, max(ql), max(kl), H, dh, slopes, q_log2=QLOG2)
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     for _ in range(reps):
-        ops.attn_varlen(q, k, v, cu_q, cu_k, max(ql), max(kl), H, dh, slopes)
+        ops.attn_varlen(q, k, v, cu_q, cu_k, max(ql), max(kl), H, dh, slopes, q_log2=QLOG2)
     e.record(); torch.cuda.synchronize()
     us = s.elapsed_time(e) / reps * 1e3
     flops = 4.0 * sum(a * b for a, b in zip(ql, kl)) * D

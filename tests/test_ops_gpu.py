@@ -337,6 +337,41 @@ def test_attention_one_block_per_window_dh64(ops, q_log2):
         np.testing.assert_allclose(got[a:e].numpy(), _bf(ref.reshape(e - a, D)).numpy(), rtol=2 ** -7, atol=6e-3)
 
 
+@pytest.mark.parametrize("q_log2", [True, False])
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_attention_one_block_per_chunk_dh64_two_passes(ops, q_log2, dtype):
+    """seq2reg's gene chunks (dh = 64, 129 ... 256 tokens; 200 in the shipped configuration) in a batch of >= 1024 (chunk, head)
+    items take one block per item in the two-pass form of attn_short2_kernel (62 KB image, two resident blocks per CU) instead
+    of four 64-query blocks of the tiled kernel.  Ragged chunks incl. the boundaries 129 / 192 / 193 / 200 / 256: bit-identical
+    to the tiled kernel (the same chunks in a batch too small for the new path), sampled chunks against the oracle."""
+    dh, H = 64, 8
+    D = H * dh
+    td = torch.bfloat16 if dtype == "bf16" else torch.float16
+    rnd = O.Rounding(dtype)
+    rng = np.random.default_rng(19)
+    ql = [200, 129, 256, 192, 193, 255, 130, 200, 224, 160] + list(rng.integers(129, 257, 120))
+    assert len(ql) * H >= 1024
+    c = math.log2(math.e) / math.sqrt(dh) if q_log2 else 1.0
+    x = rnd.r(_rand((sum(ql), 3 * D), 73, 2.0))
+    x[:, :D] = rnd.r(x[:, :D] * c)
+    dev = x.cuda().to(td)
+    cu = torch.tensor([0] + list(np.cumsum(ql)), dtype=torch.int32)
+    out = ops.attn_varlen(dev[:, :D], dev[:, D:2 * D], dev[:, 2 * D:], cu.cuda(), None, max(ql), max(ql), H, dh, q_log2=q_log2)
+    n_small = 100                                              # 100 chunks x 8 heads < 1024 items: the tiled kernel
+    t_small = int(cu[n_small])
+    small = ops.attn_varlen(dev[:t_small, :D], dev[:t_small, D:2 * D], dev[:t_small, 2 * D:], cu[:n_small + 1].cuda(), None,
+                            max(ql[:n_small]), max(ql[:n_small]), H, dh, q_log2=q_log2)
+    torch.cuda.synchronize()
+    assert torch.equal(out[:t_small].view(torch.int16), small.view(torch.int16))
+    got = out.float().cpu()
+    tol = dict(rtol=2 ** -7, atol=6e-3) if dtype == "bf16" else dict(rtol=2 ** -9, atol=2e-3)
+    for b in list(range(10)) + [60, 129]:
+        a, e = int(cu[b]), int(cu[b + 1])
+        ref = O.attention(x[a:e, :D].view(-1, H, dh), x[a:e, D:2 * D].view(-1, H, dh), x[a:e, 2 * D:].view(-1, H, dh), None, rnd,
+                          q_log2=q_log2)
+        np.testing.assert_allclose(got[a:e].numpy(), rnd.r(ref.reshape(e - a, D)).numpy(), **tol)
+
+
 def test_attention_online_softmax_rescale_branch(ops):
     """Force the running max to jump at a late key tile (guide rule 26): one key far larger than the rest."""
     dh, H, n = 64, 1, 200

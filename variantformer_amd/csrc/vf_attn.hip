@@ -991,6 +991,9 @@ __global__ __launch_bounds__(256, (QG >= 2 ? 2 : 4)) void attn_short_kernel(Attn
 // and a second computing wave per SIMD.  Arithmetic per query: attn_tile's, identical to every other kernel.
 // NPASS = 1: sequences of <= 128 queries (seq2reg windows at dh = 64: one block per (window, head) instead of two 64-query
 // blocks of the tiled kernel that each fetch K / V and wait for it).
+// NPASS = 2 at dh = 64 (round 4): 129-256-token chunks (seq2reg's gene chunks), 62 KB image = two blocks per CU.  The register
+// budget stays that of three waves per SIMD: at (256, 2) the compiler hoists loads up to 256 VGPRs + 47 spilled and the launch
+// takes 2369 us instead of 1329 us (168 VGPRs, 12 spilled) -- profiles/r04_k.
 template <int DH, bool ALIBI, int DT = VF_BF16, bool QL = false, int NPASS = 2>
 __global__ __launch_bounds__(256, 3) void attn_short2_kernel(AttnParams P, int k_rows) {
     constexpr int SM = QL ? 2 : 0;
@@ -1275,6 +1278,15 @@ int launch_attn(AttnParams P, int n_seq, int max_q, int max_k, hipStream_t st) {
             short2_rows(max_k, kr, vr);
             if (3 * (kr * KLayout<DH>::ROW + vr * VLayout<DH>::ROW) <= 160 * 1024)
                 return launch_short2<DH, ALIBI, DT, 1>(P, n_seq, max_k, st);
+        }
+        // 129-256-token chunks (seq2reg's 200-token gene chunks): the same kernel in its two-pass form, one block per (chunk,
+        // head) with a 62 KB image (two resident blocks per CU) instead of four 64-query blocks of the tiled kernel that each
+        // stage all keys: 1544 -> 1329 us per launch at 32 genes, bit-identical (profiles/r04_k; VF_ATTN_SHORT64=0: tiled kernel)
+        if (short64 && max_q > 128 && max_q <= 256 && max_k <= 256 && (long)n_seq * P.H >= 1024) {
+            int kr, vr;
+            short2_rows(max_k, kr, vr);
+            if (2 * (kr * KLayout<DH>::ROW + vr * VLayout<DH>::ROW) <= 160 * 1024)
+                return launch_short2<DH, ALIBI, DT, 2>(P, n_seq, max_k, st);
         }
     }
     // long query streams: 2 query groups per wave (halves K/V LDS traffic per MFMA; for seq2reg windows, 70-200 queries,
