@@ -82,14 +82,27 @@ def prepare(batch, dedupe_windows=None):
     stats["embedded"] += sum(pb.windows_embedded)
     return pb
 model.prepare_batch = prepare
+finished = []                                # (time, genes) of every finished batch: the steady-state rate excludes the first
+orig_finish = model.predict_finish           # batch, which one loader worker builds alone (32 genes x ~20 ms) before the GPU starts
+
+
+def finish(handle, i):
+    o = orig_finish(handle, i)
+    finished.append((time.perf_counter(), len(o["pred_gene_exp"])))
+    return o
+model.predict_finish = finish
 tag = f"{len(os.sched_getaffinity(0))} host cores, {workers} loader workers, batches of {batch_size}" + (", overlapping loci" if args.overlap else "") + (", de-duplication off" if args.no_dedupe else "")
 for rep in range(args.passes):              # first pass warms the workers' VCF / FASTA caches and the GPU
     stats.update(total=0, embedded=0, prep_s=0.0)
+    finished.clear()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     outs = trainer.predict(model, loader)
     done = sum(len(o["pred_gene_exp"]) for o in outs)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     nb = max(1, len(outs))
-    print(f"pass {rep}: {done} genes x {len(tissue_names)} tissues in {dt:.2f} s -> {done / dt:.1f} genes/s end to end ({tag}); "
+    steady = (sum(g for _, g in finished[1:]) / (finished[-1][0] - finished[0][0])) if len(finished) > 2 else float("nan")
+    first = finished[0][0] - t0 if finished else float("nan")
+    print(f"pass {rep}: {done} genes x {len(tissue_names)} tissues in {dt:.2f} s -> {done / dt:.1f} genes/s end to end, "
+          f"{steady:.1f} genes/s after the first batch (finished {first:.2f} s into the pass) ({tag}); "
           f"prepare_batch {1e3 * stats['prep_s'] / nb:.1f} ms per batch on the host; seq2reg embedded {stats['embedded']} of "
           f"{stats['total']} windows", flush=True)
