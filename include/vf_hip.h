@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define VF_ABI_VERSION 6
+#define VF_ABI_VERSION 7
 
 enum vf_status {
     VF_OK = 0,
@@ -224,6 +224,14 @@ int vf_mask_to_cu_seqlens(const uint8_t* pad, int32_t* cu, int W, int L, void* s
  * window is empty, as the reference's 0/0).  x fp32 [n_tok, d]; out fp32, bf16 or fp16 [W, d].
  * Replaces seq2reg/model.py:263-267. */
 int vf_segment_mean(const float* x, const int32_t* cu, void* out, int W, int d, int out_dtype, void* stream);
+
+/* The same masked mean over a 16-BIT stream x [n_tok, d] (row stride ldx elements; dtype VF_BF16 / VF_F16), values times
+ * in_scale: out_f32 fp32 [W, d] and / or out_split 16-bit [W, 2 d] = [hi | lo], hi = rn16(mean), lo = rn16(mean - hi), in the
+ * type of x (either may be NULL).  d a multiple of 8, at most 2048.  Used by the encoder's last layer: the mean pool
+ * (seq2reg/model.py:263-267) commutes with the last Linear of the layer (seq2reg/modules.py:184-188), so
+ * mean(src + W2 h + b) = mean(src) + W2 mean(h) + b is evaluated on W pooled rows instead of n_tok token rows. */
+int vf_segment_mean16(const void* x, int64_t ldx, int dtype, const int32_t* cu, float in_scale, float* out_f32,
+                      void* out_split, int W, int d, void* stream);
 
 /* Row gather from two fp32 sources: out[i,:] = idx[i] >= 0 ? a[idx[i],:] : b[-idx[i]-1,:].
  * out fp32, bf16 or fp16 [n, d].  Replaces MultiRegistry/prepare_input concat (layers.py:508-521,

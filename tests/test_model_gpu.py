@@ -69,6 +69,50 @@ def test_seq2reg_embeddings_vs_reference_golden(golden):
         assert _rel(got.cpu().numpy(), arrays[f"gene_tok_{i}"]) < BF16_VS_FP32
 
 
+@pytest.mark.parametrize("precision", ["bf16-mixed", "16-mixed"])
+@pytest.mark.parametrize("ln_fold", [True, False])
+def test_seq2reg_mean_pool_before_the_last_down_projection(precision, ln_fold):
+    """The encoder's mean pool is taken BEFORE the last layer's down-projection (mean(src + W2 h + b) = mean(src) + W2 mean(h) +
+    b: FlashTransformerLayer._pooled_down_projection, vf_segment_mean16) -- an exact re-ordering.  Production width (d = 512, 8
+    heads, GeGLU 2048 -> 1024), ragged windows of 1 ... 200 tokens and an empty one: the pooled embeddings agree with the
+    reference's order of operations (token rows of the last layer, then the pool) to fp32 summation-order level, 2e-5 of the
+    embedding scale, with the LayerNorm fold on and off (the self-healing path), bf16 and fp16 operands; the empty window is
+    NaN both ways (the reference's 0 / 0)."""
+    import variantformer_amd.seq2reg.model as s2r
+    from variantformer_amd import ops
+    from variantformer_amd.seq2gene.modules.layers import ln_fold_forced_off
+    import contextlib
+    torch.manual_seed(5)
+    m = s2r.Seq2RegPredictor(vocab_size=500, embedding_dim=512, num_heads=8, num_layers=2, num_tissues=2, num_classes=2,
+                             token_length=200, use_flash=True, positional_encoding="sinusoidal", seq_pool="mean").cuda()
+    with torch.no_grad():
+        for prm in m.parameters():
+            if prm.dim() > 1:
+                prm.mul_(1.5)
+    rng = np.random.default_rng(3)
+    lens = [200, 1, 2, 63, 64, 65, 199, 0] + list(rng.integers(1, 201, 56))
+    W, L = len(lens), 200
+    ids = torch.from_numpy(rng.integers(1, 500, (W, L))).long()
+    pad = torch.ones((W, L), dtype=torch.bool)
+    for w, n in enumerate(lens):
+        pad[w, :n] = False
+    try:
+        outs = {}
+        for flag in (True, False):
+            s2r.POOL_BEFORE_DOWN_PROJECTION = flag
+            with ops.compute_dtype(torch.bfloat16 if precision == "bf16-mixed" else torch.float16), \
+                    (contextlib.nullcontext() if ln_fold else ln_fold_forced_off()), torch.no_grad():
+                outs[flag] = m.embed_packed(ids.cuda(), pad.cuda(), int((~pad).sum()), torch.float32).cpu()
+    finally:
+        s2r.POOL_BEFORE_DOWN_PROJECTION = True
+    new, ref = outs[True], outs[False]
+    assert torch.isnan(new[7]).all() and torch.isnan(ref[7]).all()
+    keep = [w for w in range(W) if w != 7]
+    scale = float(ref[keep].abs().max())
+    assert scale > 0.5
+    assert float((new[keep] - ref[keep]).abs().max()) < 2e-5 * scale
+
+
 def test_reference_signature_modulator_forward_padded(golden):
     """CombinedModulator.forward with the reference's padded / per-tissue-repeated arguments reproduces the
     fixture's padded gene output (zeros at padded positions)."""

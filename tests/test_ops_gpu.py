@@ -1219,3 +1219,33 @@ def test_gelu_epilogue_accuracy_over_the_whole_range(ops):
     assert float((out - ref).abs().max()) <= 5e-7
     tail = (xd < -1) & (xd > -5)
     assert float(((out - ref).abs() / ref.abs())[tail].max()) < 5e-3
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("d", [512, 1024, 64, 192, 2048])
+def test_segment_mean16_vs_float64(ops, dtype, d):
+    """vf_segment_mean16: per-window mean of a 16-bit stream (strided rows), fp32 result and the [hi | lo] split.  Ragged windows
+    incl. 1 row, 3 rows (fewer than the rows in flight), 200 rows and an empty one (NaN, the reference's 0 / 0); against float64
+    on the same 16-bit values: fp32 to 2e-6 relative of the row scale, hi + lo to 2^-15 (two 16-bit mantissas)."""
+    td = torch.bfloat16 if dtype == "bf16" else torch.float16
+    lens = [200, 1, 3, 0, 64, 65, 7, 130, 97, 2]
+    n = sum(lens)
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32).cuda()
+    big = (_rand((n, d + 16), 81, 3.0)).cuda().to(td)
+    x = big[:, 8:8 + d]                                   # a strided view: rows d + 16 apart
+    scale = 16.0
+    f = ops.segment_mean16(x, cu, in_scale=scale)
+    sp = ops.segment_mean16(x, cu, in_scale=scale, split=True)
+    torch.cuda.synchronize()
+    assert f.shape == (len(lens), d) and sp.shape == (len(lens), 2 * d) and sp.dtype == td
+    xd = x.double().cpu()
+    for w, ln in enumerate(lens):
+        a = int(cu[w])
+        if ln == 0:
+            assert torch.isnan(f[w]).all() and torch.isnan(sp[w].float()).all()
+            continue
+        ref = xd[a:a + ln].mean(dim=0) * scale
+        tol = float(ref.abs().max())
+        assert float((f[w].double().cpu() - ref).abs().max()) <= 2e-6 * tol + 1e-30
+        rec = sp[w, :d].double().cpu() + sp[w, d:].double().cpu()
+        assert float((rec - ref).abs().max()) <= 2 ** -15 * tol

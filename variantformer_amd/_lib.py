@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libvf_hip.so")
 # enums of include/vf_hip.h
 VF_F32, VF_BF16, VF_F16 = 0, 1, 2
 EPI_BF16, EPI_F32, EPI_RES_F32, EPI_GEGLU_BF16, EPI_GELU_F32, EPI_GELU_BF16 = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -45,6 +45,7 @@ SIGNATURES = {
     "vf_embed_pack": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "vf_mask_to_cu_seqlens": [_p, _p, _i, _i, _p],
     "vf_segment_mean": [_p, _p, _p, _i, _i, _i, _p],
+    "vf_segment_mean16": [_p, _l, _i, _p, _f, _p, _p, _i, _i, _p],
     "vf_gather_rows_f32": [_p, _p, _p, _p, _l, _i, _i, _p],
     "vf_gather_rows_bf16": [_p, _l, _p, _p, _l, _l, _i, _p],
     "vf_rowdot_softplus": [_p, _p, _p, _p, _l, _i, _i, _p],

@@ -387,6 +387,79 @@ __global__ __launch_bounds__(256) void segment_mean_kernel(const float* __restri
     }
 }
 
+// The same pool over a 16-BIT stream (the GeGLU output / the fp16 trunk copy of the encoder's last layer: the mean is taken
+// BEFORE the last down-projection, which is linear -- seq2reg/modules.py).  One block per window; a thread owns one 16-byte
+// chunk (8 columns) of every RPI-th row (RPI = 256 / (d / 8) rows in flight per step), partial sums meet in LDS in a fixed order (deterministic).  Results: fp32 means
+// (out_f32) and / or the means split into two 16-bit halves hi = rn16(m), lo = rn16(m - hi) stored side by side
+// [W, 2 d] = [hi | lo]: a 16-bit MFMA GEMM against [W2 | W2] then carries m to ~2^-17 relative.
+template <int DT>
+__global__ __launch_bounds__(256) void segment_mean16_kernel(const unsigned short* __restrict__ x, int64_t ldx,
+                                                            const int32_t* __restrict__ cu, float in_scale,
+                                                            float* __restrict__ out_f32, unsigned short* __restrict__ out_split,
+                                                            int d, int split_dt) {
+    __shared__ float part[256 * 8];
+    const int w = blockIdx.x, tid = threadIdx.x;
+    const int a = cu[w], e = cu[w + 1];
+    const int nc = d >> 3, rpi = 256 / nc;                        // chunks per row, rows per iteration
+    const int c = tid % nc, rl = tid / nc;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (rl < rpi) {
+        const unsigned short* xp = x + (int64_t)a * ldx + c * 8;
+        int t = a + rl;
+        for (; t + 3 * rpi < e; t += 4 * rpi) {                     // four rows in flight per thread
+            u32x4_t v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const u32x4_t*>(xp + (int64_t)(t - a + u * rpi) * ldx);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[2 * j] += Op16<DT>::to_f32((unsigned short)(v[u][j] & 0xFFFFu));
+                    acc[2 * j + 1] += Op16<DT>::to_f32((unsigned short)(v[u][j] >> 16));
+                }
+        }
+        for (; t < e; t += rpi) {
+            const u32x4_t v = *reinterpret_cast<const u32x4_t*>(xp + (int64_t)(t - a) * ldx);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[2 * j] += Op16<DT>::to_f32((unsigned short)(v[j] & 0xFFFFu));
+                acc[2 * j + 1] += Op16<DT>::to_f32((unsigned short)(v[j] >> 16));
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) part[j * 256 + tid] = acc[j];
+    __syncthreads();
+    if (tid < nc) {
+        const float inv = in_scale / (float)(e - a);               // e == a -> inf; 0 * inf = NaN like the reference's 0/0
+        float m[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float sum = part[j * 256 + tid];
+            for (int r = 1; r < rpi; ++r) sum += part[j * 256 + r * nc + tid];
+            m[j] = sum * inv;
+        }
+        if (out_f32) {
+            float* op = out_f32 + (int64_t)w * d + tid * 8;
+            *reinterpret_cast<f32x4_t*>(op) = (f32x4_t){m[0], m[1], m[2], m[3]};
+            *reinterpret_cast<f32x4_t*>(op + 4) = (f32x4_t){m[4], m[5], m[6], m[7]};
+        }
+        if (out_split) {
+            u32x4_t hi, lo;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                hi[j] = pack2_dt(m[2 * j], m[2 * j + 1], split_dt);
+                const float h0 = split_dt == VF_F16 ? h2f((unsigned short)(hi[j] & 0xFFFFu)) : bf2f((unsigned short)(hi[j] & 0xFFFFu));
+                const float h1 = split_dt == VF_F16 ? h2f((unsigned short)(hi[j] >> 16)) : bf2f((unsigned short)(hi[j] >> 16));
+                lo[j] = pack2_dt(m[2 * j] - h0, m[2 * j + 1] - h1, split_dt);
+            }
+            unsigned short* op = out_split + (int64_t)w * 2 * d + tid * 8;
+            *reinterpret_cast<u32x4_t*>(op) = hi;
+            *reinterpret_cast<u32x4_t*>(op + d) = lo;
+        }
+    }
+}
+
 // "linear" pooling of seq2reg (reference seq2reg/model.py:268-272): out[w, c] = sum_p lin_w[p] * x[w, p, c] * valid(p)
 // + lin_b, on the packed stream: the k-th valid token of window w sits at row cu[w] + k and at position vpos[k].
 __global__ __launch_bounds__(256) void segment_linear_kernel(const float* __restrict__ x, const int32_t* __restrict__ cu,
@@ -676,6 +749,22 @@ extern "C" int vf_segment_mean(const float* x, const int32_t* cu, void* out, int
     if (W <= 0) return VF_OK;
     hipLaunchKernelGGL(segment_mean_kernel, dim3(W), dim3(256), 0, (hipStream_t)stream, x, cu, out, d, out_dtype);
     VF_CHECK_LAUNCH("vf_segment_mean");
+    return VF_OK;
+}
+
+extern "C" int vf_segment_mean16(const void* x, int64_t ldx, int dtype, const int32_t* cu, float in_scale, float* out_f32,
+                                 void* out_split, int W, int d, void* stream) {
+    VF_REQUIRE(x && cu && (out_f32 || out_split) && d >= 8 && d <= 2048 && d % 8 == 0 && ldx >= d && ldx % 8 == 0,
+               "vf_segment_mean16: bad arguments (d=%d ldx=%ld; d must be a multiple of 8, at most 2048)", d, (long)ldx);
+    VF_REQUIRE(dtype == VF_BF16 || dtype == VF_F16, "vf_segment_mean16: bad dtype %d", dtype);
+    if (W <= 0) return VF_OK;
+    if (dtype == VF_F16)
+        hipLaunchKernelGGL(segment_mean16_kernel<VF_F16>, dim3(W), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, ldx,
+                           cu, in_scale, out_f32, (unsigned short*)out_split, d, dtype);
+    else
+        hipLaunchKernelGGL(segment_mean16_kernel<VF_BF16>, dim3(W), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, ldx,
+                           cu, in_scale, out_f32, (unsigned short*)out_split, d, dtype);
+    VF_CHECK_LAUNCH("vf_segment_mean16");
     return VF_OK;
 }
 

@@ -559,6 +559,21 @@ def segment_mean(x: torch.Tensor, cu: torch.Tensor, out_dtype=None) -> torch.Ten
     return out
 
 
+def segment_mean16(x16: torch.Tensor, cu: torch.Tensor, in_scale: float = 1.0, split: bool = False) -> torch.Tensor:
+    """Per-window mean of a 16-bit stream [n_tok, d] (rows may be strided), values times in_scale (vf_segment_mean16):
+    fp32 [W, d], or with split=True the means as two 16-bit halves [W, 2 d] = [hi | lo] (lo = rn16(mean - hi)) in the type
+    of x16 -- a 16-bit GEMM operand that carries the fp32 mean to ~2^-17."""
+    _dev(x16, cu)
+    assert _is16(x16.dtype) and x16.dim() == 2 and x16.stride(1) == 1 and cu.dtype == torch.int32
+    W, d = cu.numel() - 1, x16.shape[1]
+    out = torch.empty((W, 2 * d), dtype=x16.dtype, device=x16.device) if split else torch.empty((W, d), dtype=torch.float32,
+                                                                                               device=x16.device)
+    check(_lib.load().vf_segment_mean16(x16.data_ptr(), x16.stride(0), _dt(x16.dtype), cu.data_ptr(), float(in_scale),
+                                        None if split else out.data_ptr(), out.data_ptr() if split else None, W, d,
+                                        _stream()), "vf_segment_mean16")
+    return out
+
+
 def segment_max(x: torch.Tensor, cu: torch.Tensor) -> torch.Tensor:
     _dev(x, cu)
     assert x.dtype == torch.float32 and x.is_contiguous() and cu.dtype == torch.int32

@@ -18,6 +18,11 @@ from .. import ops
 from .modules import FlashTransformerLayer
 
 
+# The encoder's mean pool is taken BEFORE the last layer's down-projection (FlashTransformerLayer._pooled_down_projection).
+# False (tests only): pool the token rows of the last layer, the reference's order of operations.
+POOL_BEFORE_DOWN_PROJECTION = True
+
+
 def positionalencoding1d(d_model: int, length: int) -> torch.Tensor:
     """Sinusoidal table [length, d_model]; same values as the reference (seq2reg/model.py:15-37)."""
     if d_model % 2 != 0:
@@ -126,8 +131,16 @@ class Seq2RegPredictor(nn.Module):
             else:
                 from ..seq2gene.modules.layers import trunk16_enabled
                 n_layers = len(self.transformer_encoder)
+                # mean pool: the last layer returns the pooled rows themselves (its down-projection commutes with the mean)
+                lg2 = self.transformer_encoder[-1].linear_geglu_2                 # (vf_segment_mean16 serves widths <= 2048)
+                pool_in_layer = (self.seq_pool == "mean" and POOL_BEFORE_DOWN_PROJECTION and lg2.in_features % 8 == 0 and
+                                 lg2.out_features % 8 == 0 and max(lg2.in_features, lg2.out_features) <= 2048)
                 for li, layer in enumerate(self.transformer_encoder):
-                    x = layer.forward_packed(x, cu, Lmax, last=li + 1 == n_layers, keep_x=not trunk16_enabled("seq2reg"))
+                    x = layer.forward_packed(x, cu, Lmax, last=li + 1 == n_layers, keep_x=not trunk16_enabled("seq2reg"),
+                                             pool_mean=pool_in_layer and li + 1 == n_layers)
+                if pool_in_layer:
+                    od = ops.cdt() if out_dtype is None else out_dtype
+                    return x if od == torch.float32 else ops.cast16(x, od)
             if isinstance(x, ops.LnStream):                           # layers exchange (x, bf16 copy, row statistics)
                 x = x.x
             if self.seq_pool == "mean":                               # :263-267

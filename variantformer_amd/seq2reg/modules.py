@@ -26,10 +26,28 @@ class FlashTransformerLayer(nn.Module):
         self.dropout = nn.Dropout(mlp_dout)
         self.linear_geglu_2 = nn.Linear(hidden_dim // 2, d_model)
 
-    def forward_packed(self, src, cu: torch.Tensor, max_seqlen: int, last: bool = False, keep_x: bool = True):
+    def _pooled_down_projection(self, hg, w2, b2, cu, res_f32=None, res16=None, res16_scale: float = 1.0):
+        """mean over each window's tokens of (src + linear_geglu_2(hg)) evaluated as mean(src) + W2 mean(hg) + b: the pool
+        (seq2reg/model.py:263-267) is linear and so is the layer's last operation (seq2reg/modules.py:184-188), so the
+        down-projection runs on W pooled rows instead of n_tok token rows and the fp32 token rows of the encoder output are
+        never written.  mean(hg) stays fp32-accurate through the 16-bit GEMM as [hi | lo] against [W2 | W2]; the residual
+        mean is taken over the very values the token-level epilogue adds: the fp32 rows, or a 16-bit copy times its scale
+        (res16: the fp16 trunk copy, or the operand-type copy of the layer input).  -> fp32 [W, d]."""
+        key = (w2.data_ptr(), w2._version)
+        if getattr(self, "_w2_split_key", None) != key:
+            self._w2_split, self._w2_split_key = torch.cat([w2, w2], dim=1).contiguous(), key
+        ph = ops.segment_mean16(hg, cu, split=True)
+        pr = ops.segment_mean16(res16, cu, in_scale=res16_scale) if res16 is not None else \
+            ops.segment_mean(res_f32, cu, torch.float32)
+        return ops.gemm(ph, self._w2_split, b2, ops.EPI_RES_F32, residual=pr, family="seq2reg")
+
+    def forward_packed(self, src, cu: torch.Tensor, max_seqlen: int, last: bool = False, keep_x: bool = True,
+                       pool_mean: bool = False):
         """src: fp32 [tokens, d] or an ops.LnStream; returns the same kind (an LnStream when LayerNorm is folded into
         the GEMMs, see seq2gene.modules.layers.ln_fold_enabled; a plain tensor from the `last` layer).  keep_x=False: the
-        result's fp32 rows have no reader (16-bit trunk, layers.trunk16_enabled) and are not stored."""
+        result's fp32 rows have no reader (16-bit trunk, layers.trunk16_enabled) and are not stored.
+        pool_mean (with last): return the per-window MEAN of the layer's output rows, fp32 [W, d], instead of the rows
+        (_pooled_down_projection)."""
         from ..seq2gene.modules.layers import (_as_stream, _as_tensor, down_projection, ln_fold_enabled, packed_linear_ln,
                                                res16_enabled, trunk_f16_active)
         if ln_fold_enabled(self.norm1.weight.numel(), self.linear_geglu_2.in_features):
@@ -40,6 +58,13 @@ class FlashTransformerLayer(nn.Module):
             w1, b1, c1 = packed_linear_ln(self.linear_geglu_1, self.norm2, geglu=True)
             hg = ops.gemm_ln_consumer(x1, w1, b1, c1, ops.EPI_GEGLU_BF16)
             w2, b2 = packed_linear(self.linear_geglu_2)
+            if last and pool_mean:          # the same residual operand down_projection would add per token
+                if trunk_f16_active():
+                    return self._pooled_down_projection(hg, w2, b2, cu, res16=s.t16 if s.t16 is not None else ops.trunk16_of(s.x),
+                                                        res16_scale=1.0 / ops.T16_SCALE)
+                if s.x is None:
+                    return self._pooled_down_projection(hg, w2, b2, cu, res16=s.x16, res16_scale=1.0 / s.scale)
+                return self._pooled_down_projection(hg, w2, b2, cu, res_f32=s.x)
             if last:        # the encoder's last layer feeds the pooling, not a LayerNorm: plain fp32 result
                 if s.x is None or trunk_f16_active():    # 16-bit trunk: the layer input exists as its trunk copy only
                     return down_projection(hg, w2, b2, s, keep_x=True, need_t16=False).x
@@ -53,6 +78,8 @@ class FlashTransformerLayer(nn.Module):
         w1, b1 = packed_linear(self.linear_geglu_1, geglu=True)
         hg = ops.gemm(h, w1, b1, ops.EPI_GEGLU_BF16)
         w2, b2 = packed_linear(self.linear_geglu_2)
+        if last and pool_mean:
+            return self._pooled_down_projection(hg, w2, b2, cu, res_f32=src)
         return ops.gemm(hg, w2, b2, ops.EPI_RES_F32, residual=src)
 
     def forward(self, src, src_key_padding_mask=None, precision=torch.float32):

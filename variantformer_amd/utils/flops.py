@@ -13,6 +13,10 @@ def gene_flops(N: int, C: int, T: int, S_c: int, S_g: int, sum_sq_cre: float, su
     d_gene = d if d_gene is None else d_gene
     per_tok = lambda w: 8 * w * w + 3 * F * w          # Wqkv 6w^2 + out 2w^2 + geglu1 2*w*F + geglu2 2*(F/2)*w  # noqa: E731
     seq2reg = ell * (S_c * per_tok(d) + S_g * per_tok(d_gene)) + ell * 4 * (sum_sq_cre * d + sum_sq_gene * d_gene)
+    if not executed_by_reference:
+        # the mean pool commutes with the last layer's down-projection (F/2 -> w): algorithmically that Linear runs on one
+        # pooled row per window / chunk instead of on every token (seq2reg/modules.py, _pooled_down_projection)
+        seq2reg -= (S_c - N) * F * d + (S_g - C) * F * d_gene
     maps = 2 * N * d * D + 2 * C * d_gene * D
     Lc, Lg = L_layers - 1, L_layers
     # CRE layer per token: self 8D^2, cross Wq 2D^2 + out 2D^2 (+ Wkv on the 9-row table: negligible), FFN 3FD
