@@ -216,6 +216,13 @@ int vf_embed_stream(const int64_t* ids, const uint8_t* pad, const int32_t* cu, c
                     float* out, void* out16, int out_dtype, float x16_scale, void* t16, float t16_scale, float* row_stats,
                     float eps, float ratio_limit, float abs_limit, int* alert, int W, int L, int d, int vocab, void* stream);
 
+/* keys[cu[w] + k] = id * key_L + position of the k-th valid token of window w (key_L = L, or 1: keys = ids), ids clamped to
+ * [0, vocab) as vf_embed_pack does.  The encoder input row nn.Embedding(id) + positional(position) (seq2reg/model.py:205-221) takes
+ * at most vocab * L distinct values: what the first layer computes per row from it alone (norm1 -> Wqkv, seq2reg/modules.py:
+ * 152-160) is computed once per distinct row and looked up by this key (vf_gather_rows_bf16). */
+int vf_token_keys(const int64_t* ids, const uint8_t* pad, const int32_t* cu, int64_t* keys, int W, int L, int vocab, int key_L,
+                  void* stream);
+
 /* Per-window valid-token count and exclusive prefix sum: cu[0]=0, cu[w+1]=cu[w]+#valid(w).
  * Replaces the cu_seqlens half of unpad_input [3p].  Single-block scan; W <= 2^24. */
 int vf_mask_to_cu_seqlens(const uint8_t* pad, int32_t* cu, int W, int L, void* stream);

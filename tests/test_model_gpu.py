@@ -113,6 +113,49 @@ def test_seq2reg_mean_pool_before_the_last_down_projection(precision, ln_fold):
     assert float((new[keep] - ref[keep]).abs().max()) < 2e-5 * scale
 
 
+@pytest.mark.parametrize("precision", ["bf16-mixed", "16-mixed"])
+@pytest.mark.parametrize("pos", ["sinusoidal", "alibi"])
+def test_seq2reg_first_layer_qkv_lookup_is_bit_identical(precision, pos):
+    """The encoder's first layer looks norm1 -> Wqkv up per distinct input row (Embedding(id) + positional(position): vocab x
+    token_length rows, Seq2RegPredictor._layer0_qkv_table + vf_token_keys + a row gather) instead of projecting every token.  A
+    GEMM row depends on its own input row only and the table rows go through the same kernels: the pooled embeddings are
+    BIT-identical to the per-token projection, for both operand types, with the positional table (key = id * L + position) and
+    without (ALiBi: key = id); ragged windows incl. interior pads, an empty window, ids at both ends of the vocabulary, and ids
+    outside it (clamped like nn.Embedding's kernel clamps them)."""
+    import variantformer_amd.seq2reg.model as s2r
+    from variantformer_amd import ops
+    torch.manual_seed(11)
+    m = s2r.Seq2RegPredictor(vocab_size=500, embedding_dim=512, num_heads=8, num_layers=2, num_tissues=2, num_classes=2,
+                             token_length=200, use_flash=True, positional_encoding=pos, seq_pool="mean").cuda()
+    rng = np.random.default_rng(4)
+    lens = [200, 1, 2, 63, 64, 65, 199, 0] + list(rng.integers(1, 201, 40))
+    W, L = len(lens), 200
+    ids = torch.from_numpy(rng.integers(0, 500, (W, L))).long()
+    ids[0, :4] = torch.tensor([0, 499, 700, -3])
+    pad = torch.ones((W, L), dtype=torch.bool)
+    for w, n in enumerate(lens):
+        pad[w, :n] = False
+    pad[6, 50:60] = True                                             # pads inside a window: positions are not ranks
+    outs = {}
+    try:
+        for flag in (True, False):
+            s2r.LAYER0_QKV_TABLE = flag
+            with ops.compute_dtype(torch.bfloat16 if precision == "bf16-mixed" else torch.float16), torch.no_grad():
+                outs[flag] = m.embed_packed(ids.cuda(), pad.cuda(), int((~pad).sum()), torch.float32).cpu()
+    finally:
+        s2r.LAYER0_QKV_TABLE = True
+    keep = [w for w in range(W) if w != 7]
+    assert torch.isfinite(outs[False][keep]).all() and float(outs[False][keep].abs().max()) > 0.1
+    assert torch.equal(outs[True][keep], outs[False][keep])
+    assert torch.isnan(outs[True][7]).all()
+    # the keys themselves
+    cu = ops.mask_to_cu_seqlens(pad.cuda())
+    keys = ops.token_keys(ids.cuda(), pad.cuda(), cu, int((~pad).sum()), 500, 200).cpu()
+    cl = ids.clamp(0, 499)
+    expect = torch.cat([(cl[w] * 200 + torch.arange(L))[~pad[w]] for w in range(W)])
+    assert torch.equal(keys, expect)
+
+
 def test_reference_signature_modulator_forward_padded(golden):
     """CombinedModulator.forward with the reference's padded / per-tissue-repeated arguments reproduces the
     fixture's padded gene output (zeros at padded positions)."""

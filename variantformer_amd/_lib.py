@@ -46,6 +46,7 @@ SIGNATURES = {
     "vf_mask_to_cu_seqlens": [_p, _p, _i, _i, _p],
     "vf_segment_mean": [_p, _p, _p, _i, _i, _i, _p],
     "vf_segment_mean16": [_p, _l, _i, _p, _f, _p, _p, _i, _i, _p],
+    "vf_token_keys": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
     "vf_gather_rows_f32": [_p, _p, _p, _p, _l, _i, _i, _p],
     "vf_gather_rows_bf16": [_p, _l, _p, _p, _l, _l, _i, _p],
     "vf_rowdot_softplus": [_p, _p, _p, _p, _l, _i, _i, _p],

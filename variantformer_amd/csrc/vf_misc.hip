@@ -277,6 +277,30 @@ __global__ __launch_bounds__(256) void embed_pack_kernel(const int64_t* __restri
     }
 }
 
+// Key of every packed valid token: id * key_L + position (key_L = L for a positional table, 1 without one).  The encoder input
+// row x0 = table[id] + pos_table[position] takes at most vocab * L distinct values, so everything the first layer computes per
+// ROW from x0 alone (LayerNorm1 -> Wqkv) is a table lookup by this key (seq2reg/model.py, _layer0_qkv_table).  One wave per window,
+// same compaction order as embed_pack_kernel.
+__global__ __launch_bounds__(64) void token_keys_kernel(const int64_t* __restrict__ ids, const uint8_t* __restrict__ pad,
+                                                        const int32_t* __restrict__ cu, int64_t* __restrict__ keys, int L, int vocab,
+                                                        int key_L) {
+    const int w = blockIdx.x, tid = threadIdx.x;
+    const int64_t row0 = cu[w];
+    int base = 0;
+    for (int p0 = 0; p0 < L; p0 += 64) {
+        const int p = p0 + tid;
+        const bool valid = p < L && pad[(int64_t)w * L + p] == 0;
+        const unsigned long long bal = __ballot(valid);
+        if (valid) {
+            const int rank = __popcll(bal & ((1ull << tid) - 1ull));
+            long long id = ids[(int64_t)w * L + p];
+            id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+            keys[row0 + base + rank] = id * key_L + (key_L > 1 ? p : 0);
+        }
+        base += __popcll(bal);
+    }
+}
+
 // The same embedding, handed to the first encoder layer as the LayerNorm-folding GEMMs exchange a stream: per valid token
 // row x = table[id] + pos_table[pos] never reaches HBM as fp32 (unless `out` is given) -- the kernel writes its 16-bit
 // operand copy, its scaled fp16 trunk copy and its (mean, rstd), with exactly the arithmetic of embed_pack_kernel followed
@@ -749,6 +773,15 @@ extern "C" int vf_segment_mean(const float* x, const int32_t* cu, void* out, int
     if (W <= 0) return VF_OK;
     hipLaunchKernelGGL(segment_mean_kernel, dim3(W), dim3(256), 0, (hipStream_t)stream, x, cu, out, d, out_dtype);
     VF_CHECK_LAUNCH("vf_segment_mean");
+    return VF_OK;
+}
+
+extern "C" int vf_token_keys(const int64_t* ids, const uint8_t* pad, const int32_t* cu, int64_t* keys, int W, int L, int vocab,
+                             int key_L, void* stream) {
+    VF_REQUIRE(ids && pad && cu && keys && L > 0 && vocab > 0 && (key_L == 1 || key_L >= L), "vf_token_keys: bad arguments (L=%d key_L=%d)", L, key_L);
+    if (W <= 0) return VF_OK;
+    hipLaunchKernelGGL(token_keys_kernel, dim3(W), dim3(64), 0, (hipStream_t)stream, ids, pad, cu, keys, L, vocab, key_L);
+    VF_CHECK_LAUNCH("vf_token_keys");
     return VF_OK;
 }
 

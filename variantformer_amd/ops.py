@@ -548,6 +548,18 @@ def embed_stream(ids: torch.Tensor, pad: torch.Tensor, cu: torch.Tensor, table: 
     return LnStream(x, x16, stats, scale, t16)
 
 
+def token_keys(ids: torch.Tensor, pad: torch.Tensor, cu: torch.Tensor, n_tokens: int, vocab: int, key_L: int) -> torch.Tensor:
+    """int64 [n_tokens]: id * key_L + position of every packed valid token (vf_token_keys; key_L = 1: the ids themselves)."""
+    _dev(ids, pad, cu)
+    pad = pad.view(torch.uint8) if pad.dtype == torch.bool else pad
+    assert ids.dtype == torch.int64 and ids.is_contiguous() and ids.dim() == 2 and pad.shape == ids.shape and pad.is_contiguous()
+    W, L = ids.shape
+    keys = torch.empty((n_tokens,), dtype=torch.int64, device=ids.device)
+    check(_lib.load().vf_token_keys(ids.data_ptr(), pad.data_ptr(), cu.data_ptr(), keys.data_ptr(), W, L, int(vocab), int(key_L),
+                                    _stream()), "vf_token_keys")
+    return keys
+
+
 def segment_mean(x: torch.Tensor, cu: torch.Tensor, out_dtype=None) -> torch.Tensor:
     _dev(x, cu)
     out_dtype = _CDT if out_dtype is None else out_dtype
@@ -642,8 +654,14 @@ def gather_rows_bf16(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     _dev(src, idx)
     assert _is16(src.dtype) and src.stride(1) == 1 and idx.dtype == torch.int64
     out = torch.empty((idx.numel(), src.shape[1]), dtype=src.dtype, device=src.device)
-    check(_lib.load().vf_gather_rows_bf16(src.data_ptr(), src.stride(0), idx.data_ptr(), out.data_ptr(), out.stride(0),
-                                          idx.numel(), src.shape[1], _stream()), "vf_gather_rows_bf16")
+
+    def launch():
+        check(_lib.load().vf_gather_rows_bf16(src.data_ptr(), src.stride(0), idx.data_ptr(), out.data_ptr(), out.stride(0),
+                                              idx.numel(), src.shape[1], _stream()), "vf_gather_rows_bf16")
+    if TIMER is not None:
+        TIMER.time("layernorm", 0.0, float(idx.numel()) * (src.shape[1] * 4 + 8), launch, f"gather_rows16 D={src.shape[1]}", _SCOPE)
+    else:
+        launch()
     return out
 
 

@@ -21,6 +21,10 @@ from .modules import FlashTransformerLayer
 # The encoder's mean pool is taken BEFORE the last layer's down-projection (FlashTransformerLayer._pooled_down_projection).
 # False (tests only): pool the token rows of the last layer, the reference's order of operations.
 POOL_BEFORE_DOWN_PROJECTION = True
+# The first layer's LayerNorm1 -> Wqkv is looked up per distinct input row (Seq2RegPredictor._layer0_qkv_table).  False (tests
+# only): project every token.
+LAYER0_QKV_TABLE = True
+LAYER0_QKV_TABLE_MAX_ROWS = 1 << 20          # vocab * token_length rows of 3 d 16-bit values (500 x 200 x 3 KB = 307 MB shipped)
 
 
 def positionalencoding1d(d_model: int, length: int) -> torch.Tensor:
@@ -98,6 +102,33 @@ class Seq2RegPredictor(nn.Module):
             self._pe_dev = self.position_encoding.to(device).contiguous()
         return self._pe_dev
 
+    def _layer0_qkv_table(self, device):
+        """16-bit [vocab * key_L, 3 d]: the first layer's packed_qkv_ln(norm1) projection of EVERY possible encoder input row
+        x0 = Embedding(id) + positional(position) (key = id * key_L + position; key_L = token_length, or 1 with ALiBi).  The
+        rows are made by the same kernels the tokens would go through (vf_embed_stream on the identity window list, then the
+        LayerNorm-consumer GEMM), and a GEMM row depends on nothing but its own input row: looking a token's projection up
+        is bit-identical to projecting the token.  Built once per weights / operand type (0.2 ms of GEMM), then every batch
+        replaces a [n_tokens, d] x [d, 3 d] GEMM by a row gather."""
+        l0 = self.transformer_encoder[0]
+        pos = self._pos_table(device)
+        V = self.token_embedding.weight.shape[0]
+        key_L = pos.shape[0] if pos is not None else 1
+        prm = [self.token_embedding.weight, l0.norm1.weight, l0.norm1.bias, l0.MHA.Wqkv.weight, l0.MHA.Wqkv.bias]
+        key = (str(device), ops.cdt(), key_L) + tuple((p.data_ptr(), p._version) for p in prm)
+        if getattr(self, "_qkv_tab_key", None) != key:
+            ids = torch.arange(V, device=device, dtype=torch.int64).view(V, 1).expand(V, key_L).contiguous()
+            pad = torch.zeros((V, key_L), dtype=torch.uint8, device=device)
+            cu = (torch.arange(V + 1, device=device, dtype=torch.int32) * key_L).contiguous()
+            # rows no token may ever show (unused ids) must not raise the LayerNorm-fold alert: the tokens of a batch raise it
+            # themselves (their own vf_embed_stream pass), and the recomputation does not come through this table
+            alert = ops._alert_flag(device)
+            before = alert.clone()
+            s = ops.embed_stream(ids, pad, cu, self.token_embedding.weight, pos, V * key_L, need_t16=False)
+            alert.copy_(before)
+            w, b, c = l0.MHA.packed_qkv_ln(l0.norm1)
+            self._qkv_tab, self._qkv_tab_key = ops.gemm_ln_consumer(s, w, b, c, ops.EPI_BF16, family="seq2reg"), key
+        return self._qkv_tab, key_L
+
     def embed_packed(self, ids: torch.Tensor, pad: torch.Tensor, n_tokens: int, out_dtype=None,
                      max_len: int = 0, context: torch.Tensor | None = None):
         """ids int64 [W, L], pad bool/u8 [W, L] (True = pad) on the GPU -> pooled [W, d].
@@ -135,9 +166,16 @@ class Seq2RegPredictor(nn.Module):
                 lg2 = self.transformer_encoder[-1].linear_geglu_2                 # (vf_segment_mean16 serves widths <= 2048)
                 pool_in_layer = (self.seq_pool == "mean" and POOL_BEFORE_DOWN_PROJECTION and lg2.in_features % 8 == 0 and
                                  lg2.out_features % 8 == 0 and max(lg2.in_features, lg2.out_features) <= 2048)
+                qkv0 = None
+                V = self.token_embedding.weight.shape[0]
+                if (LAYER0_QKV_TABLE and ln_fold_enabled(l0.norm1.weight.numel(), l0.linear_geglu_2.in_features) and
+                        self.token_embedding.weight.shape[1] <= 2048 and
+                        V * (L if self.pos_encoding_type == "sinusoidal" else 1) <= LAYER0_QKV_TABLE_MAX_ROWS):
+                    tab, key_L = self._layer0_qkv_table(ids.device)
+                    qkv0 = ops.gather_rows_bf16(tab, ops.token_keys(ids, pad, cu, n_tokens, V, key_L))
                 for li, layer in enumerate(self.transformer_encoder):
                     x = layer.forward_packed(x, cu, Lmax, last=li + 1 == n_layers, keep_x=not trunk16_enabled("seq2reg"),
-                                             pool_mean=pool_in_layer and li + 1 == n_layers)
+                                             pool_mean=pool_in_layer and li + 1 == n_layers, qkv=qkv0 if li == 0 else None)
                 if pool_in_layer:
                     od = ops.cdt() if out_dtype is None else out_dtype
                     return x if od == torch.float32 else ops.cast16(x, od)

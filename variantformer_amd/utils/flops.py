@@ -17,6 +17,9 @@ def gene_flops(N: int, C: int, T: int, S_c: int, S_g: int, sum_sq_cre: float, su
         # the mean pool commutes with the last layer's down-projection (F/2 -> w): algorithmically that Linear runs on one
         # pooled row per window / chunk instead of on every token (seq2reg/modules.py, _pooled_down_projection)
         seq2reg -= (S_c - N) * F * d + (S_g - C) * F * d_gene
+        # the first layer's Wqkv acts on Embedding(id) + positional(position): vocab x token_length distinct rows, projected
+        # once per model, looked up per token (seq2reg/model.py, _layer0_qkv_table): no per-gene arithmetic
+        seq2reg -= S_c * 6 * d * d + S_g * 6 * d_gene * d_gene
     maps = 2 * N * d * D + 2 * C * d_gene * D
     Lc, Lg = L_layers - 1, L_layers
     # CRE layer per token: self 8D^2, cross Wq 2D^2 + out 2D^2 (+ Wkv on the 9-row table: negligible), FFN 3FD
