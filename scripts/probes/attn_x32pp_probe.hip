@@ -1,5 +1,5 @@
 // Interval timing of attn_x32pp_kernel on the gene -> CRE cross attention shape (scripts/probes: measurement only).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-honor-nans -mllvm -amdgpu-mfma-vgpr-form=1 -DVF_X32PP_PROF -I../../variantformer_amd/csrc -I../../include attn_x32pp_probe.hip -o attn_x32pp_probe
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-honor-nans -mllvm -amdgpu-mfma-vgpr-form=1 -DVF_TUNING -DVF_X32PP_PROF -I../../variantformer_amd/csrc -I../../include attn_x32pp_probe.hip -o attn_x32pp_probe
 #include "../../variantformer_amd/csrc/vf_attn.hip"
 #include <cstdio>
 #include <cstdarg>

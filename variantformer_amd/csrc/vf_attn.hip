@@ -813,385 +813,9 @@ __global__ __launch_bounds__(256) void attn_x32_kernel(AttnParams P) {
     }
 }
 
-#ifdef VF_TUNING   // measured 12 % SLOWER than attn_x32_kernel on the gene -> CRE cross attention (2 940 vs 2 614 us at 32 genes,
-                   // profiles/r04_l_attn_x32_antiphase_experiment.log): its tile loop needs 21 % fewer cycles (2 750 vs 3 500 per tile and
-                   // SIMD), but a single block per CU exposes 11 k cycles of prologue / epilogue per block, and the chip holds a LOWER
-                   // clock under the denser issue stream (1.66 vs 1.88 GHz): equal cycles per query, more time.  Kept for the probe only.
-// ---------------------------------------------------------------------------------------------------------------------
-// attn_x32pp_kernel: the FAST form of attn_x32_kernel with its two kinds of work in ANTI-PHASE on every SIMD (round 4).
-//
-// Why: at dh = 48 a 64-key tile costs a wave 28 MFMAs (896 cycles of the SIMD's matrix pipe) and 64 v_exp + 32 v_cvt_pk (~650
-// cycles of vector issue): the two are the same size, and in attn_x32_kernel (two independent 4-wave blocks per CU) nothing
-// makes the two waves of a SIMD do different things at the same time -- the matrix pipe is busy 51 % of the cycles
-// (profiles/r04_j_pmc_sq.json).  Here ONE 8-wave block owns the CU; waves w and w + 4 share a SIMD and run the same program
-// half a tile apart, held there by the block barrier:
-//     interval 2t      group A (waves 0-3): PV(t-1), QK^T(t)   [MFMA]     group B (waves 4-7): exp / pack of tile t-1  [VALU]
-//     interval 2t + 1  group A: staging, exp / pack of tile t  [VALU]     group B: PV(t-1), QK^T(t)                    [MFMA]
-// so that a SIMD's matrix pipe and its vector issue are both busy in every interval (MI355X_MICROARCH.md, two waves per SIMD).
-// K / V ring: 4 stages of (64 keys x 112 B, 64 keys x 192 B).  Tile u is written into slot u % 4 during the writers' VALU
-// segments of tile u - 2 (intervals 2u-3 / 2u-2: the slot's previous tile u - 4 was last read, V(u-4) by group B, in interval
-// 2u-5), and first read in interval 2u; every barrier is preceded by lgkmcnt(0), the global loads of tile u + 1 stay in flight
-// across it (raw s_barrier, no vmcnt wait).
-// Arithmetic per query: attn_x32_kernel<., ., true>'s, operation for operation (same MFMA chains, same tile order): BIT-IDENTICAL,
-// incl. the denominator test and the recomputation with the running-maximum form (tests/test_ops_gpu.py).
-// ---------------------------------------------------------------------------------------------------------------------
-#ifndef VF_X32PP_PRIO
-#define VF_X32PP_PRIO 2
+#ifdef VF_TUNING   // attn_x32pp_kernel: anti-phase 8-wave cross attention, 12 % slower (profiles/r04_l)
+#include "tuning/attn_x32pp.inc"
 #endif
-template <int DT>
-__global__ __launch_bounds__(512) void attn_x32pp_kernel(AttnParams P) {
-    using frag_t = typename Op16<DT>::frag;
-    constexpr int DH = 48, KSTEPS = 3, KROW = 112, VROW = 192, QB = 2, NT = 512, R = 4;
-    constexpr int K_TILE = BKV * KROW, V_TILE = BKV * VROW, STAGE = K_TILE + V_TILE;
-    constexpr int CPR = DH / 8, NCHUNK = BKV * CPR, NITEM = 2 * NCHUNK, NLD = (NITEM + NT - 1) / NT;
-    constexpr int BQ = 8 * QB * 32;
-    extern __shared__ __attribute__((aligned(16))) char smem[];       // R * STAGE bytes
-
-    int seq, hd, qblk;
-    if (!block_coords(P, seq, hd, qblk)) return;
-    const int q_tok0 = P.cu_q[seq], len_q = P.cu_q[seq + 1] - q_tok0;
-    const int k_tok0 = P.cu_k[seq], len_k = P.cu_k[seq + 1] - k_tok0;
-    const int qb0 = qblk * BQ;
-    if (qb0 >= len_q) return;                         // block-uniform
-    if (len_k <= 0) {
-        zero_rows<DH>(P, q_tok0 + qb0, (len_q - qb0) < BQ ? (len_q - qb0) : BQ, hd);
-        return;
-    }
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ql = lane & 31, h = lane >> 5;
-    const bool grp_b = wave >= 4;
-
-    // padding columns 48 .. 63 of every V row of every stage, once: column 48 = 1.0 (the denominator column), the rest 0
-    for (int i = tid; i < R * BKV; i += NT) {
-        char* vp = smem + (i >> 6) * STAGE + K_TILE + (i & 63) * VROW + DH * 2;
-        *reinterpret_cast<u32x4_t*>(vp) = (u32x4_t){Op16<DT>::ONE, 0u, 0u, 0u};
-        *reinterpret_cast<u32x4_t*>(vp + 16) = (u32x4_t){0u, 0u, 0u, 0u};
-    }
-
-    // ---- Q fragments (B operand): lane (q, h) holds Q[q][16 ks + 8 h .. + 7]
-    frag_t qf[QB][KSTEPS];
-    int q_abs[QB];
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-        q_abs[qb] = qb0 + (wave * QB + qb) * 32 + ql;
-        const int row = q_abs[qb] < len_q ? q_abs[qb] : len_q - 1;
-        const unsigned short* qp = P.q + (int64_t)(q_tok0 + row) * P.q_stride + hd * DH + 8 * h;
-#pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) {
-            const u32x4_t raw = *reinterpret_cast<const u32x4_t*>(qp + 16 * ks);
-            qf[qb][ks] = __builtin_bit_cast(frag_t, raw);
-        }
-    }
-    const float c = P.scale_log2;
-    f32x16_t o[QB][2];
-    float m_run[QB];
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-        m_run[qb] = -INFINITY;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) o[qb][dt][i] = 0.f;
-    }
-
-    // ---- K/V tile staging: global -> registers -> LDS; 768 16-byte items per tile: every thread one, waves 0-3 a second one
-    const unsigned short* kbase = P.k + (int64_t)k_tok0 * P.k_stride + hd * DH;
-    const unsigned short* vbase = P.v + (int64_t)k_tok0 * P.v_stride + hd * DH;
-    const unsigned short* kv_src[NLD];
-    unsigned kv_stride[NLD];
-    int kv_row[NLD], kv_off[NLD];
-#pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-        const int item = (tid + NT * i) < NITEM ? tid + NT * i : tid;
-        const bool is_v = item >= NCHUNK;
-        const int ci = is_v ? item - NCHUNK : item;
-        kv_row[i] = ci / CPR;
-        kv_src[i] = (is_v ? vbase : kbase) + (ci % CPR) * 8;
-        kv_stride[i] = (unsigned)(is_v ? P.v_stride : P.k_stride);
-        kv_off[i] = is_v ? K_TILE + kv_row[i] * VROW + (ci % CPR) * 16 : kv_row[i] * KROW + (ci % CPR) * 16;
-    }
-    const bool second = !grp_b;                                       // wave-uniform: item tid + 512 exists (tid < 256)
-    auto load_regs = [&](int t, u32x4_t (&dst)[NLD]) {
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            if (i > 0 && !second) continue;
-            int key = t * BKV + kv_row[i];
-            key = key < len_k ? key : len_k - 1;                     // finite data for masked keys
-            dst[i] = *reinterpret_cast<const u32x4_t*>(kv_src[i] + __umul24((unsigned)key, kv_stride[i]));
-        }
-    };
-    auto write_lds = [&](int slot, const u32x4_t (&src)[NLD]) {
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            if (i > 0 && !second) continue;
-            *reinterpret_cast<u32x4_t*>(smem + slot * STAGE + kv_off[i]) = src[i];
-        }
-    };
-
-    // fragment addresses inside a stage (attn_x32_kernel's)
-    const int k_off = ql * KROW + h * 16;                                           // + kb * 32 * KROW + ks * 32
-    const int v_off = K_TILE + (4 * h + ((lane & 15) >> 2)) * VROW + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
-
-    const int nkv = (len_k + BKV - 1) / BKV;
-    const bool active = qb0 + wave * QB * 32 < len_q;                 // wave-uniform
-    u32x4_t kvreg[NLD];
-
-    // ---- the three pieces of a tile
-    f32x16_t s[QB][2];
-    frag_t pf[QB][2][2];
-    auto qk = [&](const char* st) {                                   // S^T = K . Q^T
-        frag_t kf[2][KSTEPS];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int ks = 0; ks < KSTEPS; ++ks)
-                kf[kb][ks] = *reinterpret_cast<const frag_t*>(st + k_off + kb * 32 * KROW + ks * 32);
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int qb = 0; qb < QB; ++qb) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) s[qb][kb][i] = 0.f;
-#pragma unroll
-                for (int ks = 0; ks < KSTEPS; ++ks) s[qb][kb] = Op16<DT>::mfma32(kf[kb][ks], qf[qb][ks], s[qb][kb]);
-            }
-    };
-    auto pv = [&](const char* st) {                                   // O^T += V^T . P^T
-        frag_t vf[2][2][2];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int sx = 0; sx < 2; ++sx)
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    const char* vp = st + v_off + (32 * kb + 16 * sx) * VROW + dt * 64;
-                    const s16x4_t lo = lds_tr_read(vp);
-                    const s16x4_t hi = lds_tr_read(vp + 8 * VROW);
-                    vf[kb][sx][dt] = __builtin_bit_cast(frag_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-                }
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb)
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int sx = 0; sx < 2; ++sx)
-#pragma unroll
-                    for (int dt = 0; dt < 2; ++dt) o[qb][dt] = Op16<DT>::mfma32(vf[kb][sx][dt], pf[qb][kb][sx], o[qb][dt]);
-    };
-    auto mask_tail = [&](int kb0) {                                   // keys past the sequence end (last tile only)
-        const int klim = len_k - kb0 - 4 * h;
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb)
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    s[qb][kb][i] = (32 * kb + (i & 3) + 8 * (i >> 2)) < klim ? s[qb][kb][i] : -INFINITY;
-    };
-    auto pack = [&]() {
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb)
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int sx = 0; sx < 2; ++sx) {
-                    u32x4_t pk;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) pk[j] = Op16<DT>::pack2(s[qb][kb][8 * sx + 2 * j], s[qb][kb][8 * sx + 2 * j + 1]);
-                    pf[qb][kb][sx] = __builtin_bit_cast(frag_t, pk);
-                }
-    };
-    auto exp_nomax = [&]() {                                          // p = exp2(s): no running maximum (FAST)
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb)
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) s[qb][kb][i] = __builtin_amdgcn_exp2f(s[qb][kb][i]);
-    };
-    auto exp_runmax = [&]() {                                         // attn_x32_kernel's running-maximum softmax (recomputation pass)
-        float m_new[QB];
-        bool moved = false;
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb) {
-            float ma = max3f(s[qb][0][0], s[qb][0][1], s[qb][0][2]);
-            float mb = max3f(s[qb][1][0], s[qb][1][1], s[qb][1][2]);
-#pragma unroll
-            for (int i = 3; i + 1 < 16; i += 2) {
-                ma = max3f(ma, s[qb][0][i], s[qb][0][i + 1]);
-                mb = max3f(mb, s[qb][1][i], s[qb][1][i + 1]);
-            }
-            float mx = max3f(ma, mb, max2f(s[qb][0][15], s[qb][1][15]));
-            if (P.q_log2) mx = __builtin_ceilf(mx);
-            const unsigned u = __float_as_uint(mx);
-            auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-            m_new[qb] = max3f(m_run[qb], __uint_as_float(sw[0]), __uint_as_float(sw[1]));
-            moved = moved || (m_new[qb] > m_run[qb]);
-        }
-        if (__any(moved)) {
-#pragma unroll
-            for (int qb = 0; qb < QB; ++qb) {
-                const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new[qb]) * c);
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) o[qb][dt] *= alpha;
-            }
-        }
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb) {
-            m_run[qb] = m_new[qb];
-            const float mc = -m_new[qb] * c;
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) s[qb][kb][i] = __builtin_amdgcn_exp2f(fmaf(s[qb][kb][i], c, mc));
-        }
-    };
-    // block barrier between two segments: this wave's LDS operations are done, its global loads stay in flight
-    auto bar = [&]() {
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-    };
-
-#ifdef VF_X32PP_PROF   // scripts/probes/attn_x32pp_probe.hip: cycles per kind of interval (wave 0 = group A, wave 4 = group B of every 8th block)
-    unsigned long long px[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt0 = __builtin_readcyclecounter();
-#define PPT(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); px[i] += n_ - pt0; pt0 = n_; } while (0)
-#else
-#define PPT(i) do {} while (0)
-#endif
-    // ---- prologue: tiles 0 and 1 into slots 0 and 1 (both fetched together), tile 2 requested
-    {
-        u32x4_t r0[NLD], r1[NLD];
-        load_regs(0, r0);
-        if (nkv > 1) load_regs(1, r1);
-        write_lds(0, r0);
-        if (nkv > 1) write_lds(1, r1);
-    }
-    bar();
-    if (nkv > 2) load_regs(2, kvreg);
-
-    // ---- FAST pass: group B one interval behind group A
-    auto valu_seg = [&](int t) {
-        if (t + 2 < nkv) write_lds((t + 2) & (R - 1), kvreg);
-        if (t + 3 < nkv) load_regs(t + 3, kvreg);
-        if (active) {
-            if (t == nkv - 1) mask_tail(t * BKV);
-            exp_nomax();
-            pack();
-        }
-    };
-    PPT(0);                                                           // 0: prologue
-    if (grp_b) bar();
-    PPT(4);
-    if (active) {
-        __builtin_amdgcn_s_setprio(VF_X32PP_PRIO);
-        qk(smem);
-        __builtin_amdgcn_s_setprio(0);
-    }
-    PPT(1);                                                           // 1: matrix segments
-    bar();
-    PPT(2);                                                           // 2: barrier behind a matrix segment
-    valu_seg(0);
-    PPT(3);                                                           // 3: vector segments
-    bar();
-    PPT(4);                                                           // 4: barrier behind a vector segment
-    for (int t = 1; t < nkv; ++t) {
-        if (active) {
-            // the matrix segment outranks the partner's vector segment in the SIMD's issue arbitration: its MFMAs go out back to
-            // back and the exponentials fill the issue slots between them (without it: 1 260 / 1 740 cycles per segment for 896 of MFMA)
-            __builtin_amdgcn_s_setprio(VF_X32PP_PRIO);
-            pv(smem + ((t - 1) & (R - 1)) * STAGE);
-            qk(smem + (t & (R - 1)) * STAGE);
-            __builtin_amdgcn_s_setprio(0);
-        }
-        PPT(1);
-        bar();
-        PPT(2);
-        valu_seg(t);
-        PPT(3);
-        bar();
-        PPT(4);
-    }
-    if (active) {
-        __builtin_amdgcn_s_setprio(VF_X32PP_PRIO);
-        pv(smem + ((nkv - 1) & (R - 1)) * STAGE);
-        __builtin_amdgcn_s_setprio(0);
-    }
-    PPT(1);
-    if (!grp_b) bar();
-    PPT(2);
-
-    // the denominators (row d = 48: element 8 of the dt = 1 tile in the h = 0 lanes) of the block's valid rows: see attn_x32_kernel
-    bool bad = false;
-    if (active && h == 0) {
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb) {
-            const float l_min = DT == VF_F16 ? fmaxf(0.015625f, (float)len_k * 4.8828125e-4f) : 7.8886e-31f;
-            const float l = o[qb][1][8];
-            bad = bad || !(l > l_min && l < 1.2676e30f);
-        }
-    }
-    if (__syncthreads_or(bad)) {                                      // block-uniform (also orders the LDS stages)
-        // recomputation with the running-maximum form, one tile at a time through slots 0 / 1 (rare: speed does not matter)
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb) {
-            m_run[qb] = -INFINITY;
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) o[qb][dt][i] = 0.f;
-        }
-        load_regs(0, kvreg);
-        write_lds(0, kvreg);
-        __syncthreads();
-        for (int t = 0; t < nkv; ++t) {
-            if (t + 1 < nkv) load_regs(t + 1, kvreg);
-            if (active) {
-                qk(smem + (t & 1) * STAGE);
-                if (t == nkv - 1) mask_tail(t * BKV);
-                exp_runmax();
-                pack();
-                pv(smem + (t & 1) * STAGE);
-            }
-            if (t + 1 < nkv) write_lds((t + 1) & 1, kvreg);
-            __syncthreads();
-        }
-    }
-
-    // ---- normalise and store (attn_x32_kernel's epilogue)
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-        const unsigned lu = __float_as_uint(o[qb][1][8]);
-        auto sw = __builtin_amdgcn_permlane32_swap(lu, lu, false, false);
-        const float inv = 1.0f / __uint_as_float(sw[0]);              // the lower half's value in both halves
-        if (q_abs[qb] < len_q) {
-            unsigned short* op = P.out + (int64_t)(q_tok0 + q_abs[qb]) * P.o_stride + hd * DH + 4 * h;
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                for (int gq = 0; gq < (dt == 0 ? 4 : 2); ++gq) {
-                    u32x2_t pk;
-                    pk[0] = Op16<DT>::pack2(o[qb][dt][4 * gq] * inv, o[qb][dt][4 * gq + 1] * inv);
-                    pk[1] = Op16<DT>::pack2(o[qb][dt][4 * gq + 2] * inv, o[qb][dt][4 * gq + 3] * inv);
-                    *reinterpret_cast<u32x2_t*>(op + 32 * dt + 8 * gq) = pk;
-                }
-        }
-    }
-#ifdef VF_X32PP_PROF
-    PPT(5);                                                           // 5: denominator vote + epilogue
-    if (lane == 0 && (wave == 0 || wave == 4) && (blockIdx.x & 7) == 0) {
-        unsigned long long* pp = P.prof + ((blockIdx.x >> 3) * 2 + (wave >> 2)) * 8;
-        for (int i = 0; i < 6; ++i) pp[i] = px[i];
-        pp[6] = __builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4);  // HW_ID.simd_id
-        pp[7] = nkv;
-    }
-#endif
-#undef PPT
-}
-#endif   // VF_TUNING (attn_x32pp_kernel)
 
 // Short sequences (<= 256 queries and keys: seq2reg windows, the gene stream): one block per (sequence, head).
 // The whole K/V of the sequence is staged into LDS once (all loads issued before the first store: one load latency,

@@ -713,187 +713,9 @@ __global__ __launch_bounds__(C::THREADS, 2) void gemm_mfma_kernel(const unsigned
     }
 }
 
-#ifdef VF_TUNING   // measured without gain; kept for scripts/ in libvf_hip_tuning.so only
-// Persistent variant (BK = 64): a block walks output tiles bid, bid + grid, ... (same XCD-grouped order) and the
-// LDS-DMA ring runs straight across tile boundaries, so the first K-tiles of the next output tile are already in
-// flight while the current tile's last MFMAs and its epilogue execute.  Hides the per-tile prologue latency, which
-// is what limits the K = 512 (seq2reg) shapes: 8 K-tiles per output tile.
-template <class C, int EPI, int DT = VF_BF16>
-__global__ __launch_bounds__(C::THREADS, 2) void gemm_persist_kernel(const unsigned short* __restrict__ A, int64_t lda,
-                                                                 const unsigned short* __restrict__ W,
-                                                                 const float* __restrict__ bias,
-                                                                 const float* __restrict__ res, int64_t ldr, void* out,
-                                                                 int64_t ldo, int M, int N, int K, int tiles_n, int n_tiles) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    using frag_t = typename Op16<DT>::frag;
-    constexpr int BM = C::BM, BN = C::BN, TM = C::TM, TN = C::TN, STAGES = C::STAGES, LPT = C::LPT;
-    constexpr int BK = C::BK, ROW_BYTES = C::ROW_BYTES, CPR = C::CPR, RPP = C::ROWS_PER_PIECE;
-    static_assert(C::KS == 2, "persistent kernel is written for BK = 64");
-
-    const int grid = gridDim.x, bid = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / C::WN, wn = wave % C::WN;
-    const int r = lane & 15, g = lane >> 4;
-
-    // tile id -> (m0, n0): XCD-contiguous runs, grouped order inside (see gemm_mfma_kernel)
-    auto tile_origin = [&](int t, int& m0, int& n0) {
-        const int q8 = n_tiles >> 3, r8 = n_tiles & 7, xcd = t & 7, loc = t >> 3;
-        const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
-        constexpr int GROUP_M = 8;
-        const int tiles_m = n_tiles / tiles_n;
-        const int per_group = GROUP_M * tiles_n;
-        const int grp = wg / per_group, in_grp = wg - grp * per_group;
-        const int first_m = grp * GROUP_M;
-        const int gsz = (tiles_m - first_m) < GROUP_M ? (tiles_m - first_m) : GROUP_M;
-        m0 = (first_m + in_grp % gsz) * BM;
-        n0 = (in_grp / gsz) * BN;
-    };
-
-    const int nkt = K / BK;
-    const int my_tiles = (n_tiles - bid + grid - 1) / grid;
-    const int total = my_tiles * nkt;                       // K-tiles this block consumes
-
-    // ---- producer side: LDS-DMA issue state (tile being fetched, K-tile inside it, per-lane source rows)
-    const unsigned short* srcA[C::PA];
-    const unsigned short* srcW[C::PW];
-    int iss_tile = 0, iss_kt = 0;
-    auto set_src = [&](int tl) {
-        int m0, n0;
-        tile_origin(bid + tl * grid, m0, n0);
-#pragma unroll
-        for (int i = 0; i < C::PA; ++i) {
-            const int row = RPP * (wave * C::PA + i) + lane / CPR;
-            const int c = (lane % CPR) ^ swz<BK>(row);
-            int gm = m0 + row; gm = gm < M ? gm : M - 1;
-            srcA[i] = A + (int64_t)gm * lda + c * 8;
-        }
-#pragma unroll
-        for (int i = 0; i < C::PW; ++i) {
-            const int row = RPP * (wave * C::PW + i) + lane / CPR;
-            const int c = (lane % CPR) ^ swz<BK>(row);
-            int gn = n0 + row; gn = gn < N ? gn : N - 1;
-            srcW[i] = W + (int64_t)gn * K + c * 8;
-        }
-    };
-    char* const ldsA_piece = smem + wave * C::PA * 1024;
-    char* const ldsW_piece = smem + C::A_BYTES + wave * C::PW * 1024;
-    auto issue_next = [&](int stage) {                      // fetch the next K-tile of this block's stream
-#pragma unroll
-        for (int i = 0; i < C::PA; ++i) glds16(srcA[i] + iss_kt * BK, ldsA_piece + stage * C::STAGE_BYTES + i * 1024);
-#pragma unroll
-        for (int i = 0; i < C::PW; ++i) glds16(srcW[i] + iss_kt * BK, ldsW_piece + stage * C::STAGE_BYTES + i * 1024);
-        if (++iss_kt == nkt) {
-            iss_kt = 0;
-            if (++iss_tile < my_tiles) set_src(iss_tile);
-        }
-    };
-
-    const int sw = swz<BK>(r);
-    const int offW = C::A_BYTES + (wn * (BN / C::WN) + r) * ROW_BYTES;
-    const int offA = (wm * (BM / C::WM) + r) * ROW_BYTES;
-    auto read_frags = [&](int stage, int ks, frag_t(&wf)[TN], frag_t(&af)[TM]) {
-        const char* base = smem + stage * C::STAGE_BYTES + (((4 * ks + g) ^ sw) << 4);
-#pragma unroll
-        for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const frag_t*>(base + offW + i * 16 * ROW_BYTES);
-#pragma unroll
-        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const frag_t*>(base + offA + i * 16 * ROW_BYTES);
-    };
-    auto wait_tiles = [&](int ahead) {
-        if (STAGES >= 5 && ahead >= 3) wait_vmcnt<3 * LPT>();
-        else if (STAGES >= 4 && ahead == 2) wait_vmcnt<2 * LPT>();
-        else if (STAGES >= 3 && ahead == 1) wait_vmcnt<LPT>();
-        else wait_vmcnt<0>();
-    };
-
-    set_src(0);
-    int issued = 0;
-#pragma unroll
-    for (int p = 0; p < STAGES; ++p)
-        if (issued < total) { issue_next(p); ++issued; }
-    wait_tiles((total - 1) < (STAGES - 1) ? (total - 1) : (STAGES - 1));
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-
-    int stage = 0, j = 0;                                    // j = K-tiles consumed so far
-    auto boundary = [&]() {                                  // from consumed K-tile j to j+1
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        wait_tiles((total - 2 - j) < (STAGES - 2) ? (total - 2 - j) : (STAGES - 2));
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (issued < total) { issue_next(stage); ++issued; }
-        stage = stage + 1 == STAGES ? 0 : stage + 1;
-    };
-
-    frag_t wf0[TN], af0[TM], wf1[TN], af1[TM];
-    constexpr bool RES_PRE = (EPI == VF_EPI_RES_F32) && (TN * TM <= 16);
-    for (int tl = 0; tl < my_tiles; ++tl) {
-        int m0, n0;
-        tile_origin(bid + tl * grid, m0, n0);
-        f32x4_t acc[TN][TM];
-#pragma unroll
-        for (int i = 0; i < TN; ++i)
-#pragma unroll
-            for (int k = 0; k < TM; ++k) acc[i][k] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        f32x4_t resv[RES_PRE ? TN : 1][RES_PRE ? TM : 1];
-        read_frags(stage, 0, wf0, af0);
-        for (int kt = 0; kt < nkt; ++kt) {
-            read_frags(stage, 1, wf1, af1);
-            if (RES_PRE && kt + 1 == nkt) {
-#pragma unroll
-                for (int im = 0; im < TM; ++im) {
-                    int64_t m = m0 + wm * (BM / C::WM) + im * 16 + r;
-                    m = m < M ? m : M - 1;
-#pragma unroll
-                    for (int in = 0; in < TN; ++in) {
-                        int nb = n0 + wn * (BN / C::WN) + in * 16 + 4 * g;
-                        nb = nb < N ? nb : N - 4;
-                        resv[RES_PRE ? in : 0][RES_PRE ? im : 0] = *reinterpret_cast<const f32x4_t*>(res + m * ldr + nb);
-                    }
-                }
-            }
-#pragma unroll
-            for (int in = 0; in < TN; ++in)
-#pragma unroll
-                for (int im = 0; im < TM; ++im)
-                    acc[in][im] = Op16<DT>::mfma(wf0[in], af0[im], acc[in][im]);
-            if (j + 1 < total) boundary();
-            if (kt + 1 < nkt) read_frags(stage, 0, wf0, af0);
-#pragma unroll
-            for (int in = 0; in < TN; ++in)
-#pragma unroll
-                for (int im = 0; im < TM; ++im)
-                    acc[in][im] = Op16<DT>::mfma(wf1[in], af1[im], acc[in][im]);
-            ++j;
-        }
-        // ---- epilogue of this tile (the ring already holds / is fetching the next tile's first K-tiles)
-        const int nw0 = n0 + wn * (BN / C::WN);
-#pragma unroll
-        for (int im = 0; im < TM; ++im) {
-            const int64_t m = m0 + wm * (BM / C::WM) + im * 16 + r;
-            if (m >= M) continue;
-            if (EPI == VF_EPI_GEGLU_BF16) {
-#pragma unroll
-                for (int ip = 0; ip < TN / 2; ++ip) {
-                    const int nb = nw0 + ip * 32 + 4 * g;
-                    if (nb >= N) continue;
-                    epilogue_store<EPI, DT>(acc[2 * ip][im], acc[2 * ip + 1][im], m, nb, nb + 16, nw0 / 2 + ip * 16 + 4 * g, bias,
-                                        res, ldr, out, ldo);
-                }
-            } else {
-#pragma unroll
-                for (int in = 0; in < TN; ++in) {
-                    const int nb = nw0 + in * 16 + 4 * g;
-                    if (nb >= N) continue;
-                    epilogue_store<EPI, DT>(acc[in][im], acc[in][im], m, nb, nb, nb, bias, res, ldr, out, ldo,
-                                        RES_PRE ? &resv[RES_PRE ? in : 0][RES_PRE ? im : 0] : nullptr);
-                }
-            }
-        }
-    }
-}
-
-#endif  // VF_TUNING
+#ifdef VF_TUNING   // gemm_persist_kernel: persistent 128x128 form, measured without gain (DESIGN_HISTORY.md)
+#include "tuning/gemm_persist.inc"
+#endif
 
 // ======================================================================================================================
 // 256 x 256 x 64 tile, 8 waves, two wave groups running half a phase apart ("8-phase" schedule: 4 phases per K-tile,
@@ -1805,725 +1627,13 @@ __global__ __launch_bounds__(512, 2) void gemm8x_kernel(const unsigned short* __
 #undef VF_G8_MMA
 }
 
-#ifdef VF_TUNING   // measured 15-20 % SLOWER than the 8-wave 256x256 kernels on every shape of the workload (profiles/r04_a_gemm4_two_blocks_per_cu.log):
-                   // the 256x128 tiles need 1.5x the L2 -> LDS bytes per flop and the LDS-DMA fill rate (~46 GB/s per CU) is what
-                   // bounds these kernels; kept for scripts/gemm4_probe.py in libvf_hip_tuning.so only
-// ======================================================================================================================
-// gemm4_kernel: TWO INDEPENDENT 4-WAVE BLOCKS PER CU, each persistent over its own 256 (m) x 128 (n) output tiles.
-//
-// Why: in the 8-wave kernels above both wave groups work on the SAME output tile, so all eight waves reach the epilogue
-// (VALU + LDS transpose + stores, 4-8 k cycles) together and the matrix pipe idles for 20-40 % of a K = 512 tile; nothing
-// else is resident on the CU to fill the gap.  Here a CU holds two blocks of 256 threads (one wave per SIMD each, 256
-// registers per wave, 80 KiB of LDS each).  The blocks share nothing and meet at no barrier, so they drift out of phase:
-// while one block runs its epilogue, requests its next tile or waits at a barrier, the other block's wave on the same
-// SIMD has the matrix pipe to itself.  The hardware's wave arbitration does what the two-group schedule does by hand,
-// and it also covers the epilogue.
-//
-// Wave (wm = wave / 2, wn = wave % 2) owns the same contiguous 128 (m) x 64 (n) block as in gemm8_kernel, computed in the
-// same four quadrants with the same fragment reads, so every accumulator sees the K-steps in the same order: results are
-// bit-identical to the other tile configurations.
-//
-// LDS ring: three BANKS of 24 KiB, each one PAIR = [W half-tile 64 rows x 128 B | A half-tile 128 rows x 128 B]; pair
-// 2 kt is (WL, AL) of K-tile kt, pair 2 kt + 1 is (WH, AH) (half-tile row <-> matrix row as in gemm8_kernel, XOR swizzle on
-// the LDS-DMA source side).  The pair stream runs across K-tiles AND across output tiles; pair q lives in bank q % 3.
-// Per K-tile g of the stream (pairs 2g in bank b0, 2g + 1 in b1):
-//     reads WL, AL (b0)                  vmcnt: pair 2g+1 landed     lgkmcnt(0)   s_barrier B1    -> b0 is free
-//     request pair 2g+3 into b0;  reads WH (b1);  32 MFMAs (m-lo x n-lo, m-lo x n-hi);  reads AH (b1)
-//                                        vmcnt: pair 2g+2 landed     lgkmcnt(0)   s_barrier B3    -> b1 is free
-//     request pair 2g+4 into b1;  32 MFMAs (m-hi x n-hi, m-hi x n-lo)
-//   RAW  a pair is read only after the barrier that follows every wave's counted wait for its own pieces of it.
-//   WAR  a bank is re-requested only after the barrier that follows every wave's lgkmcnt(0) behind its last read of it.
-//   The counted waits always leave exactly the youngest pair (6 LDS-DMA instructions per wave) in flight; the epilogue
-//   operands of the next tile (bias, colsum, row statistics) are requested just BEFORE a pair, so they never are among
-//   the youngest six.
-// Tile boundary: during the last K-tile of a tile the pair that would go into b1 ((WL, AL) of the next tile's K-tile 1)
-// is held back; b1 is free after B3 and is the epilogue's staging area (6 KiB per wave).  The next tile's K-tile 0 is
-// complete in the other two banks before the epilogue starts (vmcnt(0) behind the last MFMA), one barrier ends the
-// epilogue, then the held-back pair is requested and the K loop restarts without a first fill.
-// ======================================================================================================================
-struct Cfg4 {
-    static constexpr int BM = 256, BN = 128, BK = 64, NW = 4, THREADS = 256;
-    static constexpr int TM = 8, TN = 4;                            // 16x16 tiles per wave: 128 x 64
-    static constexpr int WHALF = 64 * 128, AHALF = 128 * 128;       // half-tiles: 8 KiB, 16 KiB
-    static constexpr int BANK = WHALF + AHALF, RING = 3 * BANK;     // 24 KiB, 72 KiB
-    static constexpr int SIDE = 4096;                               // bias | colsum | (mean, rstd) of a tile, double-buffered
-    static constexpr int LDS_BYTES = RING + 2 * SIDE;               // 80 KiB: two blocks per CU
-};
-
-// Epilogue of one wave's 128 (m) x 64 (n) accumulator block (lane holds out[m = mw0 + im*16 + r][n = nw0 + in*16 + 4g .. +3]):
-// staged through `region` (REGION bytes of LDS private to the wave) in passes of RP rows and written as whole rows, 16
-// bytes per lane; residual, LayerNorm producer / consumer forms as in gemm8x_kernel (same arithmetic, same order).
-// side: [0, 1K) bias, [1K, 2K) colsum, [2K, 4K) (mean, rstd) of the tile's rows; side_m / side_n = the wave tile's first
-// row / column inside the block tile.
-template <int EPI, int DT, int LN, int REGION>
-__device__ __forceinline__ void wave_tile_epilogue(f32x4_t (&acc)[4][8], char* region, const char* side, int side_m, int side_n,
-                                                   int64_t mw0, int nw0, bool has_bias, const float* __restrict__ res,
-                                                   int64_t ldr, void* out, int64_t ldo, int M, int N, const LnArgs& ln) {
-    constexpr int TM = 8, TN = 4;
-    // lane-derived addresses from a lane id the compiler cannot hoist out of the caller's tile loop (see gemm8x_kernel)
-    int lane_e;
-    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
-    const int lane = lane_e, r = lane & 15, g = lane >> 4;
-    constexpr bool OUT_F32 = (EPI == VF_EPI_F32 || EPI == VF_EPI_RES_F32 || EPI == VF_EPI_GELU_F32);
-    constexpr int ES = OUT_F32 ? 4 : 2;
-    constexpr int WT_M = 128, WT_N = 64;
-    constexpr int WT_NO = (EPI == VF_EPI_GEGLU_BF16) ? WT_N / 2 : WT_N;
-    constexpr int PITCH = WT_NO * ES + 16;
-    constexpr int RP = (((REGION / PITCH) < WT_M ? (REGION / PITCH) : WT_M) / 16) * 16;
-    constexpr int IMP = RP / 16, NPASS = (TM + IMP - 1) / IMP;
-    constexpr int CR = WT_NO * ES / 16, RI = 64 / CR, NI = RP / RI;
-    static_assert(RP >= 16 && CR >= 1 && CR <= 64 && 64 % CR == 0, "epilogue geometry");
-    constexpr bool RES = (EPI == VF_EPI_RES_F32);
-    constexpr bool R16 = ln_res_is_16(LN), T16 = LN == VF_LN_PRODUCER_T16;
-    const int n_out_total = (EPI == VF_EPI_GEGLU_BF16) ? N / 2 : N;
-    const int no0 = (EPI == VF_EPI_GEGLU_BF16) ? nw0 / 2 : nw0;
-    const int ep_row = lane / CR, ep_col = no0 + (lane % CR) * (16 / ES);
-    const int rows_left = (int)(M - mw0) - ep_row;              // item j is a row of the matrix iff j * RI < rows_left
-    const int64_t row0 = mw0 + ep_row;
-    const int colc = ep_col < N ? ep_col : N - 4;
-    using res_t = typename std::conditional<R16, u32x2_t, f32x4_t>::type;
-    const char* const res_base = R16 ? reinterpret_cast<const char*>(ln.res16) : reinterpret_cast<const char*>(res);
-    const int64_t res_ld = R16 ? ln.ldr16 : ldr;
-    constexpr int RES_ES = R16 ? 2 : 4;
-    const char* const res_last = RES ? res_base + ((int64_t)(M - 1) * res_ld + colc) * RES_ES : nullptr;
-    const int64_t res_step = (int64_t)RI * res_ld * RES_ES;
-    const int64_t out_step = (int64_t)RI * ldo * ES;
-    const int64_t o16_step = (int64_t)RI * ln.ld16;
-    const int64_t t16_step = (int64_t)RI * ln.ldt16;
-    // running pointers: one 64-bit add per item instead of a multiply (see gemm8_kernel)
-    const char* res_run = RES ? res_base + (row0 * res_ld + colc) * RES_ES : nullptr;
-    char* out_run = reinterpret_cast<char*>(out) + (row0 * ldo + ep_col) * ES;
-    unsigned short* o16_run = ln_is_producer(LN) ? reinterpret_cast<unsigned short*>(ln.out16) + row0 * ln.ld16 + ep_col : nullptr;
-    float* part_run = ln_is_producer(LN) ? ln.part_stats + ((int64_t)(ep_col >> 5) * ln.rows + row0) * 2 : nullptr;
-    unsigned short* t16_run = T16 ? ln.t16_out + row0 * ln.ldt16 + ep_col : nullptr;
-    res_t rbuf[2][RES ? NI : 1];
-    auto load_res_pass = [&](int ps, res_t (&dst)[RES ? NI : 1]) {
-        if (RES) {
-#pragma unroll
-            for (int k = 0; k < NI; ++k) {
-                const int j = ps * NI + k;
-                const char* rp = (j * RI < rows_left) ? res_run : res_last;
-                res_run += res_step;
-                dst[RES ? k : 0] = *reinterpret_cast<const res_t*>(rp);
-            }
-        }
-    };
-    auto res_value = [&](res_t v) -> f32x4_t {      // see gemm8_kernel
-        if constexpr (T16) return cvt4_16<VF_F16>(v) * ln.res16_scale;
-        else if constexpr (R16) {
-            if constexpr (DT == VF_F16) return cvt4_16<DT>(v) * ln.res16_scale;
-            else return cvt4_16<DT>(v);
-        }
-        else return v;
-    };
-    load_res_pass(0, rbuf[0]);
-    f32x4_t bvec[TN];
-    if (has_bias) {
-#pragma unroll
-        for (int in = 0; in < TN; ++in) {
-            const int nl = side_n + ((EPI == VF_EPI_GEGLU_BF16) ? (in >> 1) * 32 + (in & 1) * 16 + 4 * g : in * 16 + 4 * g);
-            bvec[in] = *reinterpret_cast<const f32x4_t*>(side + nl * 4);
-        }
-    } else {
-#pragma unroll
-        for (int in = 0; in < TN; ++in) bvec[in] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    }
-    f32x4_t svec[LN == VF_LN_CONSUMER ? TN : 1];
-    if (LN == VF_LN_CONSUMER) {
-#pragma unroll
-        for (int in = 0; in < TN; ++in) {
-            const int nl = side_n + ((EPI == VF_EPI_GEGLU_BF16) ? (in >> 1) * 32 + (in & 1) * 16 + 4 * g : in * 16 + 4 * g);
-            svec[LN == VF_LN_CONSUMER ? in : 0] = *reinterpret_cast<const f32x4_t*>(side + 1024 + nl * 4);
-        }
-    }
-    auto lnv = [&](int in, int im, f32x2_t st) -> f32x4_t {          // st = (-mean * rstd, rstd); see gemm8_kernel
-        if (LN == VF_LN_CONSUMER) return acc[in][im] * st[1] + (st[0] * svec[LN == VF_LN_CONSUMER ? in : 0] + bvec[in]);
-        return acc[in][im] + bvec[in];
-    };
-#pragma unroll
-    for (int ps = 0; ps < NPASS; ++ps) {
-        if (ps + 1 < NPASS) load_res_pass(ps + 1, rbuf[(ps + 1) & 1]);
-#pragma unroll
-        for (int iml = 0; iml < IMP; ++iml) {
-            const int im = ps * IMP + iml;
-            if (im < TM) {
-                char* rowp = region + (iml * 16 + r) * PITCH;
-                f32x2_t st = {0.f, 1.f};
-                if (LN == VF_LN_CONSUMER) {
-                    st = *reinterpret_cast<const f32x2_t*>(side + 2048 + (side_m + im * 16 + r) * 8);
-                    st[0] = -st[0] * st[1];                                   // (-mean * rstd, rstd)
-                }
-                if (EPI == VF_EPI_GEGLU_BF16) {
-#pragma unroll
-                    for (int ip = 0; ip < TN / 2; ++ip) {
-                        const f32x4_t v = lnv(2 * ip, im, st), gt = lnv(2 * ip + 1, im, st);
-                        u32x2_t pk;
-                        const f32x4_t y = v * gelu_erf4(gt);
-                        pk[0] = Op16<DT>::pack2(y[0], y[1]);
-                        pk[1] = Op16<DT>::pack2(y[2], y[3]);
-                        *reinterpret_cast<u32x2_t*>(rowp + (ip * 16 + 4 * g) * 2) = pk;
-                    }
-                } else {
-#pragma unroll
-                    for (int in = 0; in < TN; ++in) {
-                        f32x4_t v = lnv(in, im, st);
-                        if (EPI == VF_EPI_GELU_F32 || EPI == VF_EPI_GELU_BF16) v = gelu_erf4(v);
-                        if (OUT_F32) {
-                            *reinterpret_cast<f32x4_t*>(rowp + (in * 16 + 4 * g) * 4) = v;
-                        } else {
-                            u32x2_t pk;
-                            pk[0] = Op16<DT>::pack2(v[0], v[1]);
-                            pk[1] = Op16<DT>::pack2(v[2], v[3]);
-                            *reinterpret_cast<u32x2_t*>(rowp + (in * 16 + 4 * g) * 2) = pk;
-                        }
-                    }
-                }
-            }
-        }
-        // read the slice back row-wise: all LDS reads of a batch first, then the predicated stores
-        constexpr int KB = RES ? 4 : NI;
-#pragma unroll
-        for (int k0 = 0; k0 < NI; k0 += KB) {
-            u32x4_t dd[KB];
-#pragma unroll
-            for (int k = 0; k < KB; ++k)
-                if (k0 + k < NI)
-                    dd[k] = *reinterpret_cast<const u32x4_t*>(region + ((k0 + k) * RI + ep_row) * PITCH + (lane % CR) * 16);
-#pragma unroll
-            for (int k = 0; k < KB; ++k) {
-                if (k0 + k >= NI) continue;
-                const int j = ps * NI + k0 + k;                  // row j * RI + ep_row of the wave tile
-                u32x4_t d = dd[k];
-                if (RES) {
-                    f32x4_t f = __builtin_bit_cast(f32x4_t, d);
-                    f += res_value(rbuf[ps & 1][RES ? k0 + k : 0]);
-                    d = __builtin_bit_cast(u32x4_t, f);
-                }
-                const bool ok = j * RI + ep_row < WT_M && j * RI < rows_left && ep_col < n_out_total;
-                if (ln_is_producer(LN) && OUT_F32) {
-                    ln_emit<DT>(__builtin_bit_cast(f32x4_t, d), ok, o16_run, part_run, lane, ln.x16_scale, true, true,
-                                (T16 && ln.t16_out) ? t16_run : nullptr, ln.t16_scale);
-                    o16_run += o16_step;
-                    part_run += RI * 2;
-                    if (T16) t16_run += t16_step;
-                }
-                if (ok && (!ln_is_producer(LN) || out != nullptr)) *reinterpret_cast<u32x4_t*>(out_run) = d;
-                out_run += out_step;
-            }
-        }
-    }
-}
-
-template <int EPI, int DT = VF_BF16, int LN = VF_LN_NONE>
-__global__ __launch_bounds__(256, 2) void gemm4_kernel(const unsigned short* __restrict__ A, int64_t lda,
-                                                       const unsigned short* __restrict__ W,
-                                                       const float* __restrict__ bias, const float* __restrict__ res,
-                                                       int64_t ldr, void* out, int64_t ldo, int M, int N, int K,
-                                                       int tiles_n, int n_tiles, int GROUP_M, LnArgs ln) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    using frag_t = typename Op16<DT>::frag;
-    using C = Cfg4;
-    constexpr int TM = C::TM, TN = C::TN, BK = C::BK;
-
-    const int bid = blockIdx.x, grid = gridDim.x;
-#ifdef VF_TUNING   // start-up stagger experiment (VF_G4_STAGGER, units of ~0.1 us): the second half of the grid starts late
-    const int stagger = GROUP_M >> 16;
-    GROUP_M &= 255;
-    if (stagger && bid >= (grid >> 1))
-        for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(3);
+#ifdef VF_TUNING   // gemm4_kernel: two independent 4-wave blocks per CU, 15-20 % slower (profiles/r04_a)
+#include "tuning/gemm4.inc"
 #endif
-    const int my_tiles = (n_tiles - bid + grid - 1) / grid;          // output tiles bid, bid + grid, ... (>= 1)
-    auto tile_origin = [&](int t, int& m0, int& n0) {                 // XCD-contiguous runs, grouped order (see gemm_mfma_kernel)
-        const int q8 = n_tiles >> 3, r8 = n_tiles & 7, xcd = t & 7, loc = t >> 3;
-        const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
-        const int tiles_m = n_tiles / tiles_n;
-        const int per_group = GROUP_M * tiles_n;
-        const int grp = wg / per_group, in_grp = wg - grp * per_group;
-        const int first_m = grp * GROUP_M;
-        const int gsz = (tiles_m - first_m) < GROUP_M ? (tiles_m - first_m) : GROUP_M;
-        m0 = (first_m + in_grp % gsz) * C::BM;
-        n0 = (in_grp / gsz) * C::BN;
-    };
 
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int r = lane & 15, g = lane >> 4;
-
-    // ---- LDS-DMA sources of ONE output tile.  A half-tile row i <-> m = m0 + (i / 64) * 128 + i % 64 (+ 64 for the hi half),
-    // W half-tile row i <-> n = n0 + (i / 32) * 64 + i % 32 (+ 32).  Wave w fills rows 32w .. 32w+31 of an A half (four 8-row
-    // pieces) and rows 16w .. 16w+15 of a W half (two pieces).  Recomputed in place when the stream crosses into the next tile.
-    const unsigned short* srcA[2][4];
-    const unsigned short* srcW[2][2];
-    auto set_src = [&](int m0, int n0) {
-#pragma unroll
-        for (int pi = 0; pi < 4; ++pi) {
-            const int i = 32 * wave + 8 * pi + (lane >> 3);
-            const int c = (lane & 7) ^ ((i >> 1) & 7);
-            const int am = m0 + (i >> 6) * 128 + (i & 63);
-            int v;
-            v = am;       v = v < M ? v : M - 1;  srcA[0][pi] = A + (int64_t)v * lda + c * 8;
-            v = am + 64;  v = v < M ? v : M - 1;  srcA[1][pi] = A + (int64_t)v * lda + c * 8;
-        }
-#pragma unroll
-        for (int pi = 0; pi < 2; ++pi) {
-            const int i = 16 * wave + 8 * pi + (lane >> 3);
-            const int c = (lane & 7) ^ ((i >> 1) & 7);
-            const int wr = n0 + (i >> 5) * 64 + (i & 31);
-            int v;
-            v = wr;       v = v < N ? v : N - 1;  srcW[0][pi] = W + (int64_t)v * K + c * 8;
-            v = wr + 32;  v = v < N ? v : N - 1;  srcW[1][pi] = W + (int64_t)v * K + c * 8;
-        }
-    };
-    // pair (h = 0: WL, AL; h = 1: WH, AH) of K-tile kt of the tile `src` points at, into the bank at byte offset boff
-#define VF_G4_ISSUE(H, BOFF, KT)                                                     \
-    do {                                                                             \
-        char* dw_ = smem + (BOFF) + wave * 2048;                                     \
-        glds16(srcW[H][0] + (KT) * BK, dw_);                                         \
-        glds16(srcW[H][1] + (KT) * BK, dw_ + 1024);                                  \
-        char* da_ = smem + (BOFF) + C::WHALF + wave * 4096;                          \
-        _Pragma("unroll") for (int pi_ = 0; pi_ < 4; ++pi_) glds16(srcA[H][pi_] + (KT) * BK, da_ + pi_ * 1024); \
-    } while (0)
-    // epilogue operands of a tile by LDS-DMA (bias | colsum | row statistics), double-buffered by tile parity
-    auto issue_side = [&](int m0, int n0, int seq) {
-        char* const sd = smem + C::RING + (seq & 1) * C::SIDE;
-        int ln_;                                     // not hoistable out of the tile loop
-        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln_));
-        if (bias && wave == 0) {
-            int n = n0 + 4 * ln_;
-            n = n < N ? n : N - 4;
-            glds16(bias + n, sd);
-        }
-        if (LN == VF_LN_CONSUMER) {
-            if (wave == 1) {
-                int n = n0 + 4 * ln_;
-                n = n < N ? n : N - 4;
-                glds16(ln.colsum + n, sd + 1024);
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {            // every wave: 64 rows x (mean, rstd), one dword per lane, two instructions
-                int64_t m = m0 + 64 * wave + 32 * j + (ln_ >> 1);
-                m = m < M ? m : M - 1;
-                __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) void*)(ln.row_stats + 2 * m + (ln_ & 1)),
-                                                 (__attribute__((address_space(3))) void*)(sd + 2048 + wave * 512 + j * 256), 4, 0, 0);
-            }
-        }
-    };
-
-    f32x4_t acc[TN][TM];
-
-    // ---- fragment addresses (bytes inside a bank): row * 128 + ((4 ks + g) ^ swz(r)) * 16
-    const int sw = (r >> 1) & 7;
-    const int ck0 = ((g) ^ sw) << 4, ck1 = ((4 + g) ^ sw) << 4;
-    const int offW = (wn * 32 + r) * 128;                      // + in_local * 2048
-    const int offA = C::WHALF + (wm * 64 + r) * 128;           // + im_local * 2048
-    frag_t wlo[2][2], whi[2][2], af[4][2];                     // [fragment][k-step]
-    auto read_w = [&](int boff, frag_t (&f)[2][2]) {
-        const char* b = smem + boff + offW;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            f[i][0] = *reinterpret_cast<const frag_t*>(b + i * 2048 + ck0);
-            f[i][1] = *reinterpret_cast<const frag_t*>(b + i * 2048 + ck1);
-        }
-    };
-    auto read_a = [&](int boff) {
-        const char* b = smem + boff + offA;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            af[i][0] = *reinterpret_cast<const frag_t*>(b + i * 2048 + ck0);
-            af[i][1] = *reinterpret_cast<const frag_t*>(b + i * 2048 + ck1);
-        }
-    };
-    // every wave's reads of the bank retired (WAR) and its own pieces of the pair being waited for landed (RAW), then
-    // the barrier; the MFMA clusters stay between the synchronisation points (sched_barrier, priority: T5)
-#define VF_G4_BARRIER()                                          \
-    do {                                                         \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       \
-        __builtin_amdgcn_sched_barrier(0);                       \
-        __builtin_amdgcn_s_barrier();                            \
-        asm volatile("" ::: "memory");                           \
-        __builtin_amdgcn_sched_barrier(0);                       \
-    } while (0)
-#define VF_G4_MMA(WF, IN0, IM0)                                                                                      \
-    do {                                                                                                             \
-        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                             \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                            \
-                _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                        \
-                    acc[IN0 + i][IM0 + j] =                                                                          \
-                        Op16<DT>::mfma(WF[i][ks], af[j][ks], acc[IN0 + i][IM0 + j]); \
-    } while (0)
-
-    // ---- first tile: its epilogue operands, K-tile 0 (pairs 0, 1) and (WL, AL) of K-tile 1 (pair 2)
-    const int nkt = K / BK;                                  // >= 2 (launcher)
-    int m0, n0;
-    tile_origin(bid, m0, n0);
-    set_src(m0, n0);
-    issue_side(m0, n0, 0);
-    int b0 = 0, b1 = C::BANK, b2 = 2 * C::BANK;              // banks of pairs 2g, 2g + 1, 2g + 2 (wave-uniform)
-    VF_G4_ISSUE(0, b0, 0);
-    VF_G4_ISSUE(1, b1, 0);
-    VF_G4_ISSUE(0, b2, 1);
-    wait_vmcnt<12>();                                        // pair 0 (and the side operands) landed
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-
-    for (int ti = 0; ti < my_tiles; ++ti) {
-        const bool has_next = ti + 1 < my_tiles;             // block-uniform
-        tile_origin(bid + ti * grid, m0, n0);
-#pragma unroll
-        for (int i = 0; i < TN; ++i)
-#pragma unroll
-            for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        // the pair held back under the previous tile's epilogue: (WL, AL) of this tile's K-tile 1, into the staging bank
-        if (ti > 0) VF_G4_ISSUE(0, b2, 1);
-
-        for (int t = 0; t < nkt; ++t) {
-            const bool e3 = t + 1 < nkt || has_next;                         // pairs 2g+2, 2g+3 (K-tile t+1 of the stream) exist
-            const bool i4 = t + 2 < nkt || (t + 2 == nkt && has_next);       // pair 2g+4 is requested inside the loop
-            const bool cross = t + 2 == nkt && has_next;                     // the stream crosses into the next output tile
-            int m1 = 0, n1 = 0;
-            // ---- (m-lo, n-lo): W-lo, A-lo
-            read_w(b0, wlo);
-            read_a(b0);
-            if (cross) {
-                tile_origin(bid + (ti + 1) * grid, m1, n1);
-                issue_side(m1, n1, ti + 1);                  // BEFORE the pair below: never among the youngest six
-            }
-            // pair 2g+1 landed (own pieces); the first K-tile of a later tile retired it behind the previous tile's last MFMA
-            if (!(t == 0 && ti > 0)) {
-                if (e3) wait_vmcnt<6>(); else wait_vmcnt<0>();
-            }
-            VF_G4_BARRIER();                                 // B1: b0 free, pair 2g+1 visible
-            if (e3) {
-                if (t + 1 < nkt) VF_G4_ISSUE(1, b0, t + 1); else VF_G4_ISSUE(1, b0, 0);
-            }
-            if (cross) set_src(m1, n1);
-            read_w(b1, whi);
-            __builtin_amdgcn_s_setprio(1);
-            VF_G4_MMA(wlo, 0, 0);
-            VF_G4_MMA(whi, 2, 0);
-            __builtin_amdgcn_s_setprio(0);
-            // ---- (m-hi, *): A-hi
-            read_a(b1);
-            if (e3) wait_vmcnt<6>(); else wait_vmcnt<0>();   // pair 2g+2 landed (own pieces)
-            VF_G4_BARRIER();                                 // B3: b1 free, pair 2g+2 visible
-            if (i4) {
-                if (t + 2 < nkt) VF_G4_ISSUE(0, b1, t + 2); else VF_G4_ISSUE(0, b1, 0);
-            }
-            __builtin_amdgcn_s_setprio(1);
-            VF_G4_MMA(whi, 2, 4);
-            VF_G4_MMA(wlo, 0, 4);
-            __builtin_amdgcn_s_setprio(0);
-            const int tb = b0; b0 = b2; b2 = b1; b1 = tb;    // pairs 2g+2, 2g+3, 2g+4 of the next K-tile
-        }
-        // the next tile's K-tile 0 complete (own pieces) before the epilogue; its barrier publishes them
-        wait_vmcnt<0>();
-        asm volatile("" ::: "memory");
-        // ---- epilogue through the free bank (b2 after the rotation = the bank of the last (WH, AH)), 6 KiB per wave
-        wave_tile_epilogue<EPI, DT, LN, C::BANK / C::NW>(acc, smem + b2 + wave * (C::BANK / C::NW),
-                                                         smem + C::RING + (ti & 1) * C::SIDE, wm * 128, wn * 64,
-                                                         (int64_t)m0 + wm * 128, n0 + wn * 64, bias != nullptr, res, ldr, out, ldo,
-                                                         M, N, ln);
-        // every wave's staging reads are done before the held-back pair is requested into this bank
-        VF_G4_BARRIER();
-    }
-#undef VF_G4_ISSUE
-#undef VF_G4_BARRIER
-#undef VF_G4_MMA
-}
-#endif  // VF_TUNING (gemm4_kernel)
-
-#ifdef VF_TUNING   // measured: +5 % on the seq2reg Wqkv shape, +1..2 % on Wq / 8192^3, -2..4 % on Wqkv / GeGLU / fp32-residual
-                   // (gpurun_out/r2g/gemm_bench.log): not selected, kept for scripts/gemm_bench.py only
-// ----------------------------------------------------------------------------------------------------------------------
-// Persistent form of the two-group kernel: one 8-wave block per CU walks the output tiles bid, bid + grid, ... (same
-// XCD-grouped order) and the prefetch stream of half-tiles runs STRAIGHT ACROSS output-tile boundaries -- to the stream
-// the next output tile's K-tile 0 is simply "K-tile nkt".  When a tile's last MFMA retires, K-tile 0 of the next tile
-// has landed and K-tile 1 is in flight: the ~2-3 us of first-fill latency per tile (a quarter of a K = 512 tile) and the
-// block launch are gone.  The ring is therefore never free, so the epilogue stages each wave's block through a
-// private 4 KiB slice of the 32 KiB that remain of the 160 KiB LDS (XOR-swizzled 16-byte chunks instead of padded
-// rows; 16 / 32 / 64 rows per pass for fp32 / 16-bit / GeGLU outputs).  Needs K >= 128 (two K-tiles per output tile).
-// ----------------------------------------------------------------------------------------------------------------------
-template <int EPI, int DT = VF_BF16>
-__global__ __launch_bounds__(512, 2) void gemm8p_kernel(const unsigned short* __restrict__ A, int64_t lda,
-                                                        const unsigned short* __restrict__ W,
-                                                        const float* __restrict__ bias, const float* __restrict__ res,
-                                                        int64_t ldr, void* out, int64_t ldo, int M, int N, int K,
-                                                        int tiles_n, int n_tiles, int GROUP_M) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    using frag_t = typename Op16<DT>::frag;
-    using C = Cfg8;
-    constexpr int BM = C::BM, BN = C::BN, TM = C::TM, TN = C::TN, BK = C::BK;
-    constexpr int SCRATCH = 4096;                                // epilogue staging per wave, behind the ring
-
-    const int bid = blockIdx.x, grid = gridDim.x;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-    const int r = lane & 15, g = lane >> 4;
-    const int nkt = K / BK;
-    const int my_tiles = (n_tiles - bid + grid - 1) / grid;
-
-    auto tile_origin = [&](int t, int& m0, int& n0) {            // XCD-contiguous runs, grouped order (see gemm_mfma_kernel)
-        const int q8 = n_tiles >> 3, r8 = n_tiles & 7, xcd = t & 7, loc = t >> 3;
-        const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
-        const int tiles_m = n_tiles / tiles_n;
-        const int per_group = GROUP_M * tiles_n;
-        const int grp = wg / per_group, in_grp = wg - grp * per_group;
-        const int first_m = grp * GROUP_M;
-        const int gsz = (tiles_m - first_m) < GROUP_M ? (tiles_m - first_m) : GROUP_M;
-        m0 = (first_m + in_grp % gsz) * BM;
-        n0 = (in_grp / gsz) * BN;
-    };
-
-    // ---- prefetch stream: cursor (s_tile, s_kt) = the K-tile whose half-tiles are being requested; s_g = its global index
-    const unsigned short* src[4][2];
-    auto set_src = [&](int tile_seq) {
-        int m0, n0;
-        tile_origin(bid + tile_seq * grid, m0, n0);
-#pragma unroll
-        for (int pi = 0; pi < 2; ++pi) {
-            const int i = 16 * wave + 8 * pi + (lane >> 3);
-            const int c = (lane & 7) ^ ((i >> 1) & 7);
-            const int am = m0 + (i >> 6) * 128 + (i & 63);
-            const int wn_row = n0 + (i >> 5) * 64 + (i & 31);
-            int v;
-            v = am;           v = v < M ? v : M - 1;  src[C::AL][pi] = A + (int64_t)v * lda + c * 8;
-            v = am + 64;      v = v < M ? v : M - 1;  src[C::AH][pi] = A + (int64_t)v * lda + c * 8;
-            v = wn_row;       v = v < N ? v : N - 1;  src[C::WL][pi] = W + (int64_t)v * K + c * 8;
-            v = wn_row + 32;  v = v < N ? v : N - 1;  src[C::WH][pi] = W + (int64_t)v * K + c * 8;
-        }
-    };
-    int s_tile = 0, s_kt = 0, s_g = 0;
-    bool live = true;
-    char* const lds_piece = smem + wave * 2048;
-    auto issue = [&](int type) {                                 // half-tile `type` of the cursor's K-tile
-        char* dst = lds_piece + (s_g & 1) * C::TILE_BYTES + type * C::HALF_BYTES;
-        glds16(src[type][0] + s_kt * BK, dst);
-        glds16(src[type][1] + s_kt * BK, dst + 1024);
-    };
-    auto advance = [&]() {                                       // after the AH half-tile: next K-tile, maybe next output tile
-        ++s_g;
-        if (++s_kt == nkt) {
-            s_kt = 0;
-            live = ++s_tile < my_tiles;
-            if (live) set_src(s_tile);
-        }
-    };
-
-    const int sw = (r >> 1) & 7;
-    const int ck0 = ((g) ^ sw) << 4, ck1 = ((4 + g) ^ sw) << 4;
-    const int offW = (wn * 32 + r) * 128;
-    const int offA = (wm * 64 + r) * 128;
-    frag_t wlo[2][2], whi[2][2], af[4][2];
-    auto read_w = [&](const char* buf, int type, frag_t (&f)[2][2]) {
-        const char* b = buf + type * C::HALF_BYTES + offW;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            f[i][0] = *reinterpret_cast<const frag_t*>(b + i * 2048 + ck0);
-            f[i][1] = *reinterpret_cast<const frag_t*>(b + i * 2048 + ck1);
-        }
-    };
-    auto read_a = [&](const char* buf, int type) {
-        const char* b = buf + type * C::HALF_BYTES + offA;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            af[i][0] = *reinterpret_cast<const frag_t*>(b + i * 2048 + ck0);
-            af[i][1] = *reinterpret_cast<const frag_t*>(b + i * 2048 + ck1);
-        }
-    };
-#define VF_G8_SYNC_IN()                                          \
-    do {                                                         \
-        asm volatile("" ::: "memory");                           \
-        __builtin_amdgcn_sched_barrier(0);                       \
-        __builtin_amdgcn_s_barrier();                            \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       \
-        __builtin_amdgcn_sched_barrier(0);                       \
-        __builtin_amdgcn_s_setprio(1);                           \
-    } while (0)
-#define VF_G8_SYNC_OUT()                                         \
-    do {                                                         \
-        __builtin_amdgcn_s_setprio(0);                           \
-        __builtin_amdgcn_sched_barrier(0);                       \
-        __builtin_amdgcn_s_barrier();                            \
-        asm volatile("" ::: "memory");                           \
-        __builtin_amdgcn_sched_barrier(0);                       \
-    } while (0)
-#define VF_G8_MMA(WF, IN0, IM0)                                                                                      \
-    do {                                                                                                             \
-        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                             \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                            \
-                _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                        \
-                    acc[IN0 + i][IM0 + j] =                                                                          \
-                        Op16<DT>::mfma(WF[i][ks], af[j][ks], acc[IN0 + i][IM0 + j]); \
-    } while (0)
-
-    // ---- prologue (K >= 128): K-tile 0 of the first output tile complete, three half-tiles of its K-tile 1 in flight
-    set_src(0);
-    issue(C::WL); issue(C::AL); issue(C::WH); issue(C::AH);
-    advance();
-    issue(C::WL); issue(C::AL); issue(C::WH);
-    wait_vmcnt<6>();
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (wm == 1) __builtin_amdgcn_s_barrier();       // group 1 runs one barrier behind (matched after the last tile)
-
-    // ---- epilogue geometry (per wave: 128 x 64 block, SCRATCH bytes of private LDS, chunk c of row q at c ^ (q % CR))
-    constexpr bool OUT_F32 = (EPI == VF_EPI_F32 || EPI == VF_EPI_RES_F32 || EPI == VF_EPI_GELU_F32);
-    constexpr int ES = OUT_F32 ? 4 : 2;
-    constexpr int WT_M = 128, WT_N = 64;
-    constexpr int WT_NO = (EPI == VF_EPI_GEGLU_BF16) ? WT_N / 2 : WT_N;
-    constexpr int RB = WT_NO * ES;                               // bytes per staged row: 256 / 128 / 64
-    constexpr int CR = RB / 16, RI = 64 / CR;                    // 16-byte chunks per row, rows per wave-instruction
-    constexpr int RP = SCRATCH / RB, IMP = RP / 16, NPASS = TM / IMP, NI = RP / RI;
-    static_assert(RP % 16 == 0 && TM % IMP == 0 && CR >= 4 && CR <= 16, "epilogue geometry");
-    constexpr bool RES = (EPI == VF_EPI_RES_F32);
-    const int n_out_total = (EPI == VF_EPI_GEGLU_BF16) ? N / 2 : N;
-    char* const region = smem + C::LDS_BYTES + wave * SCRATCH;
-    const int ep_row = lane / CR, ep_chunk = lane % CR;
-
-    int g_cons = 0;                                              // global index of the K-tile being consumed
-    for (int ti = 0; ti < my_tiles; ++ti) {
-        int m0, n0;
-        tile_origin(bid + ti * grid, m0, n0);
-        f32x4_t acc[TN][TM];
-#pragma unroll
-        for (int i = 0; i < TN; ++i)
-#pragma unroll
-            for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
-        for (int t = 0; t < nkt; ++t, ++g_cons) {
-            const char* buf = smem + (g_cons & 1) * C::TILE_BYTES;
-            // ---- P1: (m-lo, n-lo); the stream requests AH of the cursor's K-tile and moves on
-            read_w(buf, C::WL, wlo);
-            __builtin_amdgcn_sched_barrier(0);
-            read_a(buf, C::AL);
-            if (live) { issue(C::AH); advance(); }
-            asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");   // W-lo reads retired before the barrier (WAR on WL)
-            VF_G8_SYNC_IN();
-            VF_G8_MMA(wlo, 0, 0);
-            VF_G8_SYNC_OUT();
-            // ---- P2: (m-lo, n-hi)
-            read_w(buf, C::WH, whi);
-            if (live) issue(C::WL);
-            VF_G8_SYNC_IN();
-            VF_G8_MMA(whi, 2, 0);
-            VF_G8_SYNC_OUT();
-            // ---- P3: (m-hi, n-hi)
-            read_a(buf, C::AH);
-            if (live) issue(C::AL);
-            VF_G8_SYNC_IN();
-            VF_G8_MMA(whi, 2, 4);
-            VF_G8_SYNC_OUT();
-            // ---- P4: (m-hi, n-lo); retire the next K-tile (all but the three youngest half-tiles)
-            if (live) {
-                issue(C::WH);
-                wait_vmcnt<6>();
-            } else {
-                wait_vmcnt<0>();
-            }
-            VF_G8_SYNC_IN();
-            VF_G8_MMA(wlo, 0, 4);
-            VF_G8_SYNC_OUT();
-        }
-
-        // ---- epilogue of this tile (no barrier: private accumulators, private scratch; the stream keeps landing)
-        const int64_t mw0 = m0 + wm * WT_M;
-        const int nw0 = n0 + wn * WT_N;
-        const int no0 = (EPI == VF_EPI_GEGLU_BF16) ? nw0 / 2 : nw0;
-        const int ep_col = no0 + ep_chunk * (16 / ES);
-        f32x4_t bvec[TN];
-        if (bias) {
-#pragma unroll
-            for (int in = 0; in < TN; ++in) {
-                int nb = (EPI == VF_EPI_GEGLU_BF16) ? nw0 + (in >> 1) * 32 + (in & 1) * 16 + 4 * g : nw0 + in * 16 + 4 * g;
-                nb = nb < N ? nb : 0;
-                bvec[in] = *reinterpret_cast<const f32x4_t*>(bias + nb);
-            }
-        } else {
-#pragma unroll
-            for (int in = 0; in < TN; ++in) bvec[in] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        }
-        f32x4_t rbuf[2][RES ? NI : 1];
-        auto load_res_pass = [&](int ps, f32x4_t (&dst)[RES ? NI : 1]) {
-            if (RES) {
-#pragma unroll
-                for (int k = 0; k < NI; ++k) {
-                    int64_t m = mw0 + ps * RP + k * RI + ep_row;
-                    m = m < M ? m : M - 1;
-                    const int col = ep_col < N ? ep_col : N - 4;
-                    dst[RES ? k : 0] = *reinterpret_cast<const f32x4_t*>(res + m * ldr + col);
-                }
-            }
-        };
-        load_res_pass(0, rbuf[0]);
-#pragma unroll
-        for (int ps = 0; ps < NPASS; ++ps) {
-            if (ps + 1 < NPASS) load_res_pass(ps + 1, rbuf[(ps + 1) & 1]);
-#pragma unroll
-            for (int iml = 0; iml < IMP; ++iml) {
-                const int im = ps * IMP + iml;
-                const int q = iml * 16 + r;                      // row inside the pass
-                char* rowp = region + q * RB;
-                const int sx = q & (CR - 1);
-                if (EPI == VF_EPI_GEGLU_BF16) {
-#pragma unroll
-                    for (int ip = 0; ip < TN / 2; ++ip) {
-                        const f32x4_t v = acc[2 * ip][im] + bvec[2 * ip], gt = acc[2 * ip + 1][im] + bvec[2 * ip + 1];
-                        u32x2_t pk;
-                        const f32x4_t y = v * gelu_erf4(gt);
-                        pk[0] = Op16<DT>::pack2(y[0], y[1]);
-                        pk[1] = Op16<DT>::pack2(y[2], y[3]);
-                        const int byte = (ip * 16 + 4 * g) * 2;                 // 8-byte piece inside the 64-byte row
-                        *reinterpret_cast<u32x2_t*>(rowp + ((((byte >> 4) ^ sx) << 4) | (byte & 8))) = pk;
-                    }
-                } else {
-#pragma unroll
-                    for (int in = 0; in < TN; ++in) {
-                        f32x4_t v = acc[in][im] + bvec[in];
-                        if (EPI == VF_EPI_GELU_F32 || EPI == VF_EPI_GELU_BF16) {
-                            v = gelu_erf4(v);
-                        }
-                        if (OUT_F32) {
-                            *reinterpret_cast<f32x4_t*>(rowp + (((in * 4 + g) ^ sx) << 4)) = v;
-                        } else {
-                            u32x2_t pk;
-                            pk[0] = Op16<DT>::pack2(v[0], v[1]);
-                            pk[1] = Op16<DT>::pack2(v[2], v[3]);
-                            const int byte = (in * 16 + 4 * g) * 2;
-                            *reinterpret_cast<u32x2_t*>(rowp + ((((byte >> 4) ^ sx) << 4) | (byte & 8))) = pk;
-                        }
-                    }
-                }
-            }
-            u32x4_t dd[NI];
-#pragma unroll
-            for (int k = 0; k < NI; ++k) {
-                const int q = k * RI + ep_row;
-                dd[k] = *reinterpret_cast<const u32x4_t*>(region + q * RB + ((ep_chunk ^ (q & (CR - 1))) << 4));
-            }
-#pragma unroll
-            for (int k = 0; k < NI; ++k) {
-                const int row = ps * RP + k * RI + ep_row;
-                const int64_t m = mw0 + row;
-                u32x4_t d = dd[k];
-                if (RES) {
-                    f32x4_t f = __builtin_bit_cast(f32x4_t, d);
-                    f += rbuf[ps & 1][RES ? k : 0];
-                    d = __builtin_bit_cast(u32x4_t, f);
-                }
-                if (m < M && ep_col < n_out_total)
-                    *reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(out) + (m * ldo + ep_col) * ES) = d;
-            }
-        }
-    }
-    if (wm == 0) __builtin_amdgcn_s_barrier();       // matches group 1's extra barrier
-#undef VF_G8_SYNC_IN
-#undef VF_G8_SYNC_OUT
-#undef VF_G8_MMA
-}
-
-#endif  // VF_TUNING
+#ifdef VF_TUNING   // gemm8p_kernel: prefetch-all variant of the two-group kernel, mixed results (DESIGN_HISTORY.md)
+#include "tuning/gemm8p.inc"
+#endif
 
 // Shape-generic fallback (any K % 8 == 0): 64x64 tile, fp32 FMA out of LDS.  Same lane->output
 // ownership as the MFMA kernel so the epilogues are shared.  Only small/odd shapes come here.
@@ -2581,268 +1691,9 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(const unsigned short*
     }
 }
 
-#ifdef VF_TUNING   // measured 5-7 % slower than the persistent tile kernel on its own shapes (profiles/r03_e_xs_gemm.log); tuning library only
-// ======================================================================================================================
-// X-STATIONARY GEMM for K = 512 (the seq2reg consumers: Wqkv 512 -> 1536, GeGLU 512 -> 2048).
-// At K = 512 a 256x256 output tile lives for 8 K-tiles (11 us) and pays 4-7 us of ramp + epilogue around them, and the
-// A row panel is re-read from L2 by every one of the N / 256 column tiles.  Here a block of 8 waves owns 256 ROWS for the
-// whole width N: each wave keeps its 32 rows x 512 as B-operand fragments in registers (32 k-steps x 4 VGPRs = 128),
-// W streams through an LDS ring in chunks of 128 columns x 64 k (16 KiB, LDS-DMA, full 128-byte lines, XOR-swizzled on the
-// source side like the other kernels), and the output is produced in passes of 128 columns: 8 chunks x 16 MFMAs
-// (v_mfma_f32_32x32x16, A = W fragment by ds_read_b128, B = the resident X fragment) into 64 accumulator registers, then
-// that pass's epilogue.  No per-tile prologue, no A re-reads, X is read from HBM exactly once.
-// C layout of a 32x32 tile: lane (t = lane & 31 -> ROW, h = lane >> 5), reg i -> column (i & 3) + 8 (i >> 2) + 4 h: a lane
-// holds 4 consecutive columns of its own row per register quad (8-byte 16-bit pieces), and for the GeGLU epilogue the
-// 16-row interleave of the packed weights puts `a` into regs 0-7 and its `gate` into regs 8-15 of the same lane.
-// ======================================================================================================================
-struct CfgXS {
-    static constexpr int K = 512, BM = 256, NB = 128, CK = 64;          // rows per block, columns per pass, k per chunk
-    static constexpr int CHUNK_BYTES = NB * CK * 2;                     // 16 KiB
-    static constexpr int SLOTS = 4, RING_BYTES = SLOTS * CHUNK_BYTES;   // 64 KiB
-    static constexpr int STAGE_BYTES = 8 * 32 * (NB * 2 + 16);          // per-wave output staging: 32 rows x (256 + 16) B
-    static constexpr int MAX_N = 2048;                                  // bias | colsum of all N columns live in LDS
-    static constexpr int LDS_BYTES = RING_BYTES + STAGE_BYTES + MAX_N * 2 * 4;      // 64 + 68 + 16 KiB
-};
-
-template <int EPI, int DT, int LN>
-__global__ __launch_bounds__(512, 2) void xs_gemm_kernel(const unsigned short* __restrict__ A, int64_t lda,
-                                                         const unsigned short* __restrict__ W,
-                                                         const float* __restrict__ bias, void* out, int64_t ldo, int M, int N,
-                                                         LnArgs ln) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    using frag_t = typename Op16<DT>::frag;
-    using C = CfgXS;
-    constexpr bool GEGLU = EPI == VF_EPI_GEGLU_BF16;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int t = lane & 31, h = lane >> 5;
-    const int64_t m0 = (int64_t)blockIdx.x * C::BM;
-    const int64_t row = m0 + 32 * wave + t;                              // this lane's output row
-    const int64_t row_c = row < M ? row : M - 1;
-
-    char* const ring = smem;
-    char* const stage = smem + C::RING_BYTES + wave * (32 * (C::NB * 2 + 16));
-    float* const side = reinterpret_cast<float*>(smem + C::RING_BYTES + C::STAGE_BYTES);      // bias[N] | colsum[N]
-
-    // ---- W chunk q = (pass, c): columns [128 pass, +128) x k [64 c, +64).  One LDS-DMA wave-instruction fills 8 column
-    // rows x 128 B; wave w fills rows 16 w .. 16 w + 15 of the chunk (two instructions).  Lane l of an instruction: row
-    // l >> 3, PHYSICAL 16-byte piece l & 7 = logical piece (l & 7) ^ ((row >> 1) & 7).
-    const int n_pass = N / C::NB;
-    const int total = n_pass * 8;
-    const unsigned short* wsrc[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int r = 16 * wave + 8 * i + (lane >> 3);
-        const int p = (lane & 7) ^ ((r >> 1) & 7);
-        wsrc[i] = W + (int64_t)r * C::K + p * 8;                          // + pass * 128 * K + c * 64
-    }
-    auto issue = [&](int q) {
-        const int pass = q >> 3, c = q & 7;
-        char* dst = ring + (q & (C::SLOTS - 1)) * C::CHUNK_BYTES + wave * 2048;
-        const int64_t off = (int64_t)pass * C::NB * C::K + c * C::CK;
-        glds16(wsrc[0] + off, dst);
-        glds16(wsrc[1] + off, dst + 1024);
-    };
-    // first three chunks in flight while the X fragments load
-    issue(0);
-    if (total > 1) issue(1);
-    if (total > 2) issue(2);
-
-    // ---- epilogue constants: bias (and colsum) of all N columns into LDS, (mean, rstd) of this lane's row
-    for (int i = tid; i < N / 4; i += 512) {
-        reinterpret_cast<f32x4_t*>(side)[i] = bias ? reinterpret_cast<const f32x4_t*>(bias)[i] : (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        if (LN == VF_LN_CONSUMER) reinterpret_cast<f32x4_t*>(side + N)[i] = reinterpret_cast<const f32x4_t*>(ln.colsum)[i];
-    }
-    float mu = 0.f, rs = 1.f;
-    if (LN == VF_LN_CONSUMER) {
-        const f32x2_t st = *reinterpret_cast<const f32x2_t*>(ln.row_stats + 2 * row_c);
-        mu = -st[0] * st[1];                 // -mean * rstd (the two-FMA form of the tile kernels: bit-identical results)
-        rs = st[1];
-    }
-
-    // ---- the wave's 32 rows as B-operand fragments: lane (t, h), k-step ks holds X[row][16 ks + 8 h .. + 7]
-    frag_t xf[32];
-    {
-        const unsigned short* xp = A + row_c * lda + 8 * h;
-#pragma unroll
-        for (int ks = 0; ks < 32; ++ks) xf[ks] = __builtin_bit_cast(frag_t, *reinterpret_cast<const u32x4_t*>(xp + 16 * ks));
-    }
-
-    // fragment read address inside a chunk: column row (32 ct + t) * 128 B + ((2 ksl + h) ^ swz(row)) * 16
-    int foff[4];
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) foff[ct] = (32 * ct + t) * 128;
-    const int sw = ((t >> 1) & 7);                                      // (32 ct + t) >> 1 & 7 == (t >> 1) & 7
-
-    f32x16_t acc[4];
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[ct][i] = 0.f;
-
-    // Two wave groups (waves 0-3 / 4-7 sit pairwise on the 4 SIMDs) run one barrier apart, as in gemm8_kernel: a phase is
-    //     [8 fragment reads (two 16-deep k-steps) + the chunk bookkeeping]  s_barrier  [8 MFMAs]  s_barrier
-    // so that on every SIMD one wave issues MFMAs while its partner reads fragments.  Two phases per chunk.
-    //   RAW  chunk q+1 is waited for (own pieces, counted vmcnt) before the first barrier of the SECOND phase of chunk q and
-    //        first read in the first phase of chunk q+1: every wave's wait lies at least one barrier before any read.
-    //   WAR  chunk q+3 goes into the slot of chunk q-1, requested in the read section of the second phase of chunk q: the
-    //        lagging group retired its last reads of chunk q-1 two barriers earlier.
-    const int grp = wave >> 2;
-#define VF_XS_IN()                                               \
-    do {                                                         \
-        asm volatile("" ::: "memory");                           \
-        __builtin_amdgcn_sched_barrier(0);                       \
-        __builtin_amdgcn_s_barrier();                            \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       \
-        __builtin_amdgcn_sched_barrier(0);                       \
-        __builtin_amdgcn_s_setprio(1);                           \
-    } while (0)
-#define VF_XS_OUT()                                              \
-    do {                                                         \
-        __builtin_amdgcn_s_setprio(0);                           \
-        __builtin_amdgcn_sched_barrier(0);                       \
-        __builtin_amdgcn_s_barrier();                            \
-        asm volatile("" ::: "memory");                           \
-        __builtin_amdgcn_sched_barrier(0);                       \
-    } while (0)
-    // prologue: chunk 0 landed for everybody
-    if (total > 2) wait_vmcnt<4>();
-    else if (total > 1) wait_vmcnt<2>();
-    else wait_vmcnt<0>();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // the side-area writes above
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (grp == 1) __builtin_amdgcn_s_barrier();                          // group 1 runs one barrier behind
-
-    for (int pass = 0; pass < n_pass; ++pass) {
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {                                    // compile-time c: xf[] stays in registers
-            const int q = pass * 8 + c;
-            const char* ck = ring + (q & (C::SLOTS - 1)) * C::CHUNK_BYTES;
-            frag_t wf[2][4];
-            // ---- phase A: k-steps 0, 1 of the chunk
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int ct = 0; ct < 4; ++ct)
-                    wf[kk][ct] = *reinterpret_cast<const frag_t*>(ck + foff[ct] + (((2 * kk + h) ^ sw) << 4));
-            VF_XS_IN();
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int ct = 0; ct < 4; ++ct) acc[ct] = Op16<DT>::mfma32(wf[kk][ct], xf[4 * c + kk], acc[ct]);
-            VF_XS_OUT();
-            // ---- phase B: k-steps 2, 3; request chunk q+3, retire chunk q+1
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int ct = 0; ct < 4; ++ct)
-                    wf[kk][ct] = *reinterpret_cast<const frag_t*>(ck + foff[ct] + (((2 * (kk + 2) + h) ^ sw) << 4));
-            if (q + 3 < total) {
-                issue(q + 3);
-                // queue, oldest first: chunk q+1, chunk q+2, [the NST row stores of the epilogue that just ran], chunk q+3
-                if (c == 0 && pass > 0) wait_vmcnt<4 + (GEGLU ? 4 : 8)>();
-                else wait_vmcnt<4>();
-            } else if (q + 2 < total) {
-                wait_vmcnt<2>();
-            } else {
-                wait_vmcnt<0>();
-            }
-            VF_XS_IN();
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int ct = 0; ct < 4; ++ct) acc[ct] = Op16<DT>::mfma32(wf[kk][ct], xf[4 * c + 2 + kk], acc[ct]);
-            VF_XS_OUT();
-        }
-        // ---- epilogue of this pass: columns [128 pass, +128) of the wave's 32 rows
-        const int n0 = pass * C::NB;
-        constexpr int PITCH = C::NB * 2 + 16;                            // staged 16-bit row (GeGLU: half of it is used)
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {                             // register quad gq: columns 32 ct + 8 gq + 4 h .. + 3
-                const int col = n0 + 32 * ct + 8 * gq + 4 * h;
-                f32x4_t v = {acc[ct][4 * gq], acc[ct][4 * gq + 1], acc[ct][4 * gq + 2], acc[ct][4 * gq + 3]};
-                const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(side + col);
-                if (LN == VF_LN_CONSUMER) {
-                    const f32x4_t c4 = *reinterpret_cast<const f32x4_t*>(side + N + col);
-                    v = v * rs + (mu * c4 + b4);
-                } else {
-                    v += b4;
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[ct][4 * gq + e] = v[e];
-            }
-            if (GEGLU) {
-                // quads 0, 1 = `a` columns 0-15 of this 32-row block of the packed weights, quads 2, 3 = their gates
-#pragma unroll
-                for (int gq = 0; gq < 2; ++gq) {
-                    const f32x4_t a4 = {acc[ct][4 * gq], acc[ct][4 * gq + 1], acc[ct][4 * gq + 2], acc[ct][4 * gq + 3]};
-                    const f32x4_t g4 = {acc[ct][8 + 4 * gq], acc[ct][9 + 4 * gq], acc[ct][10 + 4 * gq], acc[ct][11 + 4 * gq]};
-                    const f32x4_t y = a4 * gelu_erf4(g4);
-                    u32x2_t pk;
-                    pk[0] = Op16<DT>::pack2(y[0], y[1]);
-                    pk[1] = Op16<DT>::pack2(y[2], y[3]);
-                    *reinterpret_cast<u32x2_t*>(stage + t * PITCH + (16 * ct + 8 * gq + 4 * h) * 2) = pk;
-                }
-            } else {
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    u32x2_t pk;
-                    pk[0] = Op16<DT>::pack2(acc[ct][4 * gq], acc[ct][4 * gq + 1]);
-                    pk[1] = Op16<DT>::pack2(acc[ct][4 * gq + 2], acc[ct][4 * gq + 3]);
-                    *reinterpret_cast<u32x2_t*>(stage + t * PITCH + (32 * ct + 8 * gq + 4 * h) * 2) = pk;
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[ct][i] = 0.f;
-        }
-        // read the wave's staged rows back 16 bytes per lane (same wave: LDS operations are in order) and store whole rows
-        constexpr int OUT_COLS = GEGLU ? C::NB / 2 : C::NB;              // 16-bit columns per staged row
-        constexpr int CR = OUT_COLS * 2 / 16;                            // 16-byte pieces per row: 16 or 8
-        constexpr int RPI = 64 / CR;                                     // rows per wave-instruction: 4 or 8
-        const int no0 = GEGLU ? n0 / 2 : n0;
-        const int ldo_cols = GEGLU ? N / 2 : N;
-#pragma unroll
-        for (int it = 0; it < 32 / RPI; ++it) {
-            const int r = it * RPI + lane / CR, pc = lane % CR;
-            const u32x4_t d = *reinterpret_cast<const u32x4_t*>(stage + r * PITCH + pc * 16);
-            const int64_t m = m0 + 32 * wave + r;
-            if (m < M && no0 + pc * 8 < ldo_cols)
-                *reinterpret_cast<u32x4_t*>(reinterpret_cast<unsigned short*>(out) + m * ldo + no0 + pc * 8) = d;
-        }
-    }
-    if (grp == 0) __builtin_amdgcn_s_barrier();                          // matches group 1's extra barrier
-#undef VF_XS_IN
-#undef VF_XS_OUT
-}
-
-template <int EPI, int DT, int LN>
-int launch_xs(const void* A, int64_t lda, const void* W, const float* bias, void* out, int64_t ldo, int M, int N,
-              hipStream_t st, LnArgs ln = LnArgs{}) {
-    static bool attr_set[VF_MAX_DEVICES] = {};
-    auto kern = xs_gemm_kernel<EPI, DT, LN>;
-    const int dev = vf_current_device();
-    if (dev < 0 || !attr_set[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                CfgXS::LDS_BYTES) != hipSuccess) {
-            (void)hipGetLastError();
-            vf_set_error("vf_gemm: cannot reserve %d bytes of LDS", CfgXS::LDS_BYTES);
-            return VF_ERR_LAUNCH;
-        }
-        if (dev >= 0) attr_set[dev] = true;
-    }
-    hipLaunchKernelGGL(kern, dim3((M + CfgXS::BM - 1) / CfgXS::BM), dim3(512), CfgXS::LDS_BYTES, st, (const unsigned short*)A,
-                       lda, (const unsigned short*)W, bias, out, ldo, M, N, ln);
-    VF_CHECK_LAUNCH("vf_gemm");
-    return VF_OK;
-}
-// the shapes the X-stationary kernel takes: K = 512, whole passes of 128 columns, 16-bit epilogues
-inline bool xs_ok(int N, int K, int epilogue) {
-    return K == 512 && N % 128 == 0 && N <= CfgXS::MAX_N && (epilogue == VF_EPI_BF16 || epilogue == VF_EPI_GEGLU_BF16);
-}
-#endif  // VF_TUNING (xs_gemm_kernel)
+#ifdef VF_TUNING   // xs_gemm_kernel: projection phase of a fused seq2reg block, 5-7 % slower (profiles/r03_e)
+#include "tuning/gemm_xs.inc"
+#endif
 
 // The product library instantiates only the configurations pick_variant() can select.
 using CfgA = Cfg<128, 128, 2, 2, 2>;       // 64 KiB, 4 waves, 2 blocks/CU
