@@ -135,6 +135,8 @@ def test_range_bit_of_the_flag(dtype, monkeypatch):
     raise bit 1 -- for the fp16 trunk copy of a bf16 model and for the scaled fp16 operand copy of an fp16 one; a bf16-only
     configuration (VF_TRUNK16=0) has no fp16 copy and stays silent; ordinary rows never raise it."""
     from variantformer_amd import ops
+    monkeypatch.delenv("VF_TRUNK16", raising=False)                    # starts from the default (fp16 trunk copy) whatever the ambient switch
+    monkeypatch.delenv("VF_LN_FOLD", raising=False)
     td = torch.bfloat16 if dtype == "bf16" else torch.float16
     dev = torch.device("cuda", torch.cuda.current_device())
     M_, N, K = 300, 1536, 1024

@@ -216,6 +216,7 @@ def test_separate_layernorm_pass_mode_vs_oracle(monkeypatch):
     """VF_LN_FOLD=0: LayerNorm as a kernel of its own (vf_layernorm) in front of plain GEMMs -- the rounding points of
     round 1 -- against the oracle with fold_ln=False; and the default (LayerNorm folded into the GEMM epilogues) differs
     from it only at bf16 level on the same inputs."""
+    monkeypatch.delenv("VF_LN_FOLD", raising=False)                    # the first run is the default contract whatever the ambient switch
     kw = seq2gene_kw(layers=2)
     model = build_model(SEQ2REG_512, kw, seed=4242)
     sd = state_dict_cpu(model)
@@ -577,6 +578,7 @@ def test_fp16_trunk_copy_default_vs_fp32_trunk_and_oracle(monkeypatch):
     with ITS rounding points (Rounding(trunk16="f16" / False)) and of pure fp32 arithmetic, and the fp16 copy costs no
     accuracy against fp32 that the operand roundings have not already spent (embedding error within 1.5x of the fp32
     trunk's; the bf16 trunk that round 3 also measured was ~4x)."""
+    monkeypatch.delenv("VF_LN_FOLD", raising=False)                    # the trunk copy is part of the folded contract
     kw = seq2gene_kw(layers=3)
     model = build_model(SEQ2REG_512, kw, seed=515)
     sd = state_dict_cpu(model)
