@@ -551,6 +551,9 @@ __global__ __launch_bounds__(256, (QL && QG == 2 && ALIBI && DH <= 48 ? 3 : 1)) 
 // end (one block-wide vote) and recomputed with the running-maximum form -- correctness never depends on the range, only
 // the speed of such a block does.  The recomputation uses INTEGER offsets (ceil of the maximum): powers of two commute with
 // the roundings, so both forms round the same probabilities.
+#ifndef VF_X32_WIDE_STORE
+#define VF_X32_WIDE_STORE 1
+#endif
 template <int DT, int QB, bool FAST = false>
 __global__ __launch_bounds__(256) void attn_x32_kernel(AttnParams P) {
     using frag_t = typename Op16<DT>::frag;
@@ -786,20 +789,31 @@ __global__ __launch_bounds__(256) void attn_x32_kernel(AttnParams P) {
                     for (int i = 0; i < 16; ++i) o[qb][dt][i] = 0.f;
             }
             pass(std::false_type{});
+            __syncthreads();                                          // the stages become the output staging below
         }
     } else {
         pass(std::false_type{});
+        __syncthreads();
     }
 
     // ---- normalise and store: lane (q, h) holds O[q][d = 32 dt + (i & 3) + 8 (i >> 2) + 4 h]; the denominator is row
-    // d = 48 = element 8 of the dt = 1 tile in the h = 0 lane
+    // d = 48 = element 8 of the dt = 1 tile in the h = 0 lane.
+    // Wide form (16-byte aligned output rows, VF_X32_WIDE_STORE): the wave's 32 QB x 48 block goes through LDS (the K / V stages
+    // are free: every wave is behind the vote / the barrier that ends the pass) and leaves as whole 96-byte row segments, 16 bytes per lane,
+    // ~11 rows per store instruction -- instead of 12 QB eight-byte stores per lane that each touch 32 rows (the store path of
+    // the CU is shared with the K / V loads of the co-resident block).  Same values, same bits.
+    const bool wide = VF_X32_WIDE_STORE && ((reinterpret_cast<uintptr_t>(P.out) | (uintptr_t)(P.o_stride * 2)) & 15) == 0;
+    constexpr int OPITCH = DH * 2 + 16;
+    char* const oreg = smem + wave * (QB * 32 * OPITCH);
+    static_assert(4 * QB * 32 * OPITCH <= 2 * STAGE, "the output staging must fit the K / V stages");
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         const unsigned lu = __float_as_uint(o[qb][1][8]);
         auto sw = __builtin_amdgcn_permlane32_swap(lu, lu, false, false);
         const float inv = 1.0f / __uint_as_float(sw[0]);              // the lower half's value in both halves
-        if (q_abs[qb] < len_q) {
-            unsigned short* op = P.out + (int64_t)(q_tok0 + q_abs[qb]) * P.o_stride + hd * DH + 4 * h;
+        if (wide || q_abs[qb] < len_q) {
+            unsigned short* op = wide ? reinterpret_cast<unsigned short*>(oreg + (qb * 32 + ql) * OPITCH) + 4 * h
+                                      : P.out + (int64_t)(q_tok0 + q_abs[qb]) * P.o_stride + hd * DH + 4 * h;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -809,6 +823,22 @@ __global__ __launch_bounds__(256) void attn_x32_kernel(AttnParams P) {
                     pk[1] = Op16<DT>::pack2(o[qb][dt][4 * gq + 2] * inv, o[qb][dt][4 * gq + 3] * inv);
                     *reinterpret_cast<u32x2_t*>(op + 32 * dt + 8 * gq) = pk;
                 }
+        }
+    }
+    if (wide && active) {                                              // wave-local: a wave reads back only what it wrote
+        constexpr int NCH = QB * 32 * (DH / 8), NIT = (NCH + 63) / 64;
+        const int q_w0 = qb0 + wave * QB * 32;
+        u32x4_t v[NIT];
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int item = lane + 64 * i, row = item / (DH / 8), cc = item - row * (DH / 8);
+            v[i] = *reinterpret_cast<const u32x4_t*>(oreg + (item < NCH ? row * OPITCH + cc * 16 : 0));
+        }
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int item = lane + 64 * i, row = item / (DH / 8), cc = item - row * (DH / 8);
+            if (item < NCH && q_w0 + row < len_q)
+                *reinterpret_cast<u32x4_t*>(P.out + (int64_t)(q_tok0 + q_w0 + row) * P.o_stride + hd * DH + cc * 8) = v[i];
         }
     }
 }
