@@ -6,10 +6,12 @@
 #include <cstdio>
 #include <cstdarg>
 #include <vector>
+#include <algorithm>
 void vf_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vprintf(fmt, ap); va_end(ap); printf("\n"); }
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 
 // kind: 0 = LayerNorm consumer, 16-bit out; 1 = LayerNorm consumer GeGLU; 2 = 16-bit-residual LayerNorm producer (no fp32 rows)
+static int g_zero = 0, g_warm = 0;   // clock mode: all-zero operands / launches before the measured ones
 static void run(const char* name, int M, int N, int K, int kind) {
     unsigned short *A, *W, *x16, *r16p; float *bias, *colsum, *stats, *part; unsigned long long* prof;
     const int n_out = kind == 1 ? N / 2 : N;
@@ -22,14 +24,16 @@ static void run(const char* name, int M, int N, int K, int kind) {
     std::vector<unsigned short> h((size_t)M * K);
     unsigned x = 12345;
     for (auto& v : h) { x = x * 1664525u + 1013904223u; v = (unsigned short)(0x3c00 + ((x >> 16) & 0x3ff) - 0x200 + ((x >> 31) << 15)); }
+    if (g_zero) std::fill(h.begin(), h.end(), (unsigned short)0);
     CK(hipMemcpy(A, h.data(), h.size() * 2, hipMemcpyHostToDevice));
-    for (size_t i = 0; i < (size_t)N * K && i < h.size(); ++i) h[i] = (unsigned short)(h[i] - 0x300);
+    for (size_t i = 0; i < (size_t)N * K && i < h.size(); ++i) h[i] = g_zero ? (unsigned short)0 : (unsigned short)(h[i] - 0x300);
     CK(hipMemcpy(W, h.data(), (size_t)N * K * 2, hipMemcpyHostToDevice));
     CK(hipMemset(r16p, 0x3c, (size_t)M * N * 2)); CK(hipMemset(bias, 0, N * 4)); CK(hipMemset(colsum, 0, N * 4));
     { std::vector<float> st((size_t)M * 2); for (size_t i = 0; i < st.size(); i += 2) { st[i] = 0.01f; st[i + 1] = 1.0f; } CK(hipMemcpy(stats, st.data(), st.size() * 4, hipMemcpyHostToDevice)); }
     CK(hipMemcpyToSymbol(HIP_SYMBOL(vf_g8_prof), &prof, sizeof(prof)));
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-    for (int rep = 0; rep < 3; ++rep) {
+    const int reps = 3 + g_warm;
+    for (int rep = 0; rep < reps; ++rep) {
         CK(hipMemset(prof, 0, nrec * 64));
         CK(hipEventRecord(a));
         int rc;
@@ -38,7 +42,7 @@ static void run(const char* name, int M, int N, int K, int kind) {
         if (rc) { printf("rc %d\n", rc); return; }
         CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
         float ms; CK(hipEventElapsedTime(&ms, a, b));
-        if (rep < 2) continue;
+        if (rep < reps - 1) continue;
         std::vector<unsigned long long> hp(nrec * 8);
         CK(hipMemcpy(hp.data(), prof, hp.size() * 8, hipMemcpyDeviceToHost));
         const char* nm[5] = {"tile start (request K-tile 1, barriers)", "first K-tile", "K-tiles 1 .. n-1 (+ group barrier)", "this wave's epilogue", "wait for the other waves"};
@@ -58,7 +62,13 @@ static void run(const char* name, int M, int N, int K, int kind) {
     hipFree(A); hipFree(W); hipFree(x16); hipFree(r16p); hipFree(bias); hipFree(colsum); hipFree(stats); hipFree(part); hipFree(prof);
 }
 
-int main() {
+int main(int argc, char** argv) {
+    if (argc > 1) {          // ./gemm8x_probe clock : in-kernel clock of the step's largest GEMM on random and on all-zero operands,
+        g_warm = 600;        // after ~2 s of back-to-back launches each (MI355X_MICROARCH.md, DVFS give-back item 6)
+        g_zero = 0; run("gene Wqkv, 32 genes, RANDOM operands", 347328, 4608, 1536, 0);
+        g_zero = 1; run("gene Wqkv, 32 genes, ALL-ZERO operands", 347328, 4608, 1536, 0);
+        return 0;
+    }
     run("seq2reg Wqkv (LN consumer, 16-bit out)", 769460, 1536, 512, 0);
     run("seq2reg GeGLU (LN consumer)", 769460, 2048, 512, 1);
     run("gene Wqkv (LN consumer, 16-bit out)", 86832, 4608, 1536, 0);
