@@ -33,7 +33,8 @@ class FlashTransformerLayer(nn.Module):
         never written.  mean(hg) stays fp32-accurate through the 16-bit GEMM as [hi | lo] against [W2 | W2]; the residual
         mean is taken over the very values the token-level epilogue adds: the fp32 rows, or a 16-bit copy times its scale
         (res16: the fp16 trunk copy, or the operand-type copy of the layer input).  -> fp32 [W, d]."""
-        key = (w2.data_ptr(), w2._version)
+        wm = self.linear_geglu_2.weight                  # keyed on the MASTER parameter (as packed_linear is): the packed copy's
+        key = (wm.data_ptr(), wm._version, str(wm.device), ops.cdt())      # address can be reused by its successor
         if getattr(self, "_w2_split_key", None) != key:
             self._w2_split, self._w2_split_key = torch.cat([w2, w2], dim=1).contiguous(), key
         ph = ops.segment_mean16(hg, cu, split=True)
