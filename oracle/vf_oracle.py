@@ -317,7 +317,7 @@ class Seq2RegHP:
                    hp.get("use_context", False), hp.get("expand_context", False))
 
 
-def seq2reg_layer(x, cu, sd, pfx, hp: Seq2RegHP, slopes, rnd: Rounding, last=False):
+def seq2reg_layer(x, cu, sd, pfx, hp: Seq2RegHP, slopes, rnd: Rounding, last=False, pool_cu=None):
     """FlashTransformerLayer.forward (seq2reg/modules.py:149-191) on the packed valid tokens.
     Pad positions never influence valid ones (attention runs on the unpadded stream, :159-171;
     everything else is per-token) and are excluded from the pool, so only valid tokens are kept."""
@@ -325,6 +325,21 @@ def seq2reg_layer(x, cu, sd, pfx, hp: Seq2RegHP, slopes, rnd: Rounding, last=Fal
     a = mha_self(h, sd, pfx + "MHA.", hp.num_heads, cu, slopes, rnd)
     x1 = a + rnd.res(x)                                              # :179  x += res_short (16-bit copy: Rounding.res16)
     h = rnd.ln(x1, sd[pfx + "norm2.weight"], sd[pfx + "norm2.bias"])
+    if pool_cu is not None:
+        # the mean pool of seq2reg/model.py:263-267 taken BEFORE linear_geglu_2 (which is linear, seq2reg/modules.py:186-188):
+        # mean(W2 h + b + src) = W2 mean(h) + b + mean(src) -- what variantformer_amd executes for the encoder's last layer
+        # (FlashTransformerLayer._pooled_down_projection); mean(h) is NOT rounded again (it passes the GEMM as hi + lo)
+        hh = linear(h, sd[pfx + "linear_geglu_1.weight"], sd[pfx + "linear_geglu_1.bias"], rnd)
+        a_, g_ = hh.chunk(2, dim=-1)
+        hg, res = rnd.r(a_ * F.gelu(g_)), rnd.trunk(x)
+        W = len(pool_cu) - 1
+        out = torch.full((W, x.shape[1]), float("nan"))
+        w2, b2 = rnd.r(sd[pfx + "linear_geglu_2.weight"]), sd[pfx + "linear_geglu_2.bias"]
+        for w in range(W):
+            a, e = int(pool_cu[w]), int(pool_cu[w + 1])
+            if e > a:
+                out[w] = F.linear(hg[a:e].mean(dim=0), w2, b2) + res[a:e].mean(dim=0)
+        return out
     return rnd.out(geglu_ffn(h, sd, pfx, rnd) + rnd.trunk(x), last, s2r=True)                  # :188  x += res_long (= layer input)
 
 
@@ -340,9 +355,11 @@ def seq2reg_context_layer(x, ctx, cu, sd, pfx, hp: Seq2RegHP, slopes, rnd: Round
     return rnd.out(geglu_ffn(h, sd, pfx, rnd) + rnd.trunk(x), last, s2r=True)
 
 
-def seq2reg_embed(ids, pad_mask, sd, pfx, hp: Seq2RegHP, rnd: Rounding, context=None):
+def seq2reg_embed(ids, pad_mask, sd, pfx, hp: Seq2RegHP, rnd: Rounding, context=None, pool_before_down=False):
     """Seq2RegPredictor.forward(only_embed=True) (seq2reg/model.py:193-279).
-    ids int64 [b,1,L], pad_mask bool [b,1,L] (True = pad), context int64 [b] (use_context) -> [b,1,d]."""
+    ids int64 [b,1,L], pad_mask bool [b,1,L] (True = pad), context int64 [b] (use_context) -> [b,1,d].
+    pool_before_down (mean pool, no context layers): the exact re-ordering variantformer_amd executes -- the pool in front of
+    the last layer's linear_geglu_2 (seq2reg_layer(pool_cu=...)); the default is the reference's order of operations."""
     b, ns, L = ids.shape
     ids = ids.reshape(b * ns, L)
     pad = pad_mask.reshape(b * ns, L)
@@ -366,8 +383,13 @@ def seq2reg_embed(ids, pad_mask, sd, pfx, hp: Seq2RegHP, rnd: Rounding, context=
             xp = seq2reg_context_layer(xp, ctx, cu, sd, f"{pfx}transformer_encoder.{l}.", hp, slopes, rnd,
                                        last=l + 1 == hp.num_layers)
     else:
+        early = pool_before_down and hp.seq_pool == "mean"
         for l in range(hp.num_layers):
-            xp = seq2reg_layer(xp, cu, sd, f"{pfx}transformer_encoder.{l}.", hp, slopes, rnd, last=l + 1 == hp.num_layers)
+            lastl = l + 1 == hp.num_layers
+            xp = seq2reg_layer(xp, cu, sd, f"{pfx}transformer_encoder.{l}.", hp, slopes, rnd, last=lastl,
+                               pool_cu=cu if (early and lastl) else None)
+        if early:
+            return xp.view(b, ns, d)
     if hp.seq_pool == "mean":                                         # :263-267
         out = torch.zeros(b * ns, d)
         for w in range(b * ns):

@@ -62,6 +62,27 @@ def test_shared_cre_stream_is_exact_dedup(golden):
         np.testing.assert_allclose(a["embeddings"][i], arrays[f"embeddings_{i}"], rtol=RTOL, atol=ATOL)
 
 
+def test_mean_pool_before_the_last_down_projection_is_exact(golden):
+    """The encoder's mean pool commutes with the last layer's linear_geglu_2 (seq2reg/model.py:263-267, seq2reg/modules.py:
+    186-188): pooled first, the tokenizer embeddings equal the REFERENCE's own (fixture cre_tok / gene_tok) to fp32
+    summation-order level, in pure fp32 and under the kernels' rounding points -- the re-ordering variantformer_amd executes
+    (FlashTransformerLayer._pooled_down_projection) is algebra, not an approximation."""
+    meta, arrays, sd, batch = golden
+    cre_hp, gene_hp, _ = _hps(meta)
+    with torch.no_grad():
+        for i in range(len(meta["n_cres"])):
+            for pfx, hp_, ids, mask, key in (("cre_tokenizer.", cre_hp, batch["cre_sequences"][i], batch["cre_attention_masks"][i], "cre_tok"),
+                                             ("gene_tokenizer.", gene_hp, batch["gene_embeddings"][i], batch["gene_attention_masks"][i], "gene_tok")):
+                early = O.seq2reg_embed(ids, mask, sd, pfx, hp_, O.Rounding(None), pool_before_down=True)
+                np.testing.assert_allclose(early.numpy(), arrays[f"{key}_{i}"], rtol=RTOL, atol=ATOL)
+                late = O.seq2reg_embed(ids, mask, sd, pfx, hp_, O.Rounding(None))
+                assert float((early - late).abs().max()) < 2e-6 * float(late.abs().max())
+                for mode in ("bf16", "fp16"):
+                    e16 = O.seq2reg_embed(ids, mask, sd, pfx, hp_, O.Rounding(mode), pool_before_down=True)
+                    l16 = O.seq2reg_embed(ids, mask, sd, pfx, hp_, O.Rounding(mode))
+                    assert float((e16 - l16).abs().max()) < 2e-6 * float(l16.abs().max()), mode
+
+
 def test_bf16_rounding_mode_is_close_to_fp32(golden):
     """The kernel-contract mode (bf16 operands, fp32 everything else) stays within bf16-level
     distance of the fp32 reference outputs; documents the precision of the shipped arithmetic."""
