@@ -561,6 +561,8 @@ def main():
         for g, rec in (small or {}).items():
             out[f"batch_of_{g}"] = rec
         out["peak_hbm_allocated_gb"] = round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2)
+        from variantformer_amd.seq2gene.model_combined_modulator import ln_fold_state
+        out["ln_fold"] = ln_fold_state()                     # the fold was ON for every timed step unless this says otherwise
         if strong is not None:
             out["cfg3_strong_scaling"] = strong
         if flow is not None:

@@ -22,7 +22,7 @@ col32 = {}
 with torch.no_grad():
     pred_32, emb_32 = O.forward(batch, sd, hp, hp, ghp, rounding=None, share_cre_stream=True, collect=col32)
 model = build_model(meta["seq2reg"], meta["seq2gene"], sd).cuda()
-pb = model.prepare_batch(batch)
+pb = model.prepare_batch(batch, dedupe_windows=False).wait()    # rows align with the batch's windows; upload finished for every reader below
 with torch.no_grad():
     cre_tok = model.cre_tokenizer.embed_packed(pb.cre_ids, pb.cre_pad, pb.cre_tokens, torch.float32)
     gene_tok = model.gene_tokenizer.embed_packed(pb.gene_ids, pb.gene_pad, pb.gene_tokens, torch.float32)

@@ -18,16 +18,18 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture()
 def heal_state():
-    """The self-healing bookkeeping is per process (sticky after two alerting batches): isolate it."""
+    """The self-healing bookkeeping is per process (sticky when 2 of the last 16 finished batches alerted): isolate it."""
     from variantformer_amd.seq2gene import model_combined_modulator as M
     from variantformer_amd.seq2gene.modules import layers as L
-    saved = (dict(M._LN_HEAL), L._LN_FOLD_FORCED_OFF)
-    M._LN_HEAL.update(batches=0, logged=False)
-    L._LN_FOLD_FORCED_OFF = 0
+    saved = (dict(M._LN_HEAL, recent=list(M._LN_HEAL["recent"])), L._LN_FOLD_DISABLED)
+    M._LN_HEAL.update(batches=0, finished=0, logged=False)
+    M._LN_HEAL["recent"].clear()
+    L.ln_fold_reenable()
     yield M, L
-    M._LN_HEAL.clear()
-    M._LN_HEAL.update(saved[0])
-    L._LN_FOLD_FORCED_OFF = saved[1]
+    M._LN_HEAL.update(batches=saved[0]["batches"], finished=saved[0]["finished"], logged=saved[0]["logged"])
+    M._LN_HEAL["recent"].clear()
+    M._LN_HEAL["recent"].extend(saved[0]["recent"])
+    L._LN_FOLD_DISABLED = saved[1]
 
 
 def _forward_counter(model, monkeypatch):
@@ -82,8 +84,13 @@ def test_alerting_batch_is_recomputed_and_equals_the_unfolded_run(heal_state, mo
 
     # a second alerting batch switches the fold off for the process: from then on ONE forward per batch, same bits
     calls["n"] = 0
-    again = model.predict_step(batch, 1)
+    caplog.clear()
+    with caplog.at_level(logging.WARNING, logger="variantformer_amd"):      # the switch is announced at WARNING: visible by default
+        again = model.predict_step(batch, 1)
     assert calls["n"] == 2 and M._LN_HEAL["batches"] == 2 and not L.ln_fold_enabled(1536, 1024)
+    assert any(r.levelno == logging.WARNING and "OFF" in r.getMessage() for r in caplog.records)
+    st = M.ln_fold_state()
+    assert st["switched_off_for_process"] and not st["enabled"] and st["batches_recomputed"] == 2
     calls["n"] = 0
     third = model.predict_step(batch, 2)
     assert calls["n"] == 1
@@ -164,3 +171,93 @@ def test_range_bit_of_the_flag(dtype, monkeypatch):
             monkeypatch.setenv("VF_TRUNK16", "0")                      # no fp16 copy anywhere: nothing to overflow
             ops.gemm_ln_producer(a, w, None, res2)
             assert ops.ln_fold_alert(dev) & 2 == 0
+
+
+def test_deeper_pipelining_heals_the_right_batch(heal_state, monkeypatch):
+    """Round-4 advice: a driver that launches batch i + 1 BEFORE finishing batch i.  The alert travels with the batch (cut out
+    of the stream's flag behind the batch's last kernel, carried in the opaque handle), so finish(i) neither recomputes for
+    batch i + 1's rows nor lets batch i + 1 return unhealed numbers."""
+    M, L = heal_state
+    from variantformer_amd import ops
+    kw = seq2gene_kw(layers=2)
+    model = build_model(SEQ2REG_512, kw, seed=4242).cuda().eval()
+    good = make_batch(5, [6], [3], [[8, 9]], 200)
+    bad = make_batch(6, [4], [2], [[30]], 200)
+    for b in (good, bad):
+        for v in b["cre_sequences"] + b["gene_embeddings"]:
+            v[v == 499] = 498
+    bad["cre_sequences"][0][0, 0, 5] = 499
+    with torch.no_grad():
+        model.cre_tokenizer.token_embedding.weight[499] += 20.0
+    monkeypatch.setenv("VF_LN_FOLD", "0")
+    want = [model.predict_step(b, i) for i, b in enumerate([good, bad, good])]
+    monkeypatch.delenv("VF_LN_FOLD")
+    monkeypatch.setattr(M, "LN_HEAL_STICKY_AFTER", 10 ** 9)
+    # a stale flag of a direct forward() call (no batch owns it) must not count against the next batch either
+    with torch.no_grad():
+        model.forward_prepared(model.prepare_batch(bad))
+    calls = _forward_counter(model, monkeypatch)
+    M._LN_HEAL.update(batches=0, finished=0)
+    handles = [model.predict_launch(model.prepare_batch(b)) for b in (good, bad, good)]      # three launches in flight
+    got = [model.predict_finish(h, i) for i, h in enumerate(handles)]
+    assert calls["n"] == 4 and M._LN_HEAL["batches"] == 1 and M._LN_HEAL["finished"] == 3
+    assert list(M._LN_HEAL["recent"])[-3:] == [False, True, False]
+    assert np.array_equal(got[1]["pred_gene_exp"][0], want[1]["pred_gene_exp"][0])
+    assert np.array_equal(got[1]["embeddings"][0], want[1]["embeddings"][0])
+    for i in (0, 2):
+        np.testing.assert_allclose(got[i]["pred_gene_exp"][0], want[i]["pred_gene_exp"][0], rtol=1e-2)
+    # and out of order: finishing the flagged batch LAST still heals it, not its neighbours
+    calls["n"] = 0
+    handles = [model.predict_launch(model.prepare_batch(b)) for b in (bad, good)]
+    g1 = model.predict_finish(handles[1], 1)
+    g0 = model.predict_finish(handles[0], 0)
+    assert calls["n"] == 3
+    assert np.array_equal(g0["pred_gene_exp"][0], want[1]["pred_gene_exp"][0])
+    np.testing.assert_allclose(g1["pred_gene_exp"][0], want[0]["pred_gene_exp"][0], rtol=1e-2)
+
+
+def test_an_unused_registry_row_does_not_flag_the_batch(heal_state, monkeypatch):
+    """Gene layer 0 projects the whole 63-row registry table once per batch; only the rows of the tissues the batch asks for
+    may raise the alert (round-4 advice: one anomalous row of an unused tissue would otherwise flag every batch and switch the
+    fold off for the process)."""
+    M, L = heal_state
+    kw = seq2gene_kw(layers=2)
+    model = build_model(SEQ2REG_512, kw, seed=4242).cuda().eval()
+    batch = make_batch(7, [6], [3], [[8, 9]], 200)
+    with torch.no_grad():
+        w = model.start_tkn.registry_tokens.weight
+        w[40] += 30.0 * w[40].std()                                      # tissue 40: not in the batch
+    calls = _forward_counter(model, monkeypatch)
+    model.predict_step(batch, 0)
+    assert calls["n"] == 1 and M._LN_HEAL["batches"] == 0
+    other = make_batch(7, [6], [3], [[8, 40]], 200)                      # now it is
+    model.predict_step(other, 1)
+    assert calls["n"] == 3 and M._LN_HEAL["batches"] == 1
+
+
+def test_forced_off_is_thread_local_and_flags_are_per_stream(heal_state):
+    """A recomputation in one thread must not flip the path of a forward in another; kernels raise the flag of the stream
+    they run on."""
+    import threading
+    M, L = heal_state
+    from variantformer_amd import ops
+    seen = {}
+    with L.ln_fold_forced_off():
+        assert not L.ln_fold_enabled(1536, 1024)
+        t = threading.Thread(target=lambda: seen.update(other=L.ln_fold_enabled(1536, 1024)))
+        t.start(); t.join()
+    assert seen["other"] is True and L.ln_fold_enabled(1536, 1024)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    ops.ln_fold_alert(dev)
+    x = torch.randn(64, 1536, device=dev)
+    x[3] += 100.0
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ops.ln_stream(x)
+        side.synchronize()
+        assert ops.ln_fold_alert(dev, reset=False) & 1                   # raised on the side stream ...
+    torch.cuda.synchronize()
+    assert ops.ln_fold_alert(dev) == 0                                   # ... and invisible to the default stream
+    with torch.cuda.stream(side):
+        assert ops.ln_fold_alert(dev) & 1 and ops.ln_fold_alert(dev) == 0

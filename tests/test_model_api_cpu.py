@@ -231,3 +231,33 @@ def test_window_deduplication_is_exact_and_hash_independent():
     assert M._unique_windows(ids[:40], pad[:40]) is None             # all distinct: nothing to share
     odd = M._unique_windows(np.concatenate([ids[:, :199]] * 1), pad[:, :199])      # odd row length (padding column)
     assert odd is not None and np.array_equal(ids[:, :199][odd[0]][odd[1]], ids[:, :199])
+
+
+def test_host_staging_normalises_masks_and_does_not_wrap_ids(golden):
+    """Round-4 advice: prepare_batch narrows ids int64 -> int32 and masks -> uint8 on the host.  Masks arrive as 0 / 1 whatever
+    the caller's dtype and values (the old path used .bool()); ids beyond int32 must clamp like the kernels' own clamp
+    (< 0 -> 0, >= vocab -> vocab - 1) instead of wrapping; the de-duplication key (id | pad << 30) is only used for ids in
+    [0, 2^30)."""
+    import copy
+    meta, arrays, sd, batch = golden
+    model = build_model(meta["seq2reg"], meta["seq2gene"])
+    base = model.prepare_batch(batch)
+    odd = copy.deepcopy(batch)
+    odd["cre_attention_masks"] = [m.to(torch.int64) * 7 for m in odd["cre_attention_masks"]]        # truthy, not 1
+    odd["gene_attention_masks"] = [m.to(torch.int16) * -3 for m in odd["gene_attention_masks"]]
+    pb = model.prepare_batch(odd)
+    assert torch.equal(pb.cre_pad, base.cre_pad) and torch.equal(pb.gene_pad, base.gene_pad)
+    assert set(pb.cre_pad.unique().tolist()) <= {0, 1} and pb.cre_tokens == base.cre_tokens and pb.gene_tokens == base.gene_tokens
+    wild = copy.deepcopy(batch)
+    m0 = wild["cre_attention_masks"][0]
+    valid = (~m0[:, 0, :]).nonzero()
+    (r0, c0), (r1, c1) = valid[0].tolist(), valid[1].tolist()
+    wild["cre_sequences"][0][r0, 0, c0] = 2 ** 31 + 5        # would wrap to a negative int32 (-> token 0) without the clamp
+    wild["cre_sequences"][0][r1, 0, c1] = -(2 ** 33)         # would wrap to 0 either way; must stay negative (-> token 0)
+    pw = model.prepare_batch(wild)                           # de-duplication must be skipped (ids outside [0, 2^30)), no exception
+    n0 = 0
+    ids = pw.cre_ids if pw.cre_unique_inverse is None else pw.cre_ids[pw.cre_unique_inverse]
+    assert int(ids[n0 + r0, c0]) == 2 ** 31 - 1 and int(ids[n0 + r1, c1]) < 0
+    assert pw.cre_unique_inverse is None and pw.gene_unique_inverse is None
+    assert pw.tissues_used.tolist() == sorted({t for ts in meta["tissues"] for t in ts})
+    assert pw.wait() is pw                                   # CPU: nothing to wait for

@@ -212,10 +212,33 @@ _ALERT: dict = {}
 
 
 def _alert_flag(device) -> torch.Tensor:
-    key = (device.type, device.index)
+    """The flag of the CURRENT STREAM of `device`: kernels raise the flag of the stream they run on, so concurrent streams
+    (one model per stream / thread) never see each other's rows, and ln_fold_alert_take() -- enqueued on the same stream
+    right after a batch's kernels -- cuts out exactly that batch's bits."""
+    sid = torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0
+    key = (device.type, device.index, sid)
     if key not in _ALERT:
         _ALERT[key] = torch.zeros(1, dtype=torch.int32, device=device)
     return _ALERT[key]
+
+
+def ln_fold_alert_clear(device) -> None:
+    """Enqueue a reset of the current stream's flag (start of a batch: bits left by direct forward() calls, benchmarks or a
+    discarded batch belong to nobody)."""
+    if device.type == "cuda":
+        _alert_flag(device).zero_()
+
+
+def ln_fold_alert_take(device):
+    """Enqueue `bits = flag; flag = 0` on the current stream and return the device tensor `bits` ([1] int32): the alert of
+    everything this stream ran since the last clear / take, i.e. of ONE batch when called where the batch's last kernel was
+    enqueued.  Does not synchronise; read it with the batch's outputs.  None on a CPU device."""
+    if device.type != "cuda":
+        return None
+    flag = _alert_flag(device)
+    bits = flag.clone()
+    flag.zero_()
+    return bits
 
 
 # Elements at or beyond this magnitude could overflow a scaled fp16 copy of a stream (65504 / 2^-4 with some margin): the
@@ -233,11 +256,15 @@ def ln_fold_abs_limit() -> float:
 
 
 def ln_fold_alert(device, reset: bool = True) -> int:
-    """Non-zero when, since the last reset, a LayerNorm-folded stream left the regime its 16-bit copies serve: bit 0 -- some
-    row had |mean| > LN_FOLD_RATIO_LIMIT standard deviations; bit 1 -- some row may hold an element beyond ln_fold_abs_limit()
-    (a scaled fp16 copy could overflow).  Synchronises: call it where the outputs are copied back.  The model then recomputes
-    the batch with the separate LayerNorm on fp32 rows (layers.ln_fold_forced_off) -- degraded numbers are never returned."""
-    key = (device.type, device.index)
+    """Non-zero when, since the last reset, a LayerNorm-folded stream ON THE CURRENT STREAM left the regime its 16-bit copies
+    serve: bit 0 -- some row had |mean| > LN_FOLD_RATIO_LIMIT standard deviations; bit 1 -- some row may hold an element
+    beyond ln_fold_abs_limit() (a scaled fp16 copy could overflow).  Synchronises (op-level callers and tests; the model
+    carries a per-batch copy instead: ln_fold_alert_take).  The model recomputes a flagged batch with the separate LayerNorm
+    on fp32 rows (layers.ln_fold_forced_off) -- degraded numbers are never returned."""
+    if device.type != "cuda":
+        return 0
+    sid = torch.cuda.current_stream(device).cuda_stream
+    key = (device.type, device.index, sid)
     if key not in _ALERT:
         return 0
     hit = int(_ALERT[key].item())
@@ -246,19 +273,21 @@ def ln_fold_alert(device, reset: bool = True) -> int:
     return hit
 
 
-def ln_stream(x: torch.Tensor, eps: float = 1e-5) -> LnStream:
-    """(x, 16-bit copy, row statistics) for a stream no GEMM produced: one pass over x (vf_row_stats_cast2)."""
+def ln_stream(x: torch.Tensor, eps: float = 1e-5, raise_alert: bool = True) -> LnStream:
+    """(x, 16-bit copy, row statistics) for a stream no GEMM produced: one pass over x (vf_row_stats_cast2).
+    raise_alert=False: the rows are a TABLE of which a batch uses only some (the registry table in front of the first gene
+    layer); the caller raises the alert for the rows in use itself."""
     _dev(x)
     assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 2
     M, D = x.shape
     x16 = torch.empty((M, D), dtype=_CDT, device=x.device)
     stats = torch.empty((M, 2), dtype=torch.float32, device=x.device)
     scale = x16_scale_for(_CDT)
-    alert = _alert_flag(x.device)
+    alert_ptr = _alert_flag(x.device).data_ptr() if raise_alert else 0
 
     def launch():
         check(_lib.load().vf_row_stats_cast2(x.data_ptr(), M, D, eps, x16.data_ptr(), _dt(_CDT), scale, LN_FOLD_RATIO_LIMIT,
-                                             ln_fold_abs_limit(), alert.data_ptr(), stats.data_ptr(), _stream()),
+                                             ln_fold_abs_limit(), alert_ptr, stats.data_ptr(), _stream()),
               "vf_row_stats_cast")
     if TIMER is not None:
         TIMER.time("layernorm", 0.0, float(M) * D * 6, launch, f"stats_cast D={D}", _SCOPE)

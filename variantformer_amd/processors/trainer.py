@@ -36,4 +36,9 @@ class Trainer:
                 pb = model.prepare_batch(batch) if batch is not None else None
                 out.append(model.predict_finish(handle, i))
                 i += 1
+        try:       # what the self-healing LayerNorm fold did during this pass (finished / recomputed batches, switched off?)
+            from ..seq2gene.model_combined_modulator import ln_fold_state
+            self.ln_fold_state = ln_fold_state()
+        except Exception:                                     # a model class without the fold
+            self.ln_fold_state = None
         return out

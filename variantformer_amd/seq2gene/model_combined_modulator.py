@@ -16,9 +16,9 @@ What is different by design (all exact re-orderings of the same arithmetic, SURV
 """
 from __future__ import annotations
 
-import os
-
+import collections
 import logging
+import os
 import types
 from dataclasses import dataclass
 
@@ -76,6 +76,15 @@ class PreparedBatch:
     ready: object = None                      # event of the side-stream upload (None: tensors are ready)
     windows_total: tuple = (0, 0)             # (CRE windows, gene chunks) of the batch ...
     windows_embedded: tuple = (0, 0)          # ... and how many of them seq2reg embeds after exact de-duplication
+    tissues_used: torch.Tensor = None         # int64 [k]: distinct registry rows (tissue ids) the batch holds
+
+    def wait(self, stream=None) -> "PreparedBatch":
+        """Make `stream` (default: the current one) wait for the side-stream upload of prepare_batch.  forward_prepared does
+        this itself; anything else that reads the tensors (scripts, tests) calls it first.  Readers of cre_ids / gene_ids
+        also mind cre_unique_inverse / gene_unique_inverse: with window de-duplication the id tensors hold DISTINCT windows."""
+        if self.ready is not None:
+            (stream or torch.cuda.current_stream(self.cre_ids.device)).wait_event(self.ready)
+        return self
 
 
 class _HostStager:
@@ -146,21 +155,34 @@ def _context_kv_table(ctx_embedding: nn.Embedding, layer) -> torch.Tensor:
     return c[1]
 
 
-_LN_HEAL = {"batches": 0, "logged": False}
-LN_HEAL_STICKY_AFTER = 2      # alerting batches after which the fold stays off for the process
+_LN_HEAL = {"batches": 0, "finished": 0, "logged": False, "recent": collections.deque(maxlen=16)}
+LN_HEAL_STICKY_AFTER = 2      # alerting batches among the last len(_LN_HEAL["recent"]) finished ones (a RATE, 2 of 16 = the
+                              # point where a second forward per alerting batch costs as much as running unfolded) after which
+                              # the fold stays off for the process
 
 
-def _heal_if_ln_fold_alert(device, recompute):
-    """Called where a batch's outputs were copied back.  One device int (ops.ln_fold_alert) says whether some row of a
-    LayerNorm-folded stream left the regime the fold serves: |mean| > ops.LN_FOLD_RATIO_LIMIT standard deviations (rounding
-    the UNCENTRED row to 16 bits costs accuracy there) or an element a scaled fp16 copy could not hold.
-    Then the batch is RECOMPUTED with the separate LayerNorm on fp32 rows (layers.ln_fold_forced_off: bit for bit a
-    VF_LN_FOLD=0 run) and `recompute()`'s result is returned; degraded numbers never leave the model.  The reference's plain
-    nn.LayerNorm (seq2gene/modules/layers.py:75-77,99-163) has no such regime.  Returns None when nothing tripped.
-    After LN_HEAL_STICKY_AFTER such batches the fold is switched off for the process (one INFO line either way)."""
-    if device.type != "cuda":
-        return None
-    bits = ops.ln_fold_alert(device)
+def ln_fold_state() -> dict:
+    """The self-healing LayerNorm fold's bookkeeping, for drivers and logs: whether the fold is on, how many batches were
+    finished / recomputed, whether it was switched off for the process (WARNING-logged when it happens)."""
+    from .modules import layers as _layers
+    return {"enabled": not _layers._LN_FOLD_DISABLED and os.environ.get("VF_LN_FOLD", "1") != "0",
+            "switched_off_for_process": bool(_layers._LN_FOLD_DISABLED),
+            "batches_finished": int(_LN_HEAL["finished"]), "batches_recomputed": int(_LN_HEAL["batches"])}
+
+
+def _heal_if_ln_fold_alert(flag, recompute):
+    """Called where a batch's outputs were copied back.  `flag`: the batch's OWN alert bits (ops.ln_fold_alert_take, enqueued
+    right behind the batch's last kernel on its stream -- a device int, or already an int): whether some row of a
+    LayerNorm-folded stream of THIS batch left the regime the fold serves: |mean| > ops.LN_FOLD_RATIO_LIMIT standard
+    deviations (rounding the UNCENTRED row to 16 bits costs accuracy there) or an element a scaled fp16
+    copy could not hold.  Then the batch is RECOMPUTED with the separate LayerNorm on fp32 rows (layers.ln_fold_forced_off,
+    thread-local: bit for bit a VF_LN_FOLD=0 run) and `recompute()`'s result is returned; degraded numbers never leave the
+    model, however deep the caller pipelines predict_launch / predict_finish.  The reference's plain nn.LayerNorm
+    (seq2gene/modules/layers.py:75-77,99-163) has no such regime.  Returns None when nothing tripped.
+    When LN_HEAL_STICKY_AFTER of the last 16 finished batches alerted, the fold is switched off for the process (WARNING)."""
+    bits = 0 if flag is None else int(flag.item() if isinstance(flag, torch.Tensor) else flag)
+    _LN_HEAL["finished"] += 1
+    _LN_HEAL["recent"].append(bool(bits))
     if not bits:
         return None
     from .modules import layers as _layers
@@ -175,12 +197,22 @@ def _heal_if_ln_fold_alert(device, recompute):
                                              (2, "an element beyond the fp16 copies' range")) if bits & b))
     with _layers.ln_fold_forced_off():
         out = recompute()
-    ops.ln_fold_alert(device)         # the recomputation raises nothing; clear whatever a concurrent stream left
-    if _LN_HEAL["batches"] == LN_HEAL_STICKY_AFTER:
+    if not _layers._LN_FOLD_DISABLED and sum(_LN_HEAL["recent"]) >= LN_HEAL_STICKY_AFTER:
         _layers.ln_fold_disable()
-        log.info("variantformer_amd: %d batches tripped the folded-LayerNorm alert; the fold is off for the rest of this "
-                 "process (set VF_LN_FOLD=0 to start that way)", LN_HEAL_STICKY_AFTER)
+        log.warning("variantformer_amd: %d of the last %d batches tripped the folded-LayerNorm alert; the fold is OFF for the "
+                    "rest of this process (every batch now takes the separate LayerNorm pass; set VF_LN_FOLD=0 to start "
+                    "that way; state: variantformer_amd.seq2gene.model_combined_modulator.ln_fold_state())",
+                    sum(_LN_HEAL["recent"]), len(_LN_HEAL["recent"]))
     return out
+
+
+class PredictHandle:
+    """What predict_launch returns and predict_finish consumes.  OPAQUE: drivers pass it on, nothing else (its fields changed
+    between rounds and will again)."""
+    __slots__ = ("tissues", "pred", "emb", "model", "pb", "alert", "done")
+
+    def __init__(self, tissues, pred, emb, model, pb, alert, done):
+        self.tissues, self.pred, self.emb, self.model, self.pb, self.alert, self.done = tissues, pred, emb, model, pb, alert, done
 
 
 def _t(x):
@@ -500,10 +532,18 @@ class Seq2GenePredictorCombinedModulator(nn.Module):
             off = 0
             for v in parts:
                 n = int(v.shape[0])
-                if v.device.type == "cpu":
-                    np.copyto(dst[off:off + n], v.numpy()[:, 0, :], casting="unsafe")
-                else:
-                    buf[off:off + n].copy_(v[:, 0, :])
+                if v.device.type != "cpu":
+                    v = v.cpu()
+                src = v.numpy()[:, 0, :]
+                if dtype == torch.uint8:                          # masks: exactly 0 / 1 whatever the caller's dtype holds
+                    if src.dtype == np.bool_:
+                        np.copyto(dst[off:off + n], src, casting="unsafe")
+                    else:
+                        np.not_equal(src, 0, out=dst[off:off + n].view(np.bool_))
+                else:                                             # ids: the kernels clamp to [0, vocab); narrowing must not wrap first
+                    if n and src.dtype.itemsize > 4 and (int(src.min()) < -1 or int(src.max()) > 2 ** 31 - 1):
+                        src = np.clip(src, -1, 2 ** 31 - 1)       # same clamp result as the int64 path: < 0 -> 0, huge -> vocab - 1
+                    np.copyto(dst[off:off + n], src, casting="unsafe")
                 off += n
             return buf
         cre_ids, cre_pad = gather("cre_ids", x, torch.int32), gather("cre_pad", m, torch.uint8)
@@ -519,7 +559,9 @@ class Seq2GenePredictorCombinedModulator(nn.Module):
         cre_ctx = labels if use_ctx else None
         if dedupe_windows is not False:
             cre_np, gene_np = cre_ids.numpy(), gene_ids.numpy()
-            if (cre_np.size == 0 or int(cre_np.max()) < 2 ** 30) and (gene_np.size == 0 or int(gene_np.max()) < 2 ** 30):
+            def key_safe(a):         # the 64-bit row key packs (id | pad << 30): ids must lie in [0, 2^30)
+                return a.size == 0 or (int(a.min()) >= 0 and int(a.max()) < 2 ** 30)
+            if key_safe(cre_np) and key_safe(gene_np):
                 r = self._unique_windows(cre_np, cre_pad.numpy(), labels.numpy() if use_ctx else None)
                 if r is not None:
                     cre_keep, cre_inv = r
@@ -566,6 +608,7 @@ class Seq2GenePredictorCombinedModulator(nn.Module):
             cu_cre=cu_cre, cu_gene_self=cu_self, cu_gene_cross=cu_cross, gene_stream_idx=np.concatenate(idx),
             registry_rows=np.array(reg_rows, dtype=np.int64), cu_registry=np.arange(len(reg_rows) + 1, dtype=np.int32),
             cu_registry_cross=np.concatenate([[0], np.cumsum([len(t) for t in tissues])]).astype(np.int32))
+        host["tissues_used"] = np.unique(np.array([t for ts in tissues for t in ts], dtype=np.int64))
         if cre_ctx is not None:
             host["cre_ctx"] = cre_ctx
         if cre_inv is not None:
@@ -585,14 +628,13 @@ class Seq2GenePredictorCombinedModulator(nn.Module):
             cu_registry=d["cu_registry"], cu_registry_cross=d["cu_registry_cross"],
             max_tissues=max(len(t) for t in tissues),
             cre_unique_inverse=d.get("cre_unique_inverse"), gene_unique_inverse=d.get("gene_unique_inverse"),
-            ready=ready, windows_total=(sum(n_cre), sum(n_chunk)),
+            ready=ready, tissues_used=d["tissues_used"], windows_total=(sum(n_cre), sum(n_chunk)),
             windows_embedded=(int(cre_ids.shape[0]), int(gene_ids.shape[0])))
 
     def forward_prepared(self, pb: PreparedBatch, return_cre: bool = False):
         """The hot path: everything below runs as HIP kernels on the current stream.
         Returns (pred fp32 [sum T, 1], emb fp32 [sum T, D])."""
-        if pb.ready is not None:                         # the side-stream upload of prepare_batch
-            torch.cuda.current_stream(pb.cre_ids.device).wait_event(pb.ready)
+        pb.wait()                                        # the side-stream upload of prepare_batch
         with ops.compute_dtype(self.operand_dtype()):
             return self._forward_prepared(pb, return_cre)
 
@@ -618,7 +660,8 @@ class Seq2GenePredictorCombinedModulator(nn.Module):
             return self._forward_general(pb, cre_x, gene_x, return_cre)
         # registry token per (gene, tissue) + that gene's chunk rows (:357-366, layers.py:508-521)
         gene_stream = ops.gather_rows_f32(gene_x, self.start_tkn.registry_tokens.weight, pb.gene_stream_idx)
-        uniq = (gene_x, self.start_tkn.registry_tokens.weight, pb.gene_stream_idx)     # what gene_stream's rows are copies of
+        # what gene_stream's rows are copies of (+ the registry rows in use: only they may raise the LayerNorm-fold alert)
+        uniq = (gene_x, self.start_tkn.registry_tokens.weight, pb.gene_stream_idx, pb.tissues_used)
         if return_cre:       # VEP needs every gene token of the last layer (token-position gathers)
             gene_out, cre_out = self._modulator_forward_packed(
                 cre_x, gene_stream, pb.labels, pb.cu_cre, pb.max_cre, pb.cu_gene_self, pb.max_gene,
@@ -754,27 +797,36 @@ class Seq2GenePredictorCombinedModulator(nn.Module):
         with torch.no_grad():
             return self.predict_finish(self.predict_launch(self.prepare_batch(batch)), batch_idx, dataloader_idx)
 
-    def predict_launch(self, pb: PreparedBatch):
+    def predict_launch(self, pb: PreparedBatch) -> PredictHandle:
         """Enqueue the forward of a prepared batch; returns without waiting for the GPU (the kernels run on the
-        current stream).  `predict_finish` turns the handle into predict_step's dict.  Splitting the step lets a driver
-        build the next batch on the host while this one computes (processors/trainer.py)."""
+        current stream).  `predict_finish` turns the (opaque) handle into predict_step's dict.  Splitting the step lets a
+        driver build the next batch on the host while this one computes (processors/trainer.py); any pipelining depth
+        is fine: the batch's LayerNorm-fold alert is cut out of the stream's flag right here, behind its last kernel."""
+        dev = pb.cre_ids.device
         with torch.no_grad():
+            ops.ln_fold_alert_clear(dev)
             pred, emb = self.forward_prepared(pb)
-        return pb.tissues, pred, emb, self, pb
+            alert = ops.ln_fold_alert_take(dev)
+        done = None
+        if dev.type == "cuda":
+            done = torch.cuda.Event()
+            done.record(torch.cuda.current_stream(dev))
+        return PredictHandle(pb.tissues, pred, emb, self, pb, alert, done)
 
     @staticmethod
-    def predict_finish(handle, batch_idx, dataloader_idx=None):
-        tissues, pred, emb, model, pb = handle
-        dev = pred.device
+    def predict_finish(handle: PredictHandle, batch_idx, dataloader_idx=None):
+        tissues, model, pb = handle.tissues, handle.model, handle.pb
+        if handle.done is not None:
+            handle.done.synchronize()                        # the launch may have been enqueued on another stream
 
         def d2h(pe):
             return pe[0].detach().cpu().float().numpy(), pe[1].detach().cpu().float().numpy()
-        pred, emb = d2h((pred, emb))                         # D2H: the sync point of the step
+        pred, emb = d2h((handle.pred, handle.emb))           # D2H: the sync point of the step
 
         def recompute():
             with torch.no_grad():
                 return d2h(model.forward_prepared(pb))
-        healed = _heal_if_ln_fold_alert(dev, recompute)
+        healed = _heal_if_ln_fold_alert(handle.alert, recompute)
         if healed is not None:
             pred, emb = healed
         preds, embs, s = [], [], 0
@@ -805,10 +857,12 @@ class Seq2GenePredictorCombinedModulator(nn.Module):
                     x, batch["cre_attention_masks"], batch["tissue_context"], batch["ref_labels"], batch["strand"],
                     batch["gene_embeddings"], batch["gene_attention_masks"], return_embedding=True,
                     cre_token_position=cre_pos, gene_token_position=gene_pos, dedupe_windows=True)
-            return (pred.device, pred.cpu().float().numpy(), embd.cpu().float().numpy(), gtok.cpu().float().numpy(),
+            alert = ops.ln_fold_alert_take(pred.device)       # this batch's bits, behind its last kernel
+            return (alert, pred.cpu().float().numpy(), embd.cpu().float().numpy(), gtok.cpu().float().numpy(),
                     ctok.cpu().float().numpy())
-        dev, pred, embd, gtok, ctok = run()
-        healed = _heal_if_ln_fold_alert(dev, run)
+        ops.ln_fold_alert_clear(self.device)
+        alert, pred, embd, gtok, ctok = run()
+        healed = _heal_if_ln_fold_alert(alert, run)
         if healed is not None:
             _, pred, embd, gtok, ctok = healed
         out = {"pred_gene_exp": [], "embd": [], "variant_type": batch["variant_type"],

@@ -12,6 +12,7 @@ Nothing here falls back to PyTorch math: each step is a call into libvf_hip.so (
 from __future__ import annotations
 
 import math
+import threading
 from typing import Optional
 
 import torch
@@ -111,30 +112,37 @@ def packed_linear_ln(lin: nn.Linear, norm: nn.LayerNorm, geglu: bool = False, ws
     return wb, b, colsum
 
 
-_LN_FOLD_FORCED_OFF = 0        # > 0: inside ln_fold_forced_off() (or switched off for the process by ln_fold_disable())
+_LN_FOLD_TLS = threading.local()       # .off > 0: this THREAD is inside ln_fold_forced_off() (a recomputation in one thread must
+                                       # not flip the path of a forward running in another)
+_LN_FOLD_DISABLED = False              # ln_fold_disable(): off for the whole process, on purpose
 
 
 class ln_fold_forced_off:
-    """Context: every layer takes the separate-LayerNorm path on fp32 rows, exactly as with VF_LN_FOLD=0, whatever the
-    environment says.  The model recomputes a batch under it when the statistics kernels flagged rows the folded form does
-    not serve (ops.ln_fold_alert): the same kernels, the same arithmetic, the same bits as a VF_LN_FOLD=0 run."""
+    """Context: every layer (of forwards issued by THIS thread) takes the separate-LayerNorm path on fp32 rows, exactly as with
+    VF_LN_FOLD=0, whatever the environment says.  The model recomputes a batch under it when the statistics kernels flagged
+    rows the folded form does not serve (ops.ln_fold_alert_take): the same kernels, the same arithmetic, the same bits as a
+    VF_LN_FOLD=0 run."""
 
     def __enter__(self):
-        global _LN_FOLD_FORCED_OFF
-        _LN_FOLD_FORCED_OFF += 1
+        _LN_FOLD_TLS.off = getattr(_LN_FOLD_TLS, "off", 0) + 1
         return self
 
     def __exit__(self, *exc):
-        global _LN_FOLD_FORCED_OFF
-        _LN_FOLD_FORCED_OFF -= 1
+        _LN_FOLD_TLS.off -= 1
         return False
 
 
 def ln_fold_disable():
     """Switch the fold off for the rest of the process (a checkpoint that keeps tripping the alert: stop paying for two
     forwards and two weight packings per batch)."""
-    global _LN_FOLD_FORCED_OFF
-    _LN_FOLD_FORCED_OFF += 1 << 20
+    global _LN_FOLD_DISABLED
+    _LN_FOLD_DISABLED = True
+
+
+def ln_fold_reenable():
+    """Undo ln_fold_disable() (tests; a driver that swapped checkpoints)."""
+    global _LN_FOLD_DISABLED
+    _LN_FOLD_DISABLED = False
 
 
 def ln_fold_enabled(*widths: int) -> bool:
@@ -144,7 +152,7 @@ def ln_fold_enabled(*widths: int) -> bool:
     an fp16 stream's 16-bit copy is stored scaled by a power of two (ops.x16_scale_for), so the raw residual cannot leave
     the fp16 range."""
     import os
-    return (_LN_FOLD_FORCED_OFF == 0 and all(int(w) % 64 == 0 for w in widths)
+    return (not _LN_FOLD_DISABLED and getattr(_LN_FOLD_TLS, "off", 0) == 0 and all(int(w) % 64 == 0 for w in widths)
             and os.environ.get("VF_LN_FOLD", "1") != "0")
 
 
@@ -446,16 +454,21 @@ class ContextFlashAttentionEncoderLayer(nn.Module):
         if use_alibi:
             self.register_buffer("m", get_alibi_slopes(self.num_heads))
 
-    def self_qkv_of_unique_rows(self, rows_a, rows_b, idx):
+    def self_qkv_of_unique_rows(self, rows_a, rows_b, idx, rows_b_used=None):
         """LayerNorm1 + Wqkv of a stream whose rows are copies of the rows of two small tables (the gene stream entering
         the FIRST gene layer: every tissue's copy of a gene holds the same chunk rows, only the registry row differs):
         projected once per distinct row, then expanded.  idx int64 [tokens]: >= 0 row of rows_a, < 0 row -idx-1 of rows_b.
-        Exact: LayerNorm and the projection are row-wise.  None when the LayerNorm fold is off (fp16 mode)."""
+        Exact: LayerNorm and the projection are row-wise.  None when the LayerNorm fold is off (fp16 mode).
+        rows_b_used int64 [k] (optional): the rows of table b the stream actually holds -- only THEY may raise the
+        LayerNorm-fold alert (an anomalous registry row of a tissue nobody asked for must not flag every batch)."""
         if not ln_fold_enabled(self.norm1.weight.numel(), self.linear_geglu_2.in_features):
             return None
         w, b, c = self.mixer.MHA.packed_qkv_ln(self.norm1)
         qa = ops.gemm_ln_consumer(ops.ln_stream(rows_a.float().contiguous()), w, b, c, ops.EPI_BF16)
-        qb = ops.gemm_ln_consumer(ops.ln_stream(rows_b.float().contiguous()), w, b, c, ops.EPI_BF16)
+        tab_b = rows_b.float().contiguous()
+        if rows_b_used is not None:
+            ops.ln_stream(tab_b[rows_b_used].contiguous())       # statistics of the rows in use: raises the alert, result unused
+        qb = ops.gemm_ln_consumer(ops.ln_stream(tab_b, raise_alert=rows_b_used is None), w, b, c, ops.EPI_BF16)
         both = torch.cat([qa, qb], dim=0)                        # (a few thousand rows: index plumbing, not data movement)
         idx2 = torch.where(idx >= 0, idx, rows_a.shape[0] - idx - 1)
         return ops.gather_rows_bf16(both, idx2)

@@ -24,7 +24,8 @@ POOL_BEFORE_DOWN_PROJECTION = True
 # The first layer's LayerNorm1 -> Wqkv is looked up per distinct input row (Seq2RegPredictor._layer0_qkv_table).  False (tests
 # only): project every token.
 LAYER0_QKV_TABLE = True
-LAYER0_QKV_TABLE_MAX_ROWS = 1 << 20          # vocab * token_length rows of 3 d 16-bit values (500 x 200 x 3 KB = 307 MB shipped)
+LAYER0_QKV_TABLE_MAX_BYTES = 1 << 30         # cap on vocab * token_length rows of 3 d 16-bit values, per tokenizer and operand
+                                             # type (shipped: 500 x 200 rows x 3 KB = 307 MB); above it every token is projected
 
 
 def positionalencoding1d(d_model: int, length: int) -> torch.Tensor:
@@ -114,20 +115,32 @@ class Seq2RegPredictor(nn.Module):
         V = self.token_embedding.weight.shape[0]
         key_L = pos.shape[0] if pos is not None else 1
         prm = [self.token_embedding.weight, l0.norm1.weight, l0.norm1.bias, l0.MHA.Wqkv.weight, l0.MHA.Wqkv.bias]
-        key = (str(device), ops.cdt(), key_L) + tuple((p.data_ptr(), p._version) for p in prm)
-        if getattr(self, "_qkv_tab_key", None) != key:
-            ids = torch.arange(V, device=device, dtype=torch.int64).view(V, 1).expand(V, key_L).contiguous()
-            pad = torch.zeros((V, key_L), dtype=torch.uint8, device=device)
-            cu = (torch.arange(V + 1, device=device, dtype=torch.int32) * key_L).contiguous()
-            # rows no token may ever show (unused ids) must not raise the LayerNorm-fold alert: the tokens of a batch raise it
-            # themselves (their own vf_embed_stream pass), and the recomputation does not come through this table
-            alert = ops._alert_flag(device)
-            before = alert.clone()
-            s = ops.embed_stream(ids, pad, cu, self.token_embedding.weight, pos, V * key_L, need_t16=False)
-            alert.copy_(before)
-            w, b, c = l0.MHA.packed_qkv_ln(l0.norm1)
-            self._qkv_tab, self._qkv_tab_key = ops.gemm_ln_consumer(s, w, b, c, ops.EPI_BF16, family="seq2reg"), key
-        return self._qkv_tab, key_L
+        if pos is not None:
+            prm.append(pos)                                   # the positional table is an input of every row too
+        key = (str(device), key_L) + tuple((p.data_ptr(), p._version) for p in prm)
+        slots = self.__dict__.setdefault("_qkv_tabs", {})    # one slot per operand type (a bf16 <-> fp16 switch rebuilds nothing)
+        hit = slots.get(ops.cdt())
+        if hit is not None and hit[0] == key:
+            return hit[1], key_L
+        ids = torch.arange(V, device=device, dtype=torch.int64).view(V, 1).expand(V, key_L).contiguous()
+        pad = torch.zeros((V, key_L), dtype=torch.uint8, device=device)
+        cu = (torch.arange(V + 1, device=device, dtype=torch.int32) * key_L).contiguous()
+        # rows no token may ever show (unused ids) must not raise the LayerNorm-fold alert: the tokens of a batch raise it
+        # themselves (their own vf_embed_stream pass), and the recomputation does not come through this table
+        alert = ops._alert_flag(device)
+        before = alert.clone()
+        s = ops.embed_stream(ids, pad, cu, self.token_embedding.weight, pos, V * key_L, need_t16=False)
+        alert.copy_(before)
+        w, b, c = l0.MHA.packed_qkv_ln(l0.norm1)
+        slots[ops.cdt()] = (key, ops.gemm_ln_consumer(s, w, b, c, ops.EPI_BF16, family="seq2reg"))
+        return slots[ops.cdt()][1], key_L
+
+    def _layer0_qkv_table_bytes(self) -> int:
+        """Size the table of _layer0_qkv_table would have: vocab * key_L rows (key_L = rows of the positional table, NOT the
+        batch's window length) of 3 d 16-bit values."""
+        key_L = self.position_encoding.shape[0] if self.pos_encoding_type == "sinusoidal" else 1
+        V, d = self.token_embedding.weight.shape
+        return int(V) * int(key_L) * 3 * int(d) * 2
 
     def embed_packed(self, ids: torch.Tensor, pad: torch.Tensor, n_tokens: int, out_dtype=None,
                      max_len: int = 0, context: torch.Tensor | None = None):
@@ -170,7 +183,7 @@ class Seq2RegPredictor(nn.Module):
                 V = self.token_embedding.weight.shape[0]
                 if (LAYER0_QKV_TABLE and ln_fold_enabled(l0.norm1.weight.numel(), l0.linear_geglu_2.in_features) and
                         self.token_embedding.weight.shape[1] <= 2048 and
-                        V * (L if self.pos_encoding_type == "sinusoidal" else 1) <= LAYER0_QKV_TABLE_MAX_ROWS):
+                        self._layer0_qkv_table_bytes() <= LAYER0_QKV_TABLE_MAX_BYTES):
                     tab, key_L = self._layer0_qkv_table(ids.device)
                     qkv0 = ops.gather_rows_bf16(tab, ops.token_keys(ids, pad, cu, n_tokens, V, key_L))
                 for li, layer in enumerate(self.transformer_encoder):
