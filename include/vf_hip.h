@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define VF_ABI_VERSION 7
+#define VF_ABI_VERSION 8
 
 enum vf_status {
     VF_OK = 0,
@@ -190,6 +190,24 @@ int vf_attn_varlen_fwd_v2(const void* q, const void* k, const void* v, void* out
                           int n_seq, int max_seqlen_q, int max_seqlen_k,
                           int H, int dh, const float* alibi_slopes, float scale,
                           int operand_dtype, int flags, void* stream);
+
+/* Row-map form (ABI 8): q / k / v are TABLES of distinct rows and the gather happens in the kernel's loads -- token t's query
+ * is row q_rows[t] of q, its key / value rows are row kv_rows[t] of k / v (int64 maps over the packed tokens; either may be
+ * null = row t itself); the output row of token t is row t of out.  Serves the first layers' projection-by-lookup: the
+ * encoder's first LayerNorm1 -> Wqkv depends on (token id, position) alone (seq2reg/model.py:215-220,
+ * seq2reg/modules.py:152-160), the first gene layer's on the distinct chunk / registry rows
+ * (seq2gene/model_combined_modulator.py:622-649 repeats them per tissue), so the [tokens, 3 D] projection a row gather
+ * would materialise is never written or re-read.  Same arithmetic per query as vf_attn_varlen_fwd_v2 on the gathered rows
+ * (bit-identical).  Only the geometries vf_attn_rows_supported() reports have a row-map kernel (the one-block-per-sequence
+ * kernel: dh 64 without bias / dh 48 with ALiBi, sequences <= 256 tokens, VF_ATTN_Q_LOG2 set); any other geometry is
+ * rejected with VF_ERR_INVALID_ARG -- gather the rows (vf_gather_rows_bf16) and call the plain entry there. */
+int vf_attn_rows_supported(int dh, int alibi, int n_seq, int H, int max_seqlen_q, int max_seqlen_k, int flags);
+int vf_attn_varlen_fwd_rows(const void* q, const void* k, const void* v, void* out,
+                            int64_t q_stride, int64_t k_stride, int64_t v_stride, int64_t o_stride,
+                            const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k,
+                            int n_seq, int max_seqlen_q, int max_seqlen_k,
+                            int H, int dh, const float* alibi_slopes, float scale,
+                            int operand_dtype, int flags, const int64_t* q_rows, const int64_t* kv_rows, void* stream);
 
 /* y = LayerNorm(x) * gamma + beta over the last dim (eps inside sqrt, biased variance), optional
  * exact-erf GELU, output fp32, bf16 or fp16 (out_dtype = vf_dtype).  x fp32 [rows, D], D % 4 == 0, D <= 8192.

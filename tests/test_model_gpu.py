@@ -128,7 +128,7 @@ def test_seq2reg_first_layer_qkv_lookup_is_bit_identical(precision, pos):
     m = s2r.Seq2RegPredictor(vocab_size=500, embedding_dim=512, num_heads=8, num_layers=2, num_tissues=2, num_classes=2,
                              token_length=200, use_flash=True, positional_encoding=pos, seq_pool="mean").cuda()
     rng = np.random.default_rng(4)
-    lens = [200, 1, 2, 63, 64, 65, 199, 0] + list(rng.integers(1, 201, 40))
+    lens = [200, 1, 2, 63, 64, 65, 199, 0] + list(rng.integers(1, 201, 140))     # 148 windows x 8 heads: the row-map attention kernel serves it
     W, L = len(lens), 200
     ids = torch.from_numpy(rng.integers(0, 500, (W, L))).long()
     ids[0, :4] = torch.tensor([0, 499, 700, -3])
@@ -137,16 +137,20 @@ def test_seq2reg_first_layer_qkv_lookup_is_bit_identical(precision, pos):
         pad[w, :n] = False
     pad[6, 50:60] = True                                             # pads inside a window: positions are not ranks
     outs = {}
+    import variantformer_amd.seq2gene.modules.layers as Lyr
+    assert ops.attn_rows_supported(64, False, W, 8, 200, 200, True)
     try:
-        for flag in (True, False):
-            s2r.LAYER0_QKV_TABLE = flag
+        for flag in (True, False, "gathered"):        # lookup + gather in the attention's loads / no lookup / lookup + row gather
+            s2r.LAYER0_QKV_TABLE = bool(flag)
+            Lyr.ROWS_IN_ATTENTION = flag is True
             with ops.compute_dtype(torch.bfloat16 if precision == "bf16-mixed" else torch.float16), torch.no_grad():
                 outs[flag] = m.embed_packed(ids.cuda(), pad.cuda(), int((~pad).sum()), torch.float32).cpu()
     finally:
         s2r.LAYER0_QKV_TABLE = True
+        Lyr.ROWS_IN_ATTENTION = True
     keep = [w for w in range(W) if w != 7]
     assert torch.isfinite(outs[False][keep]).all() and float(outs[False][keep].abs().max()) > 0.1
-    assert torch.equal(outs[True][keep], outs[False][keep])
+    assert torch.equal(outs[True][keep], outs[False][keep]) and torch.equal(outs["gathered"][keep], outs[False][keep])
     assert torch.isnan(outs[True][7]).all()
     # the keys themselves
     cu = ops.mask_to_cu_seqlens(pad.cuda())
@@ -249,6 +253,27 @@ def test_first_gene_layer_projection_dedup_is_exact(monkeypatch):
     for i in range(2):
         np.testing.assert_array_equal(a["pred_gene_exp"][i], b["pred_gene_exp"][i])
         np.testing.assert_array_equal(a["embeddings"][i], b["embeddings"][i])
+
+
+def test_first_gene_layer_row_map_attention_is_exact(monkeypatch):
+    """With 129-256 gene tokens the first gene layer's self attention reads the distinct projected rows THROUGH the row map
+    (vf_attn_varlen_fwd_rows) instead of a materialised [tokens, 3 D] gather: bit-identical to the gathered form and to
+    projecting every row (ragged batch: 151- and 21-token sequences in one launch)."""
+    import variantformer_amd.seq2gene.modules.layers as Lyr
+    from variantformer_amd import ops
+    kw = seq2gene_kw(layers=2)
+    model = build_model(SEQ2REG_512, kw, seed=78).cuda()
+    batch = make_batch(6, [9, 5], [150, 20], [TISSUES_54[:3], [9, 33]], 200)
+    assert ops.attn_rows_supported(48, True, 5, 32, 151, 151, True)
+    a = model.predict_step(batch, 0)
+    monkeypatch.setattr(Lyr, "ROWS_IN_ATTENTION", False)
+    b = model.predict_step(batch, 0)
+    monkeypatch.setattr(Lyr.ContextFlashAttentionEncoderLayer, "self_qkv_of_unique_rows", lambda self, *args: None)
+    c = model.predict_step(batch, 0)
+    for i in range(2):
+        np.testing.assert_array_equal(a["pred_gene_exp"][i], b["pred_gene_exp"][i])
+        np.testing.assert_array_equal(a["embeddings"][i], b["embeddings"][i])
+        np.testing.assert_array_equal(a["embeddings"][i], c["embeddings"][i])
 
 
 def test_tissue_invariance_and_batch_independence():

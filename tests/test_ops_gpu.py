@@ -1249,3 +1249,45 @@ def test_segment_mean16_vs_float64(ops, dtype, d):
         assert float((f[w].double().cpu() - ref).abs().max()) <= 2e-6 * tol + 1e-30
         rec = sp[w, :d].double().cpu() + sp[w, d:].double().cpu()
         assert float((rec - ref).abs().max()) <= 2 ** -15 * tol
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("geom", ["seq2reg_windows", "seq2reg_chunks", "gene_self"])
+def test_attention_row_map_form_is_bit_identical_to_gather_then_attend(ops, dtype, geom):
+    """vf_attn_varlen_fwd_rows (ABI 8): q / k / v are tables of distinct projected rows and the kernel gathers in its loads
+    (the first layers' projection by lookup).  Bit for bit the plain entry on the gathered rows, for the three geometries
+    that have a row-map kernel (ragged sequences, a one-token sequence, duplicate and out-of-order table rows); any other
+    geometry is reported unsupported and rejected by name."""
+    td = torch.bfloat16 if dtype == "bf16" else torch.float16
+    rng = np.random.default_rng(11)
+    if geom == "seq2reg_windows":
+        dh, H, alibi, lens = 64, 8, False, [int(x) for x in rng.integers(1, 129, 160)] + [128, 1]
+    elif geom == "seq2reg_chunks":
+        dh, H, alibi, lens = 64, 8, False, [int(x) for x in rng.integers(100, 201, 140)] + [200, 129, 7]
+    else:
+        dh, H, alibi, lens = 48, 32, True, [201, 201, 130, 37, 201, 1, 220]      # (a 256-key image leaves no room for 3 blocks: no row-map kernel)
+    D = H * dh
+    n_tab = 5000
+    tab = (_rand((n_tab, 3 * D), 71, 1.5)).cuda().to(td)
+    T = sum(lens)
+    rows = torch.from_numpy(rng.integers(0, n_tab, T)).long()
+    rows[:7] = rows[0]                                   # duplicates
+    rows = rows.cuda().contiguous()
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32).cuda()
+    slopes = torch.tensor([2.0 ** (-(i + 1) / 4) for i in range(H)], dtype=torch.float32).cuda() if alibi else None
+    assert ops.attn_rows_supported(dh, alibi, len(lens), H, max(lens), max(lens), True)
+    got = ops.attn_varlen(tab[:, :D], tab[:, D:2 * D], tab[:, 2 * D:], cu, None, max(lens), max(lens), H, dh, slopes,
+                          q_log2=True, rows=rows)
+    g = ops.gather_rows_bf16(tab, rows)
+    want = ops.attn_varlen(g[:, :D], g[:, D:2 * D], g[:, 2 * D:], cu, None, max(lens), max(lens), H, dh, slopes, q_log2=True)
+    torch.cuda.synchronize()
+    assert got.shape == want.shape == (T, D) and torch.isfinite(got.float()).all()
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+    # geometries without a row-map kernel: reported, and rejected by the entry itself
+    assert not ops.attn_rows_supported(dh, alibi, len(lens), H, 300, 300, True)
+    assert not ops.attn_rows_supported(dh, alibi, len(lens), H, max(lens), max(lens), False)
+    assert not ops.attn_rows_supported(32, alibi, len(lens), H, max(lens), max(lens), True)
+    from variantformer_amd._lib import VFError
+    with pytest.raises(VFError, match="row-map"):
+        ops.attn_varlen(tab[:, :D], tab[:, D:2 * D], tab[:, 2 * D:], cu, None, max(lens), max(lens), H, dh, slopes,
+                        q_log2=False, rows=rows)

@@ -90,6 +90,9 @@ struct AttnParams {
                         // (flash-attn convention), 1 = query i sits at position i
     int q_log2;         // 1: Q was projected with weights pre-multiplied by scale * log2(e) (VF_ATTN_Q_LOG2): scores are
                         // base-2 logits as they leave the matrix pipe, scale_log2 = 1
+    const int64_t* q_rows;   // optional row maps (vf_attn_varlen_fwd_rows): token t's query row is row q_rows[t] of q, its key /
+    const int64_t* kv_rows;  // value rows are row kv_rows[t] of k / v -- the operands are TABLES of distinct rows (the first
+                             // layers' projections by lookup) and the gather happens in the loads; null: row t itself
 #if defined(VF_SHORT_PROF) || defined(VF_X32PP_PROF)
     unsigned long long* prof;   // scripts/probes/attn_*_probe.hip only
 #endif
@@ -1028,7 +1031,8 @@ __global__ __launch_bounds__(256, (QG >= 2 ? 2 : 4)) void attn_short_kernel(Attn
 // NPASS = 2 at dh = 64 (round 4): 129-256-token chunks (seq2reg's gene chunks), 62 KB image = two blocks per CU.  The register
 // budget stays that of three waves per SIMD: at (256, 2) the compiler hoists loads up to 256 VGPRs + 47 spilled and the launch
 // takes 2369 us instead of 1329 us (168 VGPRs, 12 spilled) -- profiles/r04_k.
-template <int DH, bool ALIBI, int DT = VF_BF16, bool QL = false, int NPASS = 2>
+// ROWS: Q / K / V rows are fetched through AttnParams::q_rows / kv_rows (one index load per row in front of the data loads).
+template <int DH, bool ALIBI, int DT = VF_BF16, bool QL = false, int NPASS = 2, bool ROWS = false>
 __global__ __launch_bounds__(256, 3) void attn_short2_kernel(AttnParams P, int k_rows) {
     constexpr int SM = QL ? 2 : 0;
     using frag_t = typename Op16<DT>::frag;
@@ -1066,7 +1070,8 @@ __global__ __launch_bounds__(256, 3) void attn_short2_kernel(AttnParams P, int k
         for (int qg = 0; qg < QG; ++qg) {
             const int qa = (wave + 4 * (QG * ps + qg)) * 16 + r;
             const int row = qa < len_q ? qa : len_q - 1;
-            const unsigned short* qp = P.q + (int64_t)(q_tok0 + row) * P.q_stride + h * DH;
+            const int64_t qrow = (ROWS && P.q_rows) ? P.q_rows[q_tok0 + row] : (int64_t)(q_tok0 + row);
+            const unsigned short* qp = P.q + qrow * P.q_stride + h * DH;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const int d0 = 32 * ks + 8 * g;
@@ -1076,10 +1081,17 @@ __global__ __launch_bounds__(256, 3) void attn_short2_kernel(AttnParams P, int k
             }
         }
     // ---- stage K (swizzled, zero pad chunks) and V; rows >= len_k replicate the last key (finite, masked later)
-    const unsigned short* kbase = P.k + (int64_t)k_tok0 * P.k_stride + h * DH;
-    const unsigned short* vbase = P.v + (int64_t)k_tok0 * P.v_stride + h * DH;
+    const unsigned short* kbase = P.k + h * DH;
+    const unsigned short* vbase = P.v + h * DH;
     {
         u32x4_t kbuf[MAXIT], vbuf[MAXIT];
+        int64_t src[MAXIT];                          // source row of every staged row: all index loads in flight before the data loads
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            const int row = (tid + 256 * it) >> 3;
+            const int key = row < len_k ? row : len_k - 1;
+            src[it] = (ROWS && P.kv_rows) ? (row < rows_v ? P.kv_rows[k_tok0 + key] : 0) : (int64_t)(k_tok0 + key);
+        }
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
             const int ci = tid + 256 * it;
@@ -1087,9 +1099,8 @@ __global__ __launch_bounds__(256, 3) void attn_short2_kernel(AttnParams P, int k
             kbuf[it] = (HwMask<DH>::value && cc == CPR) ? mask_chunk<DT>(row < len_k) : (u32x4_t){0u, 0u, 0u, 0u};
             vbuf[it] = (u32x4_t){0u, 0u, 0u, 0u};
             if (row < rows_v && cc < CPR) {
-                const int key = row < len_k ? row : len_k - 1;
-                if (row < rows_k) kbuf[it] = *reinterpret_cast<const u32x4_t*>(kbase + (int64_t)key * P.k_stride + cc * 8);
-                vbuf[it] = *reinterpret_cast<const u32x4_t*>(vbase + (int64_t)key * P.v_stride + cc * 8);
+                if (row < rows_k) kbuf[it] = *reinterpret_cast<const u32x4_t*>(kbase + src[it] * P.k_stride + cc * 8);
+                vbuf[it] = *reinterpret_cast<const u32x4_t*>(vbase + src[it] * P.v_stride + cc * 8);
             }
         }
 #pragma unroll
@@ -1227,12 +1238,12 @@ static inline void short2_rows(int max_k, int& kr, int& vr) {
     vr = tl * BKV + (rem <= 32 ? 32 : BKV);
 }
 
-template <int DH, bool ALIBI, int DT, bool QL, int NPASS>
+template <int DH, bool ALIBI, int DT, bool QL, int NPASS, bool ROWS = false>
 int launch_short2_k(AttnParams P, int n_seq, int max_k, hipStream_t st) {
     int kr, vr;
     short2_rows(max_k, kr, vr);
     const int lds = kr * KLayout<DH>::ROW + vr * VLayout<DH>::ROW;
-    auto kern = attn_short2_kernel<DH, ALIBI, DT, QL, NPASS>;
+    auto kern = attn_short2_kernel<DH, ALIBI, DT, QL, NPASS, ROWS>;
     static bool attr_set[VF_MAX_DEVICES] = {};
     const int dev = vf_current_device();
     if (dev < 0 || !attr_set[dev]) {
@@ -1252,6 +1263,13 @@ int launch_short2_k(AttnParams P, int n_seq, int max_k, hipStream_t st) {
 
 template <int DH, bool ALIBI, int DT, int NPASS = 2>
 int launch_short2(AttnParams P, int n_seq, int max_k, hipStream_t st) {
+    if (P.q_rows || P.kv_rows) {                 // only the model's call form (pre-scaled q) has a row-map instantiation
+        if constexpr ((DH == 64 && !ALIBI) || (DH == 48 && ALIBI && NPASS == 2)) {
+            if (P.q_log2) return launch_short2_k<DH, ALIBI, DT, true, NPASS, true>(P, n_seq, max_k, st);
+        }
+        vf_set_error("vf_attn_varlen_fwd_rows: no row-map kernel for this geometry (ask vf_attn_rows_supported first)");
+        return VF_ERR_INVALID_ARG;
+    }
     if (P.q_log2) return launch_short2_k<DH, ALIBI, DT, true, NPASS>(P, n_seq, max_k, st);
     return launch_short2_k<DH, ALIBI, DT, false, NPASS>(P, n_seq, max_k, st);
 }
@@ -1293,8 +1311,31 @@ int launch_x32pp(const AttnParams& P, dim3 grid, hipStream_t st) {
 }
 #endif
 
+// Geometries the row-map form (AttnParams::q_rows / kv_rows) serves: exactly those launch_attn sends to attn_short2_kernel
+// in the model's call form -- seq2reg windows / chunks (dh 64, no bias) and the gene stream's self attention (dh 48, ALiBi,
+// 129-256 tokens).  Everything else gathers the rows first (vf_gather_rows_bf16) and calls the plain entry: same bits.
+static bool rows_supported(int dh, bool alibi, long n_seq, int H, int max_q, int max_k, bool q_log2) {
+    if (!q_log2 || max_q <= 0 || max_k <= 0 || max_q > 256 || max_k > 256) return false;
+    int kr, vr;
+    short2_rows(max_k, kr, vr);
+    if (dh == 48 && alibi)
+        return max_q > 128 && vf_tuning_env("VF_ATTN_SHORT2", 1) && 3 * (kr * KLayout<48>::ROW + vr * VLayout<48>::ROW) <= 160 * 1024;
+    if (dh == 64 && !alibi) {
+        if (!vf_tuning_env("VF_ATTN_SHORT64", 1) || n_seq * H < 1024) return false;
+        const int image = kr * KLayout<64>::ROW + vr * VLayout<64>::ROW;
+        return (max_q <= 128 && max_k <= 128) ? 3 * image <= 160 * 1024 : 2 * image <= 160 * 1024;
+    }
+    return false;
+}
+
 template <int DH, bool ALIBI, int DT>
 int launch_attn(AttnParams P, int n_seq, int max_q, int max_k, hipStream_t st) {
+    if ((P.q_rows || P.kv_rows) && !rows_supported(DH, ALIBI, n_seq, P.H, max_q, max_k, P.q_log2 != 0)) {
+        vf_set_error("vf_attn_varlen_fwd_rows: no row-map kernel for dh=%d alibi=%d n_seq=%d H=%d max_q=%d max_k=%d "
+                     "(vf_attn_rows_supported says which geometries have one; gather the rows first otherwise)",
+                     DH, (int)ALIBI, n_seq, P.H, max_q, max_k);
+        return VF_ERR_INVALID_ARG;
+    }
     // Measured on MI355X (scripts/attn_bench.py, 8 genes): the one-block-per-(sequence, head) kernel wins for the gene
     // stream (201-token sequences, dh 48: 396 vs 485 us); for seq2reg windows / chunks (dh 64, <= 200 tokens) the tiled
     // kernel with 64-query blocks is faster (460 vs 613 us on 200-token chunks: more blocks in flight, fewer registers;
@@ -1386,7 +1427,8 @@ template <int DT>
 static int attn_dispatch(const void* q, const void* k, const void* v, void* out, int64_t q_stride,
                          int64_t k_stride, int64_t v_stride, int64_t o_stride, const int32_t* cu_seqlens_q,
                          const int32_t* cu_seqlens_k, int n_seq, int max_seqlen_q, int max_seqlen_k, int H,
-                         int dh, const float* alibi_slopes, float scale, int flags, void* stream) {
+                         int dh, const float* alibi_slopes, float scale, int flags, void* stream,
+                         const int64_t* q_rows = nullptr, const int64_t* kv_rows = nullptr) {
     const int q_at_start = flags & VF_ATTN_Q_AT_START, q_log2 = (flags & VF_ATTN_Q_LOG2) ? 1 : 0;
     VF_REQUIRE((flags & ~(VF_ATTN_Q_AT_START | VF_ATTN_Q_LOG2)) == 0, "vf_attn_varlen_fwd: unknown flag bits 0x%x", flags);
     VF_REQUIRE(q && k && v && out && cu_seqlens_q, "vf_attn_varlen_fwd: null pointer");
@@ -1410,6 +1452,7 @@ static int attn_dispatch(const void* q, const void* k, const void* v, void* out,
     P.cu_q = cu_seqlens_q; P.cu_k = cu_seqlens_k ? cu_seqlens_k : cu_seqlens_q;
     P.slopes = alibi_slopes; P.scale_log2 = q_log2 ? 1.0f : scale * 1.4426950408889634f; P.H = H;
     P.q_at_start = q_at_start ? 1 : 0; P.q_log2 = q_log2;
+    P.q_rows = q_rows; P.kv_rows = kv_rows;
     hipStream_t st = (hipStream_t)stream;
     const bool alibi = alibi_slopes != nullptr;
     switch (dh) {
@@ -1466,4 +1509,21 @@ extern "C" int vf_attn_varlen_fwd_v2(const void* q, const void* k, const void* v
     VF_REQUIRE(operand_dtype == VF_F16, "vf_attn_varlen_fwd_v2: operand_dtype must be VF_BF16 or VF_F16");
     return attn_dispatch<VF_F16>(q, k, v, out, q_stride, k_stride, v_stride, o_stride, cu_seqlens_q, cu_seqlens_k, n_seq,
                                  max_seqlen_q, max_seqlen_k, H, dh, alibi_slopes, scale, flags, stream);
+}
+
+extern "C" int vf_attn_rows_supported(int dh, int alibi, int n_seq, int H, int max_seqlen_q, int max_seqlen_k, int flags) {
+    return rows_supported(dh, alibi != 0, n_seq, H, max_seqlen_q, max_seqlen_k, (flags & VF_ATTN_Q_LOG2) != 0) ? 1 : 0;
+}
+
+extern "C" int vf_attn_varlen_fwd_rows(const void* q, const void* k, const void* v, void* out, int64_t q_stride,
+                                       int64_t k_stride, int64_t v_stride, int64_t o_stride, const int32_t* cu_seqlens_q,
+                                       const int32_t* cu_seqlens_k, int n_seq, int max_seqlen_q, int max_seqlen_k, int H,
+                                       int dh, const float* alibi_slopes, float scale, int operand_dtype, int flags,
+                                       const int64_t* q_rows, const int64_t* kv_rows, void* stream) {
+    VF_REQUIRE(operand_dtype == VF_BF16 || operand_dtype == VF_F16, "vf_attn_varlen_fwd_rows: operand_dtype must be VF_BF16 or VF_F16");
+    if (operand_dtype == VF_BF16)
+        return attn_dispatch<VF_BF16>(q, k, v, out, q_stride, k_stride, v_stride, o_stride, cu_seqlens_q, cu_seqlens_k, n_seq,
+                                      max_seqlen_q, max_seqlen_k, H, dh, alibi_slopes, scale, flags, stream, q_rows, kv_rows);
+    return attn_dispatch<VF_F16>(q, k, v, out, q_stride, k_stride, v_stride, o_stride, cu_seqlens_q, cu_seqlens_k, n_seq,
+                                 max_seqlen_q, max_seqlen_k, H, dh, alibi_slopes, scale, flags, stream, q_rows, kv_rows);
 }

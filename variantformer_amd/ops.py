@@ -461,21 +461,34 @@ def pack_geglu_rows(w: torch.Tensor, bias: torch.Tensor | None):
 ATTN_Q_AT_START, ATTN_Q_LOG2 = 1, 2          # enum vf_attn_flags
 
 
+def attn_rows_supported(head_dim: int, alibi: bool, n_seq: int, n_heads: int, max_q: int, max_k: int, q_log2: bool) -> bool:
+    """Whether attn_varlen(rows=...) has a kernel for this geometry (vf_attn_rows_supported); otherwise the caller gathers the
+    rows (gather_rows_bf16) and calls the plain form -- same bits either way."""
+    return bool(_lib.load().vf_attn_rows_supported(int(head_dim), int(bool(alibi)), int(n_seq), int(n_heads), int(max_q),
+                                                   int(max_k), ATTN_Q_LOG2 if q_log2 else 0))
+
+
 def attn_varlen(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_q: torch.Tensor, cu_k: torch.Tensor | None,
                 max_q: int, max_k: int, n_heads: int, head_dim: int, slopes: torch.Tensor | None = None,
                 scale: float | None = None, out: torch.Tensor | None = None, q_at_start: bool = False,
-                family: str = "", q_log2: bool = False) -> torch.Tensor:
+                family: str = "", q_log2: bool = False, rows: torch.Tensor | None = None) -> torch.Tensor:
     """q [tq, >=H*dh] / k, v [tk, >=H*dh] bf16 row-strided views whose first H*dh columns are the heads.
     q_at_start: ALiBi positions of the queries count from the start of the key sequence (default: flash-attn's
     end alignment).  q_log2: q was projected with weights pre-multiplied by scale * log2(e) (layers.q_prescale): q . k is the
-    base-2 logit, `scale` is not applied again (VF_ATTN_Q_LOG2)."""
-    _dev(q, k, v, cu_q, cu_k, slopes, out)
+    base-2 logit, `scale` is not applied again (VF_ATTN_Q_LOG2).
+    rows int64 [tokens] (self attention only, vf_attn_varlen_fwd_rows): q / k / v are tables of distinct rows, token t's
+    row is rows[t]; the gather happens in the kernel's loads (attn_rows_supported says for which geometries)."""
+    _dev(q, k, v, cu_q, cu_k, slopes, out, rows)
     for t in (q, k, v):
         assert _is16(t.dtype) and t.dtype == q.dtype and t.dim() == 2 and t.stride(1) == 1
     assert cu_q.dtype == torch.int32 and (cu_k is None or cu_k.dtype == torch.int32)
     D = n_heads * head_dim
+    tq = q.shape[0] if rows is None else rows.numel()
+    tk = k.shape[0] if rows is None else rows.numel()
+    if rows is not None:
+        assert rows.dtype == torch.int64 and rows.is_contiguous() and cu_k is None
     if out is None:
-        out = torch.empty((q.shape[0], D), dtype=q.dtype, device=q.device)
+        out = torch.empty((tq, D), dtype=q.dtype, device=q.device)
     if scale is None:
         scale = 1.0 / math.sqrt(head_dim)
     if slopes is not None:
@@ -483,6 +496,12 @@ def attn_varlen(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_q: torch.T
     def launch():
         lib = _lib.load()
         flags = (ATTN_Q_AT_START if q_at_start else 0) | (ATTN_Q_LOG2 if q_log2 else 0)
+        if rows is not None:
+            check(lib.vf_attn_varlen_fwd_rows(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), q.stride(0), k.stride(0),
+                                              v.stride(0), out.stride(0), cu_q.data_ptr(), None, cu_q.numel() - 1, int(max_q),
+                                              int(max_k), n_heads, head_dim, _ptr(slopes), float(scale), _dt(q.dtype), flags,
+                                              rows.data_ptr(), rows.data_ptr(), _stream()), "vf_attn_varlen_fwd_rows")
+            return
         check(lib.vf_attn_varlen_fwd_v2(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), q.stride(0), k.stride(0),
                                         v.stride(0), out.stride(0), cu_q.data_ptr(), _ptr(cu_k), cu_q.numel() - 1, int(max_q),
                                         int(max_k), n_heads, head_dim, _ptr(slopes), float(scale), _dt(q.dtype), flags,
@@ -492,8 +511,9 @@ def attn_varlen(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_q: torch.T
             lq = (cu_q[1:] - cu_q[:-1]).double()
             lk = lq if cu_k is None else (cu_k[1:] - cu_k[:-1]).double()
             return 4.0 * float((lq * lk).sum().item()) * D
-        TIMER.time("attn", flops, 2.0 * D * (2 * q.shape[0] + 2 * k.shape[0]), launch,
-                   f"H={n_heads} dh={head_dim} max_q={int(max_q)} max_k={int(max_k)}", family or _SCOPE)
+        TIMER.time("attn", flops, 2.0 * D * (2 * tq + 2 * tk), launch,
+                   f"H={n_heads} dh={head_dim} max_q={int(max_q)} max_k={int(max_k)}" + (" rows" if rows is not None else ""),
+                   family or _SCOPE)
     else:
         launch()
     return out

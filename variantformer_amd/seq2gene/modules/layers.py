@@ -228,6 +228,9 @@ def _ffn_residual(s):
     return s.x if s.x is not None else s
 
 
+ROWS_IN_ATTENTION = True      # False (tests only): always materialise the gathered projection in front of the attention
+
+
 def _as_stream(x):
     return x if isinstance(x, ops.LnStream) else ops.ln_stream(x)
 
@@ -341,13 +344,20 @@ class MHA(nn.Module):
         qkv = ops.gemm_ln_consumer(s, w, b, c, ops.EPI_BF16)
         return self.attend_qkv(qkv, cu_q, max_q)
 
-    def attend_qkv(self, qkv, cu_q, max_q) -> torch.Tensor:
+    def attend_qkv(self, qkv, cu_q, max_q, rows=None) -> torch.Tensor:
         """self attention on a packed [tokens, 3D] 16-bit projection (rows ordered (three, head, dh)) made with packed_qkv /
-        packed_qkv_ln (its Q third carries the softmax scale when q_prescale_enabled)."""
+        packed_qkv_ln (its Q third carries the softmax scale when q_prescale_enabled).
+        rows int64 [tokens]: qkv is a TABLE of distinct projected rows and token t's row is rows[t] (the first layers'
+        projection by lookup): the attention kernel gathers in its loads where it can (ops.attn_rows_supported); otherwise
+        the rows are gathered first -- the same bits either way."""
         D = self.embed_dim
+        pre = q_prescale_enabled()
+        if rows is not None and not (ROWS_IN_ATTENTION and ops.attn_rows_supported(
+                self.head_dim, self.alibi_slopes is not None, cu_q.numel() - 1, self.num_heads, max_q, max_q, pre)):
+            qkv, rows = ops.gather_rows_bf16(qkv, rows), None
         return ops.attn_varlen(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], cu_q, None, max_q, max_q,
                                self.num_heads, self.head_dim, self.alibi_slopes, family=self.family,
-                               q_log2=q_prescale_enabled())
+                               q_log2=pre, rows=rows)
 
     def out_ln(self, a_bf16, residual_f32, need_x: bool = True) -> "ops.LnStream":
         """out_proj(a) + residual as an LnStream (fp32 stream, its 16-bit copy, row statistics for the next LayerNorm).
@@ -457,7 +467,7 @@ class ContextFlashAttentionEncoderLayer(nn.Module):
     def self_qkv_of_unique_rows(self, rows_a, rows_b, idx, rows_b_used=None):
         """LayerNorm1 + Wqkv of a stream whose rows are copies of the rows of two small tables (the gene stream entering
         the FIRST gene layer: every tissue's copy of a gene holds the same chunk rows, only the registry row differs):
-        projected once per distinct row, then expanded.  idx int64 [tokens]: >= 0 row of rows_a, < 0 row -idx-1 of rows_b.
+        projected once per distinct row; returns (table, row per token).  idx int64 [tokens]: >= 0 row of rows_a, < 0 row -idx-1 of rows_b.
         Exact: LayerNorm and the projection are row-wise.  None when the LayerNorm fold is off (fp16 mode).
         rows_b_used int64 [k] (optional): the rows of table b the stream actually holds -- only THEY may raise the
         LayerNorm-fold alert (an anomalous registry row of a tissue nobody asked for must not flag every batch)."""
@@ -471,7 +481,7 @@ class ContextFlashAttentionEncoderLayer(nn.Module):
         qb = ops.gemm_ln_consumer(ops.ln_stream(tab_b, raise_alert=rows_b_used is None), w, b, c, ops.EPI_BF16)
         both = torch.cat([qa, qb], dim=0)                        # (a few thousand rows: index plumbing, not data movement)
         idx2 = torch.where(idx >= 0, idx, rows_a.shape[0] - idx - 1)
-        return ops.gather_rows_bf16(both, idx2)
+        return both, idx2            # (table of distinct projected rows, row of every token): gathered by the attention's loads
 
     def forward_packed(self, src, cu_src, max_src, context=None, cu_ctx=None, max_ctx=None, context_kv=None,
                        cu_cross_q=None, max_cross_q=None, self_qkv=None, keep_x=True):
@@ -493,7 +503,7 @@ class ContextFlashAttentionEncoderLayer(nn.Module):
                 # the projection was computed on the distinct rows; below only the residuals read the stream: its fp32
                 # rows (layer output) and, with res16, its 16-bit copy (self-attention block)
                 s = _as_stream(src) if r16 else ops.LnStream(_as_tensor(src), None, None)
-                a = self.mixer.MHA.attend_qkv(self_qkv, cu_src, max_src)
+                a = self.mixer.MHA.attend_qkv(self_qkv[0], cu_src, max_src, rows=self_qkv[1])
             else:
                 s = _as_stream(src)
                 a = self.mixer.MHA.attend_ln(s, self.norm1, None, cu_src, max_src, None, None)

@@ -185,7 +185,7 @@ class Seq2RegPredictor(nn.Module):
                         self.token_embedding.weight.shape[1] <= 2048 and
                         self._layer0_qkv_table_bytes() <= LAYER0_QKV_TABLE_MAX_BYTES):
                     tab, key_L = self._layer0_qkv_table(ids.device)
-                    qkv0 = ops.gather_rows_bf16(tab, ops.token_keys(ids, pad, cu, n_tokens, V, key_L))
+                    qkv0 = (tab, ops.token_keys(ids, pad, cu, n_tokens, V, key_L))      # gathered by the attention kernel's loads
                 for li, layer in enumerate(self.transformer_encoder):
                     x = layer.forward_packed(x, cu, Lmax, last=li + 1 == n_layers, keep_x=not trunk16_enabled("seq2reg"),
                                              pool_mean=pool_in_layer and li + 1 == n_layers, qkv=qkv0 if li == 0 else None)

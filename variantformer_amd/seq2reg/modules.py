@@ -43,19 +43,19 @@ class FlashTransformerLayer(nn.Module):
         return ops.gemm(ph, self._w2_split, b2, ops.EPI_RES_F32, residual=pr, family="seq2reg")
 
     def forward_packed(self, src, cu: torch.Tensor, max_seqlen: int, last: bool = False, keep_x: bool = True,
-                       pool_mean: bool = False, qkv: torch.Tensor | None = None):
+                       pool_mean: bool = False, qkv: tuple | None = None):
         """src: fp32 [tokens, d] or an ops.LnStream; returns the same kind (an LnStream when LayerNorm is folded into
         the GEMMs, see seq2gene.modules.layers.ln_fold_enabled; a plain tensor from the `last` layer).  keep_x=False: the
         result's fp32 rows have no reader (16-bit trunk, layers.trunk16_enabled) and are not stored.
         pool_mean (with last): return the per-window MEAN of the layer's output rows, fp32 [W, d], instead of the rows
         (_pooled_down_projection).  qkv (folded path): this layer's packed_qkv_ln projection of norm1(src), already made
-        (the encoder's first layer looks it up per distinct input row: Seq2RegPredictor._layer0_qkv_table)."""
+        (the encoder's first layer looks it up per distinct input row: (table, row per token) of Seq2RegPredictor._layer0_qkv_table)."""
         from ..seq2gene.modules.layers import (_as_stream, _as_tensor, down_projection, ln_fold_enabled, packed_linear_ln,
                                                res16_enabled, trunk_f16_active)
         if ln_fold_enabled(self.norm1.weight.numel(), self.linear_geglu_2.in_features):
             s = _as_stream(src)
             a = self.MHA.attend_ln(s, self.norm1, None, cu, max_seqlen, None, None) if qkv is None else \
-                self.MHA.attend_qkv(qkv, cu, max_seqlen)
+                self.MHA.attend_qkv(qkv[0], cu, max_seqlen, rows=qkv[1])
             # x1 is read only through norm2 -> linear_geglu_1: no fp32 store, and (res16) its residual is the 16-bit copy
             x1 = self.MHA.out_ln(a, s if (res16_enabled() or s.x is None) else s.x, need_x=False)
             w1, b1, c1 = packed_linear_ln(self.linear_geglu_1, self.norm2, geglu=True)
