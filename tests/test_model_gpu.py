@@ -255,6 +255,36 @@ def test_first_gene_layer_projection_dedup_is_exact(monkeypatch):
         np.testing.assert_array_equal(a["embeddings"][i], b["embeddings"][i])
 
 
+def test_first_gene_layer_input_from_16bit_copies_of_the_distinct_rows_is_exact(monkeypatch):
+    """The stream entering gene layer 0 is consumed only through its 16-bit operand copy (the self-attention block's residual)
+    and its fp16 trunk copy (the down-projection's residual): both are gathered from the copies of the DISTINCT rows, and the
+    fp32 [sum T x G, D] stream is never built.  Casts are row-wise: bit-identical to gathering fp32 rows first -- bf16 and fp16
+    operands, and the VEP path (full last layer)."""
+    import variantformer_amd.seq2gene.modules.layers as Lyr
+    kw = seq2gene_kw(layers=2)
+    model = build_model(SEQ2REG_512, kw, seed=79).cuda()
+    batch = make_batch(7, [9, 5], [150, 20], [TISSUES_54[:3], [9, 33]], 200)
+    orig = Lyr.ContextFlashAttentionEncoderLayer.self_qkv_of_unique_rows
+    calls = {"stream": 0}
+
+    def no_stream(self, *a, with_stream=False, **k):             # the round-4 form: projection lookup only, fp32 stream gathered
+        r = orig(self, *a, with_stream=with_stream, **k)
+        if with_stream and r is not None:
+            calls["stream"] += r[1] is not None
+            return r[0], None
+        return r
+    for precision in ("bf16-mixed", "16-mixed"):
+        model.trainer = type("T", (), {"precision": precision})()
+        a = model.predict_step(batch, 0)
+        monkeypatch.setattr(Lyr.ContextFlashAttentionEncoderLayer, "self_qkv_of_unique_rows", no_stream)
+        b = model.predict_step(batch, 0)
+        monkeypatch.setattr(Lyr.ContextFlashAttentionEncoderLayer, "self_qkv_of_unique_rows", orig)
+        for i in range(2):
+            np.testing.assert_array_equal(a["pred_gene_exp"][i], b["pred_gene_exp"][i])
+            np.testing.assert_array_equal(a["embeddings"][i], b["embeddings"][i])
+    assert calls["stream"] == 2, "the 16-bit stream form must have been available in both operand types"
+
+
 def test_first_gene_layer_row_map_attention_is_exact(monkeypatch):
     """With 129-256 gene tokens the first gene layer's self attention reads the distinct projected rows THROUGH the row map
     (vf_attn_varlen_fwd_rows) instead of a materialised [tokens, 3 D] gather: bit-identical to the gathered form and to

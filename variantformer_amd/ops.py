@@ -306,20 +306,21 @@ def ln_stream_rows(s: LnStream, rows: torch.Tensor) -> LnStream:
 T16_SCALE = 2.0 ** -4          # the fp16 trunk copy is fp16(x * 2^-4): |x| < 1e6 representable (x16_scale_for(fp16))
 
 
-def trunk16_of(x: torch.Tensor) -> torch.Tensor:
+def trunk16_of(x: torch.Tensor, raise_alert: bool = True) -> torch.Tensor:
     """fp16(x * T16_SCALE) of an fp32 stream no trunk-writing GEMM produced (a stack's input): one pass
-    (vf_row_stats_cast2 with an fp16 output; its statistics are not used)."""
+    (vf_row_stats_cast2 with an fp16 output; its statistics are not used).  raise_alert=False: a table of which a batch uses
+    only some rows (see ln_stream)."""
     _dev(x)
     assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 2
     M, D = x.shape
     t16 = torch.empty((M, D), dtype=torch.float16, device=x.device)
     stats = torch.empty((M, 2), dtype=torch.float32, device=x.device)
 
-    alert = _alert_flag(x.device)
+    alert_ptr = _alert_flag(x.device).data_ptr() if raise_alert else 0
 
     def launch():       # ratio limit off (1e30): this stream's statistics are the caller's business; range check on
         check(_lib.load().vf_row_stats_cast2(x.data_ptr(), M, D, 1e-5, t16.data_ptr(), VF_F16, T16_SCALE, 1e30,
-                                             60000.0 / T16_SCALE, alert.data_ptr(), stats.data_ptr(), _stream()),
+                                             60000.0 / T16_SCALE, alert_ptr, stats.data_ptr(), _stream()),
               "vf_row_stats_cast")
     if TIMER is not None:
         TIMER.time("layernorm", 0.0, float(M) * D * 6, launch, f"trunk16_of D={D}", _SCOPE)

@@ -247,7 +247,15 @@ def modulator_forward_packed(ctx_embedding, cre_layers, gene_layers, cre_x, gene
         # distinct row (exact; the other 24 gene layers see rows that differ by tissue)
         qkv0 = None
         if gene_unique is not None and hasattr(gene_layers[0], "self_qkv_of_unique_rows"):
-            qkv0 = gene_layers[0].self_qkv_of_unique_rows(*gene_unique)
+            # gene_x None: the caller left the stream to be built here -- from 16-bit copies of the distinct rows when the
+            # layer reads nothing else (no fp32 rows are ever written), else by the fp32 row gather below
+            want_stream = gene_x is None and not use_res
+            r = gene_layers[0].self_qkv_of_unique_rows(*gene_unique, with_stream=want_stream)
+            if r is not None:
+                qkv0, gene = r if want_stream else (r, gene)
+        if gene is None:                                # registry row + chunk rows per (gene, tissue) (:357-366, layers.py:508-521)
+            gene = ops.gather_rows_f32(gene_unique[0], gene_unique[1], gene_unique[2])
+            gene_x = gene
         kw0 = {} if qkv0 is None else {"self_qkv": qkv0}
         gene = gene_layers[0].forward_packed(gene, cu_gene_self, max_gene, context=cre, cu_ctx=ck, max_ctx=max_cre,
                                              cu_cross_q=cq, max_cross_q=mq, keep_x=not t16 or use_res or n == 1, **kw0)
@@ -659,8 +667,9 @@ class Seq2GenePredictorCombinedModulator(nn.Module):
         if self._general:
             return self._forward_general(pb, cre_x, gene_x, return_cre)
         # registry token per (gene, tissue) + that gene's chunk rows (:357-366, layers.py:508-521)
-        gene_stream = ops.gather_rows_f32(gene_x, self.start_tkn.registry_tokens.weight, pb.gene_stream_idx)
-        # what gene_stream's rows are copies of (+ the registry rows in use: only they may raise the LayerNorm-fold alert)
+        # what the gene stream's rows are copies of (+ the registry rows in use: only they may raise the LayerNorm-fold alert);
+        # modulator_forward_packed builds the stream from it (gene_stream = None)
+        gene_stream = None
         uniq = (gene_x, self.start_tkn.registry_tokens.weight, pb.gene_stream_idx, pb.tissues_used)
         if return_cre:       # VEP needs every gene token of the last layer (token-position gathers)
             gene_out, cre_out = self._modulator_forward_packed(

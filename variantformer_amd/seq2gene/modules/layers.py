@@ -464,24 +464,42 @@ class ContextFlashAttentionEncoderLayer(nn.Module):
         if use_alibi:
             self.register_buffer("m", get_alibi_slopes(self.num_heads))
 
-    def self_qkv_of_unique_rows(self, rows_a, rows_b, idx, rows_b_used=None):
+    def self_qkv_of_unique_rows(self, rows_a, rows_b, idx, rows_b_used=None, with_stream: bool = False):
         """LayerNorm1 + Wqkv of a stream whose rows are copies of the rows of two small tables (the gene stream entering
         the FIRST gene layer: every tissue's copy of a gene holds the same chunk rows, only the registry row differs):
         projected once per distinct row; returns (table, row per token).  idx int64 [tokens]: >= 0 row of rows_a, < 0 row -idx-1 of rows_b.
         Exact: LayerNorm and the projection are row-wise.  None when the LayerNorm fold is off (fp16 mode).
         rows_b_used int64 [k] (optional): the rows of table b the stream actually holds -- only THEY may raise the
-        LayerNorm-fold alert (an anomalous registry row of a tissue nobody asked for must not flag every batch)."""
+        LayerNorm-fold alert (an anomalous registry row of a tissue nobody asked for must not flag every batch).
+        with_stream: also return the stream itself as the layer consumes it -- an ops.LnStream WITHOUT fp32 rows, its 16-bit
+        operand copy (the residual of the self-attention block) and fp16 trunk copy (the residual of the down-projection)
+        gathered from the copies of the distinct rows: a cast is row-wise too, so this is bit for bit the copy of the
+        gathered fp32 stream, which is then never written or read (round 5: -6 GB per step).  None for that element when the
+        layer needs fp32 rows (VF_TRUNK16=0)."""
         if not ln_fold_enabled(self.norm1.weight.numel(), self.linear_geglu_2.in_features):
             return None
         w, b, c = self.mixer.MHA.packed_qkv_ln(self.norm1)
-        qa = ops.gemm_ln_consumer(ops.ln_stream(rows_a.float().contiguous()), w, b, c, ops.EPI_BF16)
+        sa = ops.ln_stream(rows_a.float().contiguous())
+        qa = ops.gemm_ln_consumer(sa, w, b, c, ops.EPI_BF16)
         tab_b = rows_b.float().contiguous()
         if rows_b_used is not None:
             ops.ln_stream(tab_b[rows_b_used].contiguous())       # statistics of the rows in use: raises the alert, result unused
-        qb = ops.gemm_ln_consumer(ops.ln_stream(tab_b, raise_alert=rows_b_used is None), w, b, c, ops.EPI_BF16)
+        sb = ops.ln_stream(tab_b, raise_alert=rows_b_used is None)
+        qb = ops.gemm_ln_consumer(sb, w, b, c, ops.EPI_BF16)
         both = torch.cat([qa, qb], dim=0)                        # (a few thousand rows: index plumbing, not data movement)
         idx2 = torch.where(idx >= 0, idx, rows_a.shape[0] - idx - 1)
-        return both, idx2            # (table of distinct projected rows, row of every token): gathered by the attention's loads
+        qkv = (both, idx2)           # (table of distinct projected rows, row of every token): gathered by the attention's loads
+        if not with_stream:
+            return qkv
+        stream = None
+        if res16_enabled() and trunk16_enabled():
+            x16 = ops.gather_rows_bf16(torch.cat([sa.x16, sb.x16], dim=0), idx2)
+            t16 = None
+            if trunk_f16_active():
+                t16 = ops.gather_rows_bf16(torch.cat([ops.trunk16_of(sa.x), ops.trunk16_of(sb.x, raise_alert=rows_b_used is None)],
+                                                     dim=0), idx2)
+            stream = ops.LnStream(None, x16, None, sa.scale, t16)
+        return qkv, stream
 
     def forward_packed(self, src, cu_src, max_src, context=None, cu_ctx=None, max_ctx=None, context_kv=None,
                        cu_cross_q=None, max_cross_q=None, self_qkv=None, keep_x=True):
