@@ -248,7 +248,7 @@ def test_first_gene_layer_projection_dedup_is_exact(monkeypatch):
     model = build_model(SEQ2REG_512, kw, seed=77).cuda()
     batch = make_batch(5, [30, 11], [4, 6], [TISSUES_54[:7], [9, 33, 2]], 200)
     a = model.predict_step(batch, 0)
-    monkeypatch.setattr(ContextFlashAttentionEncoderLayer, "self_qkv_of_unique_rows", lambda self, *args: None)
+    monkeypatch.setattr(ContextFlashAttentionEncoderLayer, "self_qkv_of_unique_rows", lambda self, *args, **kw: None)
     b = model.predict_step(batch, 0)
     for i in range(2):
         np.testing.assert_array_equal(a["pred_gene_exp"][i], b["pred_gene_exp"][i])
@@ -298,7 +298,7 @@ def test_first_gene_layer_row_map_attention_is_exact(monkeypatch):
     a = model.predict_step(batch, 0)
     monkeypatch.setattr(Lyr, "ROWS_IN_ATTENTION", False)
     b = model.predict_step(batch, 0)
-    monkeypatch.setattr(Lyr.ContextFlashAttentionEncoderLayer, "self_qkv_of_unique_rows", lambda self, *args: None)
+    monkeypatch.setattr(Lyr.ContextFlashAttentionEncoderLayer, "self_qkv_of_unique_rows", lambda self, *args, **kw: None)
     c = model.predict_step(batch, 0)
     for i in range(2):
         np.testing.assert_array_equal(a["pred_gene_exp"][i], b["pred_gene_exp"][i])
