@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define VF_ABI_VERSION 8
+#define VF_ABI_VERSION 9
 
 enum vf_status {
     VF_OK = 0,
@@ -208,6 +208,17 @@ int vf_attn_varlen_fwd_rows(const void* q, const void* k, const void* v, void* o
                             int n_seq, int max_seqlen_q, int max_seqlen_k,
                             int H, int dh, const float* alibi_slopes, float scale,
                             int operand_dtype, int flags, const int64_t* q_rows, const int64_t* kv_rows, void* stream);
+
+/* Cross attention against keys that are copies of a FEW DISTINCT ROWS (ABI 9): the CRE layers' context cross attention
+ * (seq2gene/model_combined_modulator.py:168 `second_level_context_embedding(ref_labels)`, seq2gene/modules/layers.py:421-439:
+ * K / V = Wkv of an Embedding(9) row per CRE), where softmax over the repeated keys equals softmax over the distinct ones with
+ * log(count) added to the logit.  q [tokens, >= H*dh] 16-bit, pre-scaled by softmax_scale * log2 e (VF_ATTN_Q_LOG2 form);
+ * kv_table [C, >= 2*H*dh] 16-bit = (K | V) of the C <= 16 distinct rows, heads packed (head, dh); log2_count fp32 [n_seq, C] =
+ * log2 of how often row c occurs among sequence s's keys (-inf: not at all; every sequence holds >= 1 key);
+ * out [tokens, >= H*dh] 16-bit.  fp32 scores, fp32-normalised weights, one rounding of the output. */
+int vf_attn_counted_keys(const void* q, int64_t q_stride, const void* kv_table, int64_t kv_stride, const float* log2_count,
+                         const int32_t* cu_seqlens_q, int n_seq, int max_seqlen_q, int C, int H, int dh,
+                         void* out, int64_t o_stride, int operand_dtype, void* stream);
 
 /* y = LayerNorm(x) * gamma + beta over the last dim (eps inside sqrt, biased variance), optional
  * exact-erf GELU, output fp32, bf16 or fp16 (out_dtype = vf_dtype).  x fp32 [rows, D], D % 4 == 0, D <= 8192.

@@ -249,6 +249,19 @@ def attention(q, k, v, slopes, rnd: Rounding, q_log2: bool = False):
     return o.permute(1, 0, 2)          # [sq,H,dh]
 
 
+def attention_counted(q, k_tab, v_tab, counts, q_log2: bool):
+    """Attention of q [sq, H, dh] against keys that are copies of the C distinct rows k_tab / v_tab [C, H, dh], row c occurring
+    counts[c] times: softmax over the repeated keys = softmax over the distinct rows with log(count) added to the logit.  The
+    same function as attention() on the expanded rows; restates where vf_attn_counted_keys rounds: fp32 scores and weights,
+    no 16-bit rounding of P (the caller rounds the output once)."""
+    dh = q.shape[-1]
+    s2 = torch.einsum("qhd,chd->hqc", q, k_tab) * (1.0 if q_log2 else math.log2(math.e) / math.sqrt(dh))
+    s2 = s2 + torch.log2(counts.to(s2.dtype))[None, None, :]             # -inf for a label the sequence does not hold
+    p = torch.exp2(s2 - s2.max(dim=-1, keepdim=True).values)
+    o = torch.einsum("hqc,chd->hqd", p, v_tab) / p.sum(dim=-1, keepdim=True)
+    return o.permute(1, 0, 2)
+
+
 def geglu_ffn(x, sd, pfx, rnd: Rounding):
     """LN'd input -> Linear(d,2048) -> a * gelu(gate) -> Linear(1024,d)
     (layers.py:159-162, seq2reg/modules.py:184-187; erf GELU)."""
@@ -277,9 +290,12 @@ def mha_self(x, sd, pfx, H, cu, slopes, rnd: Rounding):
     return linear(out, sd[pfx + "out_proj.weight"], sd[pfx + "out_proj.bias"], rnd)
 
 
-def mha_cross(xq, xkv, sd, pfx, H, cu_q, cu_k, rnd: Rounding, slopes=None):
+def mha_cross(xq, xkv, sd, pfx, H, cu_q, cu_k, rnd: Rounding, slopes=None, kv_labels=None):
     """flash_attn MHA cross path [3p]: Wq on the query stream, Wkv on the context stream;
-    no ALiBi in the shipped configuration (cross_alibi: false, configs/vf_model.yaml:13)."""
+    no ALiBi in the shipped configuration (cross_alibi: false, configs/vf_model.yaml:13).
+    kv_labels int64 [tokens_k] (the CRE layers' context cross attention, whose context row of a key is a function of its
+    label alone): under a rounding mode the keys are taken as the distinct rows with their counts (attention_counted: the
+    form vf_attn_counted_keys evaluates); pure fp32 arithmetic keeps the reference's expanded form -- the same function."""
     D = xq.shape[-1]
     dh = D // H
     pre = rnd.q_prescale                 # the softmax scale, in base 2, folded into Wq before its rounding (layers.q_prescale_enabled)
@@ -287,10 +303,20 @@ def mha_cross(xq, xkv, sd, pfx, H, cu_q, cu_k, rnd: Rounding, slopes=None):
                      wscale=math.log2(math.e) / math.sqrt(dh) if pre else 1.0)).view(-1, H, dh)
     kv = rnd.r(linear(xkv, sd[pfx + "Wkv.weight"], sd[pfx + "Wkv.bias"], rnd)).view(-1, 2, H, dh)
     out = torch.empty(xq.shape[0], D)
+    counted = kv_labels is not None and rnd.mode is not None and slopes is None and COUNTED_CONTEXT_KEYS
     for b in range(len(cu_q) - 1):
         a, e = int(cu_q[b]), int(cu_q[b + 1])
         ka, ke = int(cu_k[b]), int(cu_k[b + 1])
-        if e > a:
+        if e > a and counted and ke > ka:
+            lab = kv_labels[ka:ke]
+            uniq, first = [], []
+            for i, l in enumerate(lab.tolist()):                       # distinct labels, with the row of their first occurrence
+                if l not in uniq:
+                    uniq.append(l)
+                    first.append(ka + i)
+            counts = torch.tensor([int((lab == l).sum()) for l in uniq], dtype=torch.float32)
+            out[a:e] = attention_counted(q[a:e], kv[first, 0], kv[first, 1], counts, pre).reshape(e - a, D)
+        elif e > a:
             out[a:e] = attention(q[a:e], kv[ka:ke, 0], kv[ka:ke, 1], slopes, rnd, q_log2=pre).reshape(e - a, D)
     out = rnd.r(out)
     return linear(out, sd[pfx + "out_proj.weight"], sd[pfx + "out_proj.bias"], rnd)
@@ -449,8 +475,11 @@ class Seq2GeneHP:
                    use_bigger_head=kw.get("use_bigger_head", False), head_type=kw.get("head_type", "mlp"))
 
 
+COUNTED_CONTEXT_KEYS = True       # tests flip it together with layers.COUNTED_CONTEXT_KEYS
+
+
 def modulator_layer(src, ctx, cu_src, cu_ctx, sd, pfx, H, slopes, rnd: Rounding, cross_slopes=None, last=False,
-                    make_data_kv=False):
+                    make_data_kv=False, ctx_labels=None):
     """ContextFlashAttentionEncoderLayer.forward (seq2gene/modules/layers.py:88-165) on packed
     streams: LN1 -> self-MHA(ALiBi) -> +src -> LN2 -> cross-MHA(q = x, kv = ctx RAW, no norm)
     -> +res_short -> LN3 -> GeGLU -> + src (the LAYER INPUT, :99,163).
@@ -462,7 +491,7 @@ def modulator_layer(src, ctx, cu_src, cu_ctx, sd, pfx, H, slopes, rnd: Rounding,
         x2 = mha_cross(ctx, h, sd, pfx + "crossMHA.MHA.", H, cu_ctx, cu_src, rnd, cross_slopes) + rnd.res(x1)
         h = rnd.ln(x2, sd[pfx + "norm3.weight"], sd[pfx + "norm3.bias"])
         return rnd.out(geglu_ffn(h, sd, pfx, rnd) + rnd.trunk(src), last)
-    x2 = mha_cross(h, ctx, sd, pfx + "crossMHA.MHA.", H, cu_src, cu_ctx, rnd, cross_slopes) + rnd.res(x1)
+    x2 = mha_cross(h, ctx, sd, pfx + "crossMHA.MHA.", H, cu_src, cu_ctx, rnd, cross_slopes, kv_labels=ctx_labels) + rnd.res(x1)
     h = rnd.ln(x2, sd[pfx + "norm3.weight"], sd[pfx + "norm3.bias"])
     return rnd.out(geglu_ffn(h, sd, pfx, rnd) + rnd.trunk(src), last)
 
@@ -476,10 +505,11 @@ def self_only_layer(src, cu_src, sd, pfx, H, slopes, rnd: Rounding, last=False):
     return rnd.out(geglu_ffn(h, sd, pfx, rnd) + rnd.trunk(src), last)
 
 
-def cre_layer(cre, ctx, cu_cre, sd, pfx, hp, slopes, rnd: Rounding, last=False):
-    """One CRE layer: with the second-level context (:262-270) or context-free (:271-274).  Never cross_alibi (:78-88)."""
+def cre_layer(cre, ctx, cu_cre, sd, pfx, hp, slopes, rnd: Rounding, last=False, ctx_labels=None):
+    """One CRE layer: with the second-level context (:262-270) or context-free (:271-274).  Never cross_alibi (:78-88).
+    ctx_labels: the label whose embedding each context row is (ctx = Embedding(9)[ctx_labels], :168)."""
     if hp.use_context:
-        return modulator_layer(cre, ctx, cu_cre, cu_cre, sd, pfx, hp.num_heads, slopes, rnd, last=last)
+        return modulator_layer(cre, ctx, cu_cre, cu_cre, sd, pfx, hp.num_heads, slopes, rnd, last=last, ctx_labels=ctx_labels)
     return self_only_layer(cre, cu_cre, sd, pfx, hp.num_heads, slopes, rnd, last=last)
 
 
@@ -521,7 +551,8 @@ def combined_modulator(cre_x, gene_x, ctx_labels, cu_cre, cu_gene, sd, pfx, hp: 
         gene = gene + gene_res                                                   # :253-254
     for i in range(hp.num_layers - 1):                                           # :258-285
         # the CRE layers are built without cross_alibi (:78-88): their context cross attention never has a bias
-        cre = cre_layer(cre, ctx, cu_cre, sd, f"{pfx}cre_layers.{i}.", hp, slopes, rnd, last=i == nl - 2)
+        cre = cre_layer(cre, ctx, cu_cre, sd, f"{pfx}cre_layers.{i}.", hp, slopes, rnd, last=i == nl - 2,
+                        ctx_labels=ctx_labels if hp.use_context else None)
         if collect is not None and i == 0:
             collect["first_cre_layer_out"] = cre.clone()
         gene = gene_layer(gene, cre, f"{pfx}gene_layers.{i + 1}.", i + 1)
@@ -669,7 +700,8 @@ def _modulator_shared(cre_x, gene_x, labels, T, G, sd, hp: Seq2GeneHP, rnd: Roun
     if collect is not None:
         collect["first_gene_layer_out"] = gene.clone()
     for i in range(hp.num_layers - 1):
-        cre = cre_layer(cre, ctx, cu_c, sd, f"{pfx}cre_layers.{i}.", hp, slopes, rnd, last=i == nl - 2)
+        cre = cre_layer(cre, ctx, cu_c, sd, f"{pfx}cre_layers.{i}.", hp, slopes, rnd, last=i == nl - 2,
+                        ctx_labels=labels if hp.use_context else None)
         if collect is not None and i == 0:
             collect["first_cre_layer_out"] = cre.repeat(T, 1)
         gene = gene_layer(gene, cre, f"{pfx}gene_layers.{i + 1}.", i + 1 == nl - 1)

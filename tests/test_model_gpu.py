@@ -258,8 +258,8 @@ def test_first_gene_layer_projection_dedup_is_exact(monkeypatch):
 def test_first_gene_layer_input_from_16bit_copies_of_the_distinct_rows_is_exact(monkeypatch):
     """The stream entering gene layer 0 is consumed only through its 16-bit operand copy (the self-attention block's residual)
     and its fp16 trunk copy (the down-projection's residual): both are gathered from the copies of the DISTINCT rows, and the
-    fp32 [sum T x G, D] stream is never built.  Casts are row-wise: bit-identical to gathering fp32 rows first -- bf16 and fp16
-    operands, and the VEP path (full last layer)."""
+    fp32 [sum T x G, D] stream is never built (bf16 operands; fp16 operands keep the fp32 gather).  Casts are row-wise:
+    bit-identical to gathering fp32 rows first."""
     import variantformer_amd.seq2gene.modules.layers as Lyr
     kw = seq2gene_kw(layers=2)
     model = build_model(SEQ2REG_512, kw, seed=79).cuda()
@@ -282,7 +282,37 @@ def test_first_gene_layer_input_from_16bit_copies_of_the_distinct_rows_is_exact(
         for i in range(2):
             np.testing.assert_array_equal(a["pred_gene_exp"][i], b["pred_gene_exp"][i])
             np.testing.assert_array_equal(a["embeddings"][i], b["embeddings"][i])
-    assert calls["stream"] == 2, "the 16-bit stream form must have been available in both operand types"
+    assert calls["stream"] == 1, "the 16-bit stream form serves bf16 operands (fp16 operands add fp32 rows in the first down-projection)"
+
+
+def test_counted_context_keys_equal_the_expanded_context_attention(monkeypatch):
+    """The CRE layers' context cross attention over the 9 distinct label rows with counts (vf_attn_counted_keys) against the
+    round-4 form over the gathered [N, 2D] rows: the same function, different rounding points (no 16-bit P) -- expression and
+    embeddings agree at the 16-bit level, both within the north-star bar of their own same-rounding oracle; also on the
+    separate-LayerNorm path the self-healing recomputation takes."""
+    import variantformer_amd.seq2gene.modules.layers as Lyr
+    kw = seq2gene_kw(layers=3)
+    model = build_model(SEQ2REG_512, kw, seed=81)
+    sd = state_dict_cpu(model)
+    model = model.cuda()
+    batch = make_batch(8, [40, 7, 1], [4, 3, 2], [TISSUES_54[:3], [9, 33], [12]], 200)
+    hp = O.Seq2RegHP.from_hparams(SEQ2REG_512)
+    ghp = O.Seq2GeneHP.from_kwargs(kw)
+    for fold in ("1", "0"):
+        monkeypatch.setenv("VF_LN_FOLD", fold)
+        res = {}
+        for flag in (True, False):
+            monkeypatch.setattr(Lyr, "COUNTED_CONTEXT_KEYS", flag)
+            monkeypatch.setattr(O, "COUNTED_CONTEXT_KEYS", flag)
+            out = model.predict_step(batch, 0)
+            orc = O.predict_step(batch, sd, hp, hp, ghp, rounding=O.Rounding("bf16", fold_ln=fold == "1"), share_cre_stream=True)
+            for i in range(3):
+                assert prel(out["pred_gene_exp"][i], orc["pred_gene_exp"][i]) < NORTH_STAR_RTOL
+                assert _rel(out["embeddings"][i], orc["embeddings"][i]) < 3 * NORTH_STAR_RTOL
+            res[flag] = out
+        for i in range(3):
+            assert prel(res[True]["pred_gene_exp"][i], res[False]["pred_gene_exp"][i]) < NORTH_STAR_RTOL
+            assert not np.array_equal(res[True]["embeddings"][i], res[False]["embeddings"][i]) or i == 2   # (gene 2: one CRE, one label)
 
 
 def test_first_gene_layer_row_map_attention_is_exact(monkeypatch):

@@ -1291,3 +1291,44 @@ def test_attention_row_map_form_is_bit_identical_to_gather_then_attend(ops, dtyp
     with pytest.raises(VFError, match="row-map"):
         ops.attn_varlen(tab[:, :D], tab[:, D:2 * D], tab[:, 2 * D:], cu, None, max(lens), max(lens), H, dh, slopes,
                         q_log2=False, rows=rows)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("dh,H", [(48, 32), (64, 8), (32, 4)])
+def test_attention_counted_keys_matches_oracle_and_the_expanded_form(ops, dtype, dh, H):
+    """vf_attn_counted_keys (ABI 9): cross attention against keys that are copies of <= 16 distinct rows = softmax over the distinct
+    rows with log2(count) added.  Every element against oracle.attention_counted on the same rounded operands (one rounding of
+    the output: <= 1 ulp), and against the HIP attention over the EXPANDED keys (which rounds P to 16 bits: close, not equal);
+    ragged sequences, a one-query sequence, an empty one, labels that are absent from a sequence."""
+    td = torch.bfloat16 if dtype == "bf16" else torch.float16
+    rnd = O.Rounding(dtype)
+    D, C = H * dh, 9
+    rng = np.random.default_rng(3)
+    lens = [300, 1, 0, 77, 1024, 5]
+    tq = sum(lens)
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32)
+    labels = torch.from_numpy(rng.integers(0, C, tq)).long()
+    labels[cu[3]:cu[4]] = 4                                             # a sequence that holds ONE label
+    q = rnd.r(_rand((tq, D), 81, 1.2))
+    tab = rnd.r(_rand((C, 2 * D), 82, 1.5))
+    cnt = torch.zeros(len(lens), C)
+    for b in range(len(lens)):
+        cnt[b] = torch.bincount(labels[cu[b]:cu[b + 1]], minlength=C).float()
+    got = ops.attn_counted_keys(q.cuda().to(td), tab.cuda().to(td), torch.log2(cnt).cuda().contiguous(), cu.cuda(), max(lens), H, dh)
+    kv = tab[labels]                                                    # the expanded keys the reference's form attends over
+    exp = ops.attn_varlen(q.cuda().to(td), kv[:, :D].cuda().to(td).contiguous(), kv[:, D:].cuda().to(td).contiguous(), cu.cuda(),
+                          cu.cuda(), max(lens), max(lens), H, dh, q_log2=True)
+    torch.cuda.synchronize()
+    got, exp = got.float().cpu(), exp.float().cpu()
+    ref = torch.zeros(tq, D)
+    for b in range(len(lens)):
+        a, e = int(cu[b]), int(cu[b + 1])
+        if e > a:
+            present = [c for c in range(C) if cnt[b, c] > 0]
+            ref[a:e] = O.attention_counted(q[a:e].view(-1, H, dh), tab[present, :D].view(-1, H, dh), tab[present, D:].view(-1, H, dh),
+                                           cnt[b, present], True).reshape(e - a, D)
+    assert torch.isfinite(got).all()
+    ulp = 2 ** -7 if dtype == "bf16" else 2 ** -10           # one unit in the last place, relative to the smaller neighbour
+    np.testing.assert_allclose(got.numpy(), rnd.r(ref).numpy(), rtol=ulp, atol=ulp * 1e-2)
+    assert float((got != rnd.r(ref)).float().mean()) < 1e-3    # ... and only where fp32 summation order decides a tie
+    np.testing.assert_allclose(got.numpy(), exp.numpy(), rtol=2 ** -6 if dtype == "bf16" else 2 ** -9, atol=4e-3 if dtype == "bf16" else 1e-3)

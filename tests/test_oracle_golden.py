@@ -255,3 +255,22 @@ def test_make_data_kv_layers_match_the_reference_layer_classes():
         with torch.no_grad():
             out = data_kv_oracle(name, sd, src[keep], ctx[keep], cu, H, info["use_alibi"], O.Rounding(None))
         np.testing.assert_allclose(out.numpy(), z[f"{name}.out"][keep.numpy()], rtol=RTOL, atol=ATOL)
+
+
+def test_counted_key_attention_is_the_same_function_as_attention_over_the_repeated_keys():
+    """The CRE layers' context rows are copies of <= 9 label embeddings: softmax over a gene's N context keys equals softmax over
+    the distinct rows with log(count) added to the logit (oracle.attention_counted, the form vf_attn_counted_keys evaluates).
+    In fp32 the two agree to round-off, with and without the base-2 pre-scaled q, for labels that are absent or occur once."""
+    import math
+    torch.manual_seed(5)
+    H, dh, sq = 4, 48, 37
+    labels = torch.tensor([3, 3, 0, 8, 3, 0, 3, 5, 3, 3, 0, 3])                   # labels 1, 2, 4, 6, 7 absent; 5 and 8 once
+    tab_k, tab_v = torch.randn(9, H, dh), torch.randn(9, H, dh)
+    q = torch.randn(sq, H, dh)
+    uniq = sorted(set(labels.tolist()))
+    counts = torch.tensor([int((labels == u).sum()) for u in uniq], dtype=torch.float32)
+    for q_log2 in (False, True):
+        qq = q * (math.log2(math.e) / math.sqrt(dh)) if q_log2 else q
+        want = O.attention(qq, tab_k[labels], tab_v[labels], None, O.Rounding(None), q_log2=q_log2)
+        got = O.attention_counted(qq, tab_k[uniq], tab_v[uniq], counts, q_log2)
+        assert torch.allclose(got, want, rtol=2e-5, atol=2e-6), float((got - want).abs().max())

@@ -1511,6 +1511,149 @@ extern "C" int vf_attn_varlen_fwd_v2(const void* q, const void* k, const void* v
                                  max_seqlen_q, max_seqlen_k, H, dh, alibi_slopes, scale, flags, stream);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Cross attention against keys that are COPIES OF A FEW DISTINCT ROWS: the CRE layers' context cross attention reads
+// K / V = Wkv(Embedding(9)[label of every CRE]) (reference model_combined_modulator.py:168, layers.py:421-439), i.e. at most 9
+// distinct key / value rows per head, each repeated count_c times in a gene's key sequence.  Softmax over the repeated keys is
+// softmax over the distinct ones with log(count) added to the logit:
+//     out = sum_c n_c exp(q . k_c) v_c / sum_c n_c exp(q . k_c)  =  sum_c softmax_c(q . k_c + log n_c) v_c
+// -- the same function of (q, table, counts), N / 9 times less arithmetic and no [keys, 2D] gather of the table.  fp32 scores
+// (bf16 / fp16 operands, products exact in fp32, summed in ascending d), base-2 logits (q carries scale * log2 e), weights
+// normalised in fp32, output rounded once to the operand type: at least as precise as the tiled kernels, which round P to 16
+// bits in front of the PV product; oracle.attention_counted restates it.  Vector arithmetic only (0.9 GFLOP per launch).
+// Block = one sequence (gene) x a slab of its queries; thread = one (query, head) pair; the table lives in LDS as
+// [c][d / 8][head][8] so that the 16-byte reads of the heads of a query fall on consecutive bank groups.
+template <int DT, int DH>
+__global__ __launch_bounds__(256) void attn_counted_keys_kernel(const unsigned short* __restrict__ q, int64_t q_stride,
+                                                                const unsigned short* __restrict__ kv, int64_t kv_stride,
+                                                                const float* __restrict__ log2_count, const int32_t* __restrict__ cu_q,
+                                                                int C, int H, unsigned short* __restrict__ out, int64_t o_stride,
+                                                                int q_per_block) {
+    constexpr int NJ = DH / 8;
+    extern __shared__ __attribute__((aligned(16))) char smem_ck[];
+    u32x4_t* const sK = reinterpret_cast<u32x4_t*>(smem_ck);                    // [C][NJ][H] chunks of 8 values
+    u32x4_t* const sV = sK + C * NJ * H;
+    float* const sL = reinterpret_cast<float*>(sV + C * NJ * H);                // [C] log2 count of this sequence
+    const int seq = blockIdx.y;
+    const int tok0 = cu_q[seq], len = cu_q[seq + 1] - tok0;
+    const int q0 = blockIdx.x * q_per_block;
+    if (q0 >= len) return;
+    const int D = H * DH;
+    for (int i = threadIdx.x; i < 2 * C * NJ * H; i += 256) {
+        const bool is_v = i >= C * NJ * H;
+        const int ii = is_v ? i - C * NJ * H : i;
+        const int h = ii % H, j = (ii / H) % NJ, c = ii / (H * NJ);
+        (is_v ? sV : sK)[ii] = *reinterpret_cast<const u32x4_t*>(kv + (int64_t)c * kv_stride + (is_v ? D : 0) + h * DH + j * 8);
+    }
+    if (threadIdx.x < C) sL[threadIdx.x] = log2_count[(int64_t)seq * C + threadIdx.x];
+    __syncthreads();
+    const int q_end = (q0 + q_per_block < len) ? q0 + q_per_block : len;
+    const int pairs = (q_end - q0) * H;
+    auto unpack8 = [](u32x4_t v, float (&f)[8]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            f[2 * e] = Op16<DT>::to_f32((unsigned short)(v[e] & 0xffffu));
+            f[2 * e + 1] = Op16<DT>::to_f32((unsigned short)(v[e] >> 16));
+        }
+    };
+    for (int p = threadIdx.x; p < pairs; p += 256) {
+        const int t = q0 + p / H, h = p % H;
+        const unsigned short* qp = q + (int64_t)(tok0 + t) * q_stride + h * DH;
+        float qf[DH];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            float f[8];
+            unpack8(*reinterpret_cast<const u32x4_t*>(qp + 8 * j), f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qf[8 * j + e] = f[e];
+        }
+        float sc[16];
+        float m = -INFINITY;
+        for (int c = 0; c < C; ++c) {
+            float a = 0.f;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                float f[8];
+                unpack8(sK[(c * NJ + j) * H + h], f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a = __builtin_fmaf(qf[8 * j + e], f[e], a);
+            }
+            a += sL[c];                                   // -inf for a label this sequence does not hold
+            sc[c] = a;
+            m = __builtin_fmaxf(m, a);
+        }
+        float o[DH];
+#pragma unroll
+        for (int d = 0; d < DH; ++d) o[d] = 0.f;
+        float l = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float pc = __builtin_amdgcn_exp2f(sc[c] - m);
+            l += pc;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                float f[8];
+                unpack8(sV[(c * NJ + j) * H + h], f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[8 * j + e] = __builtin_fmaf(pc, f[e], o[8 * j + e]);
+            }
+        }
+        const float inv = 1.0f / l;
+        unsigned short* op = out + (int64_t)(tok0 + t) * o_stride + h * DH;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            u32x4_t pk;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pk[e] = Op16<DT>::pack2(o[8 * j + 2 * e] * inv, o[8 * j + 2 * e + 1] * inv);
+            *reinterpret_cast<u32x4_t*>(op + 8 * j) = pk;
+        }
+    }
+}
+
+template <int DT, int DH>
+static int launch_counted_keys(const void* q, int64_t q_stride, const void* kv, int64_t kv_stride, const float* log2_count,
+                               const int32_t* cu_q, int n_seq, int max_q, int C, int H, void* out, int64_t o_stride, hipStream_t st) {
+    const int lds = 2 * C * (DH / 8) * H * 16 + C * 4;
+    auto kern = attn_counted_keys_kernel<DT, DH>;
+    static bool attr_set[VF_MAX_DEVICES] = {};
+    const int dev = vf_current_device();
+    if (dev < 0 || !attr_set[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            (void)hipGetLastError();
+            vf_set_error("vf_attn_counted_keys: cannot reserve LDS");
+            return VF_ERR_LAUNCH;
+        }
+        if (dev >= 0) attr_set[dev] = true;
+    }
+    // a block re-reads the whole table: give it enough queries to amortise that (>= 64 per block), but enough blocks to fill
+    // the chip (>= 4 per CU when the batch allows)
+    int qpb = 256;
+    while (qpb > 64 && (long)n_seq * ((max_q + qpb - 1) / qpb) < 1024) qpb >>= 1;
+    hipLaunchKernelGGL(kern, dim3((max_q + qpb - 1) / qpb, n_seq), dim3(256), lds, st, (const unsigned short*)q, q_stride,
+                       (const unsigned short*)kv, kv_stride, log2_count, cu_q, C, H, (unsigned short*)out, o_stride, qpb);
+    VF_CHECK_LAUNCH("vf_attn_counted_keys");
+    return VF_OK;
+}
+
+extern "C" int vf_attn_counted_keys(const void* q, int64_t q_stride, const void* kv_table, int64_t kv_stride,
+                                    const float* log2_count, const int32_t* cu_seqlens_q, int n_seq, int max_seqlen_q, int C,
+                                    int H, int dh, void* out, int64_t o_stride, int operand_dtype, void* stream) {
+    VF_REQUIRE(q && kv_table && log2_count && cu_seqlens_q && out, "vf_attn_counted_keys: null pointer");
+    VF_REQUIRE(operand_dtype == VF_BF16 || operand_dtype == VF_F16, "vf_attn_counted_keys: operand_dtype must be VF_BF16 or VF_F16");
+    VF_REQUIRE(C >= 1 && C <= 16 && H >= 1 && H <= 256 && (dh == 32 || dh == 48 || dh == 64),
+               "vf_attn_counted_keys: C=%d (1..16) H=%d dh=%d (32 / 48 / 64) not supported", C, H, dh);
+    VF_REQUIRE(2 * C * (dh / 8) * H * 16 + C * 4 <= 160 * 1024, "vf_attn_counted_keys: the key / value table does not fit the LDS");
+    VF_REQUIRE(q_stride % 8 == 0 && kv_stride % 8 == 0 && o_stride % 8 == 0 && ((uintptr_t)q % 16 == 0) &&
+                   ((uintptr_t)kv_table % 16 == 0) && ((uintptr_t)out % 16 == 0),
+               "vf_attn_counted_keys: rows must keep 16-byte alignment");
+    if (n_seq <= 0 || max_seqlen_q <= 0) return VF_OK;
+    VF_REQUIRE(n_seq <= 65535, "vf_attn_counted_keys: n_seq=%d exceeds the grid limit", n_seq);
+    hipStream_t st = (hipStream_t)stream;
+#define VF_CK(DT_, DH_) launch_counted_keys<DT_, DH_>(q, q_stride, kv_table, kv_stride, log2_count, cu_seqlens_q, n_seq, max_seqlen_q, C, H, out, o_stride, st)
+    if (operand_dtype == VF_BF16) return dh == 32 ? VF_CK(VF_BF16, 32) : dh == 48 ? VF_CK(VF_BF16, 48) : VF_CK(VF_BF16, 64);
+    return dh == 32 ? VF_CK(VF_F16, 32) : dh == 48 ? VF_CK(VF_F16, 48) : VF_CK(VF_F16, 64);
+#undef VF_CK
+}
+
 extern "C" int vf_attn_rows_supported(int dh, int alibi, int n_seq, int H, int max_seqlen_q, int max_seqlen_k, int flags) {
     return rows_supported(dh, alibi != 0, n_seq, H, max_seqlen_q, max_seqlen_k, (flags & VF_ATTN_Q_LOG2) != 0) ? 1 : 0;
 }

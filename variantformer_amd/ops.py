@@ -462,6 +462,31 @@ def pack_geglu_rows(w: torch.Tensor, bias: torch.Tensor | None):
 ATTN_Q_AT_START, ATTN_Q_LOG2 = 1, 2          # enum vf_attn_flags
 
 
+def attn_counted_keys(q: torch.Tensor, kv_table: torch.Tensor, log2_count: torch.Tensor, cu_q: torch.Tensor, max_q: int,
+                      n_heads: int, head_dim: int, family: str = "") -> torch.Tensor:
+    """Cross attention against keys that are copies of the C <= 16 distinct rows of kv_table [C, 2 H dh] (K | V), row c
+    occurring 2^log2_count[s, c] times among sequence s's keys (vf_attn_counted_keys): softmax over the distinct rows with
+    log2(count) added to the base-2 logit.  q [tokens, >= H dh] 16-bit, pre-scaled (the model's q_log2 form)."""
+    _dev(q, kv_table, log2_count, cu_q)
+    assert _is16(q.dtype) and kv_table.dtype == q.dtype and q.stride(1) == 1 and kv_table.stride(1) == 1
+    assert log2_count.dtype == torch.float32 and log2_count.is_contiguous() and cu_q.dtype == torch.int32
+    D = n_heads * head_dim
+    n_seq, C = cu_q.numel() - 1, kv_table.shape[0]
+    assert log2_count.shape == (n_seq, C) and kv_table.shape[1] >= 2 * D
+    out = torch.empty((q.shape[0], D), dtype=q.dtype, device=q.device)
+
+    def launch():
+        check(_lib.load().vf_attn_counted_keys(q.data_ptr(), q.stride(0), kv_table.data_ptr(), kv_table.stride(0),
+                                               log2_count.data_ptr(), cu_q.data_ptr(), n_seq, int(max_q), C, n_heads, head_dim,
+                                               out.data_ptr(), out.stride(0), _dt(q.dtype), _stream()), "vf_attn_counted_keys")
+    if TIMER is not None:       # executed work: 4 * tokens * C * width
+        TIMER.time("attn", 4.0 * q.shape[0] * C * D, 2.0 * D * 2 * q.shape[0], launch,
+                   f"H={n_heads} dh={head_dim} max_q={int(max_q)} counted_keys={C}", family or _SCOPE)
+    else:
+        launch()
+    return out
+
+
 def attn_rows_supported(head_dim: int, alibi: bool, n_seq: int, n_heads: int, max_q: int, max_k: int, q_log2: bool) -> bool:
     """Whether attn_varlen(rows=...) has a kernel for this geometry (vf_attn_rows_supported); otherwise the caller gathers the
     rows (gather_rows_bf16) and calls the plain form -- same bits either way."""

@@ -261,11 +261,28 @@ def modulator_forward_packed(ctx_embedding, cre_layers, gene_layers, cre_x, gene
                                              cu_cross_q=cq, max_cross_q=mq, keep_x=not t16 or use_res or n == 1, **kw0)
     if use_res:                                     # gene-stream input added back after every gene layer (:253-254)
         gene = ops.add_rows(_t(gene), gene_x)
+    log2c = None
+    from .modules import layers as _layers
+    if (ctx_embedding is not None and n > 1 and _layers.COUNTED_CONTEXT_KEYS and ctx_embedding.num_embeddings <= 16
+            and cre_layers[0].crossMHA.MHA.head_dim in (32, 48, 64)):
+        # how often each label occurs among a gene's CREs (the same for all CRE layers): log2, -inf for an absent label
+        C = ctx_embedding.num_embeddings
+        lens = (cu_cre[1:] - cu_cre[:-1]).long()
+        gid = torch.repeat_interleave(torch.arange(lens.numel(), device=labels.device), lens, output_size=labels.numel())
+        cnt = torch.zeros(lens.numel() * C, dtype=torch.float32, device=labels.device)
+        cnt.index_add_(0, gid * C + labels.long().clamp(0, C - 1), torch.ones(labels.numel(), dtype=torch.float32, device=labels.device))
+        log2c = torch.log2(cnt).view(lens.numel(), C).contiguous()
     for i in range(n - 1):
         with ops.scope("cre_stream"):
-            kv = None if ctx_embedding is None else ops.gather_rows_bf16(_context_kv_table(ctx_embedding, cre_layers[i]), labels)
-            cre = cre_layers[i].forward_packed(cre, cu_cre, max_cre, context_kv=kv, cu_ctx=cu_cre, max_ctx=max_cre,
-                                               keep_x=not t16 or i == n - 2)
+            if ctx_embedding is None:
+                kw_ctx = {"context_kv": None}
+            elif log2c is not None:
+                # the context rows are copies of the 9 label embeddings: softmax over the distinct rows with log(count) added
+                kw_ctx = {"context_counted": (_context_kv_table(ctx_embedding, cre_layers[i]), log2c)}
+            else:
+                kw_ctx = {"context_kv": ops.gather_rows_bf16(_context_kv_table(ctx_embedding, cre_layers[i]), labels)}
+            cre = cre_layers[i].forward_packed(cre, cu_cre, max_cre, cu_ctx=cu_cre, max_ctx=max_cre,
+                                               keep_x=not t16 or i == n - 2, **kw_ctx)
         with ops.scope("gene_stream"):
             if final_rows is not None and i + 1 == n - 1:
                 # last gene layer: only the registry rows are consumed downstream -> compact [R, D] result

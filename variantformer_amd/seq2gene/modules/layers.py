@@ -229,6 +229,7 @@ def _ffn_residual(s):
 
 
 ROWS_IN_ATTENTION = True      # False (tests only): always materialise the gathered projection in front of the attention
+COUNTED_CONTEXT_KEYS = True   # False (tests only): the CRE layers' context cross attention over the gathered [keys, 2D] rows
 
 
 def _as_stream(x):
@@ -343,6 +344,20 @@ class MHA(nn.Module):
         w, b, c = self.packed_qkv_ln(norm)
         qkv = ops.gemm_ln_consumer(s, w, b, c, ops.EPI_BF16)
         return self.attend_qkv(qkv, cu_q, max_q)
+
+    def attend_counted(self, x, norm, counted, cu_q, max_q) -> torch.Tensor:
+        """Cross attention of LayerNorm(x) (x: an ops.LnStream with `norm` folded into Wq, or, norm=None, an already
+        normalised 16-bit tensor) against keys that are copies of a few distinct rows: counted = (kv_table 16-bit [C, 2D],
+        log2_count fp32 [n_seq, C]) -- ops.attn_counted_keys."""
+        assert self.cross_attn and self.alibi_slopes is None
+        c = self.q_log2_scale                                    # q always carries the base-2 softmax scale here
+        if norm is not None:
+            w, b, cs = packed_linear_ln(self.Wq, norm, wscale=c)
+            q = ops.gemm_ln_consumer(x, w, b, cs, ops.EPI_BF16)
+        else:
+            w, b = packed_linear(self.Wq, wscale=c, bscale=c)
+            q = ops.gemm(x, w, b, ops.EPI_BF16)
+        return ops.attn_counted_keys(q, counted[0], counted[1], cu_q, max_q, self.num_heads, self.head_dim, family=self.family)
 
     def attend_qkv(self, qkv, cu_q, max_q, rows=None) -> torch.Tensor:
         """self attention on a packed [tokens, 3D] 16-bit projection (rows ordered (three, head, dh)) made with packed_qkv /
@@ -475,7 +490,7 @@ class ContextFlashAttentionEncoderLayer(nn.Module):
         operand copy (the residual of the self-attention block) and fp16 trunk copy (the residual of the down-projection)
         gathered from the copies of the distinct rows: a cast is row-wise too, so this is bit for bit the copy of the
         gathered fp32 stream, which is then never written or read (round 5: -6 GB per step).  None for that element when the
-        layer needs fp32 rows (VF_TRUNK16=0)."""
+        layer needs fp32 rows (VF_TRUNK16=0, fp16 operands)."""
         if not ln_fold_enabled(self.norm1.weight.numel(), self.linear_geglu_2.in_features):
             return None
         w, b, c = self.mixer.MHA.packed_qkv_ln(self.norm1)
@@ -492,23 +507,25 @@ class ContextFlashAttentionEncoderLayer(nn.Module):
         if not with_stream:
             return qkv
         stream = None
-        if res16_enabled() and trunk16_enabled():
+        if res16_enabled() and trunk16_enabled() and trunk_f16_active():
+            # (bf16 operands with the fp16 trunk copy, the default.  With fp16 operands the FIRST layer of a stack adds its fp32
+            # input rows in the down-projection -- oracle.Rounding.trunk -- so that mode keeps the fp32 gather.)
             x16 = ops.gather_rows_bf16(torch.cat([sa.x16, sb.x16], dim=0), idx2)
-            t16 = None
-            if trunk_f16_active():
-                t16 = ops.gather_rows_bf16(torch.cat([ops.trunk16_of(sa.x), ops.trunk16_of(sb.x, raise_alert=rows_b_used is None)],
-                                                     dim=0), idx2)
+            t16 = ops.gather_rows_bf16(torch.cat([ops.trunk16_of(sa.x), ops.trunk16_of(sb.x, raise_alert=rows_b_used is None)],
+                                                 dim=0), idx2)
             stream = ops.LnStream(None, x16, None, sa.scale, t16)
         return qkv, stream
 
     def forward_packed(self, src, cu_src, max_src, context=None, cu_ctx=None, max_ctx=None, context_kv=None,
-                       cu_cross_q=None, max_cross_q=None, self_qkv=None, keep_x=True):
+                       cu_cross_q=None, max_cross_q=None, self_qkv=None, keep_x=True, context_counted=None):
         """src fp32 [tokens, D] packed residual stream.  Cross-attention keys/values come either from
         `context` (fp32 packed stream, projected here) or from a precomputed bf16 `context_kv` [tokens_k, 2D].
         `cu_cross_q` lets several self-attention sequences share one K/V block (tissue copies of a gene).
         `self_qkv`: precomputed LayerNorm1 -> Wqkv projection of src (self_qkv_of_unique_rows).
         `keep_x=False` (LayerNorm fold only): the result's fp32 rows have no reader (the next layer of the stack takes
-        the 16-bit copy, trunk16_enabled) and are not stored."""
+        the 16-bit copy, trunk16_enabled) and are not stored.
+        `context_counted` = (kv_table [C, 2D], log2_count [n_seq, C]) instead of context / context_kv: the context rows are
+        copies of C distinct rows (the CRE layers' label embeddings) -- MHA.attend_counted."""
         if self.make_data_kv:
             return self._forward_packed_data_kv(src, cu_src, max_src, context, cu_ctx, max_ctx)
         cq = cu_src if cu_cross_q is None else cu_cross_q
@@ -527,9 +544,12 @@ class ContextFlashAttentionEncoderLayer(nn.Module):
                 a = self.mixer.MHA.attend_ln(s, self.norm1, None, cu_src, max_src, None, None)
             r16 = r16 or s.x is None
             x1 = self.mixer.MHA.out_ln(a, s if r16 else s.x, need_x=not r16)
-            if context_kv is None:
-                context_kv = self.crossMHA.MHA.project_kv_of(context)
-            a = self.crossMHA.MHA.attend_ln(x1, self.norm2, context_kv, cq, mq, cu_ctx, max_ctx)
+            if context_counted is not None:
+                a = self.crossMHA.MHA.attend_counted(x1, self.norm2, context_counted, cq, mq)
+            else:
+                if context_kv is None:
+                    context_kv = self.crossMHA.MHA.project_kv_of(context)
+                a = self.crossMHA.MHA.attend_ln(x1, self.norm2, context_kv, cq, mq, cu_ctx, max_ctx)
             x2 = self.crossMHA.MHA.out_ln(a, x1 if r16 else x1.x, need_x=False)
             w1, b1, c1 = packed_linear_ln(self.linear_geglu_1, self.norm3, geglu=True)
             hg = ops.gemm_ln_consumer(x2, w1, b1, c1, ops.EPI_GEGLU_BF16)
@@ -539,9 +559,14 @@ class ContextFlashAttentionEncoderLayer(nn.Module):
         h = ops.layernorm(src, self.norm1.weight, self.norm1.bias)
         x1 = self.mixer.MHA.fused(h, src, cu_src, max_src)
         h = ops.layernorm(x1, self.norm2.weight, self.norm2.bias)
-        if context_kv is None:
-            context_kv = self.crossMHA.MHA.project_kv(ops.cast16(context))
-        x2 = self.crossMHA.MHA.fused(h, x1, cq, mq, context_kv, cu_ctx, max_ctx)
+        if context_counted is not None:
+            a = self.crossMHA.MHA.attend_counted(h, None, context_counted, cq, mq)
+            w, b = packed_linear(self.crossMHA.MHA.out_proj)
+            x2 = ops.gemm(a, w, b, ops.EPI_RES_F32, residual=x1)
+        else:
+            if context_kv is None:
+                context_kv = self.crossMHA.MHA.project_kv(ops.cast16(context))
+            x2 = self.crossMHA.MHA.fused(h, x1, cq, mq, context_kv, cu_ctx, max_ctx)
         h = ops.layernorm(x2, self.norm3.weight, self.norm3.bias)
         w1, b1 = packed_linear(self.linear_geglu_1, geglu=True)
         hg = ops.gemm(h, w1, b1, ops.EPI_GEGLU_BF16)

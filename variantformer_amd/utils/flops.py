@@ -23,7 +23,9 @@ def gene_flops(N: int, C: int, T: int, S_c: int, S_g: int, sum_sq_cre: float, su
     maps = 2 * N * d * D + 2 * C * d_gene * D
     Lc, Lg = L_layers - 1, L_layers
     # CRE layer per token: self 8D^2, cross Wq 2D^2 + out 2D^2 (+ Wkv on the 9-row table: negligible), FFN 3FD
-    cre_stream = Lc * (N * (12 * D * D + 3 * F * D) + 8 * N * N * D)
+    # context cross attention: the keys of a gene are copies of the 9 label embeddings, so algorithmically it is softmax over
+    # the 9 distinct rows with log(count) added (vf_attn_counted_keys): 4 * N * 9 * D instead of 4 * N^2 * D
+    cre_stream = Lc * (N * (12 * D * D + 3 * F * D) + 4 * N * N * D + 4 * N * 9 * D)
     cre_stream_ref = Lc * (N * (16 * D * D + 3 * F * D) + 8 * N * N * D)      # reference also projects Wkv per token
     kv_proj = Lg * N * 4 * D * D
     gene_layer = G * (12 * D * D + 3 * F * D) + 4 * G * G * D + 4 * G * N * D
