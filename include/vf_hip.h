@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define VF_ABI_VERSION 9
+#define VF_ABI_VERSION 10
 
 enum vf_status {
     VF_OK = 0,
@@ -219,6 +219,16 @@ int vf_attn_varlen_fwd_rows(const void* q, const void* k, const void* v, void* o
 int vf_attn_counted_keys(const void* q, int64_t q_stride, const void* kv_table, int64_t kv_stride, const float* log2_count,
                          const int32_t* cu_seqlens_q, int n_seq, int max_seqlen_q, int C, int H, int dh,
                          void* out, int64_t o_stride, int operand_dtype, void* stream);
+
+/* The same attention in LOW-RANK form (ABI 10): with C distinct key / value rows per head the logits are
+ * LN(x) . (Wq_h^T k_c) -- vf_gemm_ln as a CONSUMER with fp32 output (epilogue VF_EPI_F32, new in ABI 10) against an
+ * [H * Cp, D] matrix built once per weights -- and out_proj(sum_c w_c v_c) is w . (Wo_h v_c), a GEMM with K = H * Cp (Cp >= C,
+ * even, H * Cp % 64 == 0 for the GEMM; padding slots are zero).  Between the two GEMMs:
+ *   out[t, h * Cp + c] = 16-bit( softmax_c( scores[t, h * Cp + c] + log2_count[seq(t), c] ) ),  0 for c >= C.
+ * scores fp32 [tokens, lds >= H * Cp] base-2 logits; out 16-bit [tokens, ldo >= H * Cp].  Replaces, for the CRE layers, Wq + the
+ * flash-attn cross forward + the K = D half of out_proj (seq2gene/modules/layers.py:421-439, 156-158). */
+int vf_softmax_counted(const float* scores, int64_t lds, const float* log2_count, const int32_t* cu_seqlens_q, int n_seq,
+                       int max_seqlen_q, int H, int Cp, int C, void* out, int64_t ldo, int out_dtype, void* stream);
 
 /* y = LayerNorm(x) * gamma + beta over the last dim (eps inside sqrt, biased variance), optional
  * exact-erf GELU, output fp32, bf16 or fp16 (out_dtype = vf_dtype).  x fp32 [rows, D], D % 4 == 0, D <= 8192.

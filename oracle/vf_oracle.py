@@ -304,6 +304,29 @@ def mha_cross(xq, xkv, sd, pfx, H, cu_q, cu_k, rnd: Rounding, slopes=None, kv_la
     kv = rnd.r(linear(xkv, sd[pfx + "Wkv.weight"], sd[pfx + "Wkv.bias"], rnd)).view(-1, 2, H, dh)
     out = torch.empty(xq.shape[0], D)
     counted = kv_labels is not None and rnd.mode is not None and slopes is None and COUNTED_CONTEXT_KEYS
+    if counted and LOWRANK_CONTEXT and any((H * c) % 64 == 0 for c in range(9 + 1, 17, 2)):
+        # LOW-RANK form (layers.MHA.lowrank_tables / cross_lowrank): logits = LN(x) . (scale Wq_h^T k_c) as ONE rounded-operand
+        # GEMM, 16-bit softmax weights over the distinct labels (log2 count added), out_proj folded into w . (Wo_h v_c); k, v of
+        # the distinct labels in fp32 (no 16-bit q / k / v).  Restates where the two skinny GEMMs round.
+        labs = sorted(set(kv_labels.tolist()))
+        first = [int((kv_labels == l).nonzero()[0]) for l in labs]
+        kvf = (xkv[first] @ sd[pfx + "Wkv.weight"].t() + sd[pfx + "Wkv.bias"]).view(len(labs), 2, H, dh)
+        sc_ = math.log2(math.e) / math.sqrt(dh)
+        z = torch.einsum("chd,hdk->hck", kvf[:, 0], sd[pfx + "Wq.weight"].view(H, dh, D)) * sc_            # [H, C, D]
+        zb = torch.einsum("chd,hd->hc", kvf[:, 0], sd[pfx + "Wq.bias"].view(H, dh)) * sc_
+        u = torch.einsum("nhd,chd->nhc", sd[pfx + "out_proj.weight"].view(D, H, dh), kvf[:, 1])           # [D, H, C]
+        C = len(labs)
+        s2 = linear(xq, z.reshape(H * C, D), zb.reshape(H * C), rnd).view(-1, H, C)
+        w = torch.zeros_like(s2)
+        for b in range(len(cu_q) - 1):
+            a, e = int(cu_q[b]), int(cu_q[b + 1])
+            ka, ke = int(cu_k[b]), int(cu_k[b + 1])
+            if e > a:
+                cnt = torch.tensor([float((kv_labels[ka:ke] == l).sum()) for l in labs])
+                t = s2[a:e] + torch.log2(cnt)[None, None, :]
+                p = torch.exp2(t - t.max(dim=-1, keepdim=True).values)
+                w[a:e] = rnd.r(p / p.sum(dim=-1, keepdim=True))
+        return linear(w.reshape(-1, H * C), u.reshape(D, H * C), sd[pfx + "out_proj.bias"], rnd)
     for b in range(len(cu_q) - 1):
         a, e = int(cu_q[b]), int(cu_q[b + 1])
         ka, ke = int(cu_k[b]), int(cu_k[b + 1])
@@ -476,6 +499,7 @@ class Seq2GeneHP:
 
 
 COUNTED_CONTEXT_KEYS = True       # tests flip it together with layers.COUNTED_CONTEXT_KEYS
+LOWRANK_CONTEXT = True            # ... and layers.LOWRANK_CONTEXT
 
 
 def modulator_layer(src, ctx, cu_src, cu_ctx, sd, pfx, H, slopes, rnd: Rounding, cross_slopes=None, last=False,

@@ -301,9 +301,13 @@ def test_counted_context_keys_equal_the_expanded_context_attention(monkeypatch):
     for fold in ("1", "0"):
         monkeypatch.setenv("VF_LN_FOLD", fold)
         res = {}
-        for flag in (True, False):
-            monkeypatch.setattr(Lyr, "COUNTED_CONTEXT_KEYS", flag)
-            monkeypatch.setattr(O, "COUNTED_CONTEXT_KEYS", flag)
+        # "lowrank" (the default): two skinny GEMMs around a 9-way softmax; True: q -> counted-key attention -> out_proj;
+        # False: the round-4 form over the gathered [N, 2D] rows
+        for flag in ("lowrank", True, False):
+            monkeypatch.setattr(Lyr, "COUNTED_CONTEXT_KEYS", bool(flag))
+            monkeypatch.setattr(O, "COUNTED_CONTEXT_KEYS", bool(flag))
+            monkeypatch.setattr(Lyr, "LOWRANK_CONTEXT", flag == "lowrank")
+            monkeypatch.setattr(O, "LOWRANK_CONTEXT", flag == "lowrank")
             out = model.predict_step(batch, 0)
             orc = O.predict_step(batch, sd, hp, hp, ghp, rounding=O.Rounding("bf16", fold_ln=fold == "1"), share_cre_stream=True)
             for i in range(3):
@@ -312,7 +316,9 @@ def test_counted_context_keys_equal_the_expanded_context_attention(monkeypatch):
             res[flag] = out
         for i in range(3):
             assert prel(res[True]["pred_gene_exp"][i], res[False]["pred_gene_exp"][i]) < NORTH_STAR_RTOL
+            assert prel(res["lowrank"]["pred_gene_exp"][i], res[False]["pred_gene_exp"][i]) < NORTH_STAR_RTOL
             assert not np.array_equal(res[True]["embeddings"][i], res[False]["embeddings"][i]) or i == 2   # (gene 2: one CRE, one label)
+            assert not np.array_equal(res["lowrank"]["embeddings"][i], res[True]["embeddings"][i])
 
 
 def test_first_gene_layer_row_map_attention_is_exact(monkeypatch):

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libvf_hip.so")
 # enums of include/vf_hip.h
 VF_F32, VF_BF16, VF_F16 = 0, 1, 2
 EPI_BF16, EPI_F32, EPI_RES_F32, EPI_GEGLU_BF16, EPI_GELU_F32, EPI_GELU_BF16 = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -42,6 +42,7 @@ SIGNATURES = {
     "vf_attn_varlen_fwd_v2": [_p, _p, _p, _p, _l, _l, _l, _l, _p, _p, _i, _i, _i, _i, _i, _p, _f, _i, _i, _p],
     "vf_attn_rows_supported": [_i, _i, _i, _i, _i, _i, _i],
     "vf_attn_counted_keys": [_p, _l, _p, _l, _p, _p, _i, _i, _i, _i, _i, _p, _l, _i, _p],
+    "vf_softmax_counted": [_p, _l, _p, _p, _i, _i, _i, _i, _i, _p, _l, _i, _p],
     "vf_attn_varlen_fwd_rows": [_p, _p, _p, _p, _l, _l, _l, _l, _p, _p, _i, _i, _i, _i, _i, _p, _f, _i, _i, _p, _p, _p],
     "vf_layernorm": [_p, _p, _p, _p, _l, _i, _f, _i, _i, _p],
     "vf_embed_stream": [_p, _p, _p, _p, _p, _p, _p, _i, _f, _p, _f, _p, _f, _f, _f, _p, _i, _i, _i, _i, _p],

@@ -1654,6 +1654,65 @@ extern "C" int vf_attn_counted_keys(const void* q, int64_t q_stride, const void*
 #undef VF_CK
 }
 
+// Softmax over a few distinct keys with their counts, on logits a GEMM produced (vf_gemm_ln consumer with fp32 output): the
+// low-rank form of the CRE layers' context cross attention.  With C <= 16 distinct key / value rows per head the logits are
+// LN(x) . (Wq_h^T k_c) -- a GEMM against an [H * Cp, D] matrix built once per weights -- and the output projection of
+// sum_c w_c v_c is w . (Wo_h v_c) -- a GEMM with K = H * Cp; between them only this remains:
+//   w[t, h, c] = 16-bit( exp2(s[t, h, c] + log2 n[seq(t), c] - m) / sum_c' exp2(...) ),  0 for the padding slots c >= C.
+// scores fp32 [tokens, >= H * Cp] (head-major, Cp slots per head), out 16-bit [tokens, >= H * Cp].  One thread per (token, head).
+template <int DT>
+__global__ __launch_bounds__(256) void softmax_counted_kernel(const float* __restrict__ sc, int64_t lds, const float* __restrict__ log2_count,
+                                                              const int32_t* __restrict__ cu_q, int H, int Cp, int C,
+                                                              unsigned short* __restrict__ out, int64_t ldo) {
+    const int seq = blockIdx.y;
+    const int tok0 = cu_q[seq], len = cu_q[seq + 1] - tok0;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= len * H) return;
+    const int t = p / H, h = p % H;
+    const float* sp = sc + (int64_t)(tok0 + t) * lds + h * Cp;
+    const float* lc = log2_count + (int64_t)seq * C;
+    float v[16];
+    float m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        v[c] = c < C ? sp[c] + lc[c] : -INFINITY;
+        m = __builtin_fmaxf(m, v[c]);
+    }
+    float l = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        v[c] = __builtin_amdgcn_exp2f(v[c] - m);          // exp2(-inf) = 0: absent labels and padding slots
+        l += v[c];
+    }
+    const float inv = 1.0f / l;
+    unsigned short* op = out + (int64_t)(tok0 + t) * ldo + h * Cp;
+#pragma unroll
+    for (int c = 0; c < 16; c += 2) {
+        if (c + 1 < Cp) *reinterpret_cast<unsigned int*>(op + c) = Op16<DT>::pack2(v[c] * inv, v[c + 1] * inv);
+        else if (c < Cp) op[c] = (unsigned short)(Op16<DT>::pack2(v[c] * inv, 0.f) & 0xffffu);
+    }
+}
+
+extern "C" int vf_softmax_counted(const float* scores, int64_t lds, const float* log2_count, const int32_t* cu_seqlens_q, int n_seq,
+                                  int max_seqlen_q, int H, int Cp, int C, void* out, int64_t ldo, int out_dtype, void* stream) {
+    VF_REQUIRE(scores && log2_count && cu_seqlens_q && out, "vf_softmax_counted: null pointer");
+    VF_REQUIRE(out_dtype == VF_BF16 || out_dtype == VF_F16, "vf_softmax_counted: out_dtype must be VF_BF16 or VF_F16");
+    VF_REQUIRE(C >= 1 && C <= Cp && Cp <= 16 && Cp % 2 == 0 && H >= 1, "vf_softmax_counted: C=%d Cp=%d (C <= Cp <= 16, Cp even) H=%d", C, Cp, H);
+    VF_REQUIRE(lds >= (int64_t)H * Cp && ldo >= (int64_t)H * Cp && ldo % 2 == 0 && ((uintptr_t)out % 4 == 0),
+               "vf_softmax_counted: rows hold H * Cp slots; the output keeps 4-byte alignment");
+    if (n_seq <= 0 || max_seqlen_q <= 0) return VF_OK;
+    VF_REQUIRE(n_seq <= 65535, "vf_softmax_counted: n_seq=%d exceeds the grid limit", n_seq);
+    const dim3 grid((unsigned)(((long)max_seqlen_q * H + 255) / 256), n_seq);
+    if (out_dtype == VF_BF16)
+        hipLaunchKernelGGL(softmax_counted_kernel<VF_BF16>, grid, dim3(256), 0, (hipStream_t)stream, scores, lds, log2_count,
+                           cu_seqlens_q, H, Cp, C, (unsigned short*)out, ldo);
+    else
+        hipLaunchKernelGGL(softmax_counted_kernel<VF_F16>, grid, dim3(256), 0, (hipStream_t)stream, scores, lds, log2_count,
+                           cu_seqlens_q, H, Cp, C, (unsigned short*)out, ldo);
+    VF_CHECK_LAUNCH("vf_softmax_counted");
+    return VF_OK;
+}
+
 extern "C" int vf_attn_rows_supported(int dh, int alibi, int n_seq, int H, int max_seqlen_q, int max_seqlen_k, int flags) {
     return rows_supported(dh, alibi != 0, n_seq, H, max_seqlen_q, max_seqlen_k, (flags & VF_ATTN_Q_LOG2) != 0) ? 1 : 0;
 }

@@ -2104,7 +2104,9 @@ static int gemm_ln_dispatch(const void* A, int64_t lda, const void* W, const flo
         ln.colsum = colsum;
         if (epilogue == VF_EPI_BF16)
             return launch_gemm_ln<VF_EPI_BF16, DT, VF_LN_CONSUMER>(A, lda, W, bias, nullptr, 0, out, ldo, M, N, K, ln, st);
-        VF_REQUIRE(epilogue == VF_EPI_GEGLU_BF16 && N % 32 == 0, "vf_gemm_ln: consumer epilogues are BF16 and GEGLU_BF16 (16-bit out)");
+        if (epilogue == VF_EPI_F32)       // fp32 rows out (ABI 10: attention logits against a few distinct keys, vf_softmax_counted)
+            return launch_gemm_ln<VF_EPI_F32, DT, VF_LN_CONSUMER>(A, lda, W, bias, nullptr, 0, out, ldo, M, N, K, ln, st);
+        VF_REQUIRE(epilogue == VF_EPI_GEGLU_BF16 && N % 32 == 0, "vf_gemm_ln: consumer epilogues are BF16, F32 and GEGLU_BF16");
         return launch_gemm_ln<VF_EPI_GEGLU_BF16, DT, VF_LN_CONSUMER>(A, lda, W, bias, nullptr, 0, out, ldo, M, N, K, ln, st);
     }
     VF_REQUIRE(ld16 % 4 == 0 && ld16 >= N && ((uintptr_t)out16 % 8 == 0) && ((uintptr_t)part_stats % 8 == 0) && ldo % 4 == 0,

@@ -332,14 +332,16 @@ def trunk16_of(x: torch.Tensor, raise_alert: bool = True) -> torch.Tensor:
 def gemm_ln_consumer(s: LnStream, w: torch.Tensor, bias: torch.Tensor, colsum: torch.Tensor, epilogue: int,
                      family: str = "") -> torch.Tensor:
     """epilogue(LN(s.x) @ W^T + b) without materialising LN(s.x): w = 16-bit(gamma (.) W) [N, K], bias = W beta + b,
-    colsum = rowsum(w) (layers.packed_linear_ln).  epilogue EPI_BF16 or EPI_GEGLU_BF16 (16-bit output, operand type)."""
+    colsum = rowsum(w) (layers.packed_linear_ln).  epilogue EPI_BF16 or EPI_GEGLU_BF16 (16-bit output, operand type), or
+    EPI_F32 (fp32 rows: the logits of softmax_counted)."""
     a = s.x16
     _dev(a, w, bias, colsum, s.stats)
     assert _is16(a.dtype) and w.dtype == a.dtype and a.shape[1] == w.shape[1] and a.stride(1) == 1
+    assert epilogue in (EPI_BF16, EPI_GEGLU_BF16, EPI_F32)
     M, K = a.shape
     N = w.shape[0]
     n_out = N // 2 if epilogue == EPI_GEGLU_BF16 else N
-    out = torch.empty((M, n_out), dtype=a.dtype, device=a.device)
+    out = torch.empty((M, n_out), dtype=torch.float32 if epilogue == EPI_F32 else a.dtype, device=a.device)
     lib = _lib.load()
 
     def launch():
@@ -347,7 +349,7 @@ def gemm_ln_consumer(s: LnStream, w: torch.Tensor, bias: torch.Tensor, colsum: t
                              0, 0, VF_F32, out.data_ptr(), n_out, M, N, K, epilogue, _dt(a.dtype), s.stats.data_ptr(),
                              colsum.data_ptr(), 0, 0, 0, 1.0, 1.0, _stream()), "vf_gemm_ln")
     if TIMER is not None:
-        nbytes = 2.0 * (M * K + N * K) + out.numel() * 2 + 8.0 * M
+        nbytes = 2.0 * (M * K + N * K) + out.numel() * out.element_size() + 8.0 * M
         TIMER.time("gemm", 2.0 * M * N * K, nbytes, launch, f"M={M} N={N} K={K} epi={epilogue} ln=consumer", family or _SCOPE)
     else:
         launch()
@@ -482,6 +484,28 @@ def attn_counted_keys(q: torch.Tensor, kv_table: torch.Tensor, log2_count: torch
     if TIMER is not None:       # executed work: 4 * tokens * C * width
         TIMER.time("attn", 4.0 * q.shape[0] * C * D, 2.0 * D * 2 * q.shape[0], launch,
                    f"H={n_heads} dh={head_dim} max_q={int(max_q)} counted_keys={C}", family or _SCOPE)
+    else:
+        launch()
+    return out
+
+
+def softmax_counted(scores: torch.Tensor, log2_count: torch.Tensor, cu_q: torch.Tensor, max_q: int, n_heads: int, slots: int,
+                    out_dtype=None, family: str = "") -> torch.Tensor:
+    """16-bit softmax over the C = log2_count.shape[1] distinct keys of every (token, head), log2(count) added to the base-2
+    logits scores fp32 [tokens, H * slots] (slots >= C per head, the padding gets weight 0): vf_softmax_counted."""
+    _dev(scores, log2_count, cu_q)
+    assert scores.dtype == torch.float32 and scores.stride(1) == 1 and log2_count.dtype == torch.float32 and log2_count.is_contiguous()
+    T, n_seq, C = scores.shape[0], cu_q.numel() - 1, log2_count.shape[1]
+    assert scores.shape[1] >= n_heads * slots and log2_count.shape[0] == n_seq
+    dt = _CDT if out_dtype is None else out_dtype
+    out = torch.empty((T, n_heads * slots), dtype=dt, device=scores.device)
+
+    def launch():
+        check(_lib.load().vf_softmax_counted(scores.data_ptr(), scores.stride(0), log2_count.data_ptr(), cu_q.data_ptr(), n_seq,
+                                             int(max_q), n_heads, slots, C, out.data_ptr(), out.stride(0), _dt(dt), _stream()),
+              "vf_softmax_counted")
+    if TIMER is not None:
+        TIMER.time("attn", 0.0, float(T) * n_heads * slots * 6, launch, f"softmax_counted H={n_heads} C={C}", family or _SCOPE)
     else:
         launch()
     return out

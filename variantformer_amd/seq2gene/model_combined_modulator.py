@@ -278,7 +278,7 @@ def modulator_forward_packed(ctx_embedding, cre_layers, gene_layers, cre_x, gene
                 kw_ctx = {"context_kv": None}
             elif log2c is not None:
                 # the context rows are copies of the 9 label embeddings: softmax over the distinct rows with log(count) added
-                kw_ctx = {"context_counted": (_context_kv_table(ctx_embedding, cre_layers[i]), log2c)}
+                kw_ctx = {"context_counted": (_context_kv_table(ctx_embedding, cre_layers[i]), log2c, ctx_embedding.weight)}
             else:
                 kw_ctx = {"context_kv": ops.gather_rows_bf16(_context_kv_table(ctx_embedding, cre_layers[i]), labels)}
             cre = cre_layers[i].forward_packed(cre, cu_cre, max_cre, cu_ctx=cu_cre, max_ctx=max_cre,

@@ -230,6 +230,7 @@ def _ffn_residual(s):
 
 ROWS_IN_ATTENTION = True      # False (tests only): always materialise the gathered projection in front of the attention
 COUNTED_CONTEXT_KEYS = True   # False (tests only): the CRE layers' context cross attention over the gathered [keys, 2D] rows
+LOWRANK_CONTEXT = True        # False (tests only): counted keys through q / attention / out_proj instead of the two skinny GEMMs
 
 
 def _as_stream(x):
@@ -344,6 +345,65 @@ class MHA(nn.Module):
         w, b, c = self.packed_qkv_ln(norm)
         qkv = ops.gemm_ln_consumer(s, w, b, c, ops.EPI_BF16)
         return self.attend_qkv(qkv, cu_q, max_q)
+
+    def lowrank_tables(self, norm, table: torch.Tensor):
+        """Weights of the LOW-RANK form of a cross attention whose keys / values are Wkv of the C rows of `table` (fp32 [C, D]):
+            logits[t, h, c] = LN(x_t) . z[h, c] + zb[h, c],   z[h, c] = scale * Wq_h^T k[c, h],  zb = scale * bq_h . k[c, h]
+            out_proj(sum_c w_c v[c, h])  =  w . U^T + bo,     U[:, h, c] = Wo[:, h] v[c, h]
+        with k, v = Wkv table + bkv in fp32 (no 16-bit rounding of q, k, v themselves: each product matrix is rounded once).
+        Returns (wz 16-bit [H * Cp, D], bz fp32, colsum fp32 | None, u 16-bit [D, H * Cp], bo fp32, Cp) -- wz carries the
+        LayerNorm fold of `norm` (gamma folded in, W beta in the bias, colsum for the mean correction) when norm is given --
+        or None when no slot count Cp in [C, 16] makes H * Cp a multiple of 64.  Cached per (weights, operand type)."""
+        assert self.cross_attn
+        C, D, H, dh = table.shape[0], self.embed_dim, self.num_heads, self.head_dim
+        Cp = next((c for c in range(C + (C & 1), 17, 2) if (H * c) % 64 == 0), None)
+        if Cp is None:
+            return None
+        prm = [table, self.Wq.weight, self.Wq.bias, self.Wkv.weight, self.Wkv.bias, self.out_proj.weight, self.out_proj.bias]
+        if norm is not None:
+            prm += [norm.weight, norm.bias]
+        key = (ops.cdt(), norm is not None) + tuple((p.data_ptr(), p._version) for p in prm)
+        slot = "_vf_lowrank_ln" if norm is not None else "_vf_lowrank"
+        c = getattr(self, slot, None)
+        if c is not None and c[0] == key:
+            return c[1]
+        with torch.no_grad():
+            kv = table.detach().float() @ self.Wkv.weight.detach().float().t() + self.Wkv.bias.detach().float()     # [C, 2D]
+            k, v = kv[:, :D].view(C, H, dh), kv[:, D:].view(C, H, dh)
+            wq = self.Wq.weight.detach().float().view(H, dh, D)
+            z = torch.zeros((H, Cp, D), dtype=torch.float32, device=table.device)
+            z[:, :C] = torch.einsum("chd,hdk->hck", k, wq) * self.q_log2_scale
+            zb = torch.zeros((H, Cp), dtype=torch.float32, device=table.device)
+            zb[:, :C] = torch.einsum("chd,hd->hc", k, self.Wq.bias.detach().float().view(H, dh)) * self.q_log2_scale
+            z, zb = z.view(H * Cp, D), zb.view(H * Cp)
+            u = torch.zeros((D, H, Cp), dtype=torch.float32, device=table.device)
+            u[:, :, :C] = torch.einsum("nhd,chd->nhc", self.out_proj.weight.detach().float().view(D, H, dh), v)
+            u16 = ops.cast16(u.view(D, H * Cp).contiguous())
+            bo = self.out_proj.bias.detach().float().contiguous()
+            if norm is not None:
+                wz = ops.cast16((z * norm.weight.detach().float()[None, :]).contiguous())
+                bz = (z @ norm.bias.detach().float() + zb).contiguous()
+                cs = wz.float().sum(dim=1).contiguous()
+            else:
+                wz, bz, cs = ops.cast16(z.contiguous()), zb.contiguous(), None
+        out = (wz, bz, cs, u16, bo, Cp)
+        setattr(self, slot, (key, out))
+        return out
+
+    def cross_lowrank(self, x, norm, table, log2_count, cu_q, max_q, residual, tables=None):
+        """out_proj(cross attention of LayerNorm(x) against Wkv(table rows), row c counted 2^log2_count[s, c] times) + residual
+        in the low-rank form (lowrank_tables): two skinny GEMMs around vf_softmax_counted.  x: an ops.LnStream (norm folded)
+        -> returns an LnStream (16-bit copy + statistics, no fp32 rows), or, norm=None, an already normalised 16-bit tensor with
+        an fp32 residual -> fp32 rows."""
+        wz, bz, cs, u16, bo, Cp = tables if tables is not None else self.lowrank_tables(norm, table)
+        if norm is not None:
+            sc = ops.gemm_ln_consumer(x, wz, bz, cs, ops.EPI_F32)
+        else:
+            sc = ops.gemm(x, wz, bz, ops.EPI_F32)
+        w16 = ops.softmax_counted(sc, log2_count, cu_q, max_q, self.num_heads, Cp, family=self.family)
+        if norm is not None:
+            return ops.gemm_ln_producer(w16, u16, bo, residual, need_x=False)
+        return ops.gemm(w16, u16, bo, ops.EPI_RES_F32, residual=residual)
 
     def attend_counted(self, x, norm, counted, cu_q, max_q) -> torch.Tensor:
         """Cross attention of LayerNorm(x) (x: an ops.LnStream with `norm` folded into Wq, or, norm=None, an already
@@ -524,8 +584,9 @@ class ContextFlashAttentionEncoderLayer(nn.Module):
         `self_qkv`: precomputed LayerNorm1 -> Wqkv projection of src (self_qkv_of_unique_rows).
         `keep_x=False` (LayerNorm fold only): the result's fp32 rows have no reader (the next layer of the stack takes
         the 16-bit copy, trunk16_enabled) and are not stored.
-        `context_counted` = (kv_table [C, 2D], log2_count [n_seq, C]) instead of context / context_kv: the context rows are
-        copies of C distinct rows (the CRE layers' label embeddings) -- MHA.attend_counted."""
+        `context_counted` = (kv_table [C, 2D], log2_count [n_seq, C][, table fp32 [C, D]]) instead of context / context_kv: the
+        context rows are copies of C distinct rows (the CRE layers' label embeddings) -- MHA.cross_lowrank when the raw table is
+        given (two skinny GEMMs around a 9-way softmax), else MHA.attend_counted."""
         if self.make_data_kv:
             return self._forward_packed_data_kv(src, cu_src, max_src, context, cu_ctx, max_ctx)
         cq = cu_src if cu_cross_q is None else cu_cross_q
@@ -544,13 +605,19 @@ class ContextFlashAttentionEncoderLayer(nn.Module):
                 a = self.mixer.MHA.attend_ln(s, self.norm1, None, cu_src, max_src, None, None)
             r16 = r16 or s.x is None
             x1 = self.mixer.MHA.out_ln(a, s if r16 else s.x, need_x=not r16)
-            if context_counted is not None:
-                a = self.crossMHA.MHA.attend_counted(x1, self.norm2, context_counted, cq, mq)
+            lr = None
+            if context_counted is not None and LOWRANK_CONTEXT and len(context_counted) > 2:
+                lr = self.crossMHA.MHA.lowrank_tables(self.norm2, context_counted[2])
+            if lr is not None:
+                x2 = self.crossMHA.MHA.cross_lowrank(x1, self.norm2, None, context_counted[1], cq, mq, x1 if r16 else x1.x, tables=lr)
             else:
-                if context_kv is None:
-                    context_kv = self.crossMHA.MHA.project_kv_of(context)
-                a = self.crossMHA.MHA.attend_ln(x1, self.norm2, context_kv, cq, mq, cu_ctx, max_ctx)
-            x2 = self.crossMHA.MHA.out_ln(a, x1 if r16 else x1.x, need_x=False)
+                if context_counted is not None:
+                    a = self.crossMHA.MHA.attend_counted(x1, self.norm2, context_counted, cq, mq)
+                else:
+                    if context_kv is None:
+                        context_kv = self.crossMHA.MHA.project_kv_of(context)
+                    a = self.crossMHA.MHA.attend_ln(x1, self.norm2, context_kv, cq, mq, cu_ctx, max_ctx)
+                x2 = self.crossMHA.MHA.out_ln(a, x1 if r16 else x1.x, need_x=False)
             w1, b1, c1 = packed_linear_ln(self.linear_geglu_1, self.norm3, geglu=True)
             hg = ops.gemm_ln_consumer(x2, w1, b1, c1, ops.EPI_GEGLU_BF16)
             w2, b2 = packed_linear(self.linear_geglu_2)
@@ -559,7 +626,12 @@ class ContextFlashAttentionEncoderLayer(nn.Module):
         h = ops.layernorm(src, self.norm1.weight, self.norm1.bias)
         x1 = self.mixer.MHA.fused(h, src, cu_src, max_src)
         h = ops.layernorm(x1, self.norm2.weight, self.norm2.bias)
-        if context_counted is not None:
+        lr = None
+        if context_counted is not None and LOWRANK_CONTEXT and len(context_counted) > 2:
+            lr = self.crossMHA.MHA.lowrank_tables(None, context_counted[2])
+        if lr is not None:
+            x2 = self.crossMHA.MHA.cross_lowrank(h, None, None, context_counted[1], cq, mq, x1, tables=lr)
+        elif context_counted is not None:
             a = self.crossMHA.MHA.attend_counted(h, None, context_counted, cq, mq)
             w, b = packed_linear(self.crossMHA.MHA.out_proj)
             x2 = ops.gemm(a, w, b, ops.EPI_RES_F32, residual=x1)
