@@ -229,7 +229,9 @@ class VCFDataset(Dataset):
         if gene_info["strand"] == "-":
             X, masks, ref_labels = X[::-1].copy(), masks[::-1].copy(), ref_labels[::-1].copy()
         labels = np.full(n, self.cre_to_idx["Low-DNase"], dtype=np.int64)
-        return (torch.from_numpy(X), torch.from_numpy(masks).bool(), torch.from_numpy(ref_labels),
+        # (vf_build_windows writes 0 / 1 bytes: the bool view is free; torch's .bool() is a converting copy that starts an OpenMP
+        # team per call -- 50 of a gene's 120 ms on an 8-core host, scripts/sample_builder_bench.py)
+        return (torch.from_numpy(X), torch.from_numpy(masks.view(np.bool_)), torch.from_numpy(ref_labels),
                 torch.from_numpy(labels))
 
     def _get_gene(self, gene_id: str, gene_info: dict, vcf_path: str):
