@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define VF_ABI_VERSION 10
+#define VF_ABI_VERSION 11
 
 enum vf_status {
     VF_OK = 0,
@@ -361,6 +361,12 @@ int64_t vf_build_windows(const void* vcf, const void* bpe, const char* chrom, in
                          int64_t span_len, int64_t n, const int64_t* starts0, const int64_t* ends0, int snp_only,
                          int indel_policy, int revcomp, int L, int64_t pad_id, int64_t* ids_out, uint8_t* mask_out,
                          int32_t* status);
+
+/* Host staging of a batch's token ids (no GPU): src int64 [rows] rows of L ids, src_row_stride elements apart -> dst int32
+ * [rows, L], clamped to [-1, INT32_MAX] (vf_embed_* clamp ids to [0, vocab): the same token either way; narrowing never
+ * wraps).  Returns a bit mask -- 1: some id < 0, 2: some id >= 2^30 -- or -1 for bad arguments.  The batch dict's id tensors
+ * (datasets/vcfdataset.py:18-63 `cre_sequences`, `gene_embeddings`: int64 [n, 1, L]) go through it once per batch. */
+int vf_narrow_ids(const int64_t* src, int64_t src_row_stride, int32_t* dst, int64_t rows, int64_t L);
 
 #ifdef __cplusplus
 }

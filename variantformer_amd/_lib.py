@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libvf_hip.so")
 # enums of include/vf_hip.h
 VF_F32, VF_BF16, VF_F16 = 0, 1, 2
 EPI_BF16, EPI_F32, EPI_RES_F32, EPI_GEGLU_BF16, EPI_GELU_F32, EPI_GELU_BF16 = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -68,6 +68,7 @@ SIGNATURES = {
     "vf_vcf_num_records": [_p, C.c_char_p],
     "vf_vcf_consensus": [_p, C.c_char_p, _l, C.c_char_p, _l, _i, _i, _p, _l, _p],
     "vf_build_windows": [_p, _p, C.c_char_p, _l, C.c_char_p, _l, _l, _p, _p, _i, _i, _i, _i, _l, _p, _p, _p],
+    "vf_narrow_ids": [_p, _l, _p, _l, _l],
 }
 _RESTYPES = {"vf_last_error": C.c_char_p, "vf_bpe_create": C.c_void_p, "vf_bpe_destroy": None, "vf_bpe_encode": C.c_int64,
              "vf_vcf_open": C.c_void_p, "vf_vcf_close": None, "vf_vcf_num_records": C.c_int64,

@@ -80,3 +80,25 @@ extern "C" int64_t vf_build_windows(const void* vcf, const void* bpe, const char
     }
     return n;
 }
+
+// Host staging of a batch's token ids (prepare_batch): src int64 [rows, src_row_stride elements apart, L used] -> dst int32
+// [rows, L], clamped to [-1, INT32_MAX] (the embedding kernels clamp to [0, vocab): the same token either way, and narrowing
+// never wraps), in ONE pass that also says what the ids looked like.  Returns a bit mask: 1 = some id < 0, 2 = some id >= 2^30
+// (the window de-duplication packs (id | pad << 30) into one word and is skipped then).  Replaces two numpy reductions and a
+// converting copy per gene (19 + 8 ms per 32-gene batch on an 8-core host).
+extern "C" int vf_narrow_ids(const int64_t* src, int64_t src_row_stride, int32_t* dst, int64_t rows, int64_t L) {
+    if (!src || !dst || rows < 0 || L < 0) return -1;
+    int neg = 0, big = 0;
+    for (int64_t r = 0; r < rows; ++r) {
+        const int64_t* s = src + r * src_row_stride;
+        int32_t* d = dst + r * L;
+        for (int64_t i = 0; i < L; ++i) {
+            int64_t v = s[i];
+            neg |= (v < 0);
+            big |= (v >= (1LL << 30));
+            v = v < -1 ? -1 : (v > 2147483647LL ? 2147483647LL : v);
+            d[i] = (int32_t)v;
+        }
+    }
+    return neg | (big << 1);
+}

@@ -26,7 +26,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import _lib, ops
 from ..utils.constants import REF_CREs
 from ..utils.functions import precision2dtype
 from .modules.layers import (AddContext, ContextFlashAttentionEncoderLayer, ContextFlashCrossAttentionEncoderLayer,
@@ -546,6 +546,7 @@ class Seq2GenePredictorCombinedModulator(nn.Module):
             assert v.shape[1] == 1, "one strand per window (strand is picked in the dataloader)"
         st = self._stager()
         st.begin()
+        id_flags = {}                                # per id array: bit 0 = a negative id, bit 1 = an id >= 2^30
 
         def gather(name, parts, dtype):
             """per-gene [n_i, 1, L] tensors -> one staged [sum n_i, L] array of `dtype`: one narrowing copy per gene, by numpy
@@ -565,10 +566,20 @@ class Seq2GenePredictorCombinedModulator(nn.Module):
                         np.copyto(dst[off:off + n], src, casting="unsafe")
                     else:
                         np.not_equal(src, 0, out=dst[off:off + n].view(np.bool_))
-                else:                                             # ids: the kernels clamp to [0, vocab); narrowing must not wrap first
-                    if n and src.dtype.itemsize > 4 and (int(src.min()) < -1 or int(src.max()) > 2 ** 31 - 1):
-                        src = np.clip(src, -1, 2 ** 31 - 1)       # same clamp result as the int64 path: < 0 -> 0, huge -> vocab - 1
-                    np.copyto(dst[off:off + n], src, casting="unsafe")
+                elif n:                                           # ids: the kernels clamp to [0, vocab); narrowing must not wrap first
+                    if src.dtype == np.int64 and src.strides[1] == 8 and src.strides[0] % 8 == 0:
+                        # one native pass: clamp to [-1, INT32_MAX] (the same token as the int64 path's clamp), narrow, and report
+                        # what the ids looked like (bit 0: negative, bit 1: >= 2^30)
+                        f = _lib.load().vf_narrow_ids(src.ctypes.data, src.strides[0] // 8, dst[off:off + n].ctypes.data, n, L)
+                        if f < 0:
+                            raise _lib.VFError("vf_narrow_ids: bad arguments")
+                        id_flags[name] = id_flags.get(name, 0) | f
+                    else:
+                        lo, hi = int(src.min()), int(src.max())
+                        id_flags[name] = id_flags.get(name, 0) | (1 if lo < 0 else 0) | (2 if hi >= 2 ** 30 else 0)
+                        if src.dtype.itemsize > 4 and (lo < -1 or hi > 2 ** 31 - 1):
+                            src = np.clip(src, -1, 2 ** 31 - 1)
+                        np.copyto(dst[off:off + n], src, casting="unsafe")
                 off += n
             return buf
         cre_ids, cre_pad = gather("cre_ids", x, torch.int32), gather("cre_pad", m, torch.uint8)
@@ -584,9 +595,8 @@ class Seq2GenePredictorCombinedModulator(nn.Module):
         cre_ctx = labels if use_ctx else None
         if dedupe_windows is not False:
             cre_np, gene_np = cre_ids.numpy(), gene_ids.numpy()
-            def key_safe(a):         # the 64-bit row key packs (id | pad << 30): ids must lie in [0, 2^30)
-                return a.size == 0 or (int(a.min()) >= 0 and int(a.max()) < 2 ** 30)
-            if key_safe(cre_np) and key_safe(gene_np):
+            # the 64-bit row key packs (id | pad << 30): ids must lie in [0, 2^30) (seen while narrowing)
+            if not id_flags.get("cre_ids", 0) and not id_flags.get("gene_ids", 0):
                 r = self._unique_windows(cre_np, cre_pad.numpy(), labels.numpy() if use_ctx else None)
                 if r is not None:
                     cre_keep, cre_inv = r
