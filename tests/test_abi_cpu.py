@@ -49,3 +49,29 @@ def test_ops_refuse_cpu_tensors():
     from variantformer_amd._lib import VFError
     with pytest.raises(VFError):
         ops.layernorm(torch.zeros(2, 8), torch.ones(8), torch.zeros(8))
+
+
+def test_vf_narrow_ids_clamps_narrows_and_reports_ranges():
+    """vf_narrow_ids (ABI 11, host only): int64 ids -> int32, clamped to [-1, INT32_MAX] like the embedding kernels' own clamp
+    would treat them, with the range flags prepare_batch keys its window de-duplication on; strided source rows."""
+    import numpy as np
+    from variantformer_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(0)
+    src = rng.integers(0, 500, (7, 3, 40)).astype(np.int64)          # [rows, strands, L]: rows are 3 * 40 elements apart
+    view = src[:, 1, :]
+    dst = np.full((7, 40), -7, dtype=np.int32)
+    assert lib.vf_narrow_ids(view.ctypes.data, view.strides[0] // 8, dst.ctypes.data, 7, 40) == 0
+    assert np.array_equal(dst, view.astype(np.int32))
+    view[2, 5], view[4, 0] = -(2 ** 40), -1
+    assert lib.vf_narrow_ids(view.ctypes.data, view.strides[0] // 8, dst.ctypes.data, 7, 40) == 1
+    assert dst[2, 5] == -1 and dst[4, 0] == -1
+    view[2, 5], view[4, 0], view[6, 39] = 3, 4, 2 ** 31 + 9
+    assert lib.vf_narrow_ids(view.ctypes.data, view.strides[0] // 8, dst.ctypes.data, 7, 40) == 2
+    assert dst[6, 39] == 2 ** 31 - 1
+    view[6, 39], view[0, 0] = 2 ** 30, -5
+    assert lib.vf_narrow_ids(view.ctypes.data, view.strides[0] // 8, dst.ctypes.data, 7, 40) == 3 and dst[6, 39] == 2 ** 30
+    view[6, 39], view[0, 0] = 2 ** 30 - 1, 0
+    assert lib.vf_narrow_ids(view.ctypes.data, view.strides[0] // 8, dst.ctypes.data, 7, 40) == 0
+    assert lib.vf_narrow_ids(None, 0, dst.ctypes.data, 7, 40) == -1
+    assert lib.vf_narrow_ids(view.ctypes.data, view.strides[0] // 8, dst.ctypes.data, 0, 40) == 0
