@@ -342,6 +342,45 @@ def test_first_gene_layer_row_map_attention_is_exact(monkeypatch):
         np.testing.assert_array_equal(a["embeddings"][i], c["embeddings"][i])
 
 
+def test_cre_stream_on_a_side_stream_is_bit_identical(monkeypatch):
+    """model_combined_modulator.OVERLAP_CRE_STREAM (opt-in, off by default): the CRE layers run on a side stream beside the
+    gene layers (CRE layer i + 1 needs CRE layer i only; gene layer i + 1 needs gene layer i and CRE layer i).  Same kernels,
+    same inputs: bit-identical outputs over repeated calls, and a LayerNorm-fold alert raised by a CRE-stream kernel on the
+    side stream still reaches the batch (the model recomputes it)."""
+    import variantformer_amd.seq2gene.model_combined_modulator as M
+    model = build_model(SEQ2REG_512, seq2gene_kw(layers=5), seed=3).cuda()
+    batch = make_batch(4, [300, 40], [150, 20], [TISSUES_54[:5], [9, 33]], 200)
+    a = model.predict_step(batch, 0)
+    monkeypatch.setattr(M, "OVERLAP_CRE_STREAM", True)
+    for _ in range(3):
+        b = model.predict_step(batch, 0)
+        for i in range(2):
+            np.testing.assert_array_equal(a["pred_gene_exp"][i], b["pred_gene_exp"][i])
+            np.testing.assert_array_equal(a["embeddings"][i], b["embeddings"][i])
+    # an alert that only a CRE-stream kernel can raise: a huge common offset on the output bias of CRE layer 1's down-projection
+    # gives every row of the CRE stream a mean of many standard deviations from CRE layer 2 on; the gene stream never sees it in
+    # a LayerNorm-folded statistic of its own (it reads the CRE stream through K / V projections only)
+    saved = (dict(M._LN_HEAL, recent=list(M._LN_HEAL["recent"])))
+    try:
+        M._LN_HEAL.update(batches=0, finished=0)
+        M._LN_HEAL["recent"].clear()
+        monkeypatch.setattr(M, "LN_HEAL_STICKY_AFTER", 10 ** 9)
+        with torch.no_grad():
+            model.combined_modulator.cre_layers[1].linear_geglu_2.bias += 60.0
+        monkeypatch.setattr(M, "OVERLAP_CRE_STREAM", False)
+        want = model.predict_step(batch, 0)
+        assert M._LN_HEAL["batches"] == 1, "the serial path must have flagged and recomputed the batch"
+        monkeypatch.setattr(M, "OVERLAP_CRE_STREAM", True)
+        got = model.predict_step(batch, 0)
+        assert M._LN_HEAL["batches"] == 2, "the alert raised on the side stream must reach the batch"
+        for i in range(2):
+            np.testing.assert_array_equal(got["pred_gene_exp"][i], want["pred_gene_exp"][i])
+    finally:
+        M._LN_HEAL.update(batches=saved["batches"], finished=saved["finished"], logged=saved["logged"])
+        M._LN_HEAL["recent"].clear()
+        M._LN_HEAL["recent"].extend(saved["recent"])
+
+
 def test_tissue_invariance_and_batch_independence():
     """Size-independent properties: a gene's prediction does not depend on which other genes share its batch,
     nor on how many tissues are requested with it (the exact de-duplication must not leak between rows)."""

@@ -215,6 +215,17 @@ class PredictHandle:
         self.tissues, self.pred, self.emb, self.model, self.pb, self.alert, self.done = tissues, pred, emb, model, pb, alert, done
 
 
+OVERLAP_CRE_STREAM = False     # experiment: CRE layers on a side stream beside the gene layers (see modulator_forward_packed)
+_SIDE_STREAMS: dict = {}
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
+
 def _t(x):
     """fp32 tensor of a stream the layers may hand over as ops.LnStream (x, bf16 copy, row statistics)."""
     return x.x if isinstance(x, ops.LnStream) else x
@@ -272,7 +283,7 @@ def modulator_forward_packed(ctx_embedding, cre_layers, gene_layers, cre_x, gene
         cnt = torch.zeros(lens.numel() * C, dtype=torch.float32, device=labels.device)
         cnt.index_add_(0, gid * C + labels.long().clamp(0, C - 1), torch.ones(labels.numel(), dtype=torch.float32, device=labels.device))
         log2c = torch.log2(cnt).view(lens.numel(), C).contiguous()
-    for i in range(n - 1):
+    def cre_layer(i, cre_in):
         with ops.scope("cre_stream"):
             if ctx_embedding is None:
                 kw_ctx = {"context_kv": None}
@@ -281,20 +292,61 @@ def modulator_forward_packed(ctx_embedding, cre_layers, gene_layers, cre_x, gene
                 kw_ctx = {"context_counted": (_context_kv_table(ctx_embedding, cre_layers[i]), log2c, ctx_embedding.weight)}
             else:
                 kw_ctx = {"context_kv": ops.gather_rows_bf16(_context_kv_table(ctx_embedding, cre_layers[i]), labels)}
-            cre = cre_layers[i].forward_packed(cre, cu_cre, max_cre, cu_ctx=cu_cre, max_ctx=max_cre,
-                                               keep_x=not t16 or i == n - 2, **kw_ctx)
+            return cre_layers[i].forward_packed(cre_in, cu_cre, max_cre, cu_ctx=cu_cre, max_ctx=max_cre,
+                                                keep_x=not t16 or i == n - 2, **kw_ctx)
+
+    def gene_layer(i, gene_in, cre_i):
         with ops.scope("gene_stream"):
-            if final_rows is not None and i + 1 == n - 1:
+            if final_rows is not None and i == n - 1:
                 # last gene layer: only the registry rows are consumed downstream -> compact [R, D] result
                 rows, cu_rows, cu_cross_rows, max_cross_rows = final_rows
-                gene = gene_layers[i + 1].forward_packed_rows(gene, cu_gene_self, max_gene, rows, cu_rows, cre, ck, max_cre,
-                                                              cu_cross_rows, max_cross_rows)
-            else:
-                gene = gene_layers[i + 1].forward_packed(gene, cu_gene_self, max_gene, context=cre, cu_ctx=ck,
-                                                         max_ctx=max_cre, cu_cross_q=cq, max_cross_q=mq,
-                                                         keep_x=not t16 or use_res or i + 1 == n - 1)
-                if use_res:                             # :284-285
-                    gene = ops.add_rows(_t(gene), gene_x)
+                return gene_layers[i].forward_packed_rows(gene_in, cu_gene_self, max_gene, rows, cu_rows, cre_i, ck, max_cre,
+                                                          cu_cross_rows, max_cross_rows)
+            g = gene_layers[i].forward_packed(gene_in, cu_gene_self, max_gene, context=cre_i, cu_ctx=ck, max_ctx=max_cre,
+                                              cu_cross_q=cq, max_cross_q=mq, keep_x=not t16 or use_res or i == n - 1)
+            if use_res:                                 # :284-285
+                g = ops.add_rows(_t(g), gene_x)
+            return g
+
+    overlap = OVERLAP_CRE_STREAM and n > 2 and ops.TIMER is None and _t(cre_x).is_cuda
+    if not overlap:
+        for i in range(n - 1):
+            cre = cre_layer(i, cre)
+            gene = gene_layer(i + 1, gene, cre)
+        return _t(gene), _t(cre)
+    # EXPERIMENT (off by default): CRE layer i + 1 depends on CRE layer i only, gene layer i + 1 on gene layer i and CRE layer i:
+    # the small CRE-stream kernels (3-9 tiles per CU) run on a side stream beside the gene layer and fill the tails of its
+    # persistent GEMMs.  Tensors that cross streams are recorded on the stream that reads them.
+    dev = _t(cre_x).device
+    main = torch.cuda.current_stream(dev)
+    side = _side_stream(dev)
+
+    def tensors(x):
+        return [t for t in ((x.x, x.x16, x.stats, x.t16) if isinstance(x, ops.LnStream) else (x,)) if t is not None]
+
+    def launch_cre(i, cre_in):
+        with torch.cuda.stream(side):
+            out = cre_layer(i, cre_in)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        for t in tensors(out):
+            t.record_stream(main)
+        return out, ev
+    # (gene layer 0 above is already enqueued on the main stream: CRE layer 0 runs beside it)
+    side.wait_stream(main)
+    pending = launch_cre(0, cre)
+    for i in range(n - 1):
+        cre, ev = pending
+        if i + 1 < n - 1:
+            pending = launch_cre(i + 1, cre)
+        main.wait_event(ev)
+        gene = gene_layer(i + 1, gene, cre)
+    with torch.cuda.stream(side):
+        side_flag = ops._alert_flag(dev)
+    main.wait_stream(side)
+    ops._alert_flag(dev).bitwise_or_(side_flag)          # the side stream's LayerNorm-fold alerts belong to this batch too
+    side_flag.zero_()
+    side.wait_stream(main)
     return _t(gene), _t(cre)
 
 
