@@ -17,8 +17,11 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture()
-def heal_state():
-    """The self-healing bookkeeping is per process (sticky when 2 of the last 16 finished batches alerted): isolate it."""
+def heal_state(monkeypatch):
+    """The self-healing bookkeeping is per process (sticky when 2 of the last 16 finished batches alerted): isolate it.  These
+    tests are about the DEFAULT contract (fold on, fp16 trunk copy): they pin their own environment whatever the ambient one."""
+    monkeypatch.delenv("VF_LN_FOLD", raising=False)
+    monkeypatch.delenv("VF_TRUNK16", raising=False)
     from variantformer_amd.seq2gene import model_combined_modulator as M
     from variantformer_amd.seq2gene.modules import layers as L
     saved = (dict(M._LN_HEAL, recent=list(M._LN_HEAL["recent"])), L._LN_FOLD_DISABLED)

@@ -261,6 +261,8 @@ def test_first_gene_layer_input_from_16bit_copies_of_the_distinct_rows_is_exact(
     fp32 [sum T x G, D] stream is never built (bf16 operands; fp16 operands keep the fp32 gather).  Casts are row-wise:
     bit-identical to gathering fp32 rows first."""
     import variantformer_amd.seq2gene.modules.layers as Lyr
+    monkeypatch.delenv("VF_LN_FOLD", raising=False)                    # the form under test belongs to the default contract
+    monkeypatch.delenv("VF_TRUNK16", raising=False)
     kw = seq2gene_kw(layers=2)
     model = build_model(SEQ2REG_512, kw, seed=79).cuda()
     batch = make_batch(7, [9, 5], [150, 20], [TISSUES_54[:3], [9, 33]], 200)
@@ -348,6 +350,8 @@ def test_cre_stream_on_a_side_stream_is_bit_identical(monkeypatch):
     same inputs: bit-identical outputs over repeated calls, and a LayerNorm-fold alert raised by a CRE-stream kernel on the
     side stream still reaches the batch (the model recomputes it)."""
     import variantformer_amd.seq2gene.model_combined_modulator as M
+    monkeypatch.delenv("VF_LN_FOLD", raising=False)                    # the alert half needs the fold (default contract)
+    monkeypatch.delenv("VF_TRUNK16", raising=False)
     model = build_model(SEQ2REG_512, seq2gene_kw(layers=5), seed=3).cuda()
     batch = make_batch(4, [300, 40], [150, 20], [TISSUES_54[:5], [9, 33]], 200)
     a = model.predict_step(batch, 0)

@@ -55,7 +55,9 @@ def trained_like_(model, seed: int, outlier_gain: float = 25.0):
 
 
 @pytest.mark.parametrize("precision", ["bf16-mixed", "16-mixed"])
-def test_trained_like_statistics_keep_the_accuracy_of_the_reference_arithmetic(precision):
+def test_trained_like_statistics_keep_the_accuracy_of_the_reference_arithmetic(precision, monkeypatch):
+    monkeypatch.delenv("VF_LN_FOLD", raising=False)        # the bars below are the default contract's (fold on, fp16 trunk copy)
+    monkeypatch.delenv("VF_TRUNK16", raising=False)
     kw = seq2gene_kw(layers=3)
     model = build_model(SEQ2REG_512, kw, seed=777)
     trained_like_(model, 5)
