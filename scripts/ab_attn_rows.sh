@@ -7,8 +7,8 @@ for flag in 1 0; do
 python - > gpurun_out/r5b/bench_rows${flag}_$rep.json 2> gpurun_out/r5b/bench_rows${flag}_$rep.err <<P
 import sys
 sys.argv = ["bench.py", "--steps", "6", "--warmup", "2", "--no-cpu-baseline"]
-import variantformer_amd.seq2gene.modules.layers as L
-L.ROWS_IN_ATTENTION = bool($flag)
+from variantformer_amd import runtime
+runtime.set_for_this_context(rows_in_attention=bool($flag))
 import bench
 bench.main()
 P

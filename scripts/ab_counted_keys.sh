@@ -8,9 +8,8 @@ for form in lowrank counted expanded; do
 python - > gpurun_out/r5e/bench_${form}_$rep.json 2> gpurun_out/r5e/bench_${form}_$rep.err <<P
 import sys
 sys.argv = ["bench.py", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-pipelined"]
-import variantformer_amd.seq2gene.modules.layers as L
-L.COUNTED_CONTEXT_KEYS = "$form" != "expanded"
-L.LOWRANK_CONTEXT = "$form" == "lowrank"
+from variantformer_amd import runtime
+runtime.set_for_this_context(counted_context_keys="$form" != "expanded", lowrank_context="$form" == "lowrank")
 import bench
 bench.main()
 P

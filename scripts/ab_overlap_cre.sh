@@ -1,12 +1,12 @@
-# A/B on one box: CRE layers on a side stream beside the gene layers (model_combined_modulator.OVERLAP_CRE_STREAM) vs serial
+# A/B on one box: CRE layers on a side stream beside the gene layers (runtime.Switches.overlap_cre_stream, the default since round 6) vs serial
 cd $GRAFT_REPO_ROOT
 for rep in 1 2 3; do
 for flag in 1 0; do
 python - <<P 2>/dev/null | tail -1
 import sys
 sys.argv = ["bench.py", "--steps", "8", "--warmup", "3", "--no-cpu-baseline", "--no-pipelined", "--no-kernel-timing"]
-import variantformer_amd.seq2gene.model_combined_modulator as M
-M.OVERLAP_CRE_STREAM = bool($flag)
+from variantformer_amd import runtime
+runtime.set_for_this_context(overlap_cre_stream=bool($flag))
 import bench, io, contextlib, json
 buf = io.StringIO()
 with contextlib.redirect_stdout(buf):
@@ -24,8 +24,9 @@ from variantformer_amd.utils.synthetic import TISSUES_54, make_batch
 import variantformer_amd.seq2gene.model_combined_modulator as M
 model = build_model(SEQ2REG_512, seq2gene_kw(layers=5), seed=3).cuda()
 batch = make_batch(4, [300, 40], [150, 20], [TISSUES_54[:5], [9, 33]], 200)
-a = model.predict_step(batch, 0)
-M.OVERLAP_CRE_STREAM = True
+from variantformer_amd import runtime
+with runtime.override(overlap_cre_stream=False):
+    a = model.predict_step(batch, 0)
 for _ in range(3): b = model.predict_step(batch, 0)
 print("bit-identical:", all(np.array_equal(a[k][i], b[k][i]) for k in ("pred_gene_exp", "embeddings") for i in range(2)))
 P

@@ -6,8 +6,8 @@ TAG=${1:-x}
 O=gpurun_out/$TAG
 mkdir -p $O
 if [ "$2" != "--skip-tests" ] && [ "$2" != "--pmc-only" ]; then
-  python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
-  tail -3 $O/pytest_gpu.log
+  python -m pytest tests -m gpu -x -q -s > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
+  tail -3 $O/pytest_gpu.log; grep -a "\[headline\|\[trained-like" $O/pytest_gpu.log
 fi
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 if [ "$2" != "--pmc-only" ]; then
@@ -18,6 +18,11 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/${TA
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/${TAG}_pmc_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > $O/pmc_write.json 2> $O/pmc_write.err
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d gpurun_out/${TAG}_pmc_sq -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing > $O/pmc_sq.json 2> $O/pmc_sq.err
 python scripts/pmc_summary.py $O/pmc_hbm_traffic.json ${TAG}_pmc > /dev/null
+# per launch geometry (round 6): the same two counters on scripts/pmc_shapes.py, joined with the timer's launch order
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/${TAG}_shp_fetch -- python3 scripts/pmc_shapes.py run 32 $O/pmc_shapes_order.json > $O/pmc_shapes_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/${TAG}_shp_write -- python3 scripts/pmc_shapes.py run 32 $O/pmc_shapes_order.json > $O/pmc_shapes_write.log 2>&1
+python scripts/pmc_shapes.py join gpurun_out/${TAG}_shp_fetch gpurun_out/${TAG}_shp_write $O/pmc_shapes_order.json $O/pmc_hbm_traffic_by_shape.json > $O/pmc_hbm_traffic_by_shape.txt 2>&1; head -40 $O/pmc_hbm_traffic_by_shape.txt
+rm -rf gpurun_out/${TAG}_shp_fetch gpurun_out/${TAG}_shp_write $O/pmc_shapes_order.json
 python scripts/pmc_sq_summary.py gpurun_out/${TAG}_pmc_sq $O/pmc_sq.json > $O/pmc_sq_summary.txt; tail -60 $O/pmc_sq_summary.txt
 cp $(find $O/prof -name '*kernel_stats.csv' | head -1) $O/kernel_stats.csv 2>/dev/null
 rm -rf gpurun_out/${TAG}_pmc_fetch gpurun_out/${TAG}_pmc_write gpurun_out/${TAG}_pmc_sq

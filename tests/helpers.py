@@ -32,8 +32,8 @@ def signal_rel(got, want):
     return float(np.abs(g - w).max() / w.std())
 
 
-SIGNAL_RTOL = 3e-2      # expression error allowed as a fraction of the across-gene / across-tissue spread (signal_rel);
-                        # measured on MI355X: 5e-4 ... 1.5e-2 (gpurun_out/r3a/pytest.log)
+SIGNAL_RTOL = 2e-2      # expression error allowed as a fraction of the across-gene / across-tissue spread (signal_rel);
+                        # measured on MI355X: 5e-4 ... 1.5e-2 (profiles/r05_l_pytest_gpu_final.log; 3e-2 until round 6)
 
 
 def check_signal(tag, got, want, tol=SIGNAL_RTOL):

@@ -18,21 +18,17 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture()
 def heal_state(monkeypatch):
-    """The self-healing bookkeeping is per process (sticky when 2 of the last 16 finished batches alerted): isolate it.  These
-    tests are about the DEFAULT contract (fold on, fp16 trunk copy): they pin their own environment whatever the ambient one."""
+    """The self-healing bookkeeping is PER MODEL since round 6 (M.heal_state(model): a sticky switch when 2 of the model's last
+    16 finished batches alerted); only the explicit process-wide switch (layers.ln_fold_disable) needs isolating.  These tests
+    are about the DEFAULT contract (fold on, fp16 trunk copy): they pin their own environment whatever the ambient one."""
     monkeypatch.delenv("VF_LN_FOLD", raising=False)
     monkeypatch.delenv("VF_TRUNK16", raising=False)
     from variantformer_amd.seq2gene import model_combined_modulator as M
     from variantformer_amd.seq2gene.modules import layers as L
-    saved = (dict(M._LN_HEAL, recent=list(M._LN_HEAL["recent"])), L._LN_FOLD_DISABLED)
-    M._LN_HEAL.update(batches=0, finished=0, logged=False)
-    M._LN_HEAL["recent"].clear()
+    saved = L._LN_FOLD_DISABLED
     L.ln_fold_reenable()
     yield M, L
-    M._LN_HEAL.update(batches=saved[0]["batches"], finished=saved[0]["finished"], logged=saved[0]["logged"])
-    M._LN_HEAL["recent"].clear()
-    M._LN_HEAL["recent"].extend(saved[0]["recent"])
-    L._LN_FOLD_DISABLED = saved[1]
+    L._LN_FOLD_DISABLED = saved
 
 
 def _forward_counter(model, monkeypatch):
@@ -59,7 +55,8 @@ def test_alerting_batch_is_recomputed_and_equals_the_unfolded_run(heal_state, mo
 
     # an ordinary batch: one forward, nothing flagged
     clean = model.predict_step(batch, 0)
-    assert calls["n"] == 1 and M._LN_HEAL["batches"] == 0
+    hs = M.heal_state(model)
+    assert calls["n"] == 1 and hs.batches == 0
 
     # registry rows of the tissues in use get a mean of 20 standard deviations: the first gene layer's LayerNorm sees them
     with torch.no_grad():
@@ -77,7 +74,7 @@ def test_alerting_batch_is_recomputed_and_equals_the_unfolded_run(heal_state, mo
     with caplog.at_level(logging.INFO, logger="variantformer_amd"):
         healed = model.predict_step(batch, 0)
     assert calls["n"] == 2, "the flagged batch must have been recomputed once"
-    assert M._LN_HEAL["batches"] == 1 and any("recomputed" in r.getMessage() for r in caplog.records)
+    assert hs.batches == 1 and any("recomputed" in r.getMessage() for r in caplog.records)
     assert ops.ln_fold_alert(dev) == 0                                 # flag consumed
     for i in range(len(tissues)):
         assert np.array_equal(healed["pred_gene_exp"][i], plain["pred_gene_exp"][i])
@@ -85,18 +82,29 @@ def test_alerting_batch_is_recomputed_and_equals_the_unfolded_run(heal_state, mo
         assert not np.array_equal(healed["pred_gene_exp"][i], clean["pred_gene_exp"][i])     # the weights did change
     assert L.ln_fold_enabled(1536, 1024)                               # one alert: the fold is still on for the next batch
 
-    # a second alerting batch switches the fold off for the process: from then on ONE forward per batch, same bits
+    # a second alerting batch switches the fold off FOR THIS MODEL: from then on ONE forward per batch, same bits
     calls["n"] = 0
     caplog.clear()
     with caplog.at_level(logging.WARNING, logger="variantformer_amd"):      # the switch is announced at WARNING: visible by default
         again = model.predict_step(batch, 1)
-    assert calls["n"] == 2 and M._LN_HEAL["batches"] == 2 and not L.ln_fold_enabled(1536, 1024)
+    assert calls["n"] == 2 and hs.batches == 2 and hs.off
+    assert L.ln_fold_enabled(1536, 1024), "the switch is the model's own: nothing process-wide changed"
     assert any(r.levelno == logging.WARNING and "OFF" in r.getMessage() for r in caplog.records)
-    st = M.ln_fold_state()
-    assert st["switched_off_for_process"] and not st["enabled"] and st["batches_recomputed"] == 2
+    st = model.ln_fold_state()
+    assert st["switched_off_by_alerts"] and not st["switched_off_for_process"] and not st["enabled"] and st["batches_recomputed"] == 2
+    # a second, healthy model in the same process keeps the fold (round-5 advice: the sticky switch was process-global)
+    other = build_model(SEQ2REG_512, kw, seed=4243).cuda()
+    seen = {}
+    orig_fp = other._forward_prepared
+    monkeypatch.setattr(other, "_forward_prepared", lambda *a, **k: (seen.update(fold=L.ln_fold_enabled(1536, 1024)), orig_fp(*a, **k))[1])
+    other.predict_step(batch, 0)
+    assert seen["fold"] is True and not other.ln_fold_state()["switched_off_by_alerts"]
+    seen.clear()
+    orig_m = model._forward_prepared
+    monkeypatch.setattr(model, "_forward_prepared", lambda *a, **k: (seen.update(fold=L.ln_fold_enabled(1536, 1024)), orig_m(*a, **k))[1])
     calls["n"] = 0
     third = model.predict_step(batch, 2)
-    assert calls["n"] == 1
+    assert calls["n"] == 1 and seen["fold"] is False
     for i in range(len(tissues)):
         assert np.array_equal(again["pred_gene_exp"][i], plain["pred_gene_exp"][i])
         assert np.array_equal(third["pred_gene_exp"][i], plain["pred_gene_exp"][i])
@@ -130,7 +138,7 @@ def test_pipelined_trainer_heals_the_right_batch(heal_state, monkeypatch):
     monkeypatch.setattr(M, "LN_HEAL_STICKY_AFTER", 10 ** 9)
     calls = _forward_counter(model, monkeypatch)
     got = Trainer().predict(model, [good, bad, good])
-    assert calls["n"] == 4 and M._LN_HEAL["batches"] == 1              # three batches + one recomputation
+    assert calls["n"] == 4 and M.heal_state(model).batches == 1          # three batches + one recomputation
     assert np.array_equal(got[1]["pred_gene_exp"][0], want[1]["pred_gene_exp"][0])
     assert np.array_equal(got[1]["embeddings"][0], want[1]["embeddings"][0])
     # the clean batches came from the folded path: same numbers as the unfolded run at 16-bit level, not bit for bit
@@ -200,11 +208,12 @@ def test_deeper_pipelining_heals_the_right_batch(heal_state, monkeypatch):
     with torch.no_grad():
         model.forward_prepared(model.prepare_batch(bad))
     calls = _forward_counter(model, monkeypatch)
-    M._LN_HEAL.update(batches=0, finished=0)
+    hs = M.heal_state(model)
+    hs.batches = hs.finished = 0
     handles = [model.predict_launch(model.prepare_batch(b)) for b in (good, bad, good)]      # three launches in flight
     got = [model.predict_finish(h, i) for i, h in enumerate(handles)]
-    assert calls["n"] == 4 and M._LN_HEAL["batches"] == 1 and M._LN_HEAL["finished"] == 3
-    assert list(M._LN_HEAL["recent"])[-3:] == [False, True, False]
+    assert calls["n"] == 4 and hs.batches == 1 and hs.finished == 3
+    assert list(hs.recent)[-3:] == [False, True, False]
     assert np.array_equal(got[1]["pred_gene_exp"][0], want[1]["pred_gene_exp"][0])
     assert np.array_equal(got[1]["embeddings"][0], want[1]["embeddings"][0])
     for i in (0, 2):
@@ -232,10 +241,10 @@ def test_an_unused_registry_row_does_not_flag_the_batch(heal_state, monkeypatch)
         w[40] += 30.0 * w[40].std()                                      # tissue 40: not in the batch
     calls = _forward_counter(model, monkeypatch)
     model.predict_step(batch, 0)
-    assert calls["n"] == 1 and M._LN_HEAL["batches"] == 0
+    assert calls["n"] == 1 and M.heal_state(model).batches == 0
     other = make_batch(7, [6], [3], [[8, 40]], 200)                      # now it is
     model.predict_step(other, 1)
-    assert calls["n"] == 3 and M._LN_HEAL["batches"] == 1
+    assert calls["n"] == 3 and M.heal_state(model).batches == 1
 
 
 def test_forced_off_is_thread_local_and_flags_are_per_stream(heal_state):

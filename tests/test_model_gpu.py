@@ -19,6 +19,11 @@ pytestmark = pytest.mark.gpu
 
 NORTH_STAR_RTOL = 1e-3      # BASELINE.json: "within 1e-3 relative fp32 tolerance" (vs same-rounding oracle)
 BF16_VS_FP32 = 2e-2         # bf16-operand arithmetic vs the reference's fp32 fixture values
+# Embeddings of the headline-size gene against PURE fp32 arithmetic (test_headline_size_gene_vs_oracle_and_properties): limits =
+# 1.5 x the values MI355X measured (profiles/r06_a_headline_accuracy.log); max-norm = max |err| / max |ref|, element-wise =
+# max |err| / (|ref| + rms(ref)).
+HEADLINE_EMB_MAXNORM = {"bf16": 1.5e-2, "fp16": 5e-3}
+HEADLINE_EMB_ELEMENTWISE = {"bf16": 3e-2, "fp16": 1e-2}
 
 
 def _rel(a, b):
@@ -96,15 +101,13 @@ def test_seq2reg_mean_pool_before_the_last_down_projection(precision, ln_fold):
     pad = torch.ones((W, L), dtype=torch.bool)
     for w, n in enumerate(lens):
         pad[w, :n] = False
-    try:
-        outs = {}
-        for flag in (True, False):
-            s2r.POOL_BEFORE_DOWN_PROJECTION = flag
-            with ops.compute_dtype(torch.bfloat16 if precision == "bf16-mixed" else torch.float16), \
-                    (contextlib.nullcontext() if ln_fold else ln_fold_forced_off()), torch.no_grad():
-                outs[flag] = m.embed_packed(ids.cuda(), pad.cuda(), int((~pad).sum()), torch.float32).cpu()
-    finally:
-        s2r.POOL_BEFORE_DOWN_PROJECTION = True
+    from variantformer_amd import runtime
+    outs = {}
+    for flag in (True, False):
+        with runtime.override(pool_before_down_projection=flag), \
+                ops.compute_dtype(torch.bfloat16 if precision == "bf16-mixed" else torch.float16), \
+                (contextlib.nullcontext() if ln_fold else ln_fold_forced_off()), torch.no_grad():
+            outs[flag] = m.embed_packed(ids.cuda(), pad.cuda(), int((~pad).sum()), torch.float32).cpu()
     new, ref = outs[True], outs[False]
     assert torch.isnan(new[7]).all() and torch.isnan(ref[7]).all()
     keep = [w for w in range(W) if w != 7]
@@ -137,17 +140,12 @@ def test_seq2reg_first_layer_qkv_lookup_is_bit_identical(precision, pos):
         pad[w, :n] = False
     pad[6, 50:60] = True                                             # pads inside a window: positions are not ranks
     outs = {}
-    import variantformer_amd.seq2gene.modules.layers as Lyr
+    from variantformer_amd import runtime
     assert ops.attn_rows_supported(64, False, W, 8, 200, 200, True)
-    try:
-        for flag in (True, False, "gathered"):        # lookup + gather in the attention's loads / no lookup / lookup + row gather
-            s2r.LAYER0_QKV_TABLE = bool(flag)
-            Lyr.ROWS_IN_ATTENTION = flag is True
-            with ops.compute_dtype(torch.bfloat16 if precision == "bf16-mixed" else torch.float16), torch.no_grad():
-                outs[flag] = m.embed_packed(ids.cuda(), pad.cuda(), int((~pad).sum()), torch.float32).cpu()
-    finally:
-        s2r.LAYER0_QKV_TABLE = True
-        Lyr.ROWS_IN_ATTENTION = True
+    for flag in (True, False, "gathered"):        # lookup + gather in the attention's loads / no lookup / lookup + row gather
+        with runtime.override(layer0_qkv_table=bool(flag), rows_in_attention=flag is True), \
+                ops.compute_dtype(torch.bfloat16 if precision == "bf16-mixed" else torch.float16), torch.no_grad():
+            outs[flag] = m.embed_packed(ids.cuda(), pad.cuda(), int((~pad).sum()), torch.float32).cpu()
     keep = [w for w in range(W) if w != 7]
     assert torch.isfinite(outs[False][keep]).all() and float(outs[False][keep].abs().max()) > 0.1
     assert torch.equal(outs[True][keep], outs[False][keep]) and torch.equal(outs["gathered"][keep], outs[False][keep])
@@ -292,7 +290,7 @@ def test_counted_context_keys_equal_the_expanded_context_attention(monkeypatch):
     round-4 form over the gathered [N, 2D] rows: the same function, different rounding points (no 16-bit P) -- expression and
     embeddings agree at the 16-bit level, both within the north-star bar of their own same-rounding oracle; also on the
     separate-LayerNorm path the self-healing recomputation takes."""
-    import variantformer_amd.seq2gene.modules.layers as Lyr
+    from variantformer_amd import runtime
     kw = seq2gene_kw(layers=3)
     model = build_model(SEQ2REG_512, kw, seed=81)
     sd = state_dict_cpu(model)
@@ -306,11 +304,10 @@ def test_counted_context_keys_equal_the_expanded_context_attention(monkeypatch):
         # "lowrank" (the default): two skinny GEMMs around a 9-way softmax; True: q -> counted-key attention -> out_proj;
         # False: the round-4 form over the gathered [N, 2D] rows
         for flag in ("lowrank", True, False):
-            monkeypatch.setattr(Lyr, "COUNTED_CONTEXT_KEYS", bool(flag))
-            monkeypatch.setattr(O, "COUNTED_CONTEXT_KEYS", bool(flag))
-            monkeypatch.setattr(Lyr, "LOWRANK_CONTEXT", flag == "lowrank")
+            monkeypatch.setattr(O, "COUNTED_CONTEXT_KEYS", bool(flag))        # the oracle's own switches (test infrastructure)
             monkeypatch.setattr(O, "LOWRANK_CONTEXT", flag == "lowrank")
-            out = model.predict_step(batch, 0)
+            with runtime.override(counted_context_keys=bool(flag), lowrank_context=flag == "lowrank"):
+                out = model.predict_step(batch, 0)
             orc = O.predict_step(batch, sd, hp, hp, ghp, rounding=O.Rounding("bf16", fold_ln=fold == "1"), share_cre_stream=True)
             for i in range(3):
                 assert prel(out["pred_gene_exp"][i], orc["pred_gene_exp"][i]) < NORTH_STAR_RTOL
@@ -333,11 +330,12 @@ def test_first_gene_layer_row_map_attention_is_exact(monkeypatch):
     model = build_model(SEQ2REG_512, kw, seed=78).cuda()
     batch = make_batch(6, [9, 5], [150, 20], [TISSUES_54[:3], [9, 33]], 200)
     assert ops.attn_rows_supported(48, True, 5, 32, 151, 151, True)
+    from variantformer_amd import runtime
     a = model.predict_step(batch, 0)
-    monkeypatch.setattr(Lyr, "ROWS_IN_ATTENTION", False)
-    b = model.predict_step(batch, 0)
-    monkeypatch.setattr(Lyr.ContextFlashAttentionEncoderLayer, "self_qkv_of_unique_rows", lambda self, *args, **kw: None)
-    c = model.predict_step(batch, 0)
+    with runtime.override(rows_in_attention=False):
+        b = model.predict_step(batch, 0)
+        monkeypatch.setattr(Lyr.ContextFlashAttentionEncoderLayer, "self_qkv_of_unique_rows", lambda self, *args, **kw: None)
+        c = model.predict_step(batch, 0)
     for i in range(2):
         np.testing.assert_array_equal(a["pred_gene_exp"][i], b["pred_gene_exp"][i])
         np.testing.assert_array_equal(a["embeddings"][i], b["embeddings"][i])
@@ -345,44 +343,52 @@ def test_first_gene_layer_row_map_attention_is_exact(monkeypatch):
 
 
 def test_cre_stream_on_a_side_stream_is_bit_identical(monkeypatch):
-    """model_combined_modulator.OVERLAP_CRE_STREAM (opt-in, off by default): the CRE layers run on a side stream beside the
-    gene layers (CRE layer i + 1 needs CRE layer i only; gene layer i + 1 needs gene layer i and CRE layer i).  Same kernels,
-    same inputs: bit-identical outputs over repeated calls, and a LayerNorm-fold alert raised by a CRE-stream kernel on the
-    side stream still reaches the batch (the model recomputes it)."""
+    """runtime.Switches.overlap_cre_stream (the DEFAULT since round 6): the CRE layers run on a side stream beside the gene
+    layers (CRE layer i + 1 needs CRE layer i only; gene layer i + 1 needs gene layer i and CRE layer i).  Same kernels, same
+    inputs: the default path is bit-identical to the single-stream one over repeated calls (the first forward of a
+    configuration runs single-stream by itself: it builds the per-weights caches), a LayerNorm-fold alert raised by a
+    CRE-stream kernel on the side stream still reaches the batch (the model recomputes it), and stale bits on the side
+    stream's flag do not (round-5 advice)."""
     import variantformer_amd.seq2gene.model_combined_modulator as M
+    from variantformer_amd import ops, runtime
     monkeypatch.delenv("VF_LN_FOLD", raising=False)                    # the alert half needs the fold (default contract)
     monkeypatch.delenv("VF_TRUNK16", raising=False)
+    assert runtime.switches().overlap_cre_stream, "the product default"
     model = build_model(SEQ2REG_512, seq2gene_kw(layers=5), seed=3).cuda()
     batch = make_batch(4, [300, 40], [150, 20], [TISSUES_54[:5], [9, 33]], 200)
-    a = model.predict_step(batch, 0)
-    monkeypatch.setattr(M, "OVERLAP_CRE_STREAM", True)
+    with runtime.override(overlap_cre_stream=False):
+        a = model.predict_step(batch, 0)
+    warm = model.combined_modulator.cre_layers[0].__dict__["_vf_overlap_warm"]
+    assert len(warm) == 1
     for _ in range(3):
-        b = model.predict_step(batch, 0)
+        b = model.predict_step(batch, 0)                               # the default: overlapped
         for i in range(2):
             np.testing.assert_array_equal(a["pred_gene_exp"][i], b["pred_gene_exp"][i])
             np.testing.assert_array_equal(a["embeddings"][i], b["embeddings"][i])
+    hs = M.heal_state(model)
+    assert hs.batches == 0 and hs.finished == 4
+    # stale bits on the side stream's flag belong to nobody: the next batch must not be recomputed because of them
+    dev = torch.device("cuda", torch.cuda.current_device())
+    side = M._side_stream(dev)
+    with torch.cuda.stream(side):
+        ops._alert_flag(dev).fill_(1)
+    torch.cuda.synchronize()
+    b = model.predict_step(batch, 0)
+    assert hs.batches == 0, "a stale bit on the side stream's flag was taken for this batch's alert"
+    np.testing.assert_array_equal(a["embeddings"][0], b["embeddings"][0])
     # an alert that only a CRE-stream kernel can raise: a huge common offset on the output bias of CRE layer 1's down-projection
     # gives every row of the CRE stream a mean of many standard deviations from CRE layer 2 on; the gene stream never sees it in
     # a LayerNorm-folded statistic of its own (it reads the CRE stream through K / V projections only)
-    saved = (dict(M._LN_HEAL, recent=list(M._LN_HEAL["recent"])))
-    try:
-        M._LN_HEAL.update(batches=0, finished=0)
-        M._LN_HEAL["recent"].clear()
-        monkeypatch.setattr(M, "LN_HEAL_STICKY_AFTER", 10 ** 9)
-        with torch.no_grad():
-            model.combined_modulator.cre_layers[1].linear_geglu_2.bias += 60.0
-        monkeypatch.setattr(M, "OVERLAP_CRE_STREAM", False)
+    monkeypatch.setattr(M, "LN_HEAL_STICKY_AFTER", 10 ** 9)
+    with torch.no_grad():
+        model.combined_modulator.cre_layers[1].linear_geglu_2.bias += 60.0
+    with runtime.override(overlap_cre_stream=False):
         want = model.predict_step(batch, 0)
-        assert M._LN_HEAL["batches"] == 1, "the serial path must have flagged and recomputed the batch"
-        monkeypatch.setattr(M, "OVERLAP_CRE_STREAM", True)
-        got = model.predict_step(batch, 0)
-        assert M._LN_HEAL["batches"] == 2, "the alert raised on the side stream must reach the batch"
-        for i in range(2):
-            np.testing.assert_array_equal(got["pred_gene_exp"][i], want["pred_gene_exp"][i])
-    finally:
-        M._LN_HEAL.update(batches=saved["batches"], finished=saved["finished"], logged=saved["logged"])
-        M._LN_HEAL["recent"].clear()
-        M._LN_HEAL["recent"].extend(saved["recent"])
+    assert hs.batches == 1, "the serial path must have flagged and recomputed the batch"
+    got = model.predict_step(batch, 0)
+    assert hs.batches == 2, "the alert raised on the side stream must reach the batch"
+    for i in range(2):
+        np.testing.assert_array_equal(got["pred_gene_exp"][i], want["pred_gene_exp"][i])
 
 
 def test_tissue_invariance_and_batch_independence():
@@ -579,6 +585,27 @@ def test_headline_size_gene_vs_oracle_and_properties():
     assert prel(alone["pred_gene_exp"][0], orc["pred_gene_exp"][0]) < NORTH_STAR_RTOL
     assert _rel(alone["embeddings"][0], orc["embeddings"][0]) < 5e-3
     check_signal("headline gene, 54 tissues", alone["pred_gene_exp"][0], orc["pred_gene_exp"][0])
+    # The literal north-star bar at the headline size (round-5 verdict: the same-rounding oracle restates the kernels' rounding
+    # points, so at full size it is a consistency check): the SAME gene through the oracle in PURE fp32 arithmetic
+    # (rounding=None: no 16-bit rounding anywhere, plain LayerNorm, the reference's formulation), against the HIP path with bf16
+    # operands (the shipped bf16-mixed) and with fp16 operands (16-mixed).  Expression within 1e-3 relative, element-wise; the
+    # embeddings' element-wise error is printed and bounded at 1.5x what MI355X measured (profiles/r06_*: the bf16 noise of 49
+    # layers, no worse than the reference's own autocast -- tests/test_trained_like_gpu.py -- but 7-20x the expression's bar;
+    # DESIGN.md section 5 has the table).
+    pure = O.predict_step(first, sd, shp, shp, O.Seq2GeneHP.from_kwargs(kw), rounding=None, share_cre_stream=True)
+    model.precision = "16-mixed"
+    alone16 = model.predict_step(first, 0)
+    model.precision = None
+    for tag, got, emb_max_lim, emb_el_lim in (("bf16", alone, HEADLINE_EMB_MAXNORM["bf16"], HEADLINE_EMB_ELEMENTWISE["bf16"]),
+                                              ("fp16", alone16, HEADLINE_EMB_MAXNORM["fp16"], HEADLINE_EMB_ELEMENTWISE["fp16"])):
+        e_expr = prel(got["pred_gene_exp"][0], pure["pred_gene_exp"][0])
+        e_max = _rel(got["embeddings"][0], pure["embeddings"][0])
+        e_el = _erel(got["embeddings"][0], pure["embeddings"][0])
+        s_rel = check_signal(f"headline gene vs PURE fp32, {tag} operands", got["pred_gene_exp"][0], pure["pred_gene_exp"][0])
+        print(f"[headline vs pure fp32, {tag} operands] expression prel {e_expr:.2e} (bar 1e-3), signal-relative {s_rel:.2e}; "
+              f"embeddings max-norm {e_max:.2e} (limit {emb_max_lim:g}), element-wise {e_el:.2e} (limit {emb_el_lim:g})")
+        assert e_expr < NORTH_STAR_RTOL, (tag, e_expr)
+        assert e_max < emb_max_lim and e_el < emb_el_lim, (tag, e_max, e_el)
 
 
 @pytest.mark.parametrize("name", ["small_opts_a", "small_opts_b", "small_opts_c", "small_opts_d"])

@@ -1291,6 +1291,13 @@ def test_attention_row_map_form_is_bit_identical_to_gather_then_attend(ops, dtyp
     with pytest.raises(VFError, match="row-map"):
         ops.attn_varlen(tab[:, :D], tab[:, D:2 * D], tab[:, 2 * D:], cu, None, max(lens), max(lens), H, dh, slopes,
                         q_log2=False, rows=rows)
+    if geom == "seq2reg_windows":
+        # round-5 advice: <= 128 queries against 129-256 keys is served by the tiled kernel, which reads no row map; the
+        # query says so and the entry refuses instead of attending over the wrong rows (max_k != max_q is reachable through
+        # the public entry, not through the model)
+        assert not ops.attn_rows_supported(64, False, len(lens), H, 128, 200, True)
+        with pytest.raises(VFError, match="row-map"):
+            ops.attn_varlen(tab[:, :D], tab[:, D:2 * D], tab[:, 2 * D:], cu, None, 128, 200, H, dh, None, q_log2=True, rows=rows)
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])

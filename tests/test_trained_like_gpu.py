@@ -19,39 +19,9 @@ import torch
 
 from oracle import vf_oracle as O
 from tests.helpers import SEQ2REG_512, build_model, check_signal, prel, seq2gene_kw, state_dict_cpu
-from variantformer_amd.utils.synthetic import TISSUES_54, make_batch
+from variantformer_amd.utils.synthetic import TISSUES_54, make_batch, trained_like_
 
 pytestmark = pytest.mark.gpu
-
-
-def trained_like_(model, seed: int, outlier_gain: float = 25.0):
-    """In place: N(0, 0.02)-style seeded weights -> trained-like statistics (see the module docstring)."""
-    g = torch.Generator().manual_seed(seed)
-    with torch.no_grad():
-        for name, p in model.named_parameters():
-            if not torch.is_floating_point(p):
-                continue
-            D = p.shape[0]
-            if ".norm" in name or name.endswith("LayerNorm.weight") or "layer_norm" in name:
-                if name.endswith("weight") and p.dim() == 1:
-                    gain = torch.exp(0.4 * torch.randn(D, generator=g))
-                    gain[torch.randperm(D, generator=g)[:3]] *= 6.0
-                    p.copy_(gain)
-                elif name.endswith("bias") and p.dim() == 1:
-                    p.copy_(0.2 * torch.randn(D, generator=g))
-                continue
-            if p.dim() == 2 and (name.endswith("out_proj.weight") or name.endswith("linear_geglu_2.weight")):
-                # rows that write the residual stream: four outlier channels (the same ones in every layer of a width)
-                ch = torch.tensor([7, 101, D // 2 + 3, D - 5]) % D
-                p[ch] *= outlier_gain
-            if p.dim() == 2 and name.endswith("token_embedding.weight"):
-                ch = torch.tensor([7, 101, p.shape[1] // 2 + 3, p.shape[1] - 5])
-                p[:, ch] *= outlier_gain
-            if p.dim() == 2 and ("registry_tokens" in name or "context_embedding" in name or "ctx" in name.lower()):
-                p.add_(2.0 * p.std() * torch.randn(1, p.shape[1], generator=g))            # a common mean direction
-            if p.dim() == 2 and p.numel() > 4096:                                           # heavy tails: 0.1 % of the entries x 8
-                mask = torch.rand(p.shape, generator=g) < 1e-3
-                p[mask] *= 8.0
 
 
 @pytest.mark.parametrize("precision", ["bf16-mixed", "16-mixed"])

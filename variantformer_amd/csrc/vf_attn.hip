@@ -1168,6 +1168,19 @@ __global__ __launch_bounds__(256, 3) void attn_short2_kernel(AttnParams P, int k
     }
 }
 
+// A/B toggles of the one-block-per-sequence kernels, read ONCE per process and shared by the dispatch (launch_attn) and by
+// rows_supported, which must agree on every geometry (round-5 advice: rows_supported re-read them on every call)
+static int env_short2() { static const int v = vf_tuning_env("VF_ATTN_SHORT2", 1); return v; }      // 0: the one-pass kernel
+static int env_short64() { static const int v = vf_tuning_env("VF_ATTN_SHORT64", 1); return v; }    // 0: the tiled kernel at dh 64
+
+// Only attn_short2_kernel's ROWS instantiations read AttnParams::q_rows / kv_rows: every other launcher refuses a row map
+// instead of silently attending over the wrong rows (round-5 advice).
+static int no_row_map(const AttnParams& P, const char* kernel) {
+    if (!P.q_rows && !P.kv_rows) return VF_OK;
+    vf_set_error("vf_attn_varlen_fwd_rows: %s has no row-map form (ask vf_attn_rows_supported first)", kernel);
+    return VF_ERR_INVALID_ARG;
+}
+
 // fills the grid decomposition of block_coords; returns the (padded) 1-D grid size
 static unsigned set_grid(AttnParams& P, int n_seq, int nqb) {
     const long total = (long)n_seq * P.H * nqb;
@@ -1205,6 +1218,7 @@ int launch_fwd_k(const AttnParams& P, dim3 grid, hipStream_t st) {
 // q carrying the softmax scale (AttnParams::q_log2) selects the integer-maximum instantiation (attn_tile mode 2)
 template <int DH, int QG, bool ALIBI, int DT, int DBG = 0>
 int launch_fwd(const AttnParams& P, dim3 grid, hipStream_t st) {
+    if (const int rc = no_row_map(P, "attn_fwd_kernel")) return rc;
     if (DBG == 0 && P.q_log2) return launch_fwd_k<DH, QG, ALIBI, DT, 0, true>(P, grid, st);
     return launch_fwd_k<DH, QG, ALIBI, DT, DBG, false>(P, grid, st);
 }
@@ -1276,12 +1290,14 @@ int launch_short2(AttnParams P, int n_seq, int max_k, hipStream_t st) {
 
 template <int DH, int QG, bool ALIBI, int DT>
 int launch_short(AttnParams P, int n_seq, int max_k, hipStream_t st) {
+    if (const int rc = no_row_map(P, "attn_short_kernel")) return rc;
     if (P.q_log2) return launch_short_k<DH, QG, ALIBI, DT, true>(P, n_seq, max_k, st);
     return launch_short_k<DH, QG, ALIBI, DT, false>(P, n_seq, max_k, st);
 }
 
 template <int DT, int QB>
 int launch_x32(const AttnParams& P, dim3 grid, hipStream_t st) {
+    if (const int rc = no_row_map(P, "attn_x32_kernel")) return rc;
     constexpr int lds = 2 * BKV * (112 + 192);
     static const int nomax = vf_tuning_env("VF_ATTN_NOMAX", 1);    // 0: running maximum always (A/B)
     if (P.q_log2 && nomax) hipLaunchKernelGGL((attn_x32_kernel<DT, QB, true>), grid, dim3(256), lds, st, P);
@@ -1318,12 +1334,15 @@ static bool rows_supported(int dh, bool alibi, long n_seq, int H, int max_q, int
     if (!q_log2 || max_q <= 0 || max_k <= 0 || max_q > 256 || max_k > 256) return false;
     int kr, vr;
     short2_rows(max_k, kr, vr);
+    // (exactly launch_attn's conditions, in its order: a geometry it sends elsewhere has no row map)
     if (dh == 48 && alibi)
-        return max_q > 128 && vf_tuning_env("VF_ATTN_SHORT2", 1) && 3 * (kr * KLayout<48>::ROW + vr * VLayout<48>::ROW) <= 160 * 1024;
+        return max_q > 128 && env_short2() && 3 * (kr * KLayout<48>::ROW + vr * VLayout<48>::ROW) <= 160 * 1024;
     if (dh == 64 && !alibi) {
-        if (!vf_tuning_env("VF_ATTN_SHORT64", 1) || n_seq * H < 1024) return false;
+        if (!env_short64() || n_seq * H < 1024) return false;
         const int image = kr * KLayout<64>::ROW + vr * VLayout<64>::ROW;
-        return (max_q <= 128 && max_k <= 128) ? 3 * image <= 160 * 1024 : 2 * image <= 160 * 1024;
+        if (max_q <= 128 && max_k <= 128) return 3 * image <= 160 * 1024;
+        if (max_q > 128) return 2 * image <= 160 * 1024;          // (<= 256 both: checked above)
+        return false;                                               // max_q <= 128 < max_k: the tiled kernel serves it
     }
     return false;
 }
@@ -1362,7 +1381,7 @@ int launch_attn(AttnParams P, int n_seq, int max_q, int max_k, hipStream_t st) {
         if (max_q > 128 && max_q <= 256 && max_k <= 256) {
             // three resident blocks per CU (two passes of 2 query groups, trimmed LDS image) once the image leaves room
             // for them; VF_ATTN_SHORT2=0: the one-pass kernel (A/B)
-            static const int short2 = vf_tuning_env("VF_ATTN_SHORT2", 1);
+            const int short2 = env_short2();
             int kr, vr;
             short2_rows(max_k, kr, vr);
             if (short2 && 3 * (kr * KLayout<DH>::ROW + vr * VLayout<DH>::ROW) <= 160 * 1024)
@@ -1374,7 +1393,7 @@ int launch_attn(AttnParams P, int n_seq, int max_q, int max_k, hipStream_t st) {
     if constexpr (DH == 64) {
         // seq2reg windows (<= 128 tokens at dh = 64: a 36 KB image): one block per (window, head) with the whole K / V in
         // LDS instead of two 64-query blocks that each fetch K / V and wait for it (VF_ATTN_SHORT64=0: the tiled kernel)
-        static const int short64 = vf_tuning_env("VF_ATTN_SHORT64", 1);
+        const int short64 = env_short64();
         if (short64 && max_q <= 128 && max_k <= 128 && (long)n_seq * P.H >= 1024) {
             int kr, vr;
             short2_rows(max_k, kr, vr);

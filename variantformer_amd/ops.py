@@ -9,7 +9,7 @@ import math
 
 import torch
 
-from . import _lib
+from . import _lib, runtime
 from ._lib import (EPI_BF16, EPI_F32, EPI_GEGLU_BF16, EPI_GELU_BF16, EPI_GELU_F32, EPI_RES_F32, VF_BF16,  # noqa: F401
                    VF_F16, VF_F32, check)
 
@@ -56,6 +56,8 @@ class KernelTimer:
     def __init__(self, detail: bool = False):
         self.records = {}
         self.detail = detail          # also key records by launch geometry (scripts/shape_breakdown.py)
+        self.order = []               # (name, geometry, family, flops | None, bytes) of every launch, in launch order
+                                      # (scripts/pmc_shapes.py joins it with the dispatch order of a rocprofv3 counter pass)
 
     def time(self, name: str, flops, nbytes: float, launch, geometry: str = "", family: str = ""):
         """flops: a number, or a zero-argument callable evaluated in summary() (attention: the per-sequence lengths
@@ -66,6 +68,8 @@ class KernelTimer:
         b.record()
         rec = [a, b, flops, nbytes]
         self.records.setdefault(name, []).append(rec)
+        if self.detail:
+            self.order.append((name, geometry, family, None if callable(flops) else float(flops), float(nbytes)))
         if family:
             self.records.setdefault(f"{name}:{family}", []).append(rec)
         if self.detail and geometry:
@@ -249,8 +253,7 @@ def ln_fold_abs_limit() -> float:
     scales = []
     if _CDT == torch.float16:
         scales.append(x16_scale_for(torch.float16))
-    import os
-    if os.environ.get("VF_TRUNK16", "f16") == "f16":
+    if runtime.env().trunk16 == "f16":           # VF_TRUNK16, read once per forward (runtime.forward_env)
         scales.append(T16_SCALE)
     return 60000.0 / max(scales) if scales else 0.0
 

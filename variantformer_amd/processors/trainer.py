@@ -38,7 +38,7 @@ class Trainer:
                 i += 1
         try:       # what the self-healing LayerNorm fold did during this pass (finished / recomputed batches, switched off?)
             from ..seq2gene.model_combined_modulator import ln_fold_state
-            self.ln_fold_state = ln_fold_state()
+            self.ln_fold_state = ln_fold_state(model)         # this model's own bookkeeping (per model since round 6)
         except Exception:                                     # a model class without the fold
             self.ln_fold_state = None
         return out

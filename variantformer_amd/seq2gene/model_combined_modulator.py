@@ -18,15 +18,16 @@ from __future__ import annotations
 
 import collections
 import logging
-import os
+import threading
 import types
+import weakref
 from dataclasses import dataclass
 
 import numpy as np
 import torch
 import torch.nn as nn
 
-from .. import _lib, ops
+from .. import _lib, ops, runtime
 from ..utils.constants import REF_CREs
 from ..utils.functions import precision2dtype
 from .modules.layers import (AddContext, ContextFlashAttentionEncoderLayer, ContextFlashCrossAttentionEncoderLayer,
@@ -155,22 +156,54 @@ def _context_kv_table(ctx_embedding: nn.Embedding, layer) -> torch.Tensor:
     return c[1]
 
 
-_LN_HEAL = {"batches": 0, "finished": 0, "logged": False, "recent": collections.deque(maxlen=16)}
-LN_HEAL_STICKY_AFTER = 2      # alerting batches among the last len(_LN_HEAL["recent"]) finished ones (a RATE, 2 of 16 = the
-                              # point where a second forward per alerting batch costs as much as running unfolded) after which
-                              # the fold stays off for the process
+LN_HEAL_STICKY_AFTER = 2      # alerting batches among a model's last 16 finished ones (a RATE, 2 of 16 = the point where a
+                              # second forward per alerting batch costs as much as running unfolded) after which the fold stays
+                              # off FOR THAT MODEL
 
 
-def ln_fold_state() -> dict:
+class HealState:
+    """Bookkeeping of the self-healing LayerNorm fold, ONE PER MODEL INSTANCE (round-5 advice: it was per process, so a
+    checkpoint that kept alerting in one thread switched the fold off for every healthy model too).  Counters and the sticky
+    switch are guarded by a lock: predict_finish may run in several threads."""
+
+    def __init__(self):
+        self.lock = threading.Lock()
+        self.finished = 0          # batches whose outputs were handed back
+        self.batches = 0           # ... of which recomputed with the separate LayerNorm
+        self.logged = False
+        self.recent = collections.deque(maxlen=16)
+        self.off = False           # sticky: this model runs unfolded from now on (forward_prepared's runtime.forward_env)
+
+
+_MODELS = weakref.WeakSet()       # models that own a HealState (ln_fold_state() without an argument sums over them)
+
+
+def heal_state(model) -> HealState:
+    st = model.__dict__.get("_vf_heal")
+    if st is None:
+        st = HealState()
+        object.__setattr__(model, "_vf_heal", st)
+        _MODELS.add(model)
+    return st
+
+
+def ln_fold_state(model=None) -> dict:
     """The self-healing LayerNorm fold's bookkeeping, for drivers and logs: whether the fold is on, how many batches were
-    finished / recomputed, whether it was switched off for the process (WARNING-logged when it happens)."""
+    finished / recomputed, whether it was switched off -- for `model`, or summed over every live model of the process.
+    `switched_off_by_alerts`: the model's own sticky switch (WARNING-logged when it happens); `switched_off_for_process`:
+    layers.ln_fold_disable() was called (an explicit, process-wide choice)."""
     from .modules import layers as _layers
-    return {"enabled": not _layers._LN_FOLD_DISABLED and os.environ.get("VF_LN_FOLD", "1") != "0",
-            "switched_off_for_process": bool(_layers._LN_FOLD_DISABLED),
-            "batches_finished": int(_LN_HEAL["finished"]), "batches_recomputed": int(_LN_HEAL["batches"])}
+    from .. import runtime
+    states = [heal_state(model)] if model is not None else [heal_state(m) for m in list(_MODELS)]
+    off_alerts = any(st.off for st in states)
+    return {"enabled": not _layers._LN_FOLD_DISABLED and runtime.read_env().ln_fold and not off_alerts,
+            "switched_off_for_process": bool(_layers._LN_FOLD_DISABLED), "switched_off_by_alerts": bool(off_alerts),
+            "models": len(states),
+            "batches_finished": int(sum(st.finished for st in states)),
+            "batches_recomputed": int(sum(st.batches for st in states))}
 
 
-def _heal_if_ln_fold_alert(flag, recompute):
+def _heal_if_ln_fold_alert(flag, recompute, state: HealState):
     """Called where a batch's outputs were copied back.  `flag`: the batch's OWN alert bits (ops.ln_fold_alert_take, enqueued
     right behind the batch's last kernel on its stream -- a device int, or already an int): whether some row of a
     LayerNorm-folded stream of THIS batch left the regime the fold serves: |mean| > ops.LN_FOLD_RATIO_LIMIT standard
@@ -179,30 +212,34 @@ def _heal_if_ln_fold_alert(flag, recompute):
     thread-local: bit for bit a VF_LN_FOLD=0 run) and `recompute()`'s result is returned; degraded numbers never leave the
     model, however deep the caller pipelines predict_launch / predict_finish.  The reference's plain nn.LayerNorm
     (seq2gene/modules/layers.py:75-77,99-163) has no such regime.  Returns None when nothing tripped.
-    When LN_HEAL_STICKY_AFTER of the last 16 finished batches alerted, the fold is switched off for the process (WARNING)."""
+    `state`: the model's HealState.  When LN_HEAL_STICKY_AFTER of its last 16 finished batches alerted, the fold is switched
+    off for THAT MODEL (WARNING); other models of the process are not affected."""
     bits = 0 if flag is None else int(flag.item() if isinstance(flag, torch.Tensor) else flag)
-    _LN_HEAL["finished"] += 1
-    _LN_HEAL["recent"].append(bool(bits))
-    if not bits:
-        return None
+    with state.lock:
+        state.finished += 1
+        state.recent.append(bool(bits))
+        if not bits:
+            return None
+        state.batches += 1
+        first, state.logged = not state.logged, True
     from .modules import layers as _layers
-    import logging
     log = logging.getLogger("variantformer_amd")
-    _LN_HEAL["batches"] += 1
-    if not _LN_HEAL["logged"]:
-        _LN_HEAL["logged"] = True
+    if first:
         log.info("variantformer_amd: a residual-stream row left the folded-LayerNorm regime (%s); the batch was recomputed with "
                  "the separate LayerNorm pass (same results as VF_LN_FOLD=0)",
                  " and ".join(w for b, w in ((1, "|mean| > %g standard deviations" % ops.LN_FOLD_RATIO_LIMIT),
                                              (2, "an element beyond the fp16 copies' range")) if bits & b))
     with _layers.ln_fold_forced_off():
         out = recompute()
-    if not _layers._LN_FOLD_DISABLED and sum(_LN_HEAL["recent"]) >= LN_HEAL_STICKY_AFTER:
-        _layers.ln_fold_disable()
-        log.warning("variantformer_amd: %d of the last %d batches tripped the folded-LayerNorm alert; the fold is OFF for the "
-                    "rest of this process (every batch now takes the separate LayerNorm pass; set VF_LN_FOLD=0 to start "
-                    "that way; state: variantformer_amd.seq2gene.model_combined_modulator.ln_fold_state())",
-                    sum(_LN_HEAL["recent"]), len(_LN_HEAL["recent"]))
+    with state.lock:
+        trip = not state.off and sum(state.recent) >= LN_HEAL_STICKY_AFTER
+        if trip:
+            state.off = True
+            n_alert, n_recent = sum(state.recent), len(state.recent)
+    if trip:
+        log.warning("variantformer_amd: %d of the last %d batches tripped the folded-LayerNorm alert; the fold is OFF for this "
+                    "model from now on (every batch takes the separate LayerNorm pass; set VF_LN_FOLD=0 to start that "
+                    "way; state: model.ln_fold_state())", n_alert, n_recent)
     return out
 
 
@@ -215,7 +252,6 @@ class PredictHandle:
         self.tissues, self.pred, self.emb, self.model, self.pb, self.alert, self.done = tissues, pred, emb, model, pb, alert, done
 
 
-OVERLAP_CRE_STREAM = False     # experiment: CRE layers on a side stream beside the gene layers (see modulator_forward_packed)
 _SIDE_STREAMS: dict = {}
 
 
@@ -273,8 +309,7 @@ def modulator_forward_packed(ctx_embedding, cre_layers, gene_layers, cre_x, gene
     if use_res:                                     # gene-stream input added back after every gene layer (:253-254)
         gene = ops.add_rows(_t(gene), gene_x)
     log2c = None
-    from .modules import layers as _layers
-    if (ctx_embedding is not None and n > 1 and _layers.COUNTED_CONTEXT_KEYS and ctx_embedding.num_embeddings <= 16
+    if (ctx_embedding is not None and n > 1 and runtime.switches().counted_context_keys and ctx_embedding.num_embeddings <= 16
             and cre_layers[0].crossMHA.MHA.head_dim in (32, 48, 64)):
         # how often each label occurs among a gene's CREs (the same for all CRE layers): log2, -inf for an absent label
         C = ctx_embedding.num_embeddings
@@ -308,15 +343,25 @@ def modulator_forward_packed(ctx_embedding, cre_layers, gene_layers, cre_x, gene
                 g = ops.add_rows(_t(g), gene_x)
             return g
 
-    overlap = OVERLAP_CRE_STREAM and n > 2 and ops.TIMER is None and _t(cre_x).is_cuda
+    # The CRE layers run on a SIDE STREAM beside the gene layers (runtime.Switches.overlap_cre_stream, the default since round 6):
+    # CRE layer i + 1 depends on CRE layer i only, gene layer i + 1 on gene layer i and CRE layer i, so the small CRE-stream
+    # kernels (3-9 tiles per CU) fill the tails of the gene stream's persistent GEMMs: -3...5 ms per 32-gene step, bit-identical
+    # (tests/test_model_gpu.py::test_cre_stream_on_a_side_stream_is_bit_identical).  Single stream: inside an ops.KernelTimer
+    # replay (a kernel's duration must not depend on its neighbour there), and for the FIRST forward of a configuration, which
+    # builds every per-weights cache (packed operands, low-rank tables, the 9-row K/V tables) -- they are long-lived and belong
+    # in the main stream's allocator pool (round-5 advice).
+    warm_key = (ops.cdt(), ln_fold_enabled(cre_x.shape[1]), runtime.env().trunk16, runtime.switches().counted_context_keys,
+                runtime.switches().lowrank_context, log2c is not None)
+    warm = cre_layers[0].__dict__.setdefault("_vf_overlap_warm", set()) if n > 1 else set()
+    overlap = (runtime.switches().overlap_cre_stream and n > 2 and ops.TIMER is None and _t(cre_x).is_cuda
+               and warm_key in warm)
     if not overlap:
         for i in range(n - 1):
             cre = cre_layer(i, cre)
             gene = gene_layer(i + 1, gene, cre)
+        warm.add(warm_key)
         return _t(gene), _t(cre)
-    # EXPERIMENT (off by default): CRE layer i + 1 depends on CRE layer i only, gene layer i + 1 on gene layer i and CRE layer i:
-    # the small CRE-stream kernels (3-9 tiles per CU) run on a side stream beside the gene layer and fill the tails of its
-    # persistent GEMMs.  Tensors that cross streams are recorded on the stream that reads them.
+    # Tensors that cross streams are recorded on the stream that reads them.
     dev = _t(cre_x).device
     main = torch.cuda.current_stream(dev)
     side = _side_stream(dev)
@@ -334,6 +379,8 @@ def modulator_forward_packed(ctx_embedding, cre_layers, gene_layers, cre_x, gene
         return out, ev
     # (gene layer 0 above is already enqueued on the main stream: CRE layer 0 runs beside it)
     side.wait_stream(main)
+    with torch.cuda.stream(side):
+        ops._alert_flag(dev).zero_()       # stale bits on the side stream's flag (an op-level call, an aborted forward) are nobody's
     pending = launch_cre(0, cre)
     for i in range(n - 1):
         cre, ev = pending
@@ -611,7 +658,11 @@ class Seq2GenePredictorCombinedModulator(nn.Module):
             for v in parts:
                 n = int(v.shape[0])
                 if v.device.type != "cpu":
-                    v = v.cpu()
+                    # a device-resident input: ONE copy into a pinned staging slice (a .cpu() per gene allocated pageable
+                    # memory and synchronised each time; round-5 advice), narrowed from there like a host input
+                    raw = st.get(name + "_raw", (n, 1, L), v.dtype)
+                    raw.copy_(v)
+                    v = raw
                 src = v.numpy()[:, 0, :]
                 if dtype == torch.uint8:                          # masks: exactly 0 / 1 whatever the caller's dtype holds
                     if src.dtype == np.bool_:
@@ -648,7 +699,13 @@ class Seq2GenePredictorCombinedModulator(nn.Module):
         if dedupe_windows is not False:
             cre_np, gene_np = cre_ids.numpy(), gene_ids.numpy()
             # the 64-bit row key packs (id | pad << 30): ids must lie in [0, 2^30) (seen while narrowing)
-            if not id_flags.get("cre_ids", 0) and not id_flags.get("gene_ids", 0):
+            if id_flags.get("cre_ids", 0) or id_flags.get("gene_ids", 0):
+                if not getattr(self, "_vf_dedupe_gate_logged", False):       # once per model: the batch still runs, undeduplicated
+                    object.__setattr__(self, "_vf_dedupe_gate_logged", True)
+                    logger.info("variantformer_amd: window de-duplication skipped for a batch that holds token ids outside "
+                                "[0, 2^30) (a negative or very large id anywhere in the batch: the 64-bit row key packs id | pad << 30); "
+                                "results are unaffected, seq2reg embeds every window (PreparedBatch.windows_embedded == windows_total)")
+            else:
                 r = self._unique_windows(cre_np, cre_pad.numpy(), labels.numpy() if use_ctx else None)
                 if r is not None:
                     cre_keep, cre_inv = r
@@ -722,8 +779,13 @@ class Seq2GenePredictorCombinedModulator(nn.Module):
         """The hot path: everything below runs as HIP kernels on the current stream.
         Returns (pred fp32 [sum T, 1], emb fp32 [sum T, D])."""
         pb.wait()                                        # the side-stream upload of prepare_batch
-        with ops.compute_dtype(self.operand_dtype()):
+        # one read of VF_LN_FOLD / VF_TRUNK16 for the whole forward, and this model's own sticky switch of the self-healing fold
+        with ops.compute_dtype(self.operand_dtype()), runtime.forward_env(fold_off=heal_state(self).off):
             return self._forward_prepared(pb, return_cre)
+
+    def ln_fold_state(self) -> dict:
+        """ln_fold_state(self): this model's share of the self-healing LayerNorm fold's bookkeeping."""
+        return ln_fold_state(self)
 
     def _forward_prepared(self, pb: PreparedBatch, return_cre: bool = False):
         # seq2reg over every CRE window / gene chunk of the batch (HOT LOOP A, SURVEY §3.1)
@@ -914,7 +976,7 @@ class Seq2GenePredictorCombinedModulator(nn.Module):
         def recompute():
             with torch.no_grad():
                 return d2h(model.forward_prepared(pb))
-        healed = _heal_if_ln_fold_alert(handle.alert, recompute)
+        healed = _heal_if_ln_fold_alert(handle.alert, recompute, heal_state(model))
         if healed is not None:
             pred, emb = healed
         preds, embs, s = [], [], 0
@@ -950,7 +1012,7 @@ class Seq2GenePredictorCombinedModulator(nn.Module):
                     ctok.cpu().float().numpy())
         ops.ln_fold_alert_clear(self.device)
         alert, pred, embd, gtok, ctok = run()
-        healed = _heal_if_ln_fold_alert(alert, run)
+        healed = _heal_if_ln_fold_alert(alert, run, heal_state(self))
         if healed is not None:
             _, pred, embd, gtok, ctok = healed
         out = {"pred_gene_exp": [], "embd": [], "variant_type": batch["variant_type"],

@@ -18,7 +18,7 @@ from typing import Optional
 import torch
 import torch.nn as nn
 
-from ... import ops
+from ... import ops, runtime
 
 
 def get_alibi_slopes(n: int) -> torch.Tensor:
@@ -148,23 +148,12 @@ def ln_fold_reenable():
 def ln_fold_enabled(*widths: int) -> bool:
     """LayerNorm folded into the neighbouring GEMMs when EVERY contraction width of the layer's
     folded GEMMs (d_model, and hidden_dim / 2 for the down-projection producer) is one the MFMA path takes (K % 64 == 0);
-    otherwise -- and with VF_LN_FOLD=0, or inside ln_fold_forced_off() -- the separate LayerNorm pass.  Both operand types:
-    an fp16 stream's 16-bit copy is stored scaled by a power of two (ops.x16_scale_for), so the raw residual cannot leave
-    the fp16 range."""
-    import os
+    otherwise -- and with VF_LN_FOLD=0, inside ln_fold_forced_off(), or for a model whose self-healing switched the fold off
+    -- the separate LayerNorm pass.  VF_LN_FOLD is read once per forward (runtime.forward_env).  Both operand types: an fp16
+    stream's 16-bit copy is stored scaled by a power of two (ops.x16_scale_for), so the raw residual cannot leave the fp16
+    range."""
     return (not _LN_FOLD_DISABLED and getattr(_LN_FOLD_TLS, "off", 0) == 0 and all(int(w) % 64 == 0 for w in widths)
-            and os.environ.get("VF_LN_FOLD", "1") != "0")
-
-
-def res16_enabled() -> bool:
-    """Every attention block's output sum (x1 = out_proj(attn) + src, x2 = out_proj(cross) + x1) is read only through the
-    next LayerNorm -> Linear pair and as the next attention block's residual; both read it in 16 bits: the 16-bit copies
-    serve as the residuals of the two attention out-projections -- x1 = ... + float(src16), x2 = ... + float(x1_16) -- and
-    x1's fp32 rows are never written.  The trunk is unaffected: a layer's output is W2.h + (layer input), so these
-    roundings only ever enter branch inputs.  The reference's own autocast keeps these streams in 16 bits;
-    oracle.Rounding(res16=True) restates the rounding points.  Part of the LayerNorm fold (round 3 had a VF_RES16 switch;
-    the fp32 form was 3 % slower and no more accurate at the outputs, profiles/r03_c_*)."""
-    return True
+            and runtime.env().ln_fold)
 
 
 def trunk16_enabled(stack: str = "modulator") -> bool:
@@ -184,13 +173,10 @@ def trunk16_enabled(stack: str = "modulator") -> bool:
 
 
 def trunk16_mode() -> str:
-    """VF_TRUNK16: "f16" (default) -- the trunk travels between the layers of a stack as a scaled FP16 copy whatever the
-    operand type (down_projection below; with fp16 operands that is the operand-type copy itself); "0" -- fp32 rows."""
-    import os
-    mode = os.environ.get("VF_TRUNK16", "f16")
-    if mode not in ("f16", "0"):
-        raise ValueError(f"VF_TRUNK16={mode!r}: the supported values are 'f16' (default) and '0' (fp32 trunk)")
-    return mode
+    """VF_TRUNK16 (read once per forward, runtime.forward_env): "f16" (default) -- the trunk travels between the layers of
+    a stack as a scaled FP16 copy whatever the operand type (down_projection below; with fp16 operands that is the
+    operand-type copy itself); "0" -- fp32 rows."""
+    return runtime.env().trunk16
 
 
 def trunk_f16_active() -> bool:
@@ -212,25 +198,10 @@ def down_projection(hg, w2, b2, s, keep_x: bool = True, need_t16: bool | None = 
     return ops.gemm_ln_producer(hg, w2, b2, _ffn_residual(s), need_x=keep_x)
 
 
-def q_prescale_enabled() -> bool:
-    """The softmax scale and the change to base 2, 1 / sqrt(dh) * log2(e), are folded into the rows (and bias) of the query
-    projection -- Wq of a cross attention, the Q rows of a packed Wqkv -- when the 16-bit weights are packed, so that q . k
-    leaves the matrix pipe as the base-2 logit (ops.attn_varlen(q_log2=True)): one rounding of the scaled weights instead
-    of one of the unscaled ones -- the same size of error, different rounding points; oracle.Rounding(q_prescale=...)
-    restates them.  What it buys: the long-stream attention kernel drops the running maximum and the multiply-add in front
-    of every exponential (gene -> CRE cross attention -14 %).  Always on (round 3's VF_Q_PRESCALE switch is gone)."""
-    return True
-
-
 def _ffn_residual(s):
     """The layer input as the residual of the down-projection: its fp32 rows when they exist (the first layer of a stack,
     or VF_TRUNK16=0), else the stream itself = its 16-bit copy."""
     return s.x if s.x is not None else s
-
-
-ROWS_IN_ATTENTION = True      # False (tests only): always materialise the gathered projection in front of the attention
-COUNTED_CONTEXT_KEYS = True   # False (tests only): the CRE layers' context cross attention over the gathered [keys, 2D] rows
-LOWRANK_CONTEXT = True        # False (tests only): counted keys through q / attention / out_proj instead of the two skinny GEMMs
 
 
 def _as_stream(x):
@@ -294,13 +265,16 @@ class MHA(nn.Module):
             self.alibi_slopes = None
 
     def packed_qkv(self):
-        """packed_linear(Wqkv) with the Q rows carrying the base-2 softmax scale (q_prescale_enabled)."""
-        c = self.q_log2_scale if q_prescale_enabled() else 1.0
+        """packed_linear(Wqkv) with the Q rows carrying the base-2 softmax scale 1 / sqrt(dh) * log2(e): q . k leaves the
+        matrix pipe as the base-2 logit (ops.attn_varlen(q_log2=True)) -- one rounding of the scaled weights instead of one of the
+        unscaled ones; oracle.Rounding(q_prescale=...) restates the rounding point.  What it buys: the long-stream attention
+        kernel drops the running maximum and the multiply-add in front of every exponential (gene -> CRE cross attention -14 %)."""
+        c = self.q_log2_scale
         return packed_linear(self.Wqkv, wscale=c, bscale=c, qrows=self.embed_dim)
 
     def packed_qkv_ln(self, norm: nn.LayerNorm):
         """packed_linear_ln(Wqkv, norm), Q rows as in packed_qkv."""
-        return packed_linear_ln(self.Wqkv, norm, wscale=self.q_log2_scale if q_prescale_enabled() else 1.0, qrows=self.embed_dim)
+        return packed_linear_ln(self.Wqkv, norm, wscale=self.q_log2_scale, qrows=self.embed_dim)
 
     # -- pieces -------------------------------------------------------------------------------
     def project_kv(self, x_kv_bf16: torch.Tensor) -> torch.Tensor:
@@ -323,12 +297,11 @@ class MHA(nn.Module):
         """bf16 attention output [tokens_q, D] (before out_proj)."""
         D = self.embed_dim
         if self.cross_attn:
-            pre = q_prescale_enabled()
-            c = self.q_log2_scale if pre else 1.0
+            c = self.q_log2_scale                                    # q carries the base-2 softmax scale
             w, b = packed_linear(self.Wq, wscale=c, bscale=c)
             q = ops.gemm(x_bf16, w, b, ops.EPI_BF16)
             return ops.attn_varlen(q, kv_bf16[:, :D], kv_bf16[:, D:], cu_q, cu_k, max_q, max_k, self.num_heads,
-                                   self.head_dim, self.alibi_slopes, family=self.family, q_log2=pre)
+                                   self.head_dim, self.alibi_slopes, family=self.family, q_log2=True)
         w, b = self.packed_qkv()
         qkv = ops.gemm(x_bf16, w, b, ops.EPI_BF16)
         return self.attend_qkv(qkv, cu_q, max_q)
@@ -337,11 +310,10 @@ class MHA(nn.Module):
         """attend(LayerNorm(s.x)) with the LayerNorm folded into the Wqkv / Wq projection."""
         D = self.embed_dim
         if self.cross_attn:
-            pre = q_prescale_enabled()
-            w, b, c = packed_linear_ln(self.Wq, norm, wscale=self.q_log2_scale if pre else 1.0)
+            w, b, c = packed_linear_ln(self.Wq, norm, wscale=self.q_log2_scale)
             q = ops.gemm_ln_consumer(s, w, b, c, ops.EPI_BF16)
             return ops.attn_varlen(q, kv_bf16[:, :D], kv_bf16[:, D:], cu_q, cu_k, max_q, max_k, self.num_heads,
-                                   self.head_dim, self.alibi_slopes, family=self.family, q_log2=pre)
+                                   self.head_dim, self.alibi_slopes, family=self.family, q_log2=True)
         w, b, c = self.packed_qkv_ln(norm)
         qkv = ops.gemm_ln_consumer(s, w, b, c, ops.EPI_BF16)
         return self.attend_qkv(qkv, cu_q, max_q)
@@ -421,22 +393,23 @@ class MHA(nn.Module):
 
     def attend_qkv(self, qkv, cu_q, max_q, rows=None) -> torch.Tensor:
         """self attention on a packed [tokens, 3D] 16-bit projection (rows ordered (three, head, dh)) made with packed_qkv /
-        packed_qkv_ln (its Q third carries the softmax scale when q_prescale_enabled).
+        packed_qkv_ln (its Q third carries the base-2 softmax scale).
         rows int64 [tokens]: qkv is a TABLE of distinct projected rows and token t's row is rows[t] (the first layers'
         projection by lookup): the attention kernel gathers in its loads where it can (ops.attn_rows_supported); otherwise
         the rows are gathered first -- the same bits either way."""
         D = self.embed_dim
-        pre = q_prescale_enabled()
-        if rows is not None and not (ROWS_IN_ATTENTION and ops.attn_rows_supported(
-                self.head_dim, self.alibi_slopes is not None, cu_q.numel() - 1, self.num_heads, max_q, max_q, pre)):
+        if rows is not None and not (runtime.switches().rows_in_attention and ops.attn_rows_supported(
+                self.head_dim, self.alibi_slopes is not None, cu_q.numel() - 1, self.num_heads, max_q, max_q, True)):
             qkv, rows = ops.gather_rows_bf16(qkv, rows), None
         return ops.attn_varlen(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], cu_q, None, max_q, max_q,
                                self.num_heads, self.head_dim, self.alibi_slopes, family=self.family,
-                               q_log2=pre, rows=rows)
+                               q_log2=True, rows=rows)
 
     def out_ln(self, a_bf16, residual_f32, need_x: bool = True) -> "ops.LnStream":
         """out_proj(a) + residual as an LnStream (fp32 stream, its 16-bit copy, row statistics for the next LayerNorm).
-        `residual_f32`: the fp32 rows, or an LnStream whose 16-bit copy is the residual (layers.res16_enabled).
+        `residual_f32`: the fp32 rows, or an LnStream whose 16-bit copy is the residual (the attention-block sums
+        x1 = out_proj(attn) + src, x2 = out_proj(cross) + x1 are read only through the next LayerNorm -> Linear pair and as
+        the next block's residual, both in 16 bits: DESIGN.md section 3 item 9; oracle.Rounding(res16=True)).
         need_x=False when the sum is only ever read through the next LayerNorm -> Linear pair (the layers add their FFN
         to the layer INPUT, reference layers.py:99,163 / seq2reg/modules.py:188, so the stream after the last attention
         block has no other reader): the fp32 values are then not written to HBM at all."""
@@ -567,7 +540,7 @@ class ContextFlashAttentionEncoderLayer(nn.Module):
         if not with_stream:
             return qkv
         stream = None
-        if res16_enabled() and trunk16_enabled() and trunk_f16_active():
+        if trunk16_enabled() and trunk_f16_active():
             # (bf16 operands with the fp16 trunk copy, the default.  With fp16 operands the FIRST layer of a stack adds its fp32
             # input rows in the down-projection -- oracle.Rounding.trunk -- so that mode keeps the fp32 gather.)
             x16 = ops.gather_rows_bf16(torch.cat([sa.x16, sb.x16], dim=0), idx2)
@@ -594,22 +567,21 @@ class ContextFlashAttentionEncoderLayer(nn.Module):
         if ln_fold_enabled(self.norm1.weight.numel(), self.linear_geglu_2.in_features):
             # LayerNorm folded into the GEMMs: every fp32-residual GEMM also emits the bf16 copy + row statistics of its
             # output, every LayerNorm -> Linear pair runs on that copy (no LayerNorm pass, no cast of the context)
-            r16 = res16_enabled()
+            # (the attention-block sums x1, x2 travel as 16-bit copies + statistics, no fp32 rows: section 3 item 9)
             if self_qkv is not None:
                 # the projection was computed on the distinct rows; below only the residuals read the stream: its fp32
-                # rows (layer output) and, with res16, its 16-bit copy (self-attention block)
-                s = _as_stream(src) if r16 else ops.LnStream(_as_tensor(src), None, None)
+                # rows / trunk copy (layer output) and its 16-bit copy (self-attention block)
+                s = _as_stream(src)
                 a = self.mixer.MHA.attend_qkv(self_qkv[0], cu_src, max_src, rows=self_qkv[1])
             else:
                 s = _as_stream(src)
                 a = self.mixer.MHA.attend_ln(s, self.norm1, None, cu_src, max_src, None, None)
-            r16 = r16 or s.x is None
-            x1 = self.mixer.MHA.out_ln(a, s if r16 else s.x, need_x=not r16)
+            x1 = self.mixer.MHA.out_ln(a, s, need_x=False)
             lr = None
-            if context_counted is not None and LOWRANK_CONTEXT and len(context_counted) > 2:
+            if context_counted is not None and runtime.switches().lowrank_context and len(context_counted) > 2:
                 lr = self.crossMHA.MHA.lowrank_tables(self.norm2, context_counted[2])
             if lr is not None:
-                x2 = self.crossMHA.MHA.cross_lowrank(x1, self.norm2, None, context_counted[1], cq, mq, x1 if r16 else x1.x, tables=lr)
+                x2 = self.crossMHA.MHA.cross_lowrank(x1, self.norm2, None, context_counted[1], cq, mq, x1, tables=lr)
             else:
                 if context_counted is not None:
                     a = self.crossMHA.MHA.attend_counted(x1, self.norm2, context_counted, cq, mq)
@@ -617,7 +589,7 @@ class ContextFlashAttentionEncoderLayer(nn.Module):
                     if context_kv is None:
                         context_kv = self.crossMHA.MHA.project_kv_of(context)
                     a = self.crossMHA.MHA.attend_ln(x1, self.norm2, context_kv, cq, mq, cu_ctx, max_ctx)
-                x2 = self.crossMHA.MHA.out_ln(a, x1 if r16 else x1.x, need_x=False)
+                x2 = self.crossMHA.MHA.out_ln(a, x1, need_x=False)
             w1, b1, c1 = packed_linear_ln(self.linear_geglu_1, self.norm3, geglu=True)
             hg = ops.gemm_ln_consumer(x2, w1, b1, c1, ops.EPI_GEGLU_BF16)
             w2, b2 = packed_linear(self.linear_geglu_2)
@@ -627,7 +599,7 @@ class ContextFlashAttentionEncoderLayer(nn.Module):
         x1 = self.mixer.MHA.fused(h, src, cu_src, max_src)
         h = ops.layernorm(x1, self.norm2.weight, self.norm2.bias)
         lr = None
-        if context_counted is not None and LOWRANK_CONTEXT and len(context_counted) > 2:
+        if context_counted is not None and runtime.switches().lowrank_context and len(context_counted) > 2:
             lr = self.crossMHA.MHA.lowrank_tables(None, context_counted[2])
         if lr is not None:
             x2 = self.crossMHA.MHA.cross_lowrank(h, None, None, context_counted[1], cq, mq, x1, tables=lr)
@@ -688,12 +660,11 @@ class ContextFlashAttentionEncoderLayer(nn.Module):
             q = ops.gemm_ln_consumer(sr, w[:D], b[:D], c[:D], ops.EPI_BF16)            # [R, D]
             a = ops.attn_varlen(q, kv[:, :D], kv[:, D:], cu_rows, cu_src, 1, max_src, mha.num_heads, mha.head_dim,
                                 mha.alibi_slopes, q_at_start=True, family=mha.family + "_registry_rows",
-                                q_log2=q_prescale_enabled())
-            r16 = res16_enabled() or sr.x is None
-            x1 = mha.out_ln(a, sr if r16 else sr.x, need_x=not r16)
+                                q_log2=True)
+            x1 = mha.out_ln(a, sr, need_x=False)
             ckv = self.crossMHA.MHA.project_kv_of(context)
             a = self.crossMHA.MHA.attend_ln(x1, self.norm2, ckv, cu_cross_rows, max_cross_rows, cu_ctx, max_ctx)
-            x2 = self.crossMHA.MHA.out_ln(a, x1 if r16 else x1.x, need_x=False)
+            x2 = self.crossMHA.MHA.out_ln(a, x1, need_x=False)
             w1, b1, c1 = packed_linear_ln(self.linear_geglu_1, self.norm3, geglu=True)
             hg = ops.gemm_ln_consumer(x2, w1, b1, c1, ops.EPI_GEGLU_BF16)
             w2, b2 = packed_linear(self.linear_geglu_2)
@@ -710,7 +681,7 @@ class ContextFlashAttentionEncoderLayer(nn.Module):
         q = ops.gemm(hq, w[:D], None if b is None else b[:D], ops.EPI_BF16)             # [R, D]
         a = ops.attn_varlen(q, kv[:, :D], kv[:, D:], cu_rows, cu_src, 1, max_src, mha.num_heads, mha.head_dim,
                             mha.alibi_slopes, q_at_start=True, family=mha.family + "_registry_rows",
-                            q_log2=q_prescale_enabled())
+                            q_log2=True)
         src_rows = ops.gather_rows_f32(src, None, rows)
         wo, bo = packed_linear(mha.out_proj)
         x1 = ops.gemm(a, wo, bo, ops.EPI_RES_F32, residual=src_rows)
@@ -778,7 +749,7 @@ class FlashAttentionEncoderLayer(nn.Module):
         if ln_fold_enabled(self.norm1.weight.numel(), self.linear_geglu_2.in_features):
             s = _as_stream(src)
             a = self.mixer.MHA.attend_ln(s, self.norm1, None, cu_src, max_src, None, None)
-            x1 = self.mixer.MHA.out_ln(a, s if (res16_enabled() or s.x is None) else s.x, need_x=False)
+            x1 = self.mixer.MHA.out_ln(a, s, need_x=False)
             w1, b1, c1 = packed_linear_ln(self.linear_geglu_1, self.norm2, geglu=True)
             hg = ops.gemm_ln_consumer(x1, w1, b1, c1, ops.EPI_GEGLU_BF16)
             w2, b2 = packed_linear(self.linear_geglu_2)
@@ -835,7 +806,7 @@ class ContextFlashCrossAttentionEncoderLayer(nn.Module):
             if context_kv is None:
                 context_kv = self.crossMHA.MHA.project_kv_of(context)
             a = self.crossMHA.MHA.attend_ln(s, self.norm1, context_kv, cq, mq, cu_ctx, max_ctx)
-            x1 = self.crossMHA.MHA.out_ln(a, s if (res16_enabled() or s.x is None) else s.x, need_x=False)
+            x1 = self.crossMHA.MHA.out_ln(a, s, need_x=False)
             w1, b1, c1 = packed_linear_ln(self.linear_geglu_1, self.norm2, geglu=True)
             hg = ops.gemm_ln_consumer(x1, w1, b1, c1, ops.EPI_GEGLU_BF16)
             w2, b2 = packed_linear(self.linear_geglu_2)

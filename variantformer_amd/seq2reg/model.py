@@ -14,16 +14,15 @@ import types
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import ops, runtime
 from .modules import FlashTransformerLayer
 
 
-# The encoder's mean pool is taken BEFORE the last layer's down-projection (FlashTransformerLayer._pooled_down_projection).
-# False (tests only): pool the token rows of the last layer, the reference's order of operations.
-POOL_BEFORE_DOWN_PROJECTION = True
-# The first layer's LayerNorm1 -> Wqkv is looked up per distinct input row (Seq2RegPredictor._layer0_qkv_table).  False (tests
-# only): project every token.
-LAYER0_QKV_TABLE = True
+# Two exact re-orderings live here, both switchable for the tests through variantformer_amd.runtime.override:
+#   pool_before_down_projection -- the encoder's mean pool is taken BEFORE the last layer's down-projection
+#                                  (FlashTransformerLayer._pooled_down_projection); off: pool the token rows of the last layer;
+#   layer0_qkv_table            -- the first layer's LayerNorm1 -> Wqkv is looked up per distinct input row
+#                                  (Seq2RegPredictor._layer0_qkv_table); off: project every token.
 LAYER0_QKV_TABLE_MAX_BYTES = 1 << 30         # cap on vocab * token_length rows of 3 d 16-bit values, per tokenizer and operand
                                              # type (shipped: 500 x 200 rows x 3 KB = 307 MB); above it every token is projected
 
@@ -122,6 +121,8 @@ class Seq2RegPredictor(nn.Module):
         hit = slots.get(ops.cdt())
         if hit is not None and hit[0] == key:
             return hit[1], key_L
+        for dt in [d for d, v in slots.items() if v[0] != key]:      # tables of previous weights / another device: 307 MB each
+            del slots[dt]                                            # (round-5 advice: they stayed in the other slot forever)
         ids = torch.arange(V, device=device, dtype=torch.int64).view(V, 1).expand(V, key_L).contiguous()
         pad = torch.zeros((V, key_L), dtype=torch.uint8, device=device)
         cu = (torch.arange(V + 1, device=device, dtype=torch.int32) * key_L).contiguous()
@@ -148,6 +149,10 @@ class Seq2RegPredictor(nn.Module):
         n_tokens = number of valid tokens (host-known; sizes the packed buffers); max_len = longest window in valid
         tokens when the host knows it (sizes the attention grid; 0 -> L, an upper bound).
         context int64 [W]: the window's reference-cCRE label, required by a use_context tokenizer (:222-245)."""
+        with runtime.forward_env():          # VF_LN_FOLD / VF_TRUNK16 read once (the enclosing model's snapshot, if any)
+            return self._embed_packed(ids, pad, n_tokens, out_dtype, max_len, context)
+
+    def _embed_packed(self, ids, pad, n_tokens, out_dtype, max_len, context):
         W, L = ids.shape
         Lmax = max_len if 0 < max_len < L else L
         with ops.scope("seq2reg"):
@@ -177,11 +182,11 @@ class Seq2RegPredictor(nn.Module):
                 n_layers = len(self.transformer_encoder)
                 # mean pool: the last layer returns the pooled rows themselves (its down-projection commutes with the mean)
                 lg2 = self.transformer_encoder[-1].linear_geglu_2                 # (vf_segment_mean16 serves widths <= 2048)
-                pool_in_layer = (self.seq_pool == "mean" and POOL_BEFORE_DOWN_PROJECTION and lg2.in_features % 8 == 0 and
+                pool_in_layer = (self.seq_pool == "mean" and runtime.switches().pool_before_down_projection and lg2.in_features % 8 == 0 and
                                  lg2.out_features % 8 == 0 and max(lg2.in_features, lg2.out_features) <= 2048)
                 qkv0 = None
                 V = self.token_embedding.weight.shape[0]
-                if (LAYER0_QKV_TABLE and ln_fold_enabled(l0.norm1.weight.numel(), l0.linear_geglu_2.in_features) and
+                if (runtime.switches().layer0_qkv_table and ln_fold_enabled(l0.norm1.weight.numel(), l0.linear_geglu_2.in_features) and
                         self.token_embedding.weight.shape[1] <= 2048 and
                         self._layer0_qkv_table_bytes() <= LAYER0_QKV_TABLE_MAX_BYTES):
                     tab, key_L = self._layer0_qkv_table(ids.device)

@@ -51,13 +51,13 @@ class FlashTransformerLayer(nn.Module):
         (_pooled_down_projection).  qkv (folded path): this layer's packed_qkv_ln projection of norm1(src), already made
         (the encoder's first layer looks it up per distinct input row: (table, row per token) of Seq2RegPredictor._layer0_qkv_table)."""
         from ..seq2gene.modules.layers import (_as_stream, _as_tensor, down_projection, ln_fold_enabled, packed_linear_ln,
-                                               res16_enabled, trunk_f16_active)
+                                               trunk_f16_active)
         if ln_fold_enabled(self.norm1.weight.numel(), self.linear_geglu_2.in_features):
             s = _as_stream(src)
             a = self.MHA.attend_ln(s, self.norm1, None, cu, max_seqlen, None, None) if qkv is None else \
                 self.MHA.attend_qkv(qkv[0], cu, max_seqlen, rows=qkv[1])
-            # x1 is read only through norm2 -> linear_geglu_1: no fp32 store, and (res16) its residual is the 16-bit copy
-            x1 = self.MHA.out_ln(a, s if (res16_enabled() or s.x is None) else s.x, need_x=False)
+            # x1 is read only through norm2 -> linear_geglu_1: no fp32 store, and its residual is the 16-bit copy of the input
+            x1 = self.MHA.out_ln(a, s, need_x=False)
             w1, b1, c1 = packed_linear_ln(self.linear_geglu_1, self.norm2, geglu=True)
             hg = ops.gemm_ln_consumer(x1, w1, b1, c1, ops.EPI_GEGLU_BF16)
             w2, b2 = packed_linear(self.linear_geglu_2)

@@ -247,3 +247,39 @@ def restore_maps(model, saved: dict) -> None:
         for name, (W, b) in saved.items():
             getattr(model, name).weight.copy_(W)
             getattr(model, name).bias.copy_(b)
+
+
+def trained_like_(model: torch.nn.Module, seed: int, outlier_gain: float = 25.0) -> None:
+    """In place: N(0, 0.02)-style seeded weights -> the statistics TRAINED transformers show (the real 14 GB checkpoint is
+    unavailable offline): LayerNorm gains spread log-normally with a few large entries, non-zero LayerNorm biases, outlier
+    CHANNELS in the residual streams (embedding columns and the rows of the layers' output projections scaled up, so that a
+    handful of channels carry activations tens of times the rest -- 'massive activations'), heavy-tailed projection weights,
+    registry / context embeddings with a common mean.  Random numbers come from a CPU generator whatever device the model
+    is on (tests/test_trained_like_gpu.py on a CPU copy, bench.py's `trained_like` pass on the resident model)."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if not torch.is_floating_point(p):
+                continue
+            dev = p.device
+            D = p.shape[0]
+            if ".norm" in name or name.endswith("LayerNorm.weight") or "layer_norm" in name:
+                if name.endswith("weight") and p.dim() == 1:
+                    gain = torch.exp(0.4 * torch.randn(D, generator=g))
+                    gain[torch.randperm(D, generator=g)[:3]] *= 6.0
+                    p.copy_(gain)
+                elif name.endswith("bias") and p.dim() == 1:
+                    p.copy_(0.2 * torch.randn(D, generator=g))
+                continue
+            if p.dim() == 2 and (name.endswith("out_proj.weight") or name.endswith("linear_geglu_2.weight")):
+                # rows that write the residual stream: four outlier channels (the same ones in every layer of a width)
+                ch = (torch.tensor([7, 101, D // 2 + 3, D - 5]) % D).to(dev)
+                p[ch] *= outlier_gain
+            if p.dim() == 2 and name.endswith("token_embedding.weight"):
+                ch = torch.tensor([7, 101, p.shape[1] // 2 + 3, p.shape[1] - 5]).to(dev)
+                p[:, ch] *= outlier_gain
+            if p.dim() == 2 and ("registry_tokens" in name or "context_embedding" in name or "ctx" in name.lower()):
+                p.add_((2.0 * float(p.std()) * torch.randn(1, p.shape[1], generator=g)).to(dev))      # a common mean direction
+            if p.dim() == 2 and p.numel() > 4096:                                           # heavy tails: 0.1 % of the entries x 8
+                mask = (torch.rand(p.shape, generator=g) < 1e-3).to(dev)
+                p[mask] *= 8.0
