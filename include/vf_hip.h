@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define VF_ABI_VERSION 11
+#define VF_ABI_VERSION 12
 
 enum vf_status {
     VF_OK = 0,
@@ -47,6 +47,12 @@ enum vf_epilogue {
 
 int vf_version(void);
 const char* vf_last_error(void);
+/* Diagnostic (ABI 12): the kernel the calling thread's most recent GEMM (which = 0) or attention (which = 1) entry dispatched
+ * to -- a static string such as "gemm8x_kernel", "gemm_mfma_kernel<128x128>", "attn_short2_kernel<dh64,1 pass,rows>"; "" before
+ * the first launch.  No reference counterpart (the reference reaches its kernels through ATen / flash-attn [3p] dispatchers);
+ * exists so that a sweep over tokenizer geometries (scripts/s2r_dims_sweep.py: the real checkpoint's seq2reg width / heads /
+ * depth are unknown offline, processors/model_manager.py:44-51) can record which kernel served each shape. */
+const char* vf_last_kernel(int which);
 
 /* out = epilogue(A[M,K] @ W[N,K]^T + bias[N]).   A, W bf16; bias fp32 (may be NULL = 0).
  * Replaces every nn.Linear on the path: flash_attn MHA Wqkv/Wq/Wkv/out_proj [3p]
@@ -330,6 +336,12 @@ void* vf_bpe_create(const int32_t* char_ids, int n_ids, const int32_t* merges, i
 void vf_bpe_destroy(void* bpe);
 int64_t vf_bpe_encode(const void* bpe, const char* seq, int64_t len, int32_t* ids_out, int64_t* starts_out,
                       int64_t capacity);
+/* ABI 12: the first max_tokens tokens of vf_bpe_encode(seq, len), EXACTLY, without encoding the rest of a long word: the sample
+ * builder keeps max_chunks x max_length tokens of a gene body (datasets/vcfdataset.py:338-394; utils/seq.py:52-62 encodes all of
+ * it).  A cut text changes the tokens of at most n_merges x (longest token) characters in front of the cut (a difference moves
+ * left by one symbol per merge rank), so a prefix with that margin is encoded and the tokens in front of the margin are kept. */
+int64_t vf_bpe_encode_prefix(const void* bpe, const char* seq, int64_t len, int64_t max_tokens, int32_t* ids_out,
+                             int64_t* starts_out, int64_t capacity);
 
 /* ---- host-side (CPU) VCF reader + per-region IUPAC consensus: SURVEY.md section 8f row 1 ----------------------
  * Replaces the `samtools faidx | bcftools consensus -H I -e <filter> sample.vcf.gz` subprocess pair the reference

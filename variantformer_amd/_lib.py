@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libvf_hip.so")
 # enums of include/vf_hip.h
 VF_F32, VF_BF16, VF_F16 = 0, 1, 2
 EPI_BF16, EPI_F32, EPI_RES_F32, EPI_GEGLU_BF16, EPI_GELU_F32, EPI_GELU_BF16 = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -23,6 +23,7 @@ _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 SIGNATURES = {
     "vf_version": [],
     "vf_last_error": [],
+    "vf_last_kernel": [_i],
     "vf_gemm_bf16": [_p, _l, _p, _p, _p, _l, _p, _l, _i, _i, _i, _i, _p],
     "vf_gemm_bf16_ex": [_p, _l, _p, _p, _p, _l, _p, _l, _i, _i, _i, _i, _i, _p],
     "vf_gemm_f16": [_p, _l, _p, _p, _p, _l, _p, _l, _i, _i, _i, _i, _p],
@@ -63,6 +64,7 @@ SIGNATURES = {
     "vf_bpe_create": [_p, _i, _p, _i],
     "vf_bpe_destroy": [_p],
     "vf_bpe_encode": [_p, C.c_char_p, _l, _p, _p, _l],
+    "vf_bpe_encode_prefix": [_p, C.c_char_p, _l, _l, _p, _p, _l],
     "vf_vcf_open": [C.c_char_p, C.c_char_p],
     "vf_vcf_close": [_p],
     "vf_vcf_num_records": [_p, C.c_char_p],
@@ -70,7 +72,7 @@ SIGNATURES = {
     "vf_build_windows": [_p, _p, C.c_char_p, _l, C.c_char_p, _l, _l, _p, _p, _i, _i, _i, _i, _l, _p, _p, _p],
     "vf_narrow_ids": [_p, _l, _p, _l, _l],
 }
-_RESTYPES = {"vf_last_error": C.c_char_p, "vf_bpe_create": C.c_void_p, "vf_bpe_destroy": None, "vf_bpe_encode": C.c_int64,
+_RESTYPES = {"vf_last_error": C.c_char_p, "vf_last_kernel": C.c_char_p, "vf_bpe_create": C.c_void_p, "vf_bpe_destroy": None, "vf_bpe_encode": C.c_int64, "vf_bpe_encode_prefix": C.c_int64,
              "vf_vcf_open": C.c_void_p, "vf_vcf_close": None, "vf_vcf_num_records": C.c_int64,
              "vf_vcf_consensus": C.c_int64, "vf_build_windows": C.c_int64}
 

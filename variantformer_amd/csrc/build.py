@@ -15,7 +15,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["vf_gemm.hip", "vf_attn.hip", "vf_misc.hip", "vf_bpe.cpp", "vf_vcf.cpp", "vf_host.cpp"]
 HEADERS = ["vf_common.h", os.path.join("..", "..", "include", "vf_hip.h")] + \
-    [os.path.join("tuning", f) for f in ("gemm_persist.inc", "gemm4.inc", "gemm8p.inc", "gemm_xs.inc", "attn_x32pp.inc")]
+    [os.path.join("tuning", f) for f in ("gemm_persist.inc", "gemm4.inc", "gemm8p.inc", "gemm_xs.inc", "gemm8y.inc", "attn_x32pp.inc")]
 LIB = os.path.join(HERE, "libvf_hip.so")
 ARCH = "gfx950"
 # vf_attn: scores are never NaN by construction (finite inputs, -inf only as a mask), so fmaxf needs no

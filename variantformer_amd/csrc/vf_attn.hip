@@ -96,6 +96,10 @@ struct AttnParams {
 #if defined(VF_SHORT_PROF) || defined(VF_X32PP_PROF)
     unsigned long long* prof;   // scripts/probes/attn_*_probe.hip only
 #endif
+#ifdef VF_TUNING
+    int dbg;                    // VF_ATTN_SHORT_DBG (attn_short2_kernel; results meaningless): 1 = loads, LDS staging and stores only
+                                // (no tile arithmetic): the streaming ceiling of the one-block-per-(sequence, head) structure
+#endif
 };
 
 
@@ -1131,6 +1135,15 @@ __global__ __launch_bounds__(256, 3) void attn_short2_kernel(AttnParams P, int k
 #pragma unroll
             for (int dt = 0; dt < NDT; ++dt) o[qg][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         }
+#ifdef VF_TUNING
+        if (P.dbg & 1) {                                           // ceiling probe: keep the Q fragments alive, compute nothing
+#pragma unroll
+            for (int qg = 0; qg < QG; ++qg) {
+                asm volatile("" ::"v"(qf[ps][qg][0]), "v"(qf[ps][qg][1]));
+                l_acc[qg] = (f32x4_t){1.f, 1.f, 1.f, 1.f};
+            }
+        } else
+#endif
         if ((g0 + 4) * 16 < len_q) {                               // both groups hold valid queries
             for (int t = 0; t < n_full; ++t)
                 attn_tile<DH, QG, ALIBI, DT, 0, 4, SM>(sK0 + t * BKV * K_ROW_BYTES, sV0 + t * BKV * VROW, t * BKV, len_k, r, g, c,
@@ -1210,6 +1223,7 @@ int launch_fwd_k(const AttnParams& P, dim3 grid, hipStream_t st) {
             if (dev >= 0) attr_set[dev] = true;
         }
     }
+    vf_note_kernel(1, QG == 1 ? "attn_fwd_kernel<64-query blocks>" : QG == 2 ? "attn_fwd_kernel<128-query blocks>" : "attn_fwd_kernel<256-query blocks>");
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, P);
     VF_CHECK_LAUNCH("vf_attn_varlen_fwd");
     return VF_OK;
@@ -1240,6 +1254,7 @@ int launch_short_k(AttnParams P, int n_seq, int max_k, hipStream_t st) {
         if (dev >= 0) attr_set[dev] = true;
     }
     const unsigned nblk = set_grid(P, n_seq, 1);
+    vf_note_kernel(1, "attn_short_kernel");
     hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), lds, st, P, k_rows);
     VF_CHECK_LAUNCH("vf_attn_varlen_fwd");
     return VF_OK;
@@ -1270,6 +1285,17 @@ int launch_short2_k(AttnParams P, int n_seq, int max_k, hipStream_t st) {
         if (dev >= 0) attr_set[dev] = true;
     }
     const unsigned nblk = set_grid(P, n_seq, 1);
+    vf_note_kernel(1, ROWS ? (NPASS == 1 ? "attn_short2_kernel<1 pass,rows>" : "attn_short2_kernel<2 passes,rows>")
+                           : (NPASS == 1 ? "attn_short2_kernel<1 pass>" : "attn_short2_kernel<2 passes>"));
+#ifdef VF_TUNING
+    P.dbg = vf_tuning_env("VF_ATTN_SHORT_DBG", 0);
+    const int lds_probe = vf_tuning_env("VF_ATTN_SHORT_LDS", 0);     // occupancy probe: request this many bytes instead (>= lds)
+    if (lds_probe > lds) {
+        hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), lds_probe, st, P, kr);
+        VF_CHECK_LAUNCH("vf_attn_varlen_fwd");
+        return VF_OK;
+    }
+#endif
     hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), lds, st, P, kr);
     VF_CHECK_LAUNCH("vf_attn_varlen_fwd");
     return VF_OK;
@@ -1300,6 +1326,7 @@ int launch_x32(const AttnParams& P, dim3 grid, hipStream_t st) {
     if (const int rc = no_row_map(P, "attn_x32_kernel")) return rc;
     constexpr int lds = 2 * BKV * (112 + 192);
     static const int nomax = vf_tuning_env("VF_ATTN_NOMAX", 1);    // 0: running maximum always (A/B)
+    vf_note_kernel(1, QB == 2 ? "attn_x32_kernel<64 queries per wave>" : "attn_x32_kernel<32 queries per wave>");
     if (P.q_log2 && nomax) hipLaunchKernelGGL((attn_x32_kernel<DT, QB, true>), grid, dim3(256), lds, st, P);
     else hipLaunchKernelGGL((attn_x32_kernel<DT, QB, false>), grid, dim3(256), lds, st, P);
     VF_CHECK_LAUNCH("vf_attn_varlen_fwd");
@@ -1364,7 +1391,7 @@ int launch_attn(AttnParams P, int n_seq, int max_q, int max_k, hipStream_t st) {
     // query, never the arithmetic of a query: tests test_cfg3 / test_headline batch independence at 1e-5).  64 queries
     // per wave once that leaves >= 8 blocks per CU (the batched gene -> CRE cross attention), else 32 (3 waves / SIMD).
     if constexpr (DH == 48 && !ALIBI) {
-        static const int x32 = vf_tuning_env("VF_ATTN_X32", 1);      // 0: the 16x16x32 kernels (A/B)
+        const int x32 = vf_tuning_env("VF_ATTN_X32", 1);             // 0: the 16x16x32 kernels (A/B; read per launch in the tuning library)
         if (x32) {
 #ifdef VF_TUNING   // VF_ATTN_X32PP=1: the anti-phase experiment (attn_x32pp_kernel: slower, see its header)
             static const int pp = vf_tuning_env("VF_ATTN_X32PP", 0);
@@ -1472,6 +1499,9 @@ static int attn_dispatch(const void* q, const void* k, const void* v, void* out,
     P.slopes = alibi_slopes; P.scale_log2 = q_log2 ? 1.0f : scale * 1.4426950408889634f; P.H = H;
     P.q_at_start = q_at_start ? 1 : 0; P.q_log2 = q_log2;
     P.q_rows = q_rows; P.kv_rows = kv_rows;
+#ifdef VF_TUNING
+    P.dbg = 0;
+#endif
     hipStream_t st = (hipStream_t)stream;
     const bool alibi = alibi_slopes != nullptr;
     switch (dh) {
@@ -1647,6 +1677,7 @@ static int launch_counted_keys(const void* q, int64_t q_stride, const void* kv, 
     // the chip (>= 4 per CU when the batch allows)
     int qpb = 256;
     while (qpb > 64 && (long)n_seq * ((max_q + qpb - 1) / qpb) < 1024) qpb >>= 1;
+    vf_note_kernel(1, "attn_counted_keys_kernel");
     hipLaunchKernelGGL(kern, dim3((max_q + qpb - 1) / qpb, n_seq), dim3(256), lds, st, (const unsigned short*)q, q_stride,
                        (const unsigned short*)kv, kv_stride, log2_count, cu_q, C, H, (unsigned short*)out, o_stride, qpb);
     VF_CHECK_LAUNCH("vf_attn_counted_keys");

@@ -22,6 +22,7 @@ struct Bpe {
                                    // host core; the merged id follows from the rank: new_id_of_rank)
     std::vector<int32_t> new_id_of_rank;   // [n_rank] token produced by the merge of that rank
     int n_rank = 0;
+    int max_token_len = 1;         // characters of the longest token a merge can produce (vf_bpe_encode_prefix's margin)
     bool monotone = true;          // every rule that involves a merged token has a higher rank than the token's own rule
 };
 struct Sym { int32_t c, prev, next, len; };
@@ -154,6 +155,15 @@ extern "C" void* vf_bpe_create(const int32_t* char_ids, int n_ids, const int32_t
         if (born[(size_t)a] >= r || born[(size_t)b] >= r) B->monotone = false;
     }
     if (!B->monotone) { delete B; return nullptr; }          // not a BPE-trained merge list: refuse rather than mis-tokenise
+    {   // token lengths in characters: 1 for the alphabet, len(a) + len(b) for a merge product (rules in rank order: operands exist)
+        std::vector<int32_t> tl((size_t)n_ids, 1);
+        for (int r = 0; r < n_merges; ++r) {
+            const int32_t a = merges[3 * r], b = merges[3 * r + 1], c = merges[3 * r + 2];
+            if (B->rank[(size_t)a * n_ids + b] != r) continue;
+            tl[(size_t)c] = tl[(size_t)a] + tl[(size_t)b];
+            if (tl[(size_t)c] > B->max_token_len) B->max_token_len = tl[(size_t)c];
+        }
+    }
     return B;
 }
 
@@ -185,4 +195,64 @@ extern "C" int64_t vf_bpe_encode(const void* h, const char* seq, int64_t len, in
     if (ids_out) for (int64_t k = 0; k < n && k < capacity; ++k) ids_out[k] = ids[(size_t)k];
     if (starts_out) for (int64_t k = 0; k < n && k < capacity; ++k) starts_out[k] = starts[(size_t)k];
     return n;
+}
+
+// The FIRST max_tokens tokens of vf_bpe_encode(seq, len), exactly, without encoding the rest of a long word (a gene body is one
+// 300 kb word of which the sample builder keeps the first max_chunks x max_length = 40 000 tokens, reference
+// datasets/vcfdataset.py:338-394: more than half of the merges were thrown away).
+//
+// Why a prefix can be encoded on its own: merges are applied rank by rank (candidates created by a merge only enter HIGHER ranks,
+// see encode_word), and within one rank a pair (i, i + 1) fires iff its two symbols match the rule and symbol i was not consumed
+// by the pair to its LEFT (same-rank pairs overlap only in runs a a a ..., merged leftmost first).  So if two runs of the algorithm
+// hold the same symbols left of some frontier before a rank is processed, they hold the same symbols left of (frontier - 1 symbol)
+// after it: a difference on the right -- the text beyond a cut -- moves left by at most ONE symbol per rank, and a symbol never
+// exceeds the longest token.  Tokens that end at least  n_rank x max_token_len  characters before the cut are therefore those of
+// the full encoding (tests/test_bpe_cpu.py compares with the full encoding at every cut of random and repetitive texts).
+extern "C" int64_t vf_bpe_encode_prefix(const void* h, const char* seq, int64_t len, int64_t max_tokens, int32_t* ids_out,
+                                        int64_t* starts_out, int64_t capacity) {
+    if (!h || (!seq && len > 0) || len < 0 || max_tokens < 0) return -1;
+    const Bpe& B = *static_cast<const Bpe*>(h);
+    static thread_local Scratch S;
+    static thread_local std::vector<int32_t> ids, tmp_ids;
+    static thread_local std::vector<int64_t> starts, tmp_starts;
+    ids.clear();
+    starts.clear();
+    const int64_t margin = (int64_t)B.n_rank * B.max_token_len;
+    int64_t i = 0;
+    while (i < len && (int64_t)ids.size() < max_tokens) {
+        auto valid = [&](int64_t j) {
+            unsigned char ch = (unsigned char)seq[j];
+            if (ch >= 'a' && ch <= 'z') ch = (unsigned char)(ch - 32);
+            return B.char_id[ch] >= 0;
+        };
+        while (i < len && !valid(i)) ++i;
+        int64_t j = i;
+        while (j < len && valid(j)) ++j;
+        if (j == i) break;
+        const int64_t n = j - i, need = max_tokens - (int64_t)ids.size();
+        int64_t cut = need * 4 + margin;                       // ~3.6 characters per token on DNA; grown below when short
+        for (;;) {
+            if (cut >= n - margin) cut = n;                    // (a cut inside the last margin saves nothing)
+            tmp_ids.clear();
+            tmp_starts.clear();
+            encode_word(B, S, seq + i, cut, i, tmp_ids, tmp_starts);
+            int64_t exact = (int64_t)tmp_ids.size();
+            if (cut < n) {                                     // tokens that END within the last `margin` characters may differ
+                const int64_t limit = i + cut - margin;
+                while (exact > 0 && (exact == (int64_t)tmp_ids.size() ? i + cut : tmp_starts[(size_t)exact]) > limit) --exact;
+            }
+            if (exact >= need || cut == n) {
+                const int64_t take = exact < need ? exact : need;
+                ids.insert(ids.end(), tmp_ids.begin(), tmp_ids.begin() + take);
+                starts.insert(starts.end(), tmp_starts.begin(), tmp_starts.begin() + take);
+                break;
+            }
+            cut += cut / 2 + margin;
+        }
+        i = j;
+    }
+    const int64_t nt = (int64_t)ids.size();
+    if (ids_out) for (int64_t k = 0; k < nt && k < capacity; ++k) ids_out[k] = ids[(size_t)k];
+    if (starts_out) for (int64_t k = 0; k < nt && k < capacity; ++k) starts_out[k] = starts[(size_t)k];
+    return nt;
 }

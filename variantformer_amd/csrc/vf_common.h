@@ -15,6 +15,8 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 #define VF_WAVE 64
 
 void vf_set_error(const char* fmt, ...);
+// vf_last_kernel(): the launchers name the kernel they dispatched to (0 = GEMM, 1 = attention; static strings)
+void vf_note_kernel(int which, const char* name);
 
 // Per-device launch state (dynamic-LDS attributes) is indexed by the current HIP device; -1 = out of range / error,
 // in which case the caller simply redoes the (idempotent) setup.

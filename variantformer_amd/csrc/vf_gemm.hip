@@ -1314,6 +1314,44 @@ __global__ __launch_bounds__(512, 2) void gemm8x_kernel(const unsigned short* __
                         Op16<DT>::mfma(WF[i][ks], af[j][ks], acc[IN0 + i][IM0 + j]); \
     } while (0)
 
+    // Probe (tuning library only, VF_G8_DBG bits 16 / 32; results meaningless): one / two 16-byte-per-lane stores per phase
+    // into the rows of the CURRENT tile (16 rows x 64 bytes per instruction, the shape of an epilogue without LDS staging),
+    // issued in the fragment-read section -- do stores beside the LDS-DMA stream cost the K loop anything?  (round 6: the
+    // question behind an epilogue inside the K loop; 32 / 64 KiB per K-tile and block against 64 KiB of fill.)
+#ifdef VF_TUNING
+#define VF_G8X_STORE_PROBE(PH)                                                                                         \
+    do {                                                                                                               \
+        /* bits 64 / 128: the store pattern of an epilogue inside the K loop -- 4 stores (32 rows x 64 columns of 16-bit */ \
+        /* values) in P1 and P2 of a tile's first K-tile (64: they get 1.75 / 1.5 K-tiles until a counted wait needs them */ \
+        /* complete), or in P3 and behind the wait of P4 of its second K-tile (128: 1.25 / 1 K-tiles) */               \
+        if (((dbg & 64) && (PH) < 2 && t == 0 && ti > 0) || ((dbg & 128) && (PH) >= 2 && t == 1)) {                    \
+            int lp;                                                                                                    \
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lp));                   \
+            const int prow = m0 + wm * 128 + ((PH) >> 1) * 64 + ((PH) & 1) * 32 + (lp & 15);                            \
+            const int pcol = n0 + wn * 64 + (lp >> 4) * 8;                                                             \
+            if (prow + 16 < M && pcol + 32 < N) {                                                                      \
+                unsigned short* pp = reinterpret_cast<unsigned short*>(out) + (int64_t)prow * ldo + pcol;              \
+                *reinterpret_cast<f32x4_t*>(pp) = acc[0][0];                                                           \
+                *reinterpret_cast<f32x4_t*>(pp + 32) = acc[0][1];                                                      \
+                *reinterpret_cast<f32x4_t*>(pp + 16 * ldo) = acc[1][0];                                                \
+                *reinterpret_cast<f32x4_t*>(pp + 16 * ldo + 32) = acc[1][1];                                           \
+            }                                                                                                          \
+        }                                                                                                              \
+        if (dbg & 48) {                                                                                                \
+            int lp;                                                                                                    \
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lp));                   \
+            const int prow = m0 + wm * 128 + (((t * 4 + (PH)) * 16 + (lp & 15)) & 127);                                \
+            const int pcol = n0 + wn * 64 + (lp >> 4) * 8;                                                             \
+            if (prow < M && pcol + 32 < N) {                                                                           \
+                unsigned short* pp = reinterpret_cast<unsigned short*>(out) + (int64_t)prow * ldo + pcol;              \
+                *reinterpret_cast<f32x4_t*>(pp) = acc[0][0];                                                           \
+                if (dbg & 32) *reinterpret_cast<f32x4_t*>(pp + 32) = acc[0][1];                                        \
+            }                                                                                                          \
+        }                                                                                                              \
+    } while (0)
+#else
+#define VF_G8X_STORE_PROBE(PH) do { } while (0)
+#endif
     // ---- first tile: its epilogue operands and K-tile 0
     const int nkt = K / BK;                                  // >= 2 (launcher)
     int m0, n0;
@@ -1365,6 +1403,7 @@ __global__ __launch_bounds__(512, 2) void gemm8x_kernel(const unsigned short* __
             read_a(buf, C::AL);
             if (pre1) issue(g0 + t + 1, t + 1 < nkt ? t + 1 : 0, C::AH);
             asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");       // ... and retired before the barrier (WAR on WL)
+            VF_G8X_STORE_PROBE(0);
             VF_G8_SYNC_IN();
             VF_G8_MMA(wlo, 0, 0);
             VF_G8_SYNC_OUT();
@@ -1377,22 +1416,32 @@ __global__ __launch_bounds__(512, 2) void gemm8x_kernel(const unsigned short* __
             // ---- P2: (m-lo, n-hi)
             read_w(buf, C::WH, whi);
             if (pre2) issue(g0 + t + 2, into_next ? 0 : t + 2, C::WL);
+            VF_G8X_STORE_PROBE(1);
             VF_G8_SYNC_IN();
             VF_G8_MMA(whi, 2, 0);
             VF_G8_SYNC_OUT();
             // ---- P3: (m-hi, n-hi)
             read_a(buf, C::AH);
             if (pre2) issue(g0 + t + 2, into_next ? 0 : t + 2, C::AL);
+            VF_G8X_STORE_PROBE(2);
             VF_G8_SYNC_IN();
             VF_G8_MMA(whi, 2, 4);
             VF_G8_SYNC_OUT();
             // ---- P4: (m-hi, n-lo); retire stream K-tile t+1 (all but the three youngest half-tiles)
             if (pre2) {
                 issue(g0 + t + 2, into_next ? 0 : t + 2, C::WH);
+#ifdef VF_TUNING
+                if (dbg & 32) wait_vmcnt<12>();                      // store probe: its stores since AH(t + 1) may stay in flight too
+                else if (dbg & 16) wait_vmcnt<9>();
+                else if ((dbg & 64) && t == 0 && ti > 0) wait_vmcnt<14>();
+                else if ((dbg & 128) && t == 1) wait_vmcnt<10>();
+                else
+#endif
                 wait_vmcnt<6>();
             } else {
                 wait_vmcnt<0>();
             }
+            VF_G8X_STORE_PROBE(3);
             VF_G8_SYNC_IN();
             VF_G8_MMA(wlo, 0, 4);
             VF_G8_SYNC_OUT();
@@ -1625,7 +1674,12 @@ __global__ __launch_bounds__(512, 2) void gemm8x_kernel(const unsigned short* __
 #undef VF_G8_SYNC_IN
 #undef VF_G8_SYNC_OUT
 #undef VF_G8_MMA
+#undef VF_G8X_STORE_PROBE
 }
+
+#ifdef VF_TUNING   // gemm8y_kernel: the epilogue inside the K loop -- ruled out by the store probe before it ran (profiles/r06_b)
+#include "tuning/gemm8y.inc"
+#endif
 
 #ifdef VF_TUNING   // gemm4_kernel: two independent 4-wave blocks per CU, 15-20 % slower (profiles/r04_a)
 #include "tuning/gemm4.inc"
@@ -1727,6 +1781,7 @@ int launch_cfg(const void* A, int64_t lda, const void* W, const float* bias, con
     const int tiles_m = (M + C::BM - 1) / C::BM, tiles_n = (N + C::BN - 1) / C::BN;
     const int n_blocks = tiles_m * tiles_n;
     const int group_m = 8;      // m-panels per L2 group; 2 / 4 / 16 measured equal or slower for both tile sizes
+    vf_note_kernel(0, C::BM == 128 ? "gemm_mfma_kernel<128x128>" : C::BM == 64 ? "gemm_mfma_kernel<64x64>" : "gemm_mfma_kernel<other>");
     hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(C::THREADS), C::LDS_BYTES, st, (const unsigned short*)A, lda,
                        (const unsigned short*)W, bias, res, ldr, out, ldo, M, N, K, tiles_n, n_blocks, group_m, ln);
     VF_CHECK_LAUNCH("vf_gemm_bf16");
@@ -1783,6 +1838,7 @@ int launch_gemm8(const void* A, int64_t lda, const void* W, const float* bias, c
     if (const char* e = getenv("VF_G8_DBG")) group_m |= atoi(e) << 8;   // epilogue cost-centre probes
     if (const char* e = getenv("VF_G8_STAGGER")) group_m |= atoi(e) << 16;
 #endif
+    vf_note_kernel(0, "gemm8_kernel");
     hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(512), Cfg8::LDS_BYTES + Cfg8::SIDE_BYTES, st, (const unsigned short*)A, lda,
                        (const unsigned short*)W, bias, res, ldr, out, ldo, M, N, K, tiles_n, n_blocks, group_m, ln);
     VF_CHECK_LAUNCH("vf_gemm_bf16");
@@ -1823,6 +1879,7 @@ int launch_gemm8x(const void* A, int64_t lda, const void* W, const float* bias, 
     if (const char* e = getenv("VF_G8X_GROUP_M")) group_m = atoi(e);    // tile-walk sweep (scripts/gemm4_probe.py)
     if (const char* e = getenv("VF_G8_DBG")) group_m |= atoi(e) << 8;   // epilogue cost-centre probes
 #endif
+    vf_note_kernel(0, "gemm8x_kernel");
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, st, (const unsigned short*)A, lda, (const unsigned short*)W, bias,
                        res, ldr, out, ldo, M, N, K, tiles_n, n_tiles, group_m, ln);
     VF_CHECK_LAUNCH("vf_gemm_bf16");
@@ -1934,18 +1991,41 @@ int pick_variant(int M, int N, int K, int epilogue) {
     return (persist && (out16 || persist >= 2) && K % 128 == 0) ? 22 : 20;      // K / 64 even: see the kernel's staging
 }
 
+#ifdef VF_TUNING
+// Variant 23 = gemm8y_kernel (tuning library only, VF_GEMM8Y=1): the epilogue inside the K loop.  Never validated on hardware:
+// the store probe of gemm8x_kernel (VF_G8_DBG bits 64 / 128) showed that its 16 in-loop stores per wave and tile cost as much as
+// the serial epilogue they would replace, and the kernel spills 28-83 registers.
+static inline bool gemm8y_ok(int K, int epilogue) {
+    static const int on = vf_tuning_env("VF_GEMM8Y", 0);
+    return on && K % 128 == 0 && K >= 256 && (epilogue == VF_EPI_BF16 || epilogue == VF_EPI_GEGLU_BF16);
+}
+#endif
+
 template <int EPI, int DT>
 int launch_gemm(const void* A, int64_t lda, const void* W, const float* bias, const float* res, int64_t ldr, void* out,
                 int64_t ldo, int M, int N, int K, int variant, hipStream_t st) {
     if (K % 64 != 0) {
         dim3 grid((N + 63) / 64, (M + 63) / 64);
+        vf_note_kernel(0, "gemm_generic_kernel");
         hipLaunchKernelGGL((gemm_generic_kernel<EPI, DT>), grid, dim3(256), 0, st, (const unsigned short*)A, lda,
                            (const unsigned short*)W, bias, res, ldr, out, ldo, M, N, K);
         VF_CHECK_LAUNCH("vf_gemm_bf16");
         return VF_OK;
     }
-    if (variant == 0) variant = pick_variant(M, N, K, EPI);
+    if (variant == 0) {
+        variant = pick_variant(M, N, K, EPI);
+#ifdef VF_TUNING
+        if (variant == 22 && gemm8y_ok(K, EPI)) variant = 23;
+#endif
+    }
     switch (variant) {
+#ifdef VF_TUNING
+        case 23:
+            if constexpr (EPI == VF_EPI_BF16 || EPI == VF_EPI_GEGLU_BF16) {
+                if (K % 128 == 0 && K >= 256) return launch_gemm8y<EPI, DT>(A, lda, W, bias, out, ldo, M, N, K, st);
+            }
+            break;
+#endif
         case 1: return launch_cfg<CfgA, EPI, DT>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
         case 5: return launch_cfg<CfgE, EPI, DT>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
         case 20: return launch_gemm8<EPI, DT>(A, lda, W, bias, res, ldr, out, ldo, M, N, K, st);
@@ -2068,6 +2148,11 @@ static int launch_gemm_ln(const void* A, int64_t lda, const void* W, const float
         const int bit = LN == VF_LN_CONSUMER ? 1 : (ln_res_is_16(LN) ? 2 : 4);
         if ((variant == 20 || variant == 22) && K % 128 == 0 && (g4 & bit))
             return launch_gemm4<EPI, DT, LN>(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, st, ln);
+    }
+#endif
+#ifdef VF_TUNING
+    if constexpr (LN == VF_LN_CONSUMER && (EPI == VF_EPI_BF16 || EPI == VF_EPI_GEGLU_BF16)) {
+        if (variant == 22 && gemm8y_ok(K, EPI)) return launch_gemm8y<EPI, DT, LN>(A, lda, W, bias, out, ldo, M, N, K, st, ln);
     }
 #endif
     switch (variant) {

@@ -19,6 +19,10 @@ void vf_set_error(const char* fmt, ...) {
 extern "C" int vf_version(void) { return VF_ABI_VERSION; }
 extern "C" const char* vf_last_error(void) { return g_err; }
 
+static thread_local const char* g_last_kernel[2] = {"", ""};
+void vf_note_kernel(int which, const char* name) { g_last_kernel[which & 1] = name; }
+extern "C" const char* vf_last_kernel(int which) { return g_last_kernel[which & 1]; }
+
 namespace {
 
 // runtime 16-bit output type (VF_BF16 / VF_F16): uniform per launch

@@ -137,7 +137,16 @@ class VCFDataset(Dataset):
         return self._load_file(idx)
 
     def _get_gene_info(self, gene_id: str) -> dict:
-        return self.gencode_v24[self.gencode_v24["gene_id"] == gene_id].iloc[0].to_dict()
+        """First gencode row of the gene as a dict (reference :171-176 filters the frame per call: 0.8 ms of boolean-mask work
+        per gene on a 60 k-row table; the rows are indexed once here)."""
+        idx = self.__dict__.get("_gene_rows")
+        if idx is None:
+            ids = self.gencode_v24["gene_id"].to_numpy()
+            idx = {}
+            for i in range(len(ids) - 1, -1, -1):           # the FIRST row of a gene id wins, like .iloc[0] of the filtered frame
+                idx[ids[i]] = i
+            self._gene_rows = idx
+        return self.gencode_v24.iloc[idx[gene_id]].to_dict()
 
     def _adjust_length(self, token_ids):
         n = len(token_ids)
@@ -151,12 +160,12 @@ class VCFDataset(Dataset):
 
     def _get_cres(self, gene_id: str, gene_info: dict, vcf_path: str):
         """[N,1,L] ids, [N,1,L] pad mask, ref-cCRE class ids, cCRE labels (all "Low-DNase") -- reference :219-283."""
-        table = pd.read_csv(self.gene_cre_manifest.get_file_path(gene_id))
-        bed = table[["chromosome", "start_cre", "end_cre", "cre_name"]].rename(
-            columns={"chromosome": "chrom", "start_cre": "start", "end_cre": "end", "cre_name": "cCRE"})
-        fast = self._get_cres_batched(bed, gene_info, vcf_path)
+        table = pd.read_csv(self.gene_cre_manifest.get_file_path(gene_id), usecols=["chromosome", "start_cre", "end_cre", "cre_name"])
+        fast = self._get_cres_batched(table, gene_info, vcf_path)
         if fast is not None:
             return fast
+        bed = table[["chromosome", "start_cre", "end_cre", "cre_name"]].rename(
+            columns={"chromosome": "chrom", "start_cre": "start", "end_cre": "end", "cre_name": "cCRE"})
         cres = self._extractor(self.cre_neighbour_hood).process_subject(vcf_file=vcf_path, bed_regions=bed)
         minus = gene_info["strand"] != "+"
         if gene_info["strand"] == "-":
@@ -173,7 +182,7 @@ class VCFDataset(Dataset):
         labels = np.full(n, self.cre_to_idx["Low-DNase"], dtype=np.int64)
         return torch.from_numpy(X), torch.from_numpy(masks), torch.from_numpy(ref_labels), torch.from_numpy(labels)
 
-    def _get_cres_batched(self, bed: pd.DataFrame, gene_info: dict, vcf_path: str):
+    def _get_cres_batched(self, table: pd.DataFrame, gene_info: dict, vcf_path: str):
         """Same result as the per-window path above from ONE native call (vf_build_windows: consensus -> reverse
         complement -> BPE -> pad, for all windows of the gene; ~5x less host time per gene).  Returns None when the
         per-window path has to take over (windows on several chromosomes, a chromosome the genome lacks, a span too
@@ -182,17 +191,20 @@ class VCFDataset(Dataset):
 
         from .. import _lib
         from ..utils.data_process import ConsensusError, _INDEL_POLICIES, open_fasta, open_vcf
-        if len(bed) == 0 or bed["chrom"].nunique() != 1:
+        # (the manifest's own columns as arrays: building the renamed 4-column frame first cost 2 ms of pandas per gene)
+        chroms = table["chromosome"].to_numpy()
+        if len(chroms) == 0 or (chroms != chroms[0]).any():
             return None
-        chrom = str(bed["chrom"].iloc[0])
+        chrom = str(chroms[0])
+        bed = {"start": table["start_cre"].to_numpy(), "end": table["end_cre"].to_numpy(), "cCRE": table["cre_name"].to_numpy()}
         fa = open_fasta(self.fasta_path)
         if chrom not in fa.index:
             return None
         nh = self.cre_neighbour_hood
-        order = np.argsort(bed["start"].to_numpy(), kind="stable")          # process_subject sorts by start
-        starts = np.maximum(0, bed["start"].to_numpy()[order].astype(np.int64) - nh)
-        ends = np.minimum(bed["end"].to_numpy()[order].astype(np.int64) + nh, fa.length(chrom))
-        names = bed["cCRE"].to_numpy()[order]
+        order = np.argsort(bed["start"], kind="stable")          # process_subject sorts by start
+        starts = np.maximum(0, bed["start"][order].astype(np.int64) - nh)
+        ends = np.minimum(bed["end"][order].astype(np.int64) + nh, fa.length(chrom))
+        names = bed["cCRE"][order]
         keep = ends > starts                                                 # empty windows yield no row there either
         starts, ends, names = np.ascontiguousarray(starts[keep]), np.ascontiguousarray(ends[keep]), names[keep]
         if len(starts) == 0 or int(ends.max() - starts.min()) > 64_000_000:
@@ -238,7 +250,10 @@ class VCFDataset(Dataset):
         seq = self._extractor(self.gene_downstream_neighbour_hood, self.gene_upstream_neighbour_hood).process_gene(
             gene_info, vcf_path)
         assert len(seq) > 1000, f"Mutated sequence is less than 1000bp for gene {gene_id}"
-        ids = self.bpe.encode_forward(seq if gene_info["strand"] == "+" else reverse_complement(seq))
+        # only max_chunks x max_length tokens are kept (chunkify_data): the exact prefix of the full encoding (vf_bpe_encode_prefix)
+        # -- a 301 kb gene body is ~83 k tokens of which 40 k survive; round 6: 14 -> 8 ms of a gene's 39 ms on the host
+        ids = self.bpe.encode_forward(seq if gene_info["strand"] == "+" else reverse_complement(seq),
+                                      max_tokens=self.max_chunks * self.max_length)
         return self.chunkify_data(torch.from_numpy(ids.astype(np.int64)).unsqueeze(0))
 
     def _load_file(self, idx: int):

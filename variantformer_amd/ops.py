@@ -776,6 +776,13 @@ def rowdot_softplus(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor | None, so
     return out
 
 
+def last_kernel(which: str = "gemm") -> str:
+    """Name of the kernel this thread's most recent GEMM ("gemm") or attention ("attn") entry dispatched to (vf_last_kernel:
+    a diagnostic for sweeps over shapes, scripts/s2r_dims_sweep.py)."""
+    name = _lib.load().vf_last_kernel(0 if which == "gemm" else 1)
+    return name.decode() if name else ""
+
+
 def cast16(x: torch.Tensor, dtype=None) -> torch.Tensor:
     """fp32 -> 16-bit operand type (default: the current compute dtype), round to nearest even."""
     _dev(x)

@@ -253,6 +253,7 @@ class PredictHandle:
 
 
 _SIDE_STREAMS: dict = {}
+_OVERLAP_SERIALIZE_FOR_DIAG = False     # diagnostic of the side-stream experiment only (see modulator_forward_packed)
 
 
 def _side_stream(device):
@@ -343,13 +344,16 @@ def modulator_forward_packed(ctx_embedding, cre_layers, gene_layers, cre_x, gene
                 g = ops.add_rows(_t(g), gene_x)
             return g
 
-    # The CRE layers run on a SIDE STREAM beside the gene layers (runtime.Switches.overlap_cre_stream, the default since round 6):
+    # EXPERIMENT (runtime.Switches.overlap_cre_stream, off by default): the CRE layers on a SIDE STREAM beside the gene layers --
     # CRE layer i + 1 depends on CRE layer i only, gene layer i + 1 on gene layer i and CRE layer i, so the small CRE-stream
-    # kernels (3-9 tiles per CU) fill the tails of the gene stream's persistent GEMMs: -3...5 ms per 32-gene step, bit-identical
-    # (tests/test_model_gpu.py::test_cre_stream_on_a_side_stream_is_bit_identical).  Single stream: inside an ops.KernelTimer
-    # replay (a kernel's duration must not depend on its neighbour there), and for the FIRST forward of a configuration, which
-    # builds every per-weights cache (packed operands, low-rank tables, the 9-row K/V tables) -- they are long-lived and belong
-    # in the main stream's allocator pool (round-5 advice).
+    # kernels (3-9 tiles per CU) fill the tails of the gene stream's persistent GEMMs: -3.5 ms per 32-gene step (0.6 %).  NOT
+    # EXACT at full depth: the same batch evaluated twice differs by 7e-4 in the expression (bit-identical on a 5-layer model,
+    # tests/test_model_gpu.py; 0 difference single-stream at any depth) although every cross-stream tensor is event-ordered and
+    # recorded on its reader's stream (scripts/probes/overlap_diag.py: also with the two streams serialised by events the
+    # difference stays 0, i.e. it needs kernels of both streams in flight together).  Round 6 therefore keeps it out of the
+    # product default and out of `value`.  Single stream always: inside an ops.KernelTimer replay, and for the FIRST forward of a
+    # configuration, which builds every per-weights cache (packed operands, low-rank tables, the 9-row K/V tables) -- they are
+    # long-lived and belong in the main stream's allocator pool (round-5 advice).
     warm_key = (ops.cdt(), ln_fold_enabled(cre_x.shape[1]), runtime.env().trunk16, runtime.switches().counted_context_keys,
                 runtime.switches().lowrank_context, log2c is not None)
     warm = cre_layers[0].__dict__.setdefault("_vf_overlap_warm", set()) if n > 1 else set()
@@ -376,6 +380,9 @@ def modulator_forward_packed(ctx_embedding, cre_layers, gene_layers, cre_x, gene
             ev.record(side)
         for t in tensors(out):
             t.record_stream(main)
+        if _OVERLAP_SERIALIZE_FOR_DIAG:                # scripts/probes/overlap_diag.py: the same plumbing, never two streams in flight
+            main.wait_stream(side)
+            side.wait_stream(main)
         return out, ev
     # (gene layer 0 above is already enqueued on the main stream: CRE layer 0 runs beside it)
     side.wait_stream(main)

@@ -67,11 +67,22 @@ class BPEEncoder:
             raise _lib.VFError("vf_bpe_encode failed")
         return ids[:n].copy(), starts[:n].copy()
 
-    def encode_forward(self, seq: str) -> np.ndarray:
+    def encode_forward(self, seq: str, max_tokens: int | None = None) -> np.ndarray:
         """Token ids of one strand, int32.  Same ids as encode([seq, "A"])[0]: the C++ encoder upper-cases and
         splits at invalid characters itself, so the Python-side normalize() pass and the token strings are skipped
-        (the sample builders need neither)."""
-        return self.encode_ids(seq)[0]
+        (the sample builders need neither).  max_tokens: only the first max_tokens tokens -- exactly those of the full
+        encoding (vf_bpe_encode_prefix), at the cost of encoding ~5 characters per requested token instead of all of `seq`."""
+        if max_tokens is None:
+            return self.encode_ids(seq)[0]
+        if self._h is None:
+            self.load_vocabulary()
+        raw = seq.encode("ascii", errors="replace")
+        cap = min(len(raw), int(max_tokens)) + 1
+        ids = np.empty(cap, dtype=np.int32)
+        n = self._lib.vf_bpe_encode_prefix(self._h, raw, len(raw), int(max_tokens), ids.ctypes.data, None, cap)
+        if n < 0:
+            raise _lib.VFError("vf_bpe_encode_prefix failed")
+        return ids[:n].copy()
 
     # -- reference interface ------------------------------------------------------------------------
     def normalize(self, sequences):
