@@ -21,9 +21,11 @@ ap.add_argument("--overlap", action="store_true")
 ap.add_argument("--passes", type=int, default=3)
 ap.add_argument("--no-dedupe", action="store_true")
 args = ap.parse_args()
+CORES = None
 if args.cores:
     avail = sorted(os.sched_getaffinity(0))
-    os.sched_setaffinity(0, set(avail[:args.cores]))
+    CORES = set(avail[:args.cores])
+    os.sched_setaffinity(0, CORES)
     os.environ["OMP_NUM_THREADS"] = str(max(1, min(args.cores, 4)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, pandas as pd, torch
@@ -66,8 +68,17 @@ for g in range(n_genes):
 query = pd.DataFrame({"gene_id": [g["gene_id"] for g in genes], "tissues": [",".join(tissue_names)] * n_genes})
 ds = VCFDataset(200, 200, 50, pd.DataFrame(genes), LocalManifest(paths), 1000, 300000, query, fasta, os.path.join(root, "d.vcf.gz"))
 model, hp, kw = bench.build_model(torch.device("cuda:0"))
+if CORES and len(os.sched_getaffinity(0)) != len(CORES):
+    # (round 6: with --cores 1 the affinity set before the GPU was touched came back as all 256 CPUs after the runtime had
+    # initialised -- the one-core line of r05 / r06_d ran unconfined; re-assert it here and in every loader worker)
+    os.sched_setaffinity(0, CORES)
+
+
+def _pin_worker(_):
+    if CORES:
+        os.sched_setaffinity(0, CORES)
 loader = DataLoader(ds, batch_size=batch_size, num_workers=workers, collate_fn=collate_fn_batching,
-                    prefetch_factor=2 if workers else None, persistent_workers=bool(workers))
+                    prefetch_factor=2 if workers else None, persistent_workers=bool(workers), worker_init_fn=_pin_worker)
 from variantformer_amd.processors.trainer import Trainer
 trainer = Trainer(precision="bf16-mixed")
 stats = {"total": 0, "embedded": 0, "prep_s": 0.0}

@@ -20,10 +20,10 @@ pytestmark = pytest.mark.gpu
 NORTH_STAR_RTOL = 1e-3      # BASELINE.json: "within 1e-3 relative fp32 tolerance" (vs same-rounding oracle)
 BF16_VS_FP32 = 2e-2         # bf16-operand arithmetic vs the reference's fp32 fixture values
 # Embeddings of the headline-size gene against PURE fp32 arithmetic (test_headline_size_gene_vs_oracle_and_properties): limits =
-# 1.5 x the values MI355X measured (profiles/r06_a_headline_accuracy.log); max-norm = max |err| / max |ref|, element-wise =
+# 1.5 x the values MI355X measured (profiles/r06_c_headline_accuracy.log); max-norm = max |err| / max |ref|, element-wise =
 # max |err| / (|ref| + rms(ref)).
-HEADLINE_EMB_MAXNORM = {"bf16": 1.5e-2, "fp16": 5e-3}
-HEADLINE_EMB_ELEMENTWISE = {"bf16": 3e-2, "fp16": 1e-2}
+HEADLINE_EMB_MAXNORM = {"bf16": 6e-3, "fp16": 3e-3}          # measured 3.93e-3 / 1.97e-3
+HEADLINE_EMB_ELEMENTWISE = {"bf16": 2.2e-2, "fp16": 6e-3}    # measured 1.48e-2 / 3.71e-3
 
 
 def _rel(a, b):
@@ -656,7 +656,7 @@ def test_non_shipped_options_vs_reference_golden(name):
     # small_opts_b (max pooling) reads 2.0e-2 with the unscaled query projection, 3.3e-2 with the softmax scale folded into
     # the query weights (VF_Q_PRESCALE, the default) -- while the production-width, full-depth model, measured over three
     # geometries with either setting, sits at 0.7 ... 1.5e-2 and is closer to pure fp32 WITH the folding in all three
-    # (profiles/r03_m_q_prescale_accuracy.log).  The suite-wide bound (helpers.SIGNAL_RTOL = 3e-2) is kept everywhere else.
+    # (profiles/r03_m_q_prescale_accuracy.log).  The suite-wide bound (helpers.SIGNAL_RTOL = 2e-2 since round 6; measured maximum 1.9e-2: cfg3) is kept everywhere else.
     check_signal(name + " vs reference fp32", out["pred_gene_exp"],
                  [arrays[f"pred_gene_exp_{i}"] for i in range(len(meta["n_cres"]))], tol=5e-2)
     if not general:

@@ -306,13 +306,17 @@ def test_attention_prescaled_q_is_kernel_independent(ops, alibi):
 
 
 @pytest.mark.parametrize("q_log2", [True, False])
-def test_attention_one_block_per_window_dh64(ops, q_log2):
+@pytest.mark.parametrize("dh,alibi", [(64, False), (32, False), (32, True)])
+def test_attention_one_block_per_window_dh64(ops, q_log2, dh, alibi):
     """seq2reg windows (dh = 64, <= 128 tokens) in a batch of >= 1024 (window, head) items take one block per item with the
     whole K / V in LDS (attn_short2_kernel<64, .., NPASS = 1>, three resident blocks per CU) instead of the tiled kernel's two
     64-query blocks.  130 ragged windows of 1 ... 128 tokens: every element against the oracle, and bit-identical to the
-    tiled kernel (the same windows in a batch too small for the new path): the arithmetic per query is the same."""
-    dh, H = 64, 8
+    tiled kernel (the same windows in a batch too small for the new path): the arithmetic per query is the same.
+    dh = 32 (round 6: a tokenizer geometry the real checkpoint might have takes the same kernel), with and without ALiBi."""
+    H = 8
     D = H * dh
+    slopes_l = torch.tensor(O.alibi_slopes(H), dtype=torch.float32) if alibi else None      # (CPU copy for the oracle)
+    slopes = slopes_l.cuda() if alibi else None
     rng = np.random.default_rng(9)
     ql = [128, 127, 1, 16, 17, 32, 33, 64, 65, 96, 97, 112, 113, 80] + list(rng.integers(1, 129, 116))
     assert len(ql) * H >= 1024
@@ -321,18 +325,21 @@ def test_attention_one_block_per_window_dh64(ops, q_log2):
     x[:, :D] = _bf(x[:, :D] * c)
     dev = x.cuda().bfloat16()
     cu = torch.tensor([0] + list(np.cumsum(ql)), dtype=torch.int32)
-    out = ops.attn_varlen(dev[:, :D], dev[:, D:2 * D], dev[:, 2 * D:], cu.cuda(), None, max(ql), max(ql), H, dh, q_log2=q_log2)
+    out = ops.attn_varlen(dev[:, :D], dev[:, D:2 * D], dev[:, 2 * D:], cu.cuda(), None, max(ql), max(ql), H, dh, slopes, q_log2=q_log2)
+    assert ops.last_kernel("attn") == "attn_short2_kernel<1 pass>"
     n_small = 100                                              # 100 windows x 8 heads < 1024 items: the tiled kernel
     t_small = int(cu[n_small])
     small = ops.attn_varlen(dev[:t_small, :D], dev[:t_small, D:2 * D], dev[:t_small, 2 * D:], cu[:n_small + 1].cuda(), None,
-                            max(ql[:n_small]), max(ql[:n_small]), H, dh, q_log2=q_log2)
+                            max(ql[:n_small]), max(ql[:n_small]), H, dh, slopes, q_log2=q_log2)
+    assert ops.last_kernel("attn").startswith("attn_fwd_kernel")
     torch.cuda.synchronize()
-    assert torch.equal(out[:t_small].view(torch.int16), small.view(torch.int16))
+    if q_log2 or not alibi:      # (without the pre-scaled q the ALiBi bias meets the logit in a different expression per kernel)
+        assert torch.equal(out[:t_small].view(torch.int16), small.view(torch.int16))
     rnd = O.Rounding("bf16")
     got = out.float().cpu()
     for b in list(range(14)) + [40, 90, 129]:
         a, e = int(cu[b]), int(cu[b + 1])
-        ref = O.attention(x[a:e, :D].view(-1, H, dh), x[a:e, D:2 * D].view(-1, H, dh), x[a:e, 2 * D:].view(-1, H, dh), None, rnd,
+        ref = O.attention(x[a:e, :D].view(-1, H, dh), x[a:e, D:2 * D].view(-1, H, dh), x[a:e, 2 * D:].view(-1, H, dh), slopes_l, rnd,
                           q_log2=q_log2)
         np.testing.assert_allclose(got[a:e].numpy(), _bf(ref.reshape(e - a, D)).numpy(), rtol=2 ** -7, atol=6e-3)
 

@@ -1417,9 +1417,11 @@ int launch_attn(AttnParams P, int n_seq, int max_q, int max_k, hipStream_t st) {
             return launch_short<DH, 4, ALIBI, DT>(P, n_seq, max_k, st);
         }
     }
-    if constexpr (DH == 64) {
+    if constexpr (DH == 64 || DH == 32) {
         // seq2reg windows (<= 128 tokens at dh = 64: a 36 KB image): one block per (window, head) with the whole K / V in
-        // LDS instead of two 64-query blocks that each fetch K / V and wait for it (VF_ATTN_SHORT64=0: the tiled kernel)
+        // LDS instead of two 64-query blocks that each fetch K / V and wait for it (VF_ATTN_SHORT64=0: the tiled kernel).
+        // dh = 32 (a tokenizer geometry the real checkpoint might have, scripts/s2r_dims_sweep.py) takes the same kernel
+        // since round 6: the tiled kernel ran its windows at 3.2 TB/s against 4.1 for dh = 64.
         const int short64 = env_short64();
         if (short64 && max_q <= 128 && max_k <= 128 && (long)n_seq * P.H >= 1024) {
             int kr, vr;
@@ -1430,7 +1432,7 @@ int launch_attn(AttnParams P, int n_seq, int max_q, int max_k, hipStream_t st) {
         // 129-256-token chunks (seq2reg's 200-token gene chunks): the same kernel in its two-pass form, one block per (chunk,
         // head) with a 62 KB image (two resident blocks per CU) instead of four 64-query blocks of the tiled kernel that each
         // stage all keys: 1544 -> 1329 us per launch at 32 genes, bit-identical (profiles/r04_k; VF_ATTN_SHORT64=0: tiled kernel)
-        if (short64 && max_q > 128 && max_q <= 256 && max_k <= 256 && (long)n_seq * P.H >= 1024) {
+        if (DH == 64 && short64 && max_q > 128 && max_q <= 256 && max_k <= 256 && (long)n_seq * P.H >= 1024) {
             int kr, vr;
             short2_rows(max_k, kr, vr);
             if (2 * (kr * KLayout<DH>::ROW + vr * VLayout<DH>::ROW) <= 160 * 1024)
