@@ -507,21 +507,22 @@ def main():
         allocs_in_timed_region = timed_steps.device_allocs
         assert torch.isfinite(expr).all() and tuple(expr.shape) == (world * G, len(tissues))
 
-        # After the timed region: (1) the side-stream EXPERIMENT (runtime.Switches.overlap_cre_stream: CRE layers beside the gene
-        # layers; -0.6 % step time but not reproducible at full depth, so opt-in and never `value`); (2) the fallback the
-        # self-healing LayerNorm fold switches to (a batch whose rows left the folded form's regime; a model whose alerts became
-        # sticky): every LayerNorm as a pass on fp32 rows, exactly a VF_LN_FOLD=0 run (reference: plain nn.LayerNorm,
-        # seq2gene/modules/layers.py:75-77).
-        side = fold_off = None
+        # After the timed region: (1) the same steps on ONE stream (runtime.Switches.overlap_cre_stream off: the product default
+        # runs the CRE layers on a side stream beside the gene layers; bit-identical, so max_rel_diff must be 0.0); (2) the
+        # fallback the self-healing LayerNorm fold switches to (a batch whose rows left the folded form's regime; a model whose
+        # alerts became sticky): every LayerNorm as a pass on fp32 rows, exactly a VF_LN_FOLD=0 run (reference: plain
+        # nn.LayerNorm, seq2gene/modules/layers.py:75-77).
+        single = fold_off = None
         if not args.no_extra_rates:
             from variantformer_amd import runtime
             from variantformer_amd.seq2gene.modules.layers import ln_fold_forced_off
-            with runtime.override(overlap_cre_stream=True):
-                dts, (expr_side, _) = timed_steps(step, args.steps, 2, use_dist, torch.cuda.synchronize, dev)
-            side = {"value": round(world * G * args.steps / dts, 4), "unit": "genes/sec",
-                    "ms_per_step": round(dts / args.steps * 1e3, 3), "steps": args.steps,
-                    "max_rel_diff_of_expression_vs_value_path": float(((expr_side - expr).abs() / expr.abs()).max()),
-                    "note": "opt-in experiment, NOT exact at full depth (not reproducible run to run): never `value`"}
+            with runtime.override(overlap_cre_stream=False):
+                dts, (expr_single, _) = timed_steps(step, args.steps, 2, use_dist, torch.cuda.synchronize, dev)
+            single = {"value": round(world * G * args.steps / dts, 4), "unit": "genes/sec",
+                      "ms_per_step": round(dts / args.steps * 1e3, 3), "steps": args.steps,
+                      "max_rel_diff_of_expression_vs_value_path": float(((expr_single - expr).abs() / expr.abs()).max()),
+                      "note": "runtime.Switches.overlap_cre_stream=False: every kernel on one stream (the order the per-kernel "
+                              "replay behind `roofline` / `kernel_families` uses)"}
             k_off = max(2, min(args.steps, 4))
             with ln_fold_forced_off():
                 dto, (expr_off, _) = timed_steps(step, k_off, 2, use_dist, torch.cuda.synchronize, dev)
@@ -626,8 +627,8 @@ def main():
             "ms_of_each_timed_step_rank0": each_step_ms, "device_allocations_inside_timed_region": allocs_in_timed_region,
             "extra_allocator_priming_passes": extra_warmup,
         }
-        if side is not None:
-            out["cre_side_stream_experiment"] = side
+        if single is not None:
+            out["value_single_stream"] = single
         if fold_off is not None:
             out["ln_fold_off"] = fold_off
         for g, rec in (small or {}).items():

@@ -39,10 +39,9 @@ c1 = rnd(4608)
 def tup(x):
     if isinstance(x, torch.Tensor):
         return (x,)
-    if isinstance(x, (tuple, list)):
-        return tuple(t for y in x for t in tup(y))
-    return tuple(t for t in vars(x).values() if isinstance(t, torch.Tensor)) if hasattr(x, "__dict__") else \
-        tuple(t for t in x if isinstance(t, torch.Tensor))
+    if isinstance(x, ops.LnStream):
+        return tuple(t for t in (x.x, x.x16, x.stats, x.t16) if t is not None)
+    return tuple(t for y in x for t in tup(y))
 
 
 victims = {

@@ -342,71 +342,76 @@ def test_first_gene_layer_row_map_attention_is_exact(monkeypatch):
         np.testing.assert_array_equal(a["embeddings"][i], c["embeddings"][i])
 
 
-def test_cre_stream_on_a_side_stream_experiment(monkeypatch):
-    """runtime.Switches.overlap_cre_stream (an opt-in EXPERIMENT, off by default): the CRE layers on a side stream beside the
-    gene layers (CRE layer i + 1 needs CRE layer i only; gene layer i + 1 needs gene layer i and CRE layer i).  On this 5-layer
-    model the overlapped path is bit-identical to the single-stream one over repeated calls (the first forward of a
-    configuration runs single-stream by itself: it builds the per-weights caches), a LayerNorm-fold alert raised by a
-    CRE-stream kernel on the side stream still reaches the batch (the model recomputes it), and stale bits on the side stream's
-    flag do not (round-5 advice).  At FULL depth the experiment is not reproducible run to run (profiles/r06_b_*), which is
-    why it is not the product default; the default path's reproducibility at full depth is
-    test_default_path_is_reproducible_at_full_depth."""
+def test_cre_stream_on_a_side_stream_is_bit_identical(monkeypatch):
+    """runtime.Switches.overlap_cre_stream (the product default): the CRE layers on a side stream beside the gene layers (CRE
+    layer i + 1 needs CRE layer i only; gene layer i + 1 needs gene layer i and CRE layer i).  The overlapped path is
+    bit-identical to the single-stream one over repeated calls (the first forward of a configuration runs single-stream by
+    itself: it builds the per-weights caches), a LayerNorm-fold alert raised by a CRE-stream kernel on the side stream still
+    reaches the batch (the model recomputes it), and stale bits on the side stream's flag do not (round-5 advice).  Full
+    depth: test_default_path_is_reproducible_at_full_depth."""
     import variantformer_amd.seq2gene.model_combined_modulator as M
     from variantformer_amd import ops, runtime
     monkeypatch.delenv("VF_LN_FOLD", raising=False)                    # the alert half needs the fold (default contract)
     monkeypatch.delenv("VF_TRUNK16", raising=False)
-    assert not runtime.switches().overlap_cre_stream, "the product default is single-stream"
+    assert runtime.switches().overlap_cre_stream, "the product default runs the CRE layers on the side stream"
     model = build_model(SEQ2REG_512, seq2gene_kw(layers=5), seed=3).cuda()
     batch = make_batch(4, [300, 40], [150, 20], [TISSUES_54[:5], [9, 33]], 200)
-    a = model.predict_step(batch, 0)
+    with runtime.override(overlap_cre_stream=False):
+        a = model.predict_step(batch, 0)
     warm = model.combined_modulator.cre_layers[0].__dict__["_vf_overlap_warm"]
     assert len(warm) == 1
     hs = M.heal_state(model)
-    with runtime.override(overlap_cre_stream=True):
-        for _ in range(3):
-            b = model.predict_step(batch, 0)
-            for i in range(2):
-                np.testing.assert_array_equal(a["pred_gene_exp"][i], b["pred_gene_exp"][i])
-                np.testing.assert_array_equal(a["embeddings"][i], b["embeddings"][i])
-        assert hs.batches == 0 and hs.finished == 4
-        # stale bits on the side stream's flag belong to nobody: the next batch must not be recomputed because of them
-        dev = torch.device("cuda", torch.cuda.current_device())
-        side = M._side_stream(dev)
-        with torch.cuda.stream(side):
-            ops._alert_flag(dev).fill_(1)
-        torch.cuda.synchronize()
+    for _ in range(3):
         b = model.predict_step(batch, 0)
-        assert hs.batches == 0, "a stale bit on the side stream's flag was taken for this batch's alert"
-        np.testing.assert_array_equal(a["embeddings"][0], b["embeddings"][0])
+        for i in range(2):
+            np.testing.assert_array_equal(a["pred_gene_exp"][i], b["pred_gene_exp"][i])
+            np.testing.assert_array_equal(a["embeddings"][i], b["embeddings"][i])
+    assert hs.batches == 0 and hs.finished == 4
+    # stale bits on the side stream's flag belong to nobody: the next batch must not be recomputed because of them
+    dev = torch.device("cuda", torch.cuda.current_device())
+    side = M._side_stream(dev)
+    with torch.cuda.stream(side):
+        ops._alert_flag(dev).fill_(1)
+    torch.cuda.synchronize()
+    b = model.predict_step(batch, 0)
+    assert hs.batches == 0, "a stale bit on the side stream's flag was taken for this batch's alert"
+    np.testing.assert_array_equal(a["embeddings"][0], b["embeddings"][0])
     # an alert that only a CRE-stream kernel can raise: a huge common offset on the output bias of CRE layer 1's down-projection
     # gives every row of the CRE stream a mean of many standard deviations from CRE layer 2 on; the gene stream never sees it in
     # a LayerNorm-folded statistic of its own (it reads the CRE stream through K / V projections only)
     monkeypatch.setattr(M, "LN_HEAL_STICKY_AFTER", 10 ** 9)
     with torch.no_grad():
         model.combined_modulator.cre_layers[1].linear_geglu_2.bias += 60.0
-    want = model.predict_step(batch, 0)
+    with runtime.override(overlap_cre_stream=False):
+        want = model.predict_step(batch, 0)
     assert hs.batches == 1, "the serial path must have flagged and recomputed the batch"
-    with runtime.override(overlap_cre_stream=True):
-        got = model.predict_step(batch, 0)
+    got = model.predict_step(batch, 0)
     assert hs.batches == 2, "the alert raised on the side stream must reach the batch"
     for i in range(2):
         np.testing.assert_array_equal(got["pred_gene_exp"][i], want["pred_gene_exp"][i])
 
 
 def test_default_path_is_reproducible_at_full_depth():
-    """The product path at full depth (25 modulator layers, 6 seq2reg layers): the same ragged batch evaluated three times, and
-    once more inside a different batch, gives the same bits (what ruled the side-stream experiment out as a default)."""
+    """The product path at full depth (25 modulator layers, 6 seq2reg layers; CRE layers on the side stream): the same ragged
+    batch evaluated three times gives the same bits -- the bits of the single-stream order -- and once more inside a different
+    batch the same values.  (Until round 6 two streams differed run to run by 7e-4: packed-fp32 instructions beside another
+    kernel's MFMAs, tests/test_concurrency_gpu.py.)"""
     import bench
     from variantformer_amd import runtime
-    assert not runtime.switches().overlap_cre_stream
+    assert runtime.switches().overlap_cre_stream
     model, hp, kw = bench.build_model(torch.device("cuda", 0))
     batch = make_batch(77, [700, 90, 311], [150, 20, 64], [TISSUES_54, TISSUES_54[:7], TISSUES_54[:30]], 200)
-    a = model.predict_step(batch, 0)
-    for _ in range(2):
+    a = model.predict_step(batch, 0)                               # (the first forward builds the caches on one stream)
+    for _ in range(3):
         b = model.predict_step(batch, 0)
         for i in range(3):
             np.testing.assert_array_equal(a["pred_gene_exp"][i], b["pred_gene_exp"][i])
             np.testing.assert_array_equal(a["embeddings"][i], b["embeddings"][i])
+    with runtime.override(overlap_cre_stream=False):
+        s1 = model.predict_step(batch, 0)
+    for i in range(3):
+        np.testing.assert_array_equal(s1["pred_gene_exp"][i], b["pred_gene_exp"][i])
+        np.testing.assert_array_equal(s1["embeddings"][i], b["embeddings"][i])
     two = {k: v[1:] for k, v in batch.items()}
     c = model.predict_step(two, 0)
     for i in range(2):

@@ -3,7 +3,7 @@
 Two records, both per CONTEXT (a thread starts with the defaults; `with` blocks nest and restore):
 
 * `Switches` -- every exact re-ordering the product applies next to the form it replaces.  All on in
-  the product (except the side-stream experiment); the tests run a model twice under `runtime.override(<switch>=False)` to prove that a re-ordering changes no
+  the product; the tests run a model twice under `runtime.override(<switch>=False)` to prove that a re-ordering changes no
   bit (or only the stated rounding points).  Nothing here is an environment variable and nothing is a mutable module
   attribute: a test that flips a switch cannot leak it into another thread's forward.
 * `Env` -- the two deployment switches that ARE environment variables (`VF_LN_FOLD`, `VF_TRUNK16`), read ONCE per forward:
@@ -27,12 +27,12 @@ class Switches:
     lowrank_context: bool = True              # ... in its low-rank form (two skinny GEMMs around a 9-way softmax)
     layer0_qkv_table: bool = True             # seq2reg's first-layer Wqkv by lookup (3.12)
     pool_before_down_projection: bool = True  # seq2reg's mean pool before its last down-projection (3.11)
-    overlap_cre_stream: bool = False          # EXPERIMENT, not exact at full depth: CRE layers on a side stream beside the gene
-                                              # layers.  Round 5 found it bit-identical on a 5-layer model and 3...5 ms faster; made
-                                              # the default in round 6 it turned out NOT reproducible at full depth -- the same batch
-                                              # twice differs by 7e-4 in the expression, while the single-stream path differs by 0
-                                              # (scripts/probes/overlap_diag.py, profiles/r06_b_*) -- so it stays opt-in and outside
-                                              # `value`
+    overlap_cre_stream: bool = True           # the CRE layers on a side stream beside the gene layers (their small kernels fill the
+                                              # tails of the gene stream's persistent GEMMs: -0.4 ... 0.8 % step time).  Bit-identical
+                                              # to the single-stream order at full depth SINCE the library is built without
+                                              # packed-fp32 instructions (round 6: the run-to-run differences of two streams were a
+                                              # gfx950 hazard of v_pk_*_f32 op_sel forms beside another kernel's MFMAs --
+                                              # csrc/build.py NO_PACKED_FP32, profiles/r06_d_*); False = one stream
 
 
 _SW: contextvars.ContextVar = contextvars.ContextVar("vf_switches", default=Switches())

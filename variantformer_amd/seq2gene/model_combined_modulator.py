@@ -253,13 +253,16 @@ class PredictHandle:
 
 
 _SIDE_STREAMS: dict = {}
-_OVERLAP_SERIALIZE_FOR_DIAG = False     # diagnostic of the side-stream experiment only (see modulator_forward_packed)
+_OVERLAP_SERIALIZE_FOR_DIAG = False     # scripts/probes/overlap_diag.py only: the two-stream plumbing with the streams serialised
 
 
-def _side_stream(device):
-    key = (device.type, device.index)
+def _side_stream(device, main=None):
+    """The side stream that belongs to `main` (default: the current stream of `device`): one per main stream, so that two
+    models driven from two threads / streams neither queue behind each other nor share a LayerNorm-fold alert flag."""
+    main = torch.cuda.current_stream(device) if main is None else main
+    key = (device.type, device.index, main.cuda_stream)
     if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+        _SIDE_STREAMS.setdefault(key, torch.cuda.Stream(device=device))     # (two threads racing here agree on one)
     return _SIDE_STREAMS[key]
 
 
@@ -344,16 +347,18 @@ def modulator_forward_packed(ctx_embedding, cre_layers, gene_layers, cre_x, gene
                 g = ops.add_rows(_t(g), gene_x)
             return g
 
-    # EXPERIMENT (runtime.Switches.overlap_cre_stream, off by default): the CRE layers on a SIDE STREAM beside the gene layers --
-    # CRE layer i + 1 depends on CRE layer i only, gene layer i + 1 on gene layer i and CRE layer i, so the small CRE-stream
-    # kernels (3-9 tiles per CU) fill the tails of the gene stream's persistent GEMMs: -3.5 ms per 32-gene step (0.6 %).  NOT
-    # EXACT at full depth: the same batch evaluated twice differs by 7e-4 in the expression (bit-identical on a 5-layer model,
-    # tests/test_model_gpu.py; 0 difference single-stream at any depth) although every cross-stream tensor is event-ordered and
-    # recorded on its reader's stream (scripts/probes/overlap_diag.py: also with the two streams serialised by events the
-    # difference stays 0, i.e. it needs kernels of both streams in flight together).  Round 6 therefore keeps it out of the
-    # product default and out of `value`.  Single stream always: inside an ops.KernelTimer replay, and for the FIRST forward of a
-    # configuration, which builds every per-weights cache (packed operands, low-rank tables, the 9-row K/V tables) -- they are
-    # long-lived and belong in the main stream's allocator pool (round-5 advice).
+    # runtime.Switches.overlap_cre_stream (default on): the CRE layers on a SIDE STREAM beside the gene layers -- CRE layer i + 1
+    # depends on CRE layer i only, gene layer i + 1 on gene layer i and CRE layer i, so the small CRE-stream kernels (3-9 tiles
+    # per CU) fill the tails of the gene stream's persistent GEMMs: -2 ... 4 ms per 32-gene step.  Every tensor that crosses
+    # streams is event-ordered and recorded on its reader's stream.  Bit-identical to the single-stream order, at full depth and
+    # run to run (tests/test_model_gpu.py, scripts/probes/overlap_diag.py) -- since round 6: until then the same batch evaluated
+    # twice differed by 7e-4, because LayerNorm-consumer GEMMs of the CRE stream shared SIMDs with the gene stream's cross
+    # attention and hipcc had packed their epilogue into v_pk_fma_f32 ... op_sel:[0,1,0], which gfx950 computes with a wrong
+    # src1 in lanes 48..63 beside another kernel's MFMAs (scripts/probes/pk_hazard_probe.hip, profiles/r06_d_*); the library now
+    # contains no packed-fp32 instruction (csrc/build.py).  Single stream always: inside an ops.KernelTimer replay (per-kernel
+    # times must not depend on a neighbour), and for the FIRST forward of a configuration, which builds every per-weights cache
+    # (packed operands, low-rank tables, the 9-row K/V tables) -- they are long-lived and belong in the main stream's allocator
+    # pool (round-5 advice).
     warm_key = (ops.cdt(), ln_fold_enabled(cre_x.shape[1]), runtime.env().trunk16, runtime.switches().counted_context_keys,
                 runtime.switches().lowrank_context, log2c is not None)
     warm = cre_layers[0].__dict__.setdefault("_vf_overlap_warm", set()) if n > 1 else set()
@@ -368,7 +373,7 @@ def modulator_forward_packed(ctx_embedding, cre_layers, gene_layers, cre_x, gene
     # Tensors that cross streams are recorded on the stream that reads them.
     dev = _t(cre_x).device
     main = torch.cuda.current_stream(dev)
-    side = _side_stream(dev)
+    side = _side_stream(dev, main)
 
     def tensors(x):
         return [t for t in ((x.x, x.x16, x.stats, x.t16) if isinstance(x, ops.LnStream) else (x,)) if t is not None]
