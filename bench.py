@@ -92,12 +92,12 @@ def host_threads() -> int:
 
 
 def source_sha() -> str:
-    """Hash of the kernel sources the loaded library was built from (ties a PMC profile to a build)."""
+    """Hash of the kernel sources and build flags the loaded library was built from (ties a PMC profile to a build)."""
     import hashlib
     h = hashlib.sha256()
     csrc = os.path.join(REPO, "variantformer_amd", "csrc")
     for f in sorted(os.listdir(csrc)):
-        if f.endswith((".hip", ".h", ".cpp")):
+        if f.endswith((".hip", ".h", ".cpp")) or f == "build.py":          # build.py: the compile flags are part of a build
             with open(os.path.join(csrc, f), "rb") as fh:
                 h.update(fh.read())
     return h.hexdigest()[:16]
