@@ -406,7 +406,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=3)      # 3 passes prime the caching allocator of both streams: no extra pass
     ap.add_argument("--genes-per-step", type=int, default=32,
                     help="genes per rank per step; 32 = BASELINE configs[2]'s 256-gene batch over the 8 GPUs of a node (the "
                          "reference's DataLoader default, configs/vcfloader.yaml:5, is 8: that rate is reported beside "
@@ -424,13 +424,22 @@ def main():
     ap.add_argument("--no-cfg3", action="store_true", help="N > 1: skip the extra strong-scaling pass over BASELINE configs[2]")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the host-inclusive product-flow measurement")
     ap.add_argument("--no-extra-rates", action="store_true",
-                    help="skip value_single_stream / ln_fold_off / trained_like (the passes after the timed region)")
+                    help="skip value_single_stream / ln_fold_off / trained_like / batch_of_8 / batch_of_1 (the passes after the timed region): "
+                         "the process then runs W + K + K identical steps, which is what the rocprofv3 passes of "
+                         "scripts/run_profile_set.sh profile")
+    ap.add_argument("--single-stream", action="store_true",
+                    help="runtime.Switches.overlap_cre_stream off for the whole run (the order the per-kernel replay uses): what "
+                         "the rocprofv3 --kernel-trace --stats pass profiles, because with two streams a kernel's traced "
+                         "duration includes the time it shares the CUs with the other stream's kernels")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)      # launcher test: no model, gloo on CPU
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:        # no launcher around us: start the ranks as a child process
         sys.exit(self_launch(args, sys.argv[1:]))
 
+    if args.single_stream:
+        from variantformer_amd import runtime
+        runtime.set_for_this_context(overlap_cre_stream=False)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -581,7 +590,7 @@ def main():
                 kernels[f"{kind}/{fam}"] = ent
 
         small = None
-        if rank == 0 and world == 1 and not args.no_kernel_timing:
+        if rank == 0 and world == 1 and not args.no_kernel_timing and not args.no_extra_rates:
             # the same step at the reference's own DataLoader batch size (8 genes, configs/vcfloader.yaml:5) and for one
             # gene alone (SURVEY 8d's cfg-2 row: B = 1), inputs resident, same K / W
             small = {}
@@ -619,7 +628,8 @@ def main():
                                     "batch_of_1 beside it)" % (kw["num_layers"], kw["emb_dim"], kw["num_heads"],
                                                                len(tissues), G)),
                        "genes_per_step_per_gpu": G, "n_cre_windows": args.n_cre, "gene_chunks": args.n_chunks,
-                       "tissues": len(tissues), "tokens_per_window": 200, "parallelism": f"gene-shard x{world}"},
+                       "tissues": len(tissues), "tokens_per_window": 200, "parallelism": f"gene-shard x{world}",
+                       "streams": "one (--single-stream)" if args.single_stream else "CRE layers on a side stream (default)"},
             "algorithmic_tflop_per_gene": round(flops_step / G / 1e12, 3),
             "reference_executed_tflop_per_gene": round(executed_step / G / 1e12, 3),
             "achieved_algorithmic_tflops_whole_step": round(world * flops_step * args.steps / dt / 1e12, 1),

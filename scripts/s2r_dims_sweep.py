@@ -11,7 +11,7 @@ against their own FLOP / byte model, which GEMM / attention kernels were dispatc
 which attention kernel, whether the first-layer lookup gathered inside the attention or by a row gather first), and the
 first-layer lookup table's bytes.  Output: one JSON (profiles/r06_s2r_dims.json) + a table on stdout.
 
-usage: python scripts/s2r_dims_sweep.py [out.json] [--quick]
+usage: python scripts/s2r_dims_sweep.py [out.json] [--quick] [--widths=512,768]
 """
 import json
 import os
@@ -79,6 +79,9 @@ class Spy:
 batch = make_batch(20251205, [1024] * G, [200] * G, [TISSUES_54] * G, 200)
 rows = []
 widths = [512] if quick else [512, 256, 768, 1024]
+for a in sys.argv[1:]:
+    if a.startswith("--widths="):                    # e.g. --widths=512,768 (512 must be there: the default geometry is the yardstick)
+        widths = [int(x) for x in a.split("=", 1)[1].split(",")]
 for d in widths:
     kw = dict(bench.SEQ2GENE_KW, token_dim=d, gene_emb_dim=d)
     with torch.device(dev):

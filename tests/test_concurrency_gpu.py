@@ -71,3 +71,40 @@ def test_gemm_beside_attention_on_another_stream_is_bit_identical(setup, victim,
                 assert torch.equal(o, ref), f"{victim}: {int((o != ref).sum())} elements differ beside the attention kernel"
             for o in couts:
                 assert torch.equal(o, coref)
+
+
+def test_two_models_in_two_threads_on_their_own_streams():
+    """Two model instances driven from two threads, each on its own HIP stream (and, by default, its own CRE side stream): every
+    result equals the one the model gives alone, bit for bit, while the other model's kernels share the GPU."""
+    import threading
+    from tests.helpers import SEQ2REG_512, build_model, seq2gene_kw
+    from variantformer_amd.utils.synthetic import TISSUES_54, make_batch
+    models = [build_model(SEQ2REG_512, seq2gene_kw(layers=6), seed=21 + i).cuda() for i in range(2)]
+    batches = [make_batch(31 + i, [280 + 40 * i, 64], [120, 30 + 5 * i], [TISSUES_54[:9], TISSUES_54[3:8]], 200) for i in range(2)]
+    alone = [m.predict_step(b, 0) for m, b in zip(models, batches)]          # (also the cache-building first forwards)
+    alone = [m.predict_step(b, 0) for m, b in zip(models, batches)]
+    errors, results = [], [[], []]
+    gate = threading.Barrier(2)
+
+    def work(i):
+        try:
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                gate.wait()
+                for _ in range(6):
+                    results[i].append(models[i].predict_step(batches[i], 0))
+            stream.synchronize()
+        except Exception as e:                                    # noqa: BLE001 (re-raised in the main thread)
+            errors.append(e)
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for i in range(2):
+        assert len(results[i]) == 6
+        for out in results[i]:
+            for g in range(2):
+                np.testing.assert_array_equal(out["pred_gene_exp"][g], alone[i]["pred_gene_exp"][g])
+                np.testing.assert_array_equal(out["embeddings"][g], alone[i]["embeddings"][g])

@@ -344,6 +344,42 @@ def test_attention_one_block_per_window_dh64(ops, q_log2, dh, alibi):
         np.testing.assert_allclose(got[a:e].numpy(), _bf(ref.reshape(e - a, D)).numpy(), rtol=2 ** -7, atol=6e-3)
 
 
+@pytest.mark.parametrize("alibi", [False, True])
+def test_attention_dh96_windows_as_one_128_query_block(ops, alibi):
+    """dh = 96 (a tokenizer geometry the real checkpoint might have, e.g. d = 768 with 8 heads): windows of 65 ... 128 tokens in
+    a batch of >= 1024 (window, head) items run as ONE 128-query block of the tiled kernel (round 6; two query groups per wave)
+    instead of two 64-query blocks that each stage all keys.  Every element of a few windows against the oracle, and
+    bit-identical to the 64-query form (the same windows in a batch too small for the new path)."""
+    H, dh = 8, 96
+    D = H * dh
+    slopes_l = torch.tensor(O.alibi_slopes(H), dtype=torch.float32) if alibi else None
+    slopes = slopes_l.cuda() if alibi else None
+    rng = np.random.default_rng(19)
+    ql = [128, 127, 65, 66, 96, 97, 112, 113, 80, 1, 17, 64] + list(rng.integers(1, 129, 120))
+    assert len(ql) * H >= 1024
+    c = math.log2(math.e) / math.sqrt(dh)
+    x = _bf(_rand((sum(ql), 3 * D), 73, 2.0))
+    x[:, :D] = _bf(x[:, :D] * c)
+    dev = x.cuda().bfloat16()
+    cu = torch.tensor([0] + list(np.cumsum(ql)), dtype=torch.int32)
+    out = ops.attn_varlen(dev[:, :D], dev[:, D:2 * D], dev[:, 2 * D:], cu.cuda(), None, max(ql), max(ql), H, dh, slopes, q_log2=True)
+    assert ops.last_kernel("attn") == "attn_fwd_kernel<128-query blocks>", ops.last_kernel("attn")
+    n_small = 100
+    t_small = int(cu[n_small])
+    small = ops.attn_varlen(dev[:t_small, :D], dev[:t_small, D:2 * D], dev[:t_small, 2 * D:], cu[:n_small + 1].cuda(), None,
+                            max(ql[:n_small]), max(ql[:n_small]), H, dh, slopes, q_log2=True)
+    assert ops.last_kernel("attn") == "attn_fwd_kernel<64-query blocks>", ops.last_kernel("attn")
+    torch.cuda.synchronize()
+    assert torch.equal(out[:t_small].view(torch.int16), small.view(torch.int16))
+    rnd = O.Rounding("bf16")
+    got = out.float().cpu()
+    for b in list(range(12)) + [40, 131]:
+        a, e = int(cu[b]), int(cu[b + 1])
+        ref = O.attention(x[a:e, :D].view(-1, H, dh), x[a:e, D:2 * D].view(-1, H, dh), x[a:e, 2 * D:].view(-1, H, dh), slopes_l, rnd,
+                          q_log2=True)
+        np.testing.assert_allclose(got[a:e].numpy(), _bf(ref.reshape(e - a, D)).numpy(), rtol=2 ** -7, atol=6e-3)
+
+
 @pytest.mark.parametrize("q_log2", [True, False])
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 def test_attention_one_block_per_chunk_dh64_two_passes(ops, q_log2, dtype):

@@ -1444,7 +1444,7 @@ int launch_attn(AttnParams P, int n_seq, int max_q, int max_k, hipStream_t st) {
     // short ones (seq2reg windows, gene stream): 64-query blocks to limit tail waste.
     // 2 query groups per wave only when that still leaves >= 4 blocks per CU (measured: CRE stream, 256 blocks, is
     // 15% faster with 64-query blocks; the 10^4-query gene->CRE cross attention is 17% faster with 128-query blocks).
-    // dh = 96 / 128 (not a shape of the shipped model) always take one query group per wave.
+    // dh = 128 (not a shape of the shipped model) always takes one query group per wave; dh = 96: below.
     if constexpr (DH <= 64) {
         if (max_q > 256 && (long)n_seq * P.H * ((max_q + 127) / 128) >= 1024) {
             const dim3 grid(set_grid(P, n_seq, (max_q + 127) / 128));
@@ -1465,6 +1465,13 @@ int launch_attn(AttnParams P, int n_seq, int max_q, int max_k, hipStream_t st) {
             }
             return launch_fwd<DH, 2, ALIBI, DT>(P, grid, st);
         }
+    }
+    if constexpr (DH == 96) {
+        // dh = 96 (a tokenizer geometry the real checkpoint might have, scripts/s2r_dims_sweep.py): windows of 65-128 tokens
+        // as ONE 128-query block per (window, head) -- two 64-query blocks would each stage all keys: 3.0 -> 3.5 TB/s.  (At
+        // dh = 128 the two-group form needs all 256 VGPRs, one wave per SIMD, and is slower: 3.4 -> 3.1 TB/s.)
+        if (max_q > 64 && max_q <= 128 && (long)n_seq * P.H >= 1024)
+            return launch_fwd<DH, 2, ALIBI, DT>(P, dim3(set_grid(P, n_seq, 1)), st);
     }
     return launch_fwd<DH, 1, ALIBI, DT>(P, dim3(set_grid(P, n_seq, (max_q + 63) / 64)), st);
 }
