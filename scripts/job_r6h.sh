@@ -1,6 +1,9 @@
 #!/bin/bash
 # round 6, job h: which kernels are at risk beside another kind of kernel; cost of a library without packed-fp32 VALU
 # instructions; the CRE side-stream experiment on that library
+# NOTE: libvf_nopk_* / libvf_wait0 were built by the first version of scripts/probes/build_probe_libs.py (the round-5 flags plus
+# -target-feature -packed-fp32-ops on ONE object; wait0 = a temporary s_waitcnt vmcnt(0) hook).  The product build now carries the
+# flag itself and the script builds the inverse variants (libvf_pk_*): the same comparison with the roles swapped.
 mkdir -p gpurun_out/r6h
 L=variantformer_amd/csrc/probe_libs
 timeout 400 python scripts/probes/concurrency_probe5.py > gpurun_out/r6h/concurrency_probe5.log 2>&1
