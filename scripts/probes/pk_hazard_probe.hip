@@ -59,6 +59,31 @@ template <int FORM> __global__ __launch_bounds__(256) void victim(unsigned long 
         } else if (FORM == 11) {
             asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(d) : "v"(a), "v"(b));
             e[0] = sadd(a[0], b[1]); e[1] = sadd(a[1], b[1]);
+        } else if (FORM == 12) {  // v_fma_mix_f32 with src1 = the f16 in the HIGH half of a register (what hipcc emits for fp32 += float(half) * s:
+                                  // 1 296 of them in the product library, e.g. the fp16 trunk residual of the producer epilogues)
+            const unsigned hb = __builtin_bit_cast(unsigned, b[1]) & 0xffff0000u;          // a half in the high 16 bits
+            float lo;
+            asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(lo) : "v"(a[0]), "v"(hb), "v"(c[0]));
+            float hf;
+            asm volatile("v_cvt_f32_f16 %0, %1" : "=v"(hf) : "v"(hb >> 16));
+            d[0] = lo; d[1] = lo;
+            e[0] = sfma(a[0], hf, c[0]); e[1] = e[0];
+        } else if (FORM == 13) {  // the same with the half in the LOW 16 bits
+            const unsigned hb = (__builtin_bit_cast(unsigned, b[1]) >> 16);
+            float lo;
+            asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[0,1,0]" : "=v"(lo) : "v"(a[0]), "v"(hb), "v"(c[0]));
+            float hf;
+            asm volatile("v_cvt_f32_f16 %0, %1" : "=v"(hf) : "v"(hb));
+            d[0] = lo; d[1] = lo;
+            e[0] = sfma(a[0], hf, c[0]); e[1] = e[0];
+        } else if (FORM == 14) {  // packed f16: low result from the HIGH half of src1
+            const unsigned ah = 0x3c003800u ^ (threadIdx.x & 0xff), bh = 0x40004100u + ((it & 7) << 4), ch = 0x34003200u;
+            unsigned dd, e0, e1;
+            asm volatile("v_pk_fma_f16 %0, %1, %2, %3 op_sel:[0,1,0]" : "=v"(dd) : "v"(ah), "v"(bh), "v"(ch));
+            asm volatile("v_fma_f16 %0, %1, %2, %3" : "=v"(e0) : "v"(ah), "v"(bh >> 16), "v"(ch));
+            asm volatile("v_fma_f16 %0, %1, %2, %3" : "=v"(e1) : "v"(ah >> 16), "v"(bh >> 16), "v"(ch >> 16));
+            d[0] = __builtin_bit_cast(float, dd & 0xffffu); d[1] = __builtin_bit_cast(float, dd >> 16);
+            e[0] = __builtin_bit_cast(float, e0 & 0xffffu); e[1] = __builtin_bit_cast(float, e1 & 0xffffu);
         } else {                  // control: two scalar fused multiply-adds
             asm volatile("v_fma_f32 %0, %2, %3, %4\n\tv_fma_f32 %1, %5, %3, %6" : "=&v"(d[0]), "=&v"(d[1]) : "v"(a[0]), "v"(b[1]), "v"(c[0]), "v"(a[1]), "v"(c[1]));
             e[0] = sfma(a[0], b[1], c[0]); e[1] = sfma(a[1], b[1], c[1]);
@@ -128,10 +153,11 @@ int main(int argc, char** argv) {
     hipStream_t s0, s1;
     CK(hipStreamCreate(&s0));
     CK(hipStreamCreate(&s1));
-    vk_t vks[] = {victim<0>, victim<1>, victim<2>, victim<3>, victim<4>, victim<5>, victim<6>, victim<7>, victim<8>, victim<9>, victim<10>, victim<11>};
+    vk_t vks[] = {victim<0>, victim<1>, victim<2>, victim<3>, victim<4>, victim<5>, victim<6>, victim<7>, victim<8>, victim<9>, victim<10>, victim<11>, victim<12>, victim<13>, victim<14>};
     const char* vn[] = {"v_pk_fma_f32 op_sel:[0,1,0]", "v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32", "2 x v_fma_f32 (control)", "v_pk_fma_f32 op_sel:[1,0,0]", "v_pk_fma_f32 op_sel:[0,0,1]",
                         "v_pk_fma_f32 op_sel_hi:[1,0,1]", "v_pk_fma_f32 op_sel_hi:[0,1,1]", "v_pk_mul_f32 op_sel:[0,1]", "v_pk_mul_f32 op_sel_hi:[1,0]",
-                        "v_pk_add_f32 op_sel:[0,1]"};
+                        "v_pk_add_f32 op_sel:[0,1]", "v_fma_mix_f32 (f16 src1 in the high half)", "v_fma_mix_f32 (f16 src1 in the low half)",
+                        "v_pk_fma_f16 op_sel:[0,1,0]"};
     ck_t cks[] = {corunner<0>, corunner<1>, corunner<2>, corunner<3>, corunner<4>, corunner<5>, corunner<6>, corunner<7>, corunner<8>,
                   corunner<9>, corunner<10>, corunner<11>, corunner<12>, corunner<13>};
     const char* cn[] = {"v_nop", "v_exp_f32", "v_rcp_f32 + v_rsq_f32", "v_permlane32_swap + v_permlane16_swap", "DPP row_shr + row_bcast",
@@ -139,7 +165,7 @@ int main(int argc, char** argv) {
                         "v_pk_mul_f32", "v_max3_f32 + v_fma_f32", "global loads", "mix: mfma + exp + permlane + cvt_pk", "v_readlane + s_nop"};
     hipEvent_t e0, e1, e2, e3;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2)); CK(hipEventCreate(&e3));
-    for (int v = 0; v < 12; ++v) {
+    for (int v = 0; v < 15; ++v) {
         for (int c = -1; c < 14; ++c) {
             if (v >= 5 && c >= 0 && c != 6 && c != 7) continue;
             CK(hipMemset(err, 0, 16 * sizeof(unsigned long long)));
@@ -158,7 +184,7 @@ int main(int argc, char** argv) {
             CK(hipEventElapsedTime(&tc, e2, e3));
             unsigned long long tot = 0;
             for (int i = 0; i < 8; ++i) tot += h[i];
-            printf("victim %-31s co-runner %-40s: %12llu wrong of %.3g  (victim %.1f ms, co-runner %.1f ms)", vn[v], c < 0 ? "(none)" : cn[c], tot,
+            printf("victim %-42s co-runner %-40s: %12llu wrong of %.3g  (victim %.1f ms, co-runner %.1f ms)", vn[v], c < 0 ? "(none)" : cn[c], tot,
                    (double)viters * 512 * 256 * 2, tv, tc);
             if (tot) {
                 printf("  by quarter-wave (low, high half):");

@@ -24,4 +24,8 @@ def test_library_has_no_packed_fp32_instructions(tmp_path):
         n_mfma += dis.count("v_mfma_f32_")
         for ins in ("v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32"):
             assert ins not in dis, f"{ins} in the device code of {f}"
+        # the only instruction left that carries an op_sel operand selection is v_fma_mix_f32 (fp32 += float(half) * x), which the
+        # probe shows unaffected, with the half in either half of its register; anything else must be probed before it ships
+        others = {line.split()[0] for line in dis.splitlines() if "op_sel" in line and line.split()} - {"v_fma_mix_f32"}
+        assert not others, f"instructions with op_sel other than v_fma_mix_f32 in {f}: {sorted(others)}"
     assert n_mfma > 1000                                               # (the disassembly really is the kernels)
